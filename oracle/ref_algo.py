@@ -1,0 +1,349 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU fp32 restatement (plain torch) of DINO-Tracker's inference hot path.
+
+This module is the ORACLE the HIP path is checked against.  It may be imported only from `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg -- never from `dino_tracker_amd/`.
+
+Pinning status (see tests/test_oracle_vs_reference.py and tests/golden/):
+  * tracker path (sampling, cosine maps, TrackerHead, ModelInference.infer, occlusion): PINNED against the
+    un-modified reference run on CPU in the build container (oracle/ref_harness.py) and against golden
+    fixtures written by tests/golden/make_golden.py from that reference.
+  * DeltaDINO / align_cnn_vit_features: PINNED against the reference modules, with `antialiased_cnns.BlurPool`
+    being a restatement itself (oracle/shims/antialiased_cnns) -- BlurPool is "parity unpinned".
+  * DINOv2 encoder: upstream facebookresearch/dinov2 is un-vendored (torch.hub, network) => the block
+    arithmetic is restated from its published definition and cross-checked against the independent
+    `transformers.Dinov2Model` port (blocks only).  "parity unpinned" for the encoder.
+
+All citations are file:line in /root/reference.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+EPS = 1e-8  # models/tracker.py:14
+
+
+# --------------------------------------------------------------------------------------------------------------
+# geometry helpers
+# --------------------------------------------------------------------------------------------------------------
+def feature_grid(video_h: int, video_w: int, patch: int = 14, stride: int = 7) -> Tuple[int, int]:
+    """Number of ViT tokens per axis, models/extractor.py:171-177."""
+    return 1 + (video_h - patch) // stride, 1 + (video_w - patch) // stride
+
+
+def points_to_grid_coords(points: torch.Tensor, video_h: int, video_w: int, patch: int = 14, stride: int = 7):
+    """models/tracker.py:77-94: pixel (x, y[, t]) -> grid_sample coordinates in [-1, 1] of the token grid
+    whose first / last token centres sit at patch/2 and last_coord."""
+    half = patch / 2
+    last_h = ((video_h - patch) // stride) * stride + half
+    last_w = ((video_w - patch) // stride) * stride + half
+    ah, aw = 2 / (last_h - half), 2 / (last_w - half)
+    bh, bw = 1 - last_h * 2 / (last_h - half), 1 - last_w * 2 / (last_w - half)
+    a = torch.tensor([[aw, ah, 1.0]], dtype=points.dtype)
+    b = torch.tensor([[bw, bh, 0.0]], dtype=points.dtype)
+    return a * points + b
+
+
+def sample_embeddings_literal(emb: torch.Tensor, pts_norm: torch.Tensor) -> torch.Tensor:
+    """Literal form of Tracker.sample_embeddings (models/tracker.py:96-111 -> utils.py:75-101):
+    5-D grid_sample of the [1,C,T,h,w] volume, time normalised by (T-1), border clamp, align_corners."""
+    t = emb.shape[0]
+    vol = emb.permute(1, 0, 2, 3)[None]  # 1 C T h w
+    g = pts_norm[None, None, :, None].clone()
+    if t > 1:
+        g[..., 2] = g[..., 2] / (t - 1)
+    g[..., 2] = g[..., 2] * 2 - 1
+    out = F.grid_sample(vol, g, align_corners=True, padding_mode="border")  # 1 C 1 B 1
+    return out[0, :, 0, :, 0].permute(1, 0)
+
+
+def sample_bilinear(emb: torch.Tensor, xy_px: torch.Tensor, t_idx: torch.Tensor, video_h: int, video_w: int,
+                    patch: int = 14, stride: int = 7) -> torch.Tensor:
+    """Algorithmic form: cell coordinate u=(x-patch/2)/stride, v=(y-patch/2)/stride, clamped to the
+    grid, bilinear inside frame t (t integral).  emb [T,C,h,w]; xy_px [B,2]; t_idx [B] -> [B,C]."""
+    _, c, h, w = emb.shape
+    half = patch / 2
+    u = ((xy_px[:, 0] - half) / stride).clamp(0, w - 1)
+    v = ((xy_px[:, 1] - half) / stride).clamp(0, h - 1)
+    u0 = u.floor().clamp(max=w - 1)
+    v0 = v.floor().clamp(max=h - 1)
+    fu, fv = u - u0, v - v0
+    u0, v0 = u0.long(), v0.long()
+    u1, v1 = (u0 + 1).clamp(max=w - 1), (v0 + 1).clamp(max=h - 1)
+    t = t_idx.long()
+    f00, f01 = emb[t, :, v0, u0], emb[t, :, v0, u1]
+    f10, f11 = emb[t, :, v1, u0], emb[t, :, v1, u1]
+    fu, fv = fu[:, None], fv[:, None]
+    return (f00 * (1 - fu) + f01 * fu) * (1 - fv) + (f10 * (1 - fu) + f11 * fu) * fv
+
+
+# --------------------------------------------------------------------------------------------------------------
+# correlation + tracker head
+# --------------------------------------------------------------------------------------------------------------
+def cosine_maps(src: torch.Tensor, frames: torch.Tensor) -> torch.Tensor:
+    """models/tracker.py:158-169 for the diagonal only: src [B,C], frames [B,C,h,w] (already the target frame of
+    each source) -> [B,h,w]: <s, F(:,r,c)> / max(|s| |F(:,r,c)|, 1e-8)."""
+    dot = torch.einsum("bc,bchw->bhw", src, frames)
+    den = src.norm(dim=1)[:, None, None] * frames.norm(dim=1)
+    return dot / den.clamp(min=EPS)
+
+
+def normalized_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """models/networks/conv_norm.py:34-46: each (out,in) 3x3 kernel divided by its own sum; |sum|<1e-8 -> sign*1e-8."""
+    s = w.sum(dim=(2, 3), keepdim=True).clone()
+    bad = s.abs() < EPS
+    s[bad] = torch.sign(s[bad]) * EPS
+    return w / s
+
+
+def head_refiner(x: torch.Tensor, head: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """cnn_refiner of TrackerHead (models/networks/tracker_head.py:54-58): x [B,1,h,w] -> z [B,1,h,w]."""
+    w1 = normalized_conv_weight(head["cnn_refiner.0.weight"])
+    w2 = normalized_conv_weight(head["cnn_refiner.2.weight"])
+    hid = F.relu(F.conv2d(x, w1, head["cnn_refiner.0.bias"], padding=1))
+    return F.conv2d(hid, w2, head["cnn_refiner.2.bias"], padding=1)
+
+
+def tracker_head(x: torch.Tensor, head: Dict[str, torch.Tensor], video_h: int, video_w: int, patch: int = 14,
+                 stride: int = 7, radius: float = 35.0, return_aux: bool = False):
+    """TrackerHead.forward (models/networks/tracker_head.py:107-121) on the ReLU'd cost volume x [B,h,w] (>=0).
+    Returns normalised (x,y) in [-1,1] ([B,2]); with return_aux also (argmax_flat, z, fallback_mask)."""
+    b, h, w = x.shape
+    k = x.reshape(b, -1).argmax(dim=1)  # :115  (first maximum)
+    row, col = k // w, k % w
+    z = head_refiner(x[:, None], head)[:, 0]
+    p = torch.softmax(z.reshape(b, -1), dim=1).reshape(b, h, w)  # :100-105
+    half = patch // 2
+    ys = torch.arange(h, dtype=torch.float32) * stride + half  # :72-78
+    xs = torch.arange(w, dtype=torch.float32) * stride + half
+    px, py = (col * stride + half).float(), (row * stride + half).float()
+    d2 = (xs[None, None, :] - px[:, None, None]) ** 2 + (ys[None, :, None] - py[:, None, None]) ** 2
+    mask = d2.sqrt() <= radius  # :84
+    q = p * mask
+    qs = q.sum(dim=(1, 2))
+    fb = qs < 1e-8  # :86-94
+    if fb.any():
+        uni = 1.0 / mask[fb].sum(dim=(1, 2)).float()
+        q[fb] = (q[fb] + uni[:, None, None]) * mask[fb]
+        qs[fb] = q[fb].sum(dim=(1, 2))
+    x_hat = (q * xs[None, None, :]).sum(dim=(1, 2)) / qs  # :96
+    y_hat = (q * ys[None, :, None]).sum(dim=(1, 2)) / qs
+    out = torch.stack([2 * x_hat / (video_w - 1) - 1, 2 * y_hat / (video_h - 1) - 1], dim=1)  # :112,121
+    if return_aux:
+        return out, k, z, fb
+    return out
+
+
+def track(src: torch.Tensor, feats: torch.Tensor, tgt: torch.Tensor, head: Dict[str, torch.Tensor], video_h: int,
+          video_w: int, patch: int = 14, stride: int = 7, chunk: int = 64) -> torch.Tensor:
+    """Track source embeddings src [M,C] into frames tgt [M] of feats [T,C,h,w]; returns pixel (x,y) [M,2]
+    (models/tracker.py:171-180 + model_inference.py:52 un-normalisation)."""
+    outs = []
+    for i in range(0, src.shape[0], chunk):
+        s = src[i:i + chunk]
+        x = F.relu(cosine_maps(s, feats[tgt[i:i + chunk].long()]))
+        o = tracker_head(x, head, video_h, video_w, patch, stride)
+        outs.append(torch.stack([(o[:, 0] + 1) / 2 * (video_w - 1), (o[:, 1] + 1) / 2 * (video_h - 1)], dim=1))
+    return torch.cat(outs) if outs else src.new_zeros((0, 2))
+
+
+# --------------------------------------------------------------------------------------------------------------
+# ModelInference.infer -- six-step algorithmic restatement
+# --------------------------------------------------------------------------------------------------------------
+def lower_median(x: torch.Tensor, dim: int = 0) -> torch.Tensor:
+    return torch.median(x, dim=dim).values  # torch.median = lower median
+
+
+def occlusion_for_query(green: torch.Tensor, traj_xy: torch.Tensor, cs: torch.Tensor, anchor_th: float,
+                        cos_th: float) -> torch.Tensor:
+    """models/model_inference.py:169-177. green [A,T,2], traj_xy [T,2], cs [T] -> occ [T] bool."""
+    vis = cs >= anchor_th
+    d = (green - traj_xy[vis][:, None]).norm(dim=-1)  # [A,T]
+    tau = lower_median(d[:, vis], 0).max()
+    return (lower_median(d, 0) > tau) | (cs < cos_th)
+
+
+def infer(feats: torch.Tensor, queries: torch.Tensor, head: Dict[str, torch.Tensor], video_h: int, video_w: int,
+          anchor_th: float = 0.7, cos_th: float = 0.6, patch: int = 14, stride: int = 7,
+          return_aux: bool = False):
+    """ModelInference.infer (models/model_inference.py:203-216) on cached refined features feats [T,C,h,w];
+    queries [N,3] = (x,y,t) at model resolution.  Returns traj [N,T,2] f32 (pixels), occ [N,T] bool."""
+    t_len = feats.shape[0]
+    n = queries.shape[0]
+    tq = queries[:, 2].long()
+    # 1-2: query embeddings and first-pass trajectories (:8-74)
+    q_emb = sample_bilinear(feats, queries[:, :2], tq, video_h, video_w, patch, stride)
+    src = q_emb[:, None].expand(n, t_len, -1).reshape(n * t_len, -1)
+    tgt = torch.arange(t_len).repeat(n)
+    traj = track(src, feats, tgt, head, video_h, video_w, patch, stride).reshape(n, t_len, 2)
+    # 4: embeddings along the trajectory and their cosine to the one at the query frame (:110-126)
+    s_emb = sample_bilinear(feats, traj.reshape(-1, 2), tgt, video_h, video_w, patch, stride).reshape(n, t_len, -1)
+    ref = s_emb[torch.arange(n), tq]
+    cs = F.cosine_similarity(ref[:, None], s_emb, dim=-1)
+    # 5-6: anchors and occlusion (:130-200)
+    occ = torch.zeros(n, t_len, dtype=torch.bool)
+    greens: List[torch.Tensor] = []
+    for i in range(n):
+        anchors = torch.nonzero(cs[i] >= anchor_th)[:, 0]
+        if anchors.numel() == 0:
+            raise RuntimeError("stack expects a non-empty TensorList")  # torch.stack([]) at :152
+        a_src = s_emb[i][None].expand(anchors.numel(), t_len, -1).reshape(-1, s_emb.shape[-1])
+        a_tgt = anchors[:, None].expand(-1, t_len).reshape(-1)
+        g = track(a_src, feats, a_tgt, head, video_h, video_w, patch, stride).reshape(anchors.numel(), t_len, 2)
+        greens.append(g)
+        occ[i] = occlusion_for_query(g, traj[i], cs[i], anchor_th, cos_th)
+    if return_aux:
+        return traj, occ, cs, greens
+    return traj, occ
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Delta-DINO (models/networks/delta_dino.py) + alignment (models/utils.py:7-45)
+# --------------------------------------------------------------------------------------------------------------
+def blur_pool(x: torch.Tensor) -> torch.Tensor:
+    """antialiased_cnns.BlurPool(stride=2, filt_size=4, reflect): see oracle/shims/antialiased_cnns (unpinned)."""
+    a = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    k = (a[:, None] * a[None, :] / 64.0)[None, None].repeat(x.shape[1], 1, 1, 1)
+    return F.conv2d(F.pad(x, (1, 2, 1, 2), mode="reflect"), k, stride=2, groups=x.shape[1])
+
+
+def delta_dino_cnn(frames: torch.Tensor, sd: Dict[str, torch.Tensor], bn_eps: float = 1e-5) -> torch.Tensor:
+    """DeltaDINO.layers in eval mode (delta_dino.py:23-46): 4x [5x5 reflect conv -> BN(running stats) -> ReLU* ->
+    BlurPool*] (*: not on the last layer, whose conv has dilation 2).  frames [B,3,H,W] in [0,1]."""
+    x = frames
+    conv_ids, bn_ids = (0, 4, 8, 12), (1, 5, 9, 13)
+    for li, (ci, bi) in enumerate(zip(conv_ids, bn_ids)):
+        dil = 2 if li == 3 else 1
+        pad = 2 * dil
+        x = F.conv2d(F.pad(x, (pad,) * 4, mode="reflect"), sd[f"layers.{ci}.weight"], sd[f"layers.{ci}.bias"],
+                     dilation=dil)
+        x = F.batch_norm(x, sd[f"layers.{bi}.running_mean"], sd[f"layers.{bi}.running_var"],
+                         sd[f"layers.{bi}.weight"], sd[f"layers.{bi}.bias"], training=False, eps=bn_eps)
+        if li < 3:
+            x = blur_pool(F.relu(x))
+    return x
+
+
+def align_to_vit_grid(cnn: torch.Tensor, vit_h: int, vit_w: int, patch: int = 14, vit_stride: int = 7,
+                      cnn_stride: int = 8) -> torch.Tensor:
+    """models/utils.py:7-45: bilinear (border, align_corners) resample of the stride-8 CNN map (cell j at pixel 8j)
+    at the ViT token centres 7i+7."""
+    ch, cw = cnn.shape[-2:]
+    br_y, br_x = (ch - 1) * cnn_stride, (cw - 1) * cnn_stride
+    vx = torch.arange(vit_w, dtype=torch.float32) * vit_stride + patch / 2.0
+    vy = torch.arange(vit_h, dtype=torch.float32) * vit_stride + patch / 2.0
+    gx = -1.0 - 1.0 / br_x + 2.0 * vx / br_x
+    gy = -1.0 - 1.0 / br_y + 2.0 * vy / br_y
+    grid = torch.stack(torch.meshgrid(gx, gy, indexing="xy"), dim=-1)[None].expand(cnn.shape[0], -1, -1, -1)
+    return F.grid_sample(cnn, grid, mode="bilinear", padding_mode="border", align_corners=True)
+
+
+def refine_features(frames: torch.Tensor, dino: torch.Tensor, sd: Dict[str, torch.Tensor], batch: int = 8) -> torch.Tensor:
+    """Tracker.get_refined_embeddings (models/tracker.py:113-129): dino + align(DeltaDINO(frames))."""
+    out = torch.empty_like(dino)
+    for i in range(0, frames.shape[0], batch):
+        cnn = delta_dino_cnn(frames[i:i + batch], sd)
+        out[i:i + batch] = dino[i:i + batch] + align_to_vit_grid(cnn, dino.shape[-2], dino.shape[-1])
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------------
+# DINOv2 ViT encoder as driven by VitExtractor (models/extractor.py) -- parity unpinned (un-vendored upstream)
+# --------------------------------------------------------------------------------------------------------------
+VIT_CONFIGS = {  # models/extractor.py:183-222
+    "dinov2_vits14": dict(dim=384, depth=12, heads=6),
+    "dinov2_vitb14": dict(dim=768, depth=12, heads=12),
+    "dinov2_vitl14": dict(dim=1024, depth=24, heads=16),
+}
+
+
+def make_vit_weights(model_name: str, seed: int = 2, pos_grid: int = 37, patch: int = 14) -> Dict[str, torch.Tensor]:
+    """Seeded random weights with upstream's parameter names (no checkpoint exists in this environment)."""
+    cfg = VIT_CONFIGS[model_name]
+    d, depth = cfg["dim"], cfg["depth"]
+    g = torch.Generator().manual_seed(seed)
+
+    def tn(*shape, std=0.02):
+        return torch.randn(*shape, generator=g) * std
+
+    sd = {
+        "cls_token": tn(1, 1, d, std=1e-6 * 1e4),
+        "pos_embed": tn(1, 1 + pos_grid * pos_grid, d),
+        "patch_embed.proj.weight": tn(d, 3, patch, patch, std=0.05),
+        "patch_embed.proj.bias": tn(d),
+    }
+    for i in range(depth):
+        p = f"blocks.{i}."
+        sd[p + "norm1.weight"] = 1.0 + tn(d, std=0.1)
+        sd[p + "norm1.bias"] = tn(d, std=0.05)
+        sd[p + "attn.qkv.weight"] = tn(3 * d, d, std=0.04)
+        sd[p + "attn.qkv.bias"] = tn(3 * d)
+        sd[p + "attn.proj.weight"] = tn(d, d, std=0.04)
+        sd[p + "attn.proj.bias"] = tn(d)
+        sd[p + "ls1.gamma"] = 1.0 + tn(d, std=0.1)  # upstream hub models: init_values=1.0
+        sd[p + "norm2.weight"] = 1.0 + tn(d, std=0.1)
+        sd[p + "norm2.bias"] = tn(d, std=0.05)
+        sd[p + "mlp.fc1.weight"] = tn(4 * d, d, std=0.04)
+        sd[p + "mlp.fc1.bias"] = tn(4 * d)
+        sd[p + "mlp.fc2.weight"] = tn(d, 4 * d, std=0.03)
+        sd[p + "mlp.fc2.bias"] = tn(d)
+        sd[p + "ls2.gamma"] = 1.0 + tn(d, std=0.1)
+    return sd
+
+
+def vit_pos_embed(sd: Dict[str, torch.Tensor], h0: int, w0: int) -> torch.Tensor:
+    """models/extractor.py:57-85 (`_fix_pos_enc`).  NB the upstream caller passes (x, w:=H, h:=W) so the reference's
+    local `w0` is the token-ROW count and `h0` the token-COLUMN count; here h0/w0 are rows/cols directly.
+    bicubic, align_corners=False, scale_factor=((rows+.1)/n, (cols+.1)/n), recompute_scale_factor=False."""
+    pe = sd["pos_embed"]
+    n = int(math.sqrt(pe.shape[1] - 1))
+    d = pe.shape[-1]
+    grid = pe[:, 1:].reshape(1, n, n, d).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid, scale_factor=((h0 + 0.1) / n, (w0 + 0.1) / n), mode="bicubic", align_corners=False,
+                         recompute_scale_factor=False)
+    assert grid.shape[-2] == h0 and grid.shape[-1] == w0
+    grid = grid.permute(0, 2, 3, 1).reshape(1, -1, d)
+    return torch.cat([pe[:, :1], grid], dim=1)
+
+
+def vit_block(x: torch.Tensor, sd: Dict[str, torch.Tensor], i: int, heads: int) -> torch.Tensor:
+    """DINOv2 NestedTensorBlock at eval: x += g1*proj(MHSA(LN1 x)); x += g2*fc2(GELU(fc1(LN2 x))); LN eps 1e-6."""
+    p = f"blocks.{i}."
+    b, s, d = x.shape
+    y = F.layer_norm(x, (d,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps=1e-6)
+    qkv = F.linear(y, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]).reshape(b, s, 3, heads, d // heads)
+    q, k, v = qkv.permute(2, 0, 3, 1, 4)
+    a = F.scaled_dot_product_attention(q, k, v)
+    a = a.transpose(1, 2).reshape(b, s, d)
+    x = x + sd[p + "ls1.gamma"] * F.linear(a, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+    y = F.layer_norm(x, (d,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps=1e-6)
+    y = F.linear(F.gelu(F.linear(y, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])), sd[p + "mlp.fc2.weight"],
+                 sd[p + "mlp.fc2.bias"])
+    return x + sd[p + "ls2.gamma"] * y
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)  # utils.py:46
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def vit_tokens(frame: torch.Tensor, sd: Dict[str, torch.Tensor], model_name: str, layer: Optional[int] = None,
+               stride: int = 7, patch: int = 14, normalize: bool = True) -> torch.Tensor:
+    """get_dino_features_video for one frame, facet 'tokens' (utils.py:54-67, models/extractor.py:137-150):
+    frame [1,3,H,W] in [0,1] -> block-`layer` output without CLS, laid out [C, ph, pw]."""
+    cfg = VIT_CONFIGS[model_name]
+    layer = cfg["depth"] - 1 if layer is None else layer
+    x = frame
+    if normalize:
+        m = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
+        s = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+        x = (x - m) / s
+    ph, pw = feature_grid(frame.shape[-2], frame.shape[-1], patch, stride)
+    tok = F.conv2d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=stride)
+    tok = tok.flatten(2).transpose(1, 2)
+    tok = torch.cat([sd["cls_token"].expand(tok.shape[0], -1, -1), tok], dim=1) + vit_pos_embed(sd, ph, pw)
+    for i in range(layer + 1):
+        tok = vit_block(tok, sd, i, cfg["heads"])
+    return tok[0, 1:].reshape(ph, pw, -1).permute(2, 0, 1)

@@ -1,0 +1,62 @@
+"""CPU, build container only: oracle restatements vs the live UN-MODIFIED reference modules (skipped where
+/root/reference is absent, e.g. on the GPU box)."""
+import pytest
+import torch
+
+from oracle import ref_algo as A
+from oracle import ref_harness
+
+pytestmark = pytest.mark.skipif(not ref_harness.available(), reason="/root/reference not present")
+
+
+def test_delta_dino_and_align_match_reference():
+    from dino_tracker_amd import synth
+    R = ref_harness.load()
+    c = 24
+    sd = synth.synth_delta_dino_weights(c, seed=7)
+    net = R.delta_dino.DeltaDINO(channels=[3, 64, 128, 256, c], vit_stride=7).eval()
+    net.load_state_dict(sd)
+    frames = synth.synth_video(2, 98, 126, seed=5)
+    vit = torch.zeros(2, c, 13, 17)
+    with torch.no_grad():
+        ref = net(frames, vit)
+    cnn = A.delta_dino_cnn(frames, sd)
+    assert cnn.shape[-2:] == (13, 16)  # 98->49->25->13, 126->63->32->16
+    out = A.align_to_vit_grid(cnn, 13, 17)
+    assert (out - ref).abs().max() < 1e-6
+
+
+def test_tracker_forward_matches_reference():
+    import os
+    import tempfile
+    from dino_tracker_amd import synth
+    R = ref_harness.load()
+    H, W, T, C = 112, 154, 5, 16
+    ph, pw = A.feature_grid(H, W)
+    video = synth.synth_video(T, H, W, seed=21)
+    feats = synth.synth_features(T, C, ph, pw, seed=22)
+    head = synth.synth_head_weights(23)
+    tmp = tempfile.mkdtemp()
+    torch.save(feats, os.path.join(tmp, "e.pt"))
+    trk = R.tracker.Tracker(video=video, ckpt_path=tmp, dino_embed_path=os.path.join(tmp, "e.pt"), device="cpu")
+    trk.tracker_head.load_state_dict(head)
+    pts = torch.tensor([[30.0, 40.0, 1.0], [100.5, 77.25, 3.0], [2.0, 3.0, 0.0], [150.0, 110.0, 4.0]])
+    fs = torch.arange(T).int()
+    with torch.no_grad():
+        ref = trk((pts, pts[:, 2].long(), torch.tensor([4, 0, 2, 2]), fs), use_raw_features=True)
+    src = A.sample_bilinear(feats, pts[:, :2], pts[:, 2], H, W)
+    mine = A.track(src, feats, torch.tensor([4, 0, 2, 2]), head, H, W)
+    refpx = torch.stack([(ref[:, 0] + 1) / 2 * (W - 1), (ref[:, 1] + 1) / 2 * (H - 1)], 1)
+    assert (mine - refpx).abs().max() < 1e-3
+
+
+def test_vit_blocks_match_hf_port():
+    """DINOv2 block arithmetic vs the independent transformers port (random weights mapped across).  Runs in a
+    clean interpreter: the torchvision shim used for the reference must not be visible to transformers."""
+    import os
+    import subprocess
+    import sys
+    pytest.importorskip("transformers")
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hf_crosscheck.py")
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
