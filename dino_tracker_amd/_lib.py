@@ -1,0 +1,77 @@
+"""ctypes binding of libdtk.so (include/dtk.h).  No torch types cross the boundary: device pointers, sizes, a stream.
+
+The hot path has NO CPU fallback: `lib()` raises if the shared library has not been built, and every wrapper in
+ops.py raises if a tensor does not live on a GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdtk.so")
+
+c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+
+class Geom(ctypes.Structure):
+    """struct dtk_geom (include/dtk.h)."""
+    _fields_ = [("T", ctypes.c_int32), ("C", ctypes.c_int32), ("ph", ctypes.c_int32), ("pw", ctypes.c_int32),
+                ("video_h", ctypes.c_int32), ("video_w", ctypes.c_int32), ("patch", ctypes.c_int32),
+                ("stride", ctypes.c_int32), ("radius", ctypes.c_float)]
+
+    @property
+    def HW(self) -> int:
+        return self.ph * self.pw
+
+
+def make_geom(T: int, C: int, video_h: int, video_w: int, patch: int = 14, stride: int = 7, radius: float = 35.0) -> Geom:
+    ph = 1 + (video_h - patch) // stride
+    pw = 1 + (video_w - patch) // stride
+    return Geom(T, C, ph, pw, video_h, video_w, patch, stride, radius)
+
+
+# name -> (restype, argtypes); must list every symbol include/dtk.h declares (tests/test_abi.py checks this)
+SIGNATURES = {
+    "dtk_version": (c_int, []),
+    "dtk_last_error": (ctypes.c_char_p, []),
+    "dtk_pack_features": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dtk_unpack_features": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dtk_feature_norms": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dtk_sample_points": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "dtk_head_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dtk_head_forward": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "dtk_track_workspace_bytes": (c_size_t, [ctypes.POINTER(Geom), c_int, c_int]),
+    "dtk_track": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                          c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "dtk_feat_f16_bytes": (c_size_t, [ctypes.POINTER(Geom)]),
+    "dtk_make_feat_f16": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dtk_traj_cos_sims": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dtk_build_anchor_sources": (c_int, [c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dtk_occlusion": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_int,
+                              c_int, c_void_p]),
+}
+
+_LIB = None
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                "g.build()' or make -C dino_tracker_amd/csrc). There is no CPU fallback for the hot path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = handle
+    return _LIB
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError(f"libdtk error {rc}: {lib().dtk_last_error().decode()}")

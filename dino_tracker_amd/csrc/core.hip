@@ -1,0 +1,179 @@
+// core.hip -- error plumbing, layout conversion, norms, bilinear point sampling, trajectory cos-sims.
+#include <stdarg.h>
+#include <stdio.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void dtk_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int dtk_version(void) { return 1; }
+extern "C" const char* dtk_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------------------
+// [T][C][HW] <-> [T][HW][C] through a 32x33 LDS tile: both global sides coalesced.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                        int R, int Cn) {
+    // src: [batch][R][Cn] -> dst: [batch][Cn][R]
+    __shared__ float tile[32][33];
+    const size_t base = (size_t)blockIdx.z * R * Cn;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        int r = r0 + ty + j, c = c0 + tx;
+        if (r < R && c < Cn) tile[ty + j][tx] = src[base + (size_t)r * Cn + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        int c = c0 + ty + j, r = r0 + tx;
+        if (r < R && c < Cn) dst[base + (size_t)c * R + r] = tile[tx][ty + j];
+    }
+}
+
+// one wave per cell: |F[t][cell][:]|_2
+__global__ __launch_bounds__(256) void norms_kernel(const float* __restrict__ thwc, float* __restrict__ norms,
+                                                    long long cells, int C) {
+    const long long cell = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cell >= cells) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = thwc + cell * C;
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 v = *reinterpret_cast<const float4*>(p + c);
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s = wave_sum(s);
+    if (lane == 0) norms[cell] = sqrtf(s);
+}
+
+static int launch_transpose(const float* src, float* dst, int batch, int R, int Cn, hipStream_t st) {
+    dim3 grid(dtk_cdiv(Cn, 32), dtk_cdiv(R, 32), batch);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, st, src, dst, R, Cn);
+    DTK_LAUNCHED();
+    return DTK_OK;
+}
+
+extern "C" int dtk_feature_norms(const float* thwc, float* norms, int T, int C, int HW, void* stream) {
+    DTK_REQUIRE(thwc && norms && T > 0 && HW > 0 && C > 0 && C % 4 == 0, "dtk_feature_norms: bad args (C %% 4)");
+    long long cells = (long long)T * HW;
+    hipLaunchKernelGGL(norms_kernel, dim3(dtk_cdiv(cells, 4)), dim3(256), 0, dtk_stream(stream), thwc, norms, cells, C);
+    DTK_LAUNCHED();
+    return DTK_OK;
+}
+
+extern "C" int dtk_pack_features(const float* chw, float* thwc, float* norms, int T, int C, int HW, void* stream) {
+    DTK_REQUIRE(chw && thwc && T > 0 && HW > 0 && C > 0 && C % 4 == 0, "dtk_pack_features: bad args (C %% 4)");
+    int rc = launch_transpose(chw, thwc, T, C, HW, dtk_stream(stream));
+    if (rc) return rc;
+    if (norms) return dtk_feature_norms(thwc, norms, T, C, HW, stream);
+    return DTK_OK;
+}
+
+extern "C" int dtk_unpack_features(const float* thwc, float* chw, int T, int C, int HW, void* stream) {
+    DTK_REQUIRE(chw && thwc && T > 0 && HW > 0 && C > 0, "dtk_unpack_features: bad args");
+    return launch_transpose(thwc, chw, T, HW, C, dtk_stream(stream));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K8: one wave per point, lanes over channels (float4).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_kernel(dtk_geom g, const float* __restrict__ feat,
+                                                     const float* __restrict__ xy, const int32_t* __restrict__ t_idx,
+                                                     const int32_t* __restrict__ out_row, float* __restrict__ out,
+                                                     int B) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    const float half = 0.5f * (float)g.patch;
+    float u = (xy[2 * b] - half) / (float)g.stride;
+    float v = (xy[2 * b + 1] - half) / (float)g.stride;
+    u = fminf(fmaxf(u, 0.f), (float)(g.pw - 1));
+    v = fminf(fmaxf(v, 0.f), (float)(g.ph - 1));
+    const float u0f = floorf(u), v0f = floorf(v);
+    const float fu = u - u0f, fv = v - v0f;
+    const int u0 = (int)u0f, v0 = (int)v0f;
+    const int u1 = min(u0 + 1, g.pw - 1), v1 = min(v0 + 1, g.ph - 1);
+    int t = t_idx[b];
+    t = min(max(t, 0), g.T - 1);
+    const size_t fb = (size_t)t * g.ph * g.pw;
+    const float* p00 = feat + (fb + (size_t)v0 * g.pw + u0) * g.C;
+    const float* p01 = feat + (fb + (size_t)v0 * g.pw + u1) * g.C;
+    const float* p10 = feat + (fb + (size_t)v1 * g.pw + u0) * g.C;
+    const float* p11 = feat + (fb + (size_t)v1 * g.pw + u1) * g.C;
+    float* o = out + (size_t)(out_row ? out_row[b] : b) * g.C;
+    for (int c = lane * 4; c < g.C; c += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(p00 + c), bq = *reinterpret_cast<const float4*>(p01 + c);
+        const float4 cq = *reinterpret_cast<const float4*>(p10 + c), d = *reinterpret_cast<const float4*>(p11 + c);
+        float4 r;
+        r.x = (a.x * (1.f - fu) + bq.x * fu) * (1.f - fv) + (cq.x * (1.f - fu) + d.x * fu) * fv;
+        r.y = (a.y * (1.f - fu) + bq.y * fu) * (1.f - fv) + (cq.y * (1.f - fu) + d.y * fu) * fv;
+        r.z = (a.z * (1.f - fu) + bq.z * fu) * (1.f - fv) + (cq.z * (1.f - fu) + d.z * fu) * fv;
+        r.w = (a.w * (1.f - fu) + bq.w * fu) * (1.f - fv) + (cq.w * (1.f - fu) + d.w * fu) * fv;
+        *reinterpret_cast<float4*>(o + c) = r;
+    }
+}
+
+static int check_geom(const dtk_geom* g, const char* who) {
+    DTK_REQUIRE(g != nullptr, "%s: null geometry", who);
+    DTK_REQUIRE(g->T > 0 && g->C > 0 && g->ph > 0 && g->pw > 0 && g->patch > 0 && g->stride > 0, "%s: bad geometry", who);
+    DTK_REQUIRE(g->C % 4 == 0, "%s: C must be a multiple of 4", who);
+    DTK_REQUIRE(g->ph == 1 + (g->video_h - g->patch) / g->stride && g->pw == 1 + (g->video_w - g->patch) / g->stride,
+                "%s: token grid %dx%d inconsistent with video %dx%d patch %d stride %d", who, g->ph, g->pw, g->video_h,
+                g->video_w, g->patch, g->stride);
+    return DTK_OK;
+}
+
+extern "C" int dtk_sample_points(const dtk_geom* g, const float* feat, const float* xy, const int32_t* t_idx,
+                                 const int32_t* out_row, float* out, int B, void* stream) {
+    int rc = check_geom(g, "dtk_sample_points");
+    if (rc) return rc;
+    DTK_REQUIRE(feat && xy && t_idx && out && B >= 0, "dtk_sample_points: null pointer");
+    if (B == 0) return DTK_OK;
+    hipLaunchKernelGGL(sample_kernel, dim3(dtk_cdiv(B, 4)), dim3(256), 0, dtk_stream(stream), *g, feat, xy, t_idx,
+                       out_row, out, B);
+    DTK_LAUNCHED();
+    return DTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K14: cs[n][t] = <a,b> / (max(|a|,eps) max(|b|,eps)), a = S[n][tq[n]], b = S[n][t]; one wave per (n,t).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cos_sims_kernel(const float* __restrict__ S, const int32_t* __restrict__ tq,
+                                                       float* __restrict__ cs, int N, int T, int C) {
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (long long)N * T) return;
+    const int lane = threadIdx.x & 63;
+    const int n = (int)(w / T);
+    int q = tq[n];
+    q = min(max(q, 0), T - 1);
+    const float* a = S + ((size_t)n * T + q) * C;
+    const float* b = S + (size_t)w * C;
+    float ab = 0.f, aa = 0.f, bb = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 x = *reinterpret_cast<const float4*>(a + c), y = *reinterpret_cast<const float4*>(b + c);
+        ab += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        aa += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+        bb += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+    }
+    ab = wave_sum(ab);
+    aa = wave_sum(aa);
+    bb = wave_sum(bb);
+    if (lane == 0) cs[w] = ab / (fmaxf(sqrtf(aa), 1e-8f) * fmaxf(sqrtf(bb), 1e-8f));
+}
+
+extern "C" int dtk_traj_cos_sims(const float* S, const int32_t* tq, float* cs, int N, int T, int C, void* stream) {
+    DTK_REQUIRE(S && tq && cs && N >= 0 && T > 0 && C > 0 && C % 4 == 0, "dtk_traj_cos_sims: bad args");
+    if (N == 0) return DTK_OK;
+    hipLaunchKernelGGL(cos_sims_kernel, dim3(dtk_cdiv((long long)N * T, 4)), dim3(256), 0, dtk_stream(stream), S, tq,
+                       cs, N, T, C);
+    DTK_LAUNCHED();
+    return DTK_OK;
+}

@@ -1,0 +1,49 @@
+// track.hip -- dtk_track dispatcher (exact fp32 path / fused MFMA path).
+#include "common.h"
+
+size_t dtk_track_exact_workspace_bytes(const dtk_geom* g, int M);
+int dtk_track_exact(const dtk_geom* g, const float* feat, const float* norms, const float* head, const float* emb,
+                    const int32_t* src_row, const int32_t* tgt, const int32_t* out_idx, float* out_xy, int M,
+                    const int32_t* dM, int normalized, void* workspace, size_t workspace_bytes, void* stream);
+size_t dtk_track_mfma_workspace_bytes(const dtk_geom* g, int M);
+int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, const void* feat_f16, const float* head,
+                   const float* emb, const int32_t* src_row, const int32_t* tgt, const int32_t* out_idx, float* out_xy,
+                   int M, const int32_t* dM, int normalized, void* workspace, size_t workspace_bytes, void* stream);
+
+static int check_track_geom(const dtk_geom* g) {
+    DTK_REQUIRE(g != nullptr, "dtk_track: null geometry");
+    DTK_REQUIRE(g->T > 0 && g->C > 0 && g->ph > 0 && g->pw > 0 && g->patch > 0 && g->stride > 0 && g->radius >= 0.f,
+                "dtk_track: bad geometry");
+    DTK_REQUIRE(g->ph == 1 + (g->video_h - g->patch) / g->stride && g->pw == 1 + (g->video_w - g->patch) / g->stride,
+                "dtk_track: token grid %dx%d inconsistent with video %dx%d", g->ph, g->pw, g->video_h, g->video_w);
+    return DTK_OK;
+}
+
+extern "C" size_t dtk_track_workspace_bytes(const dtk_geom* g, int M, int method) {
+    if (!g || M <= 0) return 0;
+    // the MFMA path falls back to the exact path for inconclusive sources, so it needs both regions
+    const size_t ex = dtk_track_exact_workspace_bytes(g, M);
+    if (method == DTK_TRACK_MFMA) return ex + dtk_track_mfma_workspace_bytes(g, M);
+    return ex;
+}
+
+extern "C" int dtk_track(const dtk_geom* g, const float* feat, const float* norms, const void* feat_f16,
+                         const float* head, const float* emb, const int32_t* src_row, const int32_t* tgt,
+                         const int32_t* out_idx, float* out_xy, int M, const int32_t* dM, int normalized, int method,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_track_geom(g);
+    if (rc) return rc;
+    DTK_REQUIRE(feat && norms && head && emb && tgt && out_xy && workspace, "dtk_track: null pointer");
+    DTK_REQUIRE(M >= 0, "dtk_track: negative M");
+    if (M == 0) return DTK_OK;
+    if (method == DTK_TRACK_EXACT)
+        return dtk_track_exact(g, feat, norms, head, emb, src_row, tgt, out_idx, out_xy, M, dM, normalized, workspace,
+                               workspace_bytes, stream);
+    if (method == DTK_TRACK_MFMA) {
+        DTK_REQUIRE(feat_f16 != nullptr, "dtk_track(mfma): feat_f16 is null (call dtk_make_feat_f16)");
+        return dtk_track_mfma(g, feat, norms, feat_f16, head, emb, src_row, tgt, out_idx, out_xy, M, dM, normalized,
+                              workspace, workspace_bytes, stream);
+    }
+    dtk_set_error("dtk_track: unknown method %d", method);
+    return DTK_E_INVALID;
+}

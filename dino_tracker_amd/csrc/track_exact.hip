@@ -1,0 +1,408 @@
+// track_exact.hip -- DTK_TRACK_EXACT: the fp32 path of dtk_track.
+//
+//   corr_exact_kernel : rho[m][cell] = relu( <s_m, F[a_m][cell]> / max(|s_m| |F[a_m][cell]|, 1e-8) )
+//                       (models/tracker.py:158-173), fp32 FMA chains over C, 64x64 LDS-tiled, staged through
+//                       `workspace` in chunks that stay inside the 256 MiB Infinity Cache.
+//   head_exact_kernel : TrackerHead.forward (models/networks/tracker_head.py:107-121) on one map per workgroup:
+//                       first-max argmax, 3x3 conv(1->16) + ReLU + 3x3 conv(16->1) with zero padding, softmax over
+//                       all cells, radius-35 disk around the argmax, zero-sum fallback, weighted mean.
+//
+// This path is the arithmetic ground truth on the device (fp32 everywhere) and the fallback of the fused MFMA path
+// for the rare sources whose low-precision pass is inconclusive.
+#include <limits.h>
+#include "common.h"
+
+namespace {
+
+constexpr int TM = 64, TN = 64, TK = 16;
+constexpr int HR = 6;  // output rows per conv block in head_exact_kernel
+
+// ---- head parameter packing: W / sum(W) per (out,in) kernel, conv_norm.py:34-46 ---------------------------
+__global__ void head_prepare_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
+                                    const float* __restrict__ w2, const float* __restrict__ b2,
+                                    float* __restrict__ head) {
+    const int ch = threadIdx.x;  // 0..15
+    if (ch >= DTK_HEAD_HIDDEN) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int t = 0; t < 9; ++t) {
+        s1 += w1[ch * 9 + t];  // [16][1][3][3]
+        s2 += w2[ch * 9 + t];  // [1][16][3][3]
+    }
+    auto fix = [](float s) {
+        if (fabsf(s) < 1e-8f) s = (s > 0.f ? 1.f : (s < 0.f ? -1.f : 0.f)) * 1e-8f;
+        return s;
+    };
+    s1 = fix(s1);
+    s2 = fix(s2);
+    for (int t = 0; t < 9; ++t) {
+        head[ch * 9 + t] = w1[ch * 9 + t] / s1;
+        head[144 + 16 + ch * 9 + t] = w2[ch * 9 + t] / s2;
+    }
+    head[144 + ch] = b1[ch];
+    if (ch == 0) head[144 + 16 + 144] = b2[0];
+}
+
+// ---- |s_m| for the sources of one chunk; one wave per source ---------------------------------------------
+__global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict__ emb,
+                                                        const int32_t* __restrict__ src_row,
+                                                        float* __restrict__ snorm, int m0, int count, int M,
+                                                        const int32_t* __restrict__ dM, int C) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= count) return;
+    const int lane = threadIdx.x & 63;
+    const int m = m0 + i;
+    float s = 0.f;
+    if (m < dtk_active(M, dM)) {
+        const float* p = emb + (size_t)(src_row ? src_row[m] : m) * C;
+        for (int c = lane * 4; c < C; c += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(p + c);
+            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        s = wave_sum(s);
+    }
+    if (lane == 0) snorm[i] = sqrtf(s);
+}
+
+// ---- correlation: 64 sources x 64 cells per workgroup, 4x4 per thread ------------------------------------
+__global__ __launch_bounds__(256) void corr_exact_kernel(dtk_geom g, const float* __restrict__ feat,
+                                                         const float* __restrict__ norms,
+                                                         const float* __restrict__ emb,
+                                                         const int32_t* __restrict__ src_row,
+                                                         const int32_t* __restrict__ tgt,
+                                                         const float* __restrict__ snorm, float* __restrict__ maps,
+                                                         int m0, int count, int M, const int32_t* __restrict__ dM,
+                                                         int HWs) {
+    __shared__ __attribute__((aligned(16))) float As[TK][TM + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[TK][TN + 4];
+    __shared__ int s_tgt[TM];
+    __shared__ int s_row[TM];
+    __shared__ int s_fr[2];
+    const int HW = g.ph * g.pw;
+    const int active = min(dtk_active(M, dM), m0 + count);
+    const int tile_m0 = m0 + blockIdx.y * TM;
+    if (tile_m0 >= active) return;
+    const int cell0 = blockIdx.x * TN;
+    const int tid = threadIdx.x;
+    if (tid < TM) {
+        const int m = tile_m0 + tid;
+        const bool ok = m < active;
+        int f = ok ? tgt[m] : -1;
+        if (ok) f = min(max(f, 0), g.T - 1);
+        s_tgt[tid] = f;
+        s_row[tid] = ok ? (src_row ? src_row[m] : m) : (src_row ? src_row[tile_m0] : tile_m0);
+        int lo = ok ? f : INT_MAX, hi = f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o, WAVE));
+            hi = max(hi, __shfl_xor(hi, o, WAVE));
+        }
+        if (tid == 0) {
+            s_fr[0] = lo;
+            s_fr[1] = hi;
+        }
+    }
+    __syncthreads();
+    const int fmin = s_fr[0], fmax = s_fr[1];
+    const int ty = tid >> 4, tx = tid & 15;
+    const int lr = tid >> 2, lk = (tid & 3) * 4;  // loader: row / cell lr, k offset lk
+    const float* arow = emb + (size_t)s_row[lr] * g.C;
+    const int lcell = cell0 + lr;
+    for (int f = fmin; f <= fmax; ++f) {
+        bool mine = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mine |= (s_tgt[ty * 4 + i] == f);
+        if (!__syncthreads_or(mine)) continue;
+        const float* brow = feat + ((size_t)f * HW + min(lcell, HW - 1)) * g.C;
+        float acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+        for (int k0 = 0; k0 < g.C; k0 += TK) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if (k0 + lk < g.C) {
+                a = *reinterpret_cast<const float4*>(arow + k0 + lk);
+                if (lcell < HW) b = *reinterpret_cast<const float4*>(brow + k0 + lk);
+            }
+            As[lk + 0][lr] = a.x; As[lk + 1][lr] = a.y; As[lk + 2][lr] = a.z; As[lk + 3][lr] = a.w;
+            Bs[lk + 0][lr] = b.x; Bs[lk + 1][lr] = b.y; Bs[lk + 2][lr] = b.z; Bs[lk + 3][lr] = b.w;
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < TK; ++kk) {
+                const float4 av = *reinterpret_cast<const float4*>(&As[kk][ty * 4]);
+                const float4 bv = *reinterpret_cast<const float4*>(&Bs[kk][tx * 4]);
+                const float aa[4] = {av.x, av.y, av.z, av.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(aa[i], bb[j], acc[i][j]);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = ty * 4 + i;
+            if (s_tgt[r] != f) continue;
+            const int ml = tile_m0 - m0 + r;
+            const float sn = snorm[ml];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cell = cell0 + tx * 4 + j;
+                if (cell < HW) {
+                    const float den = fmaxf(sn * norms[(size_t)f * HW + cell], 1e-8f);
+                    maps[(size_t)ml * HWs + cell] = fmaxf(acc[i][j] / den, 0.f);
+                }
+            }
+        }
+    }
+}
+
+// ---- block reductions (256 threads = 4 waves); `red` is >= 8 floats of LDS ------------------------------
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+}  // namespace
+
+// Shared with the MFMA path: finish one source from its (exact fp32) refined logits inside the disk.
+// Runs on ONE wave.  zfun(row, col) returns z at a cell; zmax / Z are the softmax statistics of the whole map.
+// Returns through lane 0.  (tracker_head.py:68-98,112,121 + model_inference.py:52)
+template <typename ZF>
+__device__ __forceinline__ void dtk_disk_softargmax(const dtk_geom& g, int kstar, float zmax, float Z, ZF zfun,
+                                                    int normalized, float* out2) {
+    const int lane = threadIdx.x & 63;
+    const int rs = kstar / g.pw, cs = kstar % g.pw;
+    const float half = (float)(g.patch / 2);
+    const float px = (float)(cs * g.stride) + half, py = (float)(rs * g.stride) + half;
+    const int R = (int)(g.radius / (float)g.stride) + 1;
+    const int side = 2 * R + 1;
+    float sq = 0.f, sqx = 0.f, sqy = 0.f, cnt = 0.f, sx = 0.f, sy = 0.f;
+    for (int i = lane; i < side * side; i += WAVE) {
+        const int r = rs - R + i / side, c = cs - R + i % side;
+        if (r < 0 || r >= g.ph || c < 0 || c >= g.pw) continue;
+        const float x = (float)(c * g.stride) + half, y = (float)(r * g.stride) + half;
+        const float dx = x - px, dy = y - py;
+        if (sqrtf(dx * dx + dy * dy) <= g.radius) {
+            const float q = expf(zfun(r, c) - zmax) / Z;
+            sq += q; sqx += q * x; sqy += q * y;
+            cnt += 1.f; sx += x; sy += y;
+        }
+    }
+    sq = wave_sum(sq); sqx = wave_sum(sqx); sqy = wave_sum(sqy);
+    cnt = wave_sum(cnt); sx = wave_sum(sx); sy = wave_sum(sy);
+    if (lane == 0) {
+        if (sq < 1e-8f) {  // tracker_head.py:86-94: q <- (q + 1/|mask|) * mask
+            const float uni = 1.f / cnt;
+            sqx = sqx + uni * sx;
+            sqy = sqy + uni * sy;
+            sq = sq + uni * cnt;
+        }
+        const float xh = sqx / sq, yh = sqy / sq;
+        float vx = 2.f * (xh / (float)(g.video_w - 1)) - 1.f;  // RangeNormalizer.forward, dst=(-1,1)
+        float vy = 2.f * (yh / (float)(g.video_h - 1)) - 1.f;
+        if (!normalized) {  // RangeNormalizer.unnormalize, src=(-1,1)
+            vx = ((vx + 1.f) / 2.f) * (float)(g.video_w - 1);
+            vy = ((vy + 1.f) / 2.f) * (float)(g.video_h - 1);
+        }
+        out2[0] = vx;
+        out2[1] = vy;
+    }
+}
+
+namespace {
+
+__global__ __launch_bounds__(256) void head_exact_kernel(dtk_geom g, const float* __restrict__ head,
+                                                         const float* __restrict__ maps, int HWs,
+                                                         const int32_t* __restrict__ out_idx,
+                                                         float* __restrict__ out_xy, int m0, int count, int M,
+                                                         const int32_t* __restrict__ dM, int normalized) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HW = g.ph * g.pw, pw = g.pw, ph = g.ph;
+    const int HWp = (HW + 3) & ~3;
+    float* sx = smem;                 // relu'd cosine map
+    float* sz = sx + HWp;             // refined logits
+    float* sh = sz + HWp;             // hidden ring [16][HR+2][pw]
+    float* red = sh + DTK_HEAD_HIDDEN * (HR + 2) * pw;  // 16 floats
+    int* redi = reinterpret_cast<int*>(red + 8);
+    const int i = blockIdx.x;
+    const int m = m0 + i;
+    if (i >= count || m >= dtk_active(M, dM)) return;
+    const int tid = threadIdx.x;
+    const float* map = maps + (size_t)i * HWs;
+    for (int c = tid; c < HW; c += 256) sx[c] = map[c];
+    __syncthreads();
+
+    // first maximum (torch.argmax): larger value wins, ties -> lower flat index
+    float best = -1.f;
+    int bi = INT_MAX;
+    for (int c = tid; c < HW; c += 256) {
+        const float v = sx[c];
+        if (v > best) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, WAVE);
+        const int oi = __shfl_xor(bi, o, WAVE);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { red[tid >> 6] = best; redi[tid >> 6] = bi; }
+    __syncthreads();
+    best = red[0]; bi = redi[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (red[w] > best || (red[w] == best && redi[w] < bi)) { best = red[w]; bi = redi[w]; }
+    const int kstar = bi;
+    __syncthreads();
+
+    const float* w1 = head;              // [16][9]
+    const float* b1 = head + 144;        // [16]
+    const float* w2 = head + 160;        // [16][9]
+    const float b2 = head[304];
+    const int ring = HR + 2;
+    for (int r0 = 0; r0 < ph; r0 += HR) {
+        const int nout = min(HR, ph - r0);
+        // hidden rows r0-1 .. r0+nout (zero outside the map: conv2's zero padding)
+        for (int idx = tid; idx < (nout + 2) * pw; idx += 256) {
+            const int hr = idx / pw, c = idx - hr * pw;
+            const int row = r0 - 1 + hr;
+            if (row < 0 || row >= ph) {
+#pragma unroll
+                for (int ch = 0; ch < DTK_HEAD_HIDDEN; ++ch) sh[(ch * ring + hr) * pw + c] = 0.f;
+                continue;
+            }
+            float x9[9];
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int rr = row + dy, cc = c + dx;
+                    x9[(dy + 1) * 3 + dx + 1] = (rr >= 0 && rr < ph && cc >= 0 && cc < pw) ? sx[rr * pw + cc] : 0.f;
+                }
+#pragma unroll
+            for (int ch = 0; ch < DTK_HEAD_HIDDEN; ++ch) {
+                float a = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) a = fmaf(w1[ch * 9 + t], x9[t], a);
+                a += b1[ch];
+                sh[(ch * ring + hr) * pw + c] = fmaxf(a, 0.f);
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < nout * pw; idx += 256) {
+            const int ro = idx / pw, c = idx - ro * pw;
+            float a = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < DTK_HEAD_HIDDEN; ++ch) {
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int cc = c + dx;
+                        const float hv = (cc >= 0 && cc < pw) ? sh[(ch * ring + ro + 1 + dy) * pw + cc] : 0.f;
+                        a = fmaf(w2[ch * 9 + (dy + 1) * 3 + dx + 1], hv, a);
+                    }
+            }
+            sz[(r0 + ro) * pw + c] = a + b2;
+        }
+        __syncthreads();
+    }
+
+    float zm = -INFINITY;
+    for (int c = tid; c < HW; c += 256) zm = fmaxf(zm, sz[c]);
+    zm = block_max(zm, red);
+    float zs = 0.f;
+    for (int c = tid; c < HW; c += 256) zs += expf(sz[c] - zm);
+    zs = block_sum(zs, red);
+    if (tid < 64) {
+        auto zfun = [&](int r, int c) { return sz[r * pw + c]; };
+        dtk_disk_softargmax(g, kstar, zm, zs, zfun, normalized, out_xy + 2 * (size_t)(out_idx ? out_idx[m] : m));
+    }
+}
+
+}  // namespace
+
+extern "C" int dtk_head_prepare(const float* w1, const float* b1, const float* w2, const float* b2, float* head,
+                                void* stream) {
+    DTK_REQUIRE(w1 && b1 && w2 && b2 && head, "dtk_head_prepare: null pointer");
+    hipLaunchKernelGGL(head_prepare_kernel, dim3(1), dim3(64), 0, dtk_stream(stream), w1, b1, w2, b2, head);
+    DTK_LAUNCHED();
+    return DTK_OK;
+}
+
+extern "C" int dtk_head_forward(const dtk_geom* g, const float* head, const float* maps, float* out_xy, int B,
+                                int normalized, void* stream);
+
+// ---- host driver of the exact path -----------------------------------------------------------------------
+static inline int exact_hws(const dtk_geom* g) { return (g->ph * g->pw + 63) & ~63; }
+static inline size_t exact_head_lds(const dtk_geom* g) {
+    const int HWp = (g->ph * g->pw + 3) & ~3;
+    return sizeof(float) * (size_t)(2 * HWp + DTK_HEAD_HIDDEN * (HR + 2) * g->pw + 16);
+}
+constexpr int EXACT_CHUNK = 4096;  // 4096 maps x 32 KB = 133 MB: stays in the 256 MiB Infinity Cache
+
+size_t dtk_track_exact_workspace_bytes(const dtk_geom* g, int M) {
+    const int chunk = M < EXACT_CHUNK ? (M < 64 ? 64 : M) : EXACT_CHUNK;
+    return (size_t)chunk * (exact_hws(g) + 1) * sizeof(float);
+}
+
+int dtk_track_exact(const dtk_geom* g, const float* feat, const float* norms, const float* head, const float* emb,
+                    const int32_t* src_row, const int32_t* tgt, const int32_t* out_idx, float* out_xy, int M,
+                    const int32_t* dM, int normalized, void* workspace, size_t workspace_bytes, void* stream) {
+    DTK_REQUIRE(g->C % TK == 0, "dtk_track(exact): C=%d must be a multiple of %d", g->C, TK);
+    const int HWs = exact_hws(g);
+    const size_t lds = exact_head_lds(g);
+    DTK_REQUIRE(lds <= 160 * 1024, "dtk_track(exact): token grid %dx%d needs %zu B of LDS (> 160 KiB)", g->ph, g->pw, lds);
+    long long chunk = (long long)(workspace_bytes / ((size_t)(HWs + 1) * sizeof(float)));
+    if (chunk > M) chunk = M;
+    if (chunk > 65535LL * TM) chunk = 65535LL * TM;
+    if (chunk < 1) {
+        dtk_set_error("dtk_track(exact): workspace of %zu B holds no map (need %zu B per source)", workspace_bytes,
+                      (size_t)(HWs + 1) * sizeof(float));
+        return DTK_E_WORKSPACE;
+    }
+    hipStream_t st = dtk_stream(stream);
+    DTK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head_exact_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    float* maps = reinterpret_cast<float*>(workspace);
+    float* snorm = maps + (size_t)chunk * HWs;
+    const int HW = g->ph * g->pw;
+    for (long long m0 = 0; m0 < M; m0 += chunk) {
+        const int cnt = (int)((M - m0) < chunk ? (M - m0) : chunk);
+        hipLaunchKernelGGL(row_norms_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, emb, src_row, snorm, (int)m0,
+                           cnt, M, dM, g->C);
+        DTK_LAUNCHED();
+        hipLaunchKernelGGL(corr_exact_kernel, dim3(dtk_cdiv(HW, TN), dtk_cdiv(cnt, TM)), dim3(256), 0, st, *g, feat,
+                           norms, emb, src_row, tgt, snorm, maps, (int)m0, cnt, M, dM, HWs);
+        DTK_LAUNCHED();
+        hipLaunchKernelGGL(head_exact_kernel, dim3(cnt), dim3(256), lds, st, *g, head, maps, HWs, out_idx, out_xy,
+                           (int)m0, cnt, M, dM, normalized);
+        DTK_LAUNCHED();
+    }
+    return DTK_OK;
+}
+
+extern "C" int dtk_head_forward(const dtk_geom* g, const float* head, const float* maps, float* out_xy, int B,
+                                int normalized, void* stream) {
+    DTK_REQUIRE(g && head && maps && out_xy && B >= 0, "dtk_head_forward: null pointer");
+    DTK_REQUIRE(g->ph > 0 && g->pw > 0 && g->stride > 0 && g->patch > 0, "dtk_head_forward: bad geometry");
+    if (B == 0) return DTK_OK;
+    const size_t lds = exact_head_lds(g);
+    DTK_REQUIRE(lds <= 160 * 1024, "dtk_head_forward: token grid %dx%d needs %zu B of LDS (> 160 KiB)", g->ph, g->pw, lds);
+    DTK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head_exact_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(head_exact_kernel, dim3(B), dim3(256), lds, dtk_stream(stream), *g, head, maps, g->ph * g->pw,
+                       (const int32_t*)nullptr, out_xy, 0, B, B, (const int32_t*)nullptr, normalized);
+    DTK_LAUNCHED();
+    return DTK_OK;
+}

@@ -1,0 +1,150 @@
+"""Thin tensor-level wrappers over the C-ABI (include/dtk.h): pointer extraction, shape checks, stream hand-off.
+PyTorch is used for device memory and streams only; every function here requires GPU tensors."""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import Geom, check, lib
+
+TRACK_EXACT, TRACK_MFMA = 0, 1
+
+
+def _p(t: Optional[torch.Tensor], dtype: Optional[torch.dtype] = None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("dino_tracker_amd: tensor is not on a GPU -- the hot path has no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError("dino_tracker_amd: tensor must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"dino_tracker_amd: expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def pack_features(chw: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[T,C,h,w] fp32 -> token-major [T,h*w,C] + per-cell norms [T,h*w]."""
+    T, C, h, w = chw.shape
+    thwc = torch.empty((T, h * w, C), dtype=torch.float32, device=chw.device)
+    norms = torch.empty((T, h * w), dtype=torch.float32, device=chw.device)
+    check(lib().dtk_pack_features(_p(chw, torch.float32), _p(thwc), _p(norms), T, C, h * w, _stream()))
+    return thwc, norms
+
+
+def unpack_features(thwc: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    T, HW, C = thwc.shape
+    chw = torch.empty((T, C, h, w), dtype=torch.float32, device=thwc.device)
+    check(lib().dtk_unpack_features(_p(thwc, torch.float32), _p(chw), T, C, HW, _stream()))
+    return chw
+
+
+def feature_norms(thwc: torch.Tensor) -> torch.Tensor:
+    T, HW, C = thwc.shape
+    norms = torch.empty((T, HW), dtype=torch.float32, device=thwc.device)
+    check(lib().dtk_feature_norms(_p(thwc, torch.float32), _p(norms), T, C, HW, _stream()))
+    return norms
+
+
+def sample_points(g: Geom, feat: torch.Tensor, xy: torch.Tensor, t_idx: torch.Tensor,
+                  out: Optional[torch.Tensor] = None, out_row: Optional[torch.Tensor] = None) -> torch.Tensor:
+    B = xy.shape[0]
+    if out is None:
+        out = torch.empty((B, g.C), dtype=torch.float32, device=feat.device)
+    check(lib().dtk_sample_points(g, _p(feat, torch.float32), _p(xy, torch.float32), _p(t_idx, torch.int32),
+                                  _p(out_row, torch.int32), _p(out, torch.float32), B, _stream()))
+    return out
+
+
+def head_prepare(sd: Dict[str, torch.Tensor], device) -> torch.Tensor:
+    """TrackerHead.cnn_refiner state dict -> packed normalised parameters (dtk.h DTK_HEAD_PARAMS)."""
+    w1 = sd["cnn_refiner.0.weight"].detach().to(device=device, dtype=torch.float32).contiguous()
+    b1 = sd["cnn_refiner.0.bias"].detach().to(device=device, dtype=torch.float32).contiguous()
+    w2 = sd["cnn_refiner.2.weight"].detach().to(device=device, dtype=torch.float32).contiguous()
+    b2 = sd["cnn_refiner.2.bias"].detach().to(device=device, dtype=torch.float32).contiguous()
+    if tuple(w1.shape) != (16, 1, 3, 3) or tuple(w2.shape) != (1, 16, 3, 3):
+        raise RuntimeError("dino_tracker_amd: TrackerHead must be 1->16->1 with 3x3 kernels")
+    head = torch.empty(305, dtype=torch.float32, device=device)
+    check(lib().dtk_head_prepare(_p(w1), _p(b1), _p(w2), _p(b2), _p(head), _stream()))
+    return head
+
+
+def head_forward(g: Geom, head: torch.Tensor, maps: torch.Tensor, normalized: bool = True) -> torch.Tensor:
+    B = maps.shape[0]
+    out = torch.empty((B, 2), dtype=torch.float32, device=maps.device)
+    check(lib().dtk_head_forward(g, _p(head, torch.float32), _p(maps, torch.float32), _p(out), B, int(normalized),
+                                 _stream()))
+    return out
+
+
+def track_workspace_bytes(g: Geom, M: int, method: int) -> int:
+    return int(lib().dtk_track_workspace_bytes(g, M, method))
+
+
+def feat_f16_bytes(g: Geom) -> int:
+    return int(lib().dtk_feat_f16_bytes(g))
+
+
+def make_feat_f16(g: Geom, feat: torch.Tensor, norms: torch.Tensor) -> torch.Tensor:
+    buf = torch.empty(feat_f16_bytes(g), dtype=torch.uint8, device=feat.device)
+    check(lib().dtk_make_feat_f16(g, _p(feat, torch.float32), _p(norms, torch.float32), _p(buf), _stream()))
+    return buf
+
+
+def track(g: Geom, feat: torch.Tensor, norms: torch.Tensor, feat_f16: Optional[torch.Tensor], head: torch.Tensor,
+          emb: torch.Tensor, src_row: Optional[torch.Tensor], tgt: torch.Tensor, out_idx: Optional[torch.Tensor],
+          out_xy: torch.Tensor, M: int, workspace: torch.Tensor, dM: Optional[torch.Tensor] = None,
+          normalized: bool = False, method: int = TRACK_EXACT) -> torch.Tensor:
+    check(lib().dtk_track(g, _p(feat, torch.float32), _p(norms, torch.float32), _p(feat_f16), _p(head, torch.float32),
+                          _p(emb, torch.float32), _p(src_row, torch.int32), _p(tgt, torch.int32),
+                          _p(out_idx, torch.int32), _p(out_xy, torch.float32), M, _p(dM, torch.int32), int(normalized),
+                          method, _p(workspace), workspace.numel() * workspace.element_size(), _stream()))
+    return out_xy
+
+
+def traj_cos_sims(S: torch.Tensor, tq: torch.Tensor, N: int, T: int) -> torch.Tensor:
+    C = S.shape[-1]
+    cs = torch.empty((N, T), dtype=torch.float32, device=S.device)
+    check(lib().dtk_traj_cos_sims(_p(S, torch.float32), _p(tq, torch.int32), _p(cs), N, T, C, _stream()))
+    return cs
+
+
+class AnchorSources:
+    """Device-side result of dtk_build_anchor_sources (worst-case sized buffers, valid prefix given by counts)."""
+
+    def __init__(self, N: int, T: int, device):
+        i32 = dict(dtype=torch.int32, device=device)
+        self.N, self.T = N, T
+        self.n_anchors = torch.empty(N, **i32)
+        self.pair_off = torch.empty(N + 1, **i32)
+        self.pair_frame = torch.empty(N * T, **i32)
+        self.src_row = torch.empty(N * T * T, **i32)
+        self.tgt = torch.empty(N * T * T, **i32)
+        self.out_idx = torch.empty(N * T * T, **i32)
+        self.counts = torch.zeros(4, **i32)
+        self.scratch = torch.empty(2 * T + 2, **i32)
+
+
+def build_anchor_sources(cs: torch.Tensor, anchor_th: float, buf: Optional[AnchorSources] = None) -> AnchorSources:
+    N, T = cs.shape
+    if buf is None or buf.N != N or buf.T != T:
+        buf = AnchorSources(N, T, cs.device)
+    check(lib().dtk_build_anchor_sources(_p(cs, torch.float32), float(anchor_th), N, T, _p(buf.n_anchors),
+                                         _p(buf.pair_off), _p(buf.pair_frame), _p(buf.src_row), _p(buf.tgt),
+                                         _p(buf.out_idx), _p(buf.counts), _p(buf.scratch), _stream()))
+    return buf
+
+
+def occlusion(green: torch.Tensor, pair_off: torch.Tensor, pair_frame: torch.Tensor, traj: torch.Tensor,
+              cs: torch.Tensor, anchor_th: float, cos_th: float) -> torch.Tensor:
+    N, T = cs.shape
+    occ = torch.empty((N, T), dtype=torch.uint8, device=cs.device)
+    check(lib().dtk_occlusion(_p(green, torch.float32), _p(pair_off, torch.int32), _p(pair_frame, torch.int32),
+                              _p(traj, torch.float32), _p(cs, torch.float32), float(anchor_th), float(cos_th),
+                              _p(occ), N, T, _stream()))
+    return occ.bool()

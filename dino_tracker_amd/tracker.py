@@ -1,0 +1,226 @@
+"""Tracker -- the reference's models/tracker.py:17-325 API on top of the HIP device programs.
+
+Differences in mechanism (not in results):
+  * features live token-major on the device ([T][HW][C] fp32 + per-cell norms, computed once per video) instead of
+    being gathered per call (tracker.py:316-317) and re-normalised per call (tracker.py:162);
+  * one correlation map per (source, target frame) is computed instead of B x n maps of which B are kept
+    (tracker.py:159-160);
+  * DeltaDINO's width follows the embedding file (the reference hard-codes 1024, delta_dino.py:9).
+"""
+from __future__ import annotations
+
+import gc
+import os
+from pathlib import Path
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import make_geom
+from .dataset import RangeNormalizer
+from .networks import DeltaDINO, TrackerHead
+
+
+def load_pre_trained_model(pre_trained_sd, target_model):
+    """models/utils.py:71-76."""
+    target_model.load_state_dict(dict(pre_trained_sd))
+    return target_model
+
+
+class Tracker(nn.Module):
+    def __init__(self, video=None, ckpt_path="", dino_embed_path="", dino_patch_size=14, stride=7, device="cuda:0",
+                 cyc_n_frames=4, cyc_batch_size_per_frame=256, cyc_fg_points_ratio=0.7, cyc_thresh=4,
+                 track_method: Optional[int] = None):
+        super().__init__()
+        self.stride = stride
+        self.dino_patch_size = dino_patch_size
+        self.device = device
+        self.dino_embed_path = dino_embed_path
+        self.ckpt_path = ckpt_path
+        self.cyc_n_frames, self.cyc_batch_size_per_frame = cyc_n_frames, cyc_batch_size_per_frame
+        self.cyc_fg_points_ratio, self.cyc_thresh = cyc_fg_points_ratio, cyc_thresh
+        self.video = video
+        self.track_method = ops.TRACK_EXACT if track_method is None else track_method
+
+        self._dino = None          # token-major raw embeddings  [T][HW][C]
+        self._dino_norms = None
+        self._refined = None       # token-major refined features
+        self._refined_norms = None
+        self._refined_f16 = None
+        self._dino_f16 = None
+        self._refined_chw = None   # lazily unpacked view for callers reading `.refined_features`
+        self._workspace = None
+
+        self.load_dino_embed_video()
+        t, c, h, w = self.video.shape
+        emb_c = self.dino_embed_video.shape[1]
+        self.delta_dino = DeltaDINO(channels=[3, 64, 128, 256, emb_c], vit_stride=self.stride).to(device)
+        self.tracker_head = TrackerHead(use_cnn_refiner=True, patch_size=dino_patch_size, step_h=stride, step_w=stride,
+                                        video_h=h, video_w=w).to(device)
+        self.range_normalizer = RangeNormalizer(shapes=(w, h, t), device=device)
+        self.geom = make_geom(t, emb_c, h, w, dino_patch_size, stride, float(self.tracker_head.argmax_radius))
+        eh, ew = self.dino_embed_video.shape[-2:]
+        if (eh, ew) != (self.geom.ph, self.geom.pw) or self.dino_embed_video.shape[0] != t:
+            raise RuntimeError(f"dino embeddings {tuple(self.dino_embed_video.shape)} do not match video "
+                               f"{tuple(self.video.shape)} at patch {dino_patch_size} stride {stride}")
+
+    # ---- embeddings ------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def load_dino_embed_video(self):
+        """tracker.py:64-71: T x C x h x w tensor written by preprocessing/save_dino_embed_video.py."""
+        assert os.path.exists(self.dino_embed_path)
+        self.dino_embed_video = torch.load(self.dino_embed_path, map_location=self.device).to(torch.float32).contiguous()
+
+    def set_dino_embed_video(self, emb: torch.Tensor):
+        """In-memory hand-off from the extractor (no .pt round trip)."""
+        self.dino_embed_video = emb.to(self.device, torch.float32).contiguous()
+        self._dino = self._dino_norms = self._dino_f16 = None
+
+    def _packed_dino(self):
+        if self._dino is None:
+            self._dino, self._dino_norms = ops.pack_features(self.dino_embed_video)
+        return self._dino, self._dino_norms
+
+    def get_dino_embed_video(self, frames_set_t):
+        return self.dino_embed_video[frames_set_t.to(self.dino_embed_video.device).long()]
+
+    @property
+    def refined_features(self):
+        """T x C x h x w like the reference's attribute (None until cache_refined_embeddings())."""
+        if self._refined is None:
+            return None
+        if self._refined_chw is None:
+            self._refined_chw = ops.unpack_features(self._refined, self.geom.ph, self.geom.pw)
+        return self._refined_chw
+
+    @refined_features.setter
+    def refined_features(self, value):
+        if value is None:
+            self._refined = self._refined_norms = self._refined_f16 = self._refined_chw = None
+        else:  # accept a T x C x h x w tensor (e.g. features refined elsewhere)
+            self._refined, self._refined_norms = ops.pack_features(value.to(self.device, torch.float32).contiguous())
+            self._refined_f16 = None
+            self._refined_chw = None
+
+    def normalize_points_for_sampling(self, points):
+        """tracker.py:77-94 (kept for API parity; the kernels take pixel coordinates directly)."""
+        t, c, h, w = self.video.shape
+        half = self.dino_patch_size / 2
+        last_h = ((h - self.dino_patch_size) // self.stride) * self.stride + half
+        last_w = ((w - self.dino_patch_size) // self.stride) * self.stride + half
+        a = torch.tensor([[2 / (last_w - half), 2 / (last_h - half), 1]], device=points.device, dtype=points.dtype)
+        b = torch.tensor([[1 - last_w * 2 / (last_w - half), 1 - last_h * 2 / (last_h - half), 0]],
+                         device=points.device, dtype=points.dtype)
+        return a * points + b
+
+    def _unnormalize_sampling_points(self, pts_norm):
+        t, c, h, w = self.video.shape
+        half = self.dino_patch_size / 2
+        last_h = ((h - self.dino_patch_size) // self.stride) * self.stride + half
+        last_w = ((w - self.dino_patch_size) // self.stride) * self.stride + half
+        x = (pts_norm[:, 0] + 1) / 2 * (last_w - half) + half
+        y = (pts_norm[:, 1] + 1) / 2 * (last_h - half) + half
+        return torch.stack([x, y], dim=1)
+
+    def sample_embeddings(self, embeddings, source_points):
+        """tracker.py:96-111.  embeddings: T' x C x h x w, source_points: B x 3 (x,y in [-1,1] token-grid coords,
+        t = integral index into embeddings) -> B x C."""
+        if embeddings is self.refined_features and self._refined is not None:
+            feat = self._refined
+        else:
+            feat, _ = ops.pack_features(embeddings.to(torch.float32).contiguous())
+        g = make_geom(feat.shape[0], feat.shape[2], self.geom.video_h, self.geom.video_w, self.dino_patch_size,
+                      self.stride, self.geom.radius)
+        xy = self._unnormalize_sampling_points(source_points.to(torch.float32)).contiguous()
+        t_idx = source_points[:, 2].round().to(torch.int32).contiguous()
+        return ops.sample_points(g, feat, xy, t_idx)
+
+    # ---- Delta-DINO --------------------------------------------------------------------------------------
+    def get_refined_embeddings(self, frames_set_t, return_raw_embeddings=False):
+        """tracker.py:113-129 for an arbitrary frame subset (T' x C x h x w tensors, reference layout)."""
+        from .delta_dino import refine_frames
+        idx = frames_set_t.to(self.dino_embed_video.device).long()
+        dino = self.dino_embed_video[idx].contiguous()
+        refined = refine_frames(self.delta_dino, self.video[idx].contiguous(), dino, self.geom)
+        residual = refined - dino
+        if return_raw_embeddings:
+            return refined, residual, dino
+        return refined, residual
+
+    @torch.no_grad()
+    def cache_refined_embeddings(self, move_dino_to_cpu=False):
+        """tracker.py:131-135: refined = dino + DeltaDINO(video) for all frames, kept token-major on the device."""
+        from .delta_dino import refine_video_packed
+        dino, _ = self._packed_dino()
+        self._refined = refine_video_packed(self.delta_dino, self.video, dino, self.geom)
+        self._refined_norms = ops.feature_norms(self._refined)
+        self._refined_f16 = None
+        self._refined_chw = None
+        if move_dino_to_cpu:
+            self.dino_embed_video = self.dino_embed_video.to("cpu")
+
+    def uncache_refined_embeddings(self, move_dino_to_gpu=False):
+        self.refined_features = None
+        torch.cuda.empty_cache()
+        gc.collect()
+        if move_dino_to_gpu:
+            self.dino_embed_video = self.dino_embed_video.to(self.device)
+
+    # ---- checkpoints (tracker.py:144-156) ------------------------------------------------------------------
+    def save_weights(self, iter):
+        torch.save(self.tracker_head.state_dict(), Path(self.ckpt_path) / f"tracker_head_{iter}.pt")
+        torch.save(self.delta_dino.state_dict(), Path(self.ckpt_path) / f"delta_dino_{iter}.pt")
+
+    def load_weights(self, iter):
+        self.tracker_head = load_pre_trained_model(
+            torch.load(os.path.join(self.ckpt_path, f"tracker_head_{iter}.pt"), map_location=self.device), self.tracker_head)
+        self.delta_dino = load_pre_trained_model(
+            torch.load(os.path.join(self.ckpt_path, f"delta_dino_{iter}.pt"), map_location=self.device), self.delta_dino)
+
+    # ---- device state used by ModelInference -----------------------------------------------------------------
+    def features(self, use_raw_features=False):
+        """(feat [T][HW][C], norms [T][HW], fp16 copy or None) of the volume the tracker correlates against."""
+        if use_raw_features or self._refined is None:
+            if not use_raw_features and self._refined is None:
+                raise RuntimeError("refined features are not cached: call cache_refined_embeddings() first")
+            feat, norms = self._packed_dino()
+            if self.track_method == ops.TRACK_MFMA and self._dino_f16 is None:
+                self._dino_f16 = ops.make_feat_f16(self.geom, feat, norms)
+            return feat, norms, self._dino_f16
+        if self.track_method == ops.TRACK_MFMA and self._refined_f16 is None:
+            self._refined_f16 = ops.make_feat_f16(self.geom, self._refined, self._refined_norms)
+        return self._refined, self._refined_norms, self._refined_f16
+
+    def workspace(self, M: int) -> torch.Tensor:
+        need = ops.track_workspace_bytes(self.geom, M, self.track_method)
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._workspace
+
+    def track_sources(self, feats, emb, src_row, tgt, out_idx, out_xy, M, dM=None, normalized=False):
+        feat, norms, f16 = feats
+        head = self.tracker_head.packed_params(feat.device)
+        return ops.track(self.geom, feat, norms, f16, head, emb, src_row, tgt, out_idx, out_xy, M, self.workspace(M),
+                         dM=dM, normalized=normalized, method=self.track_method)
+
+    # ---- forward (tracker.py:303-325) ----------------------------------------------------------------------------
+    def forward(self, inp, use_raw_features=False):
+        """inp = (source_points B x 3 in pixels (x,y,t), source_frame_indices B, target_frame_indices B,
+        frames_set_t n): embeddings are sampled at source_points in frame frames_set_t[source_frame_indices] and
+        tracked into frame frames_set_t[target_frame_indices]; returns B x 2 in [-1,1]."""
+        source_points, source_frame_indices, target_frame_indices, frames_set_t = inp
+        if not use_raw_features and self._refined is None:
+            self.cache_refined_embeddings()
+        feats = self.features(use_raw_features)
+        fs = frames_set_t.to(self.device).long()
+        src_t = fs[source_frame_indices.to(self.device).long()].to(torch.int32).contiguous()
+        tgt_t = fs[target_frame_indices.to(self.device).long()].to(torch.int32).contiguous()
+        xy = source_points[:, :2].to(self.device, torch.float32).contiguous()
+        emb = ops.sample_points(self.geom, feats[0], xy, src_t)
+        B = xy.shape[0]
+        out = torch.empty((B, 2), dtype=torch.float32, device=self.device)
+        order = torch.argsort(tgt_t, stable=True).to(torch.int32)  # index plumbing: group sources by target frame
+        self.track_sources(feats, emb, order, tgt_t[order.long()].contiguous(), order, out, B, normalized=True)
+        return out

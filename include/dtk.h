@@ -1,0 +1,127 @@
+/*
+ * dtk.h -- C-ABI of libdtk.so: the MI355X (gfx950) device programs behind DINO-Tracker's per-video
+ * inference hot path.  Plain pointers and sizes only; every pointer is a DEVICE pointer unless said otherwise.
+ *
+ * The reference (/root/reference, pure PyTorch) has no FFI of its own: the boundary it exposes is the Python API
+ * of models/tracker.py, models/model_inference.py, models/extractor.py.  Each entry point
+ * below names the reference call site(s) it replaces (file:line in /root/reference); the Python classes in
+ * dino_tracker_amd/ keep the reference's names and signatures and call these through ctypes
+ * (INTEGRATION.md shows the binding a reference maintainer would add).
+ *
+ * Conventions
+ *   - return 0 on success, negative DTK_E_* on failure; dtk_last_error() gives a message (thread-local).
+ *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream); no host sync inside unless
+ *     stated; the caller owns every buffer, nothing is allocated or retained by the library.
+ *   - feature volume layout ("token-major"): F[t][cell][c], cell = row*pw + col, c contiguous, fp32.
+ *   - pixel coordinates are (x, y) at model resolution; cell (row, col) centre = (stride*col + patch/2,
+ *     stride*row + patch/2)  (models/networks/tracker_head.py:72-81).
+ */
+#ifndef DTK_H_
+#define DTK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DTK_OK 0
+#define DTK_E_INVALID (-1)   /* bad argument / unsupported size */
+#define DTK_E_HIP (-2)       /* a HIP runtime call or kernel launch failed */
+#define DTK_E_WORKSPACE (-3) /* workspace too small */
+
+/* geometry of one video at model resolution; ph/pw = 1 + (dim - patch) / stride (models/extractor.py:171-181) */
+typedef struct dtk_geom {
+    int32_t T;        /* frames */
+    int32_t C;        /* feature width (384 ViT-S, 768 ViT-B, 1024 ViT-L) */
+    int32_t ph, pw;   /* token grid */
+    int32_t video_h, video_w;
+    int32_t patch, stride;
+    float radius;     /* soft-argmax disk radius in px (tracker_head.py:47, 35) */
+} dtk_geom;
+
+/* TrackerHead.cnn_refiner parameters AFTER NormalizedConv2d's W / sum(W) (conv_norm.py:34-46), which
+ * dtk_head_prepare computes on device.  Layout: w1[16][9], b1[16], w2[16][9] (w2[ch][tap]), b2[1]; tap = 3*ky+kx. */
+#define DTK_HEAD_HIDDEN 16
+#define DTK_HEAD_PARAMS (16 * 9 + 16 + 16 * 9 + 1)
+
+int dtk_version(void);
+const char* dtk_last_error(void);
+
+/* ---- feature volume ------------------------------------------------------------------------------------ */
+/* Reference layout [T][C][ph][pw] (dino_embed_video.pt, models/tracker.py:65-71) -> token-major [T][HW][C]
+ * plus per-cell L2 norms [T][HW] (the `.norm(dim=1)` of models/tracker.py:162, hoisted to once per video). */
+int dtk_pack_features(const float* chw, float* thwc, float* norms, int T, int C, int HW, void* stream);
+/* inverse layout conversion (for callers that read `.refined_features` as T x C x h x w) */
+int dtk_unpack_features(const float* thwc, float* chw, int T, int C, int HW, void* stream);
+/* norms only (after refinement wrote thwc in place) */
+int dtk_feature_norms(const float* thwc, float* norms, int T, int C, int HW, void* stream);
+
+/* ---- K8: bilinear point sampling -------------------------------------------------------------------------
+ * Tracker.sample_embeddings (models/tracker.py:96-111 -> utils.py:75-101) for integral frame indices:
+ * out[b][:] = bilinear(F[t_idx[b]], (xy[b] - patch/2) / stride), border clamp, align_corners.
+ * out row b is written at out + out_row[b]*C if out_row != NULL else out + b*C. */
+int dtk_sample_points(const dtk_geom* g, const float* feat, const float* xy, const int32_t* t_idx,
+                      const int32_t* out_row, float* out, int B, void* stream);
+
+/* ---- TrackerHead parameters ---------------------------------------------------------------------------- */
+/* raw state-dict tensors (cnn_refiner.0.weight [16,1,3,3], .0.bias [16], .2.weight [1,16,3,3], .2.bias [1])
+ * -> normalised packed parameters head[DTK_HEAD_PARAMS] (conv_norm.py:34-46). */
+int dtk_head_prepare(const float* w1, const float* b1, const float* w2, const float* b2, float* head, void* stream);
+
+/* TrackerHead.forward alone (models/networks/tracker_head.py:107-121) on B ReLU'd cost volumes maps[B][ph*pw]:
+ * out[b] = normalised (x, y) in [-1,1] (normalized != 0) or pixels. */
+int dtk_head_forward(const dtk_geom* g, const float* head, const float* maps, float* out_xy, int B, int normalized,
+                     void* stream);
+
+/* ---- K9-K13: track sources into target frames ------------------------------------------------------------
+ * For each source m < M:  s = emb[src_row[m]] (row of an [R][C] fp32 matrix), a = tgt[m]:
+ *   rho = relu(cos(s, F[a](:, r, c)))                     models/tracker.py:158-173
+ *   (x, y) = TrackerHead(rho)                             models/networks/tracker_head.py:107-121
+ * and out_xy[out_idx[m]] = (x, y) in PIXELS (model_inference.py:52 already applied), or normalised to [-1,1]
+ * if normalized != 0 (the value Tracker.forward returns, tracker.py:303-325).
+ * src_row / out_idx may be NULL (identity).  Any order of tgt is correct; sources sorted by tgt run fastest.
+ * `method`: DTK_TRACK_EXACT = fp32 everywhere (correlation volume staged through `workspace`);
+ *           DTK_TRACK_MFMA  = fused fp16-MFMA sweep + fp32 window refinement (volume never leaves the CU).
+ * `dM` (device int32*, may be NULL): if given, the number of sources is min(M, *dM) read on device -- lets the
+ * anchor stage run without a host sync on the data-dependent anchor count. */
+#define DTK_TRACK_EXACT 0
+#define DTK_TRACK_MFMA 1
+size_t dtk_track_workspace_bytes(const dtk_geom* g, int M, int method);
+int dtk_track(const dtk_geom* g, const float* feat, const float* norms, const void* feat_f16,
+              const float* head, const float* emb, const int32_t* src_row, const int32_t* tgt,
+              const int32_t* out_idx, float* out_xy, int M, const int32_t* dM, int normalized, int method,
+              void* workspace, size_t workspace_bytes, void* stream);
+
+/* fp16 unit-norm copy of the feature volume consumed by DTK_TRACK_MFMA: f16[t][cell][c] = F/|F| (cells padded
+ * to a multiple of 16 per frame with zeros; C must be a multiple of 32). */
+size_t dtk_feat_f16_bytes(const dtk_geom* g);
+int dtk_make_feat_f16(const dtk_geom* g, const float* feat, const float* norms, void* feat_f16, void* stream);
+
+/* ---- K14: cosine similarity along trajectories -----------------------------------------------------------
+ * ModelInference.compute_trajectory_cos_sims (models/model_inference.py:110-126):
+ * cs[n][t] = cos(S[n][tq[n]], S[n][t]) with F.cosine_similarity semantics (eps 1e-8). S is [N][T][C]. */
+int dtk_traj_cos_sims(const float* S, const int32_t* tq, float* cs, int N, int T, int C, void* stream);
+
+/* ---- anchor bookkeeping (models/model_inference.py:156-165) ---------------------------------------------
+ * From cs [N][T] and the anchor threshold build, on device and without host sync:
+ *   n_anchors[N], pair_off[N+1] (pairs in n-major order, pair p of query n with its k-th anchor = pair_off[n]+k),
+ *   and the source lists of the anchor stage sorted by anchor frame:
+ *   src_row[m] = n*T + t, tgt[m] = a, out_idx[m] = p*T + t, for m < M_total = P*T (P = pair_off[N]).
+ * counts[0] = P, counts[1] = M_total, counts[2] = number of queries with zero anchors (counts has 4 entries).
+ * pair_frame must hold N*T entries, the three lists N*T*T entries (worst case), scratch 2*T+2 entries. */
+int dtk_build_anchor_sources(const float* cs, float anchor_th, int N, int T, int32_t* n_anchors, int32_t* pair_off,
+                             int32_t* pair_frame, int32_t* src_row, int32_t* tgt, int32_t* out_idx,
+                             int32_t* counts, int32_t* scratch, void* stream);
+
+/* ---- K15: occlusion (models/model_inference.py:169-200) ---------------------------------------------------
+ * green [P][T][2] (anchor trajectories, pair-major), pair_off [N+1], pair_frame [P] (anchor frame of pair p),
+ * traj [N][T][2], cs [N][T]  ->  occ [N][T] (uint8 0/1). */
+int dtk_occlusion(const float* green, const int32_t* pair_off, const int32_t* pair_frame, const float* traj,
+                  const float* cs, float anchor_th, float cos_th, uint8_t* occ, int N, int T, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DTK_H_ */
