@@ -57,7 +57,8 @@ def test_head_forward_golden(name):
     rnd[4] = 0.0
     ref = A.tracker_head(rnd[:, 0], head, cfg["H"], cfg["W"])
     got = th(rnd.cuda()).cpu()
-    assert (got - ref).abs().max() < 2e-6
+    # wild kernels (W/sum(W) with sum near 0) give |z| ~ 100: the fp32 oracle itself sits 4e-6 from an fp64 evaluation
+    assert (got - ref).abs().max() < (2e-6 if cfg["benign"] else 5e-5)
 
 
 @pytest.mark.parametrize("method", METHODS, ids=["exact", "mfma"])
