@@ -35,6 +35,11 @@ def make_geom(T: int, C: int, video_h: int, video_w: int, patch: int = 14, strid
 SIGNATURES = {
     "dtk_version": (c_int, []),
     "dtk_last_error": (ctypes.c_char_p, []),
+    "dtk_profile_enable": (c_int, [c_int]),
+    "dtk_profile_collect": (c_int, []),
+    "dtk_profile_name": (ctypes.c_char_p, [c_int]),
+    "dtk_profile_ms": (ctypes.c_double, [c_int]),
+    "dtk_profile_launches": (ctypes.c_longlong, [c_int]),
     "dtk_pack_features": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dtk_unpack_features": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dtk_feature_norms": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -171,19 +171,13 @@ extern "C" int dtk_build_anchor_sources(const float* cs, float anchor_th, int N,
     hipStream_t st = dtk_stream(stream);
     int32_t* frame_cnt = scratch;          // [T]
     int32_t* frame_off = scratch + T;      // [T+1]
-    hipLaunchKernelGGL(anchor_count_kernel, dim3(dtk_cdiv(N, 256)), dim3(256), 0, st, cs, anchor_th, N, T, n_anchors);
-    DTK_LAUNCHED();
-    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(256), 0, st, n_anchors, pair_off, N, counts + 2);
-    DTK_LAUNCHED();
-    hipLaunchKernelGGL(frame_count_kernel, dim3(T), dim3(256), 0, st, cs, anchor_th, N, T, frame_cnt);
-    DTK_LAUNCHED();
-    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(256), 0, st, frame_cnt, frame_off, T, (int32_t*)nullptr);
-    DTK_LAUNCHED();
-    hipLaunchKernelGGL(finalize_counts_kernel, dim3(1), dim3(64), 0, st, pair_off, N, T, counts);
-    DTK_LAUNCHED();
-    hipLaunchKernelGGL(emit_sources_kernel, dim3(T), dim3(256), 0, st, cs, anchor_th, N, T, pair_off, frame_off,
+    DTK_LAUNCH("anchor_count", anchor_count_kernel, dim3(dtk_cdiv(N, 256)), dim3(256), 0, st, cs, anchor_th, N, T, n_anchors);
+    DTK_LAUNCH("exclusive_scan", exclusive_scan_kernel, dim3(1), dim3(256), 0, st, n_anchors, pair_off, N, counts + 2);
+    DTK_LAUNCH("frame_count", frame_count_kernel, dim3(T), dim3(256), 0, st, cs, anchor_th, N, T, frame_cnt);
+    DTK_LAUNCH("exclusive_scan", exclusive_scan_kernel, dim3(1), dim3(256), 0, st, frame_cnt, frame_off, T, (int32_t*)nullptr);
+    DTK_LAUNCH("finalize_counts", finalize_counts_kernel, dim3(1), dim3(64), 0, st, pair_off, N, T, counts);
+    DTK_LAUNCH("emit_sources", emit_sources_kernel, dim3(T), dim3(256), 0, st, cs, anchor_th, N, T, pair_off, frame_off,
                        pair_frame, src_row, tgt, out_idx);
-    DTK_LAUNCHED();
     return DTK_OK;
 }
 
@@ -192,8 +186,7 @@ extern "C" int dtk_occlusion(const float* green, const int32_t* pair_off, const 
     DTK_REQUIRE(green && pair_off && pair_frame && traj && cs && occ && N >= 0 && T > 0, "dtk_occlusion: bad args");
     DTK_REQUIRE((size_t)T * sizeof(float) <= 60 * 1024, "dtk_occlusion: T=%d too large", T);
     if (N == 0) return DTK_OK;
-    hipLaunchKernelGGL(occlusion_kernel, dim3(N), dim3(256), (size_t)T * sizeof(float), dtk_stream(stream), green,
+    DTK_LAUNCH("occlusion", occlusion_kernel, dim3(N), dim3(256), (size_t)T * sizeof(float), dtk_stream(stream), green,
                        pair_off, pair_frame, traj, cs, anchor_th, cos_th, occ, N, T);
-    DTK_LAUNCHED();
     return DTK_OK;
 }

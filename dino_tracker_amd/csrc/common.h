@@ -25,6 +25,17 @@ void dtk_set_error(const char* fmt, ...);
 
 #define DTK_LAUNCHED() DTK_HIP(hipGetLastError())
 
+// optional per-kernel timing (dtk_profile_* in dtk.h): hipEvents on the launch stream, off by default
+void dtk_prof_begin(const char* name, hipStream_t st);
+void dtk_prof_end(const char* name, hipStream_t st);
+#define DTK_LAUNCH(NAME, kernel, grid, block, lds, st, ...)           \
+    do {                                                              \
+        dtk_prof_begin(NAME, st);                                     \
+        hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__); \
+        dtk_prof_end(NAME, st);                                       \
+        DTK_LAUNCHED();                                               \
+    } while (0)
+
 static inline hipStream_t dtk_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int dtk_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

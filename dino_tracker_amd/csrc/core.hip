@@ -13,6 +13,67 @@ void dtk_set_error(const char* fmt, ...) {
 }
 
 extern "C" int dtk_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------------------------
+// per-kernel timing with hipEvents on the launch stream (bench.py's `roofline` figures come from here).
+// Off by default: no events are recorded and launches are untouched.
+// ------------------------------------------------------------------------------------------------------------
+#include <string.h>
+#include <mutex>
+#include <string>
+#include <vector>
+namespace {
+struct ProfRec { const char* name; hipEvent_t a, b; };
+struct ProfAgg { std::string name; double ms; long long launches; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_open;
+std::vector<ProfAgg> g_prof_agg;
+}  // namespace
+
+void dtk_prof_begin(const char* name, hipStream_t st) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r{name, nullptr, nullptr};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, st);
+    g_prof_open.push_back(r);
+}
+void dtk_prof_end(const char* name, hipStream_t st) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_open.empty() && g_prof_open.back().name == name) (void)hipEventRecord(g_prof_open.back().b, st);
+}
+
+extern "C" int dtk_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof_open) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof_open.clear();
+    g_prof_agg.clear();
+    g_prof_on = on != 0;
+    return DTK_OK;
+}
+// waits for all recorded kernels, folds them into per-name totals; returns the number of distinct kernels
+extern "C" int dtk_profile_collect(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof_open) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            ProfAgg* slot = nullptr;
+            for (auto& a : g_prof_agg) if (a.name == r.name) slot = &a;
+            if (!slot) { g_prof_agg.push_back(ProfAgg{r.name, 0.0, 0}); slot = &g_prof_agg.back(); }
+            slot->ms += ms;
+            slot->launches += 1;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof_open.clear();
+    return (int)g_prof_agg.size();
+}
+extern "C" const char* dtk_profile_name(int i) { return (i >= 0 && i < (int)g_prof_agg.size()) ? g_prof_agg[i].name.c_str() : ""; }
+extern "C" double dtk_profile_ms(int i) { return (i >= 0 && i < (int)g_prof_agg.size()) ? g_prof_agg[i].ms : 0.0; }
+extern "C" long long dtk_profile_launches(int i) { return (i >= 0 && i < (int)g_prof_agg.size()) ? g_prof_agg[i].launches : 0; }
 extern "C" const char* dtk_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -56,16 +117,14 @@ __global__ __launch_bounds__(256) void norms_kernel(const float* __restrict__ th
 
 static int launch_transpose(const float* src, float* dst, int batch, int R, int Cn, hipStream_t st) {
     dim3 grid(dtk_cdiv(Cn, 32), dtk_cdiv(R, 32), batch);
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, st, src, dst, R, Cn);
-    DTK_LAUNCHED();
+    DTK_LAUNCH("transpose", transpose_kernel, grid, dim3(256), 0, st, src, dst, R, Cn);
     return DTK_OK;
 }
 
 extern "C" int dtk_feature_norms(const float* thwc, float* norms, int T, int C, int HW, void* stream) {
     DTK_REQUIRE(thwc && norms && T > 0 && HW > 0 && C > 0 && C % 4 == 0, "dtk_feature_norms: bad args (C %% 4)");
     long long cells = (long long)T * HW;
-    hipLaunchKernelGGL(norms_kernel, dim3(dtk_cdiv(cells, 4)), dim3(256), 0, dtk_stream(stream), thwc, norms, cells, C);
-    DTK_LAUNCHED();
+    DTK_LAUNCH("norms", norms_kernel, dim3(dtk_cdiv(cells, 4)), dim3(256), 0, dtk_stream(stream), thwc, norms, cells, C);
     return DTK_OK;
 }
 
@@ -137,9 +196,8 @@ extern "C" int dtk_sample_points(const dtk_geom* g, const float* feat, const flo
     if (rc) return rc;
     DTK_REQUIRE(feat && xy && t_idx && out && B >= 0, "dtk_sample_points: null pointer");
     if (B == 0) return DTK_OK;
-    hipLaunchKernelGGL(sample_kernel, dim3(dtk_cdiv(B, 4)), dim3(256), 0, dtk_stream(stream), *g, feat, xy, t_idx,
+    DTK_LAUNCH("sample", sample_kernel, dim3(dtk_cdiv(B, 4)), dim3(256), 0, dtk_stream(stream), *g, feat, xy, t_idx,
                        out_row, out, B);
-    DTK_LAUNCHED();
     return DTK_OK;
 }
 
@@ -172,8 +230,7 @@ __global__ __launch_bounds__(256) void cos_sims_kernel(const float* __restrict__
 extern "C" int dtk_traj_cos_sims(const float* S, const int32_t* tq, float* cs, int N, int T, int C, void* stream) {
     DTK_REQUIRE(S && tq && cs && N >= 0 && T > 0 && C > 0 && C % 4 == 0, "dtk_traj_cos_sims: bad args");
     if (N == 0) return DTK_OK;
-    hipLaunchKernelGGL(cos_sims_kernel, dim3(dtk_cdiv((long long)N * T, 4)), dim3(256), 0, dtk_stream(stream), S, tq,
+    DTK_LAUNCH("cos_sims", cos_sims_kernel, dim3(dtk_cdiv((long long)N * T, 4)), dim3(256), 0, dtk_stream(stream), S, tq,
                        cs, N, T, C);
-    DTK_LAUNCHED();
     return DTK_OK;
 }

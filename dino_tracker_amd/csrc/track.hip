@@ -21,10 +21,9 @@ static int check_track_geom(const dtk_geom* g) {
 
 extern "C" size_t dtk_track_workspace_bytes(const dtk_geom* g, int M, int method) {
     if (!g || M <= 0) return 0;
-    // the MFMA path falls back to the exact path for inconclusive sources, so it needs both regions
-    const size_t ex = dtk_track_exact_workspace_bytes(g, M);
-    if (method == DTK_TRACK_MFMA) return ex + dtk_track_mfma_workspace_bytes(g, M);
-    return ex;
+    // (the MFMA figure already contains a region for the exact path, which re-does inconclusive sources)
+    if (method == DTK_TRACK_MFMA) return dtk_track_mfma_workspace_bytes(g, M);
+    return dtk_track_exact_workspace_bytes(g, M);
 }
 
 extern "C" int dtk_track(const dtk_geom* g, const float* feat, const float* norms, const void* feat_f16,

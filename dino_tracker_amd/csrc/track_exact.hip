@@ -11,6 +11,7 @@
 // for the rare sources whose low-precision pass is inconclusive.
 #include <limits.h>
 #include "common.h"
+#include "head_common.h"
 
 namespace {
 
@@ -175,51 +176,6 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 }  // namespace
 
-// Shared with the MFMA path: finish one source from its (exact fp32) refined logits inside the disk.
-// Runs on ONE wave.  zfun(row, col) returns z at a cell; zmax / Z are the softmax statistics of the whole map.
-// Returns through lane 0.  (tracker_head.py:68-98,112,121 + model_inference.py:52)
-template <typename ZF>
-__device__ __forceinline__ void dtk_disk_softargmax(const dtk_geom& g, int kstar, float zmax, float Z, ZF zfun,
-                                                    int normalized, float* out2) {
-    const int lane = threadIdx.x & 63;
-    const int rs = kstar / g.pw, cs = kstar % g.pw;
-    const float half = (float)(g.patch / 2);
-    const float px = (float)(cs * g.stride) + half, py = (float)(rs * g.stride) + half;
-    const int R = (int)(g.radius / (float)g.stride) + 1;
-    const int side = 2 * R + 1;
-    float sq = 0.f, sqx = 0.f, sqy = 0.f, cnt = 0.f, sx = 0.f, sy = 0.f;
-    for (int i = lane; i < side * side; i += WAVE) {
-        const int r = rs - R + i / side, c = cs - R + i % side;
-        if (r < 0 || r >= g.ph || c < 0 || c >= g.pw) continue;
-        const float x = (float)(c * g.stride) + half, y = (float)(r * g.stride) + half;
-        const float dx = x - px, dy = y - py;
-        if (sqrtf(dx * dx + dy * dy) <= g.radius) {
-            const float q = expf(zfun(r, c) - zmax) / Z;
-            sq += q; sqx += q * x; sqy += q * y;
-            cnt += 1.f; sx += x; sy += y;
-        }
-    }
-    sq = wave_sum(sq); sqx = wave_sum(sqx); sqy = wave_sum(sqy);
-    cnt = wave_sum(cnt); sx = wave_sum(sx); sy = wave_sum(sy);
-    if (lane == 0) {
-        if (sq < 1e-8f) {  // tracker_head.py:86-94: q <- (q + 1/|mask|) * mask
-            const float uni = 1.f / cnt;
-            sqx = sqx + uni * sx;
-            sqy = sqy + uni * sy;
-            sq = sq + uni * cnt;
-        }
-        const float xh = sqx / sq, yh = sqy / sq;
-        float vx = 2.f * (xh / (float)(g.video_w - 1)) - 1.f;  // RangeNormalizer.forward, dst=(-1,1)
-        float vy = 2.f * (yh / (float)(g.video_h - 1)) - 1.f;
-        if (!normalized) {  // RangeNormalizer.unnormalize, src=(-1,1)
-            vx = ((vx + 1.f) / 2.f) * (float)(g.video_w - 1);
-            vy = ((vy + 1.f) / 2.f) * (float)(g.video_h - 1);
-        }
-        out2[0] = vx;
-        out2[1] = vy;
-    }
-}
-
 namespace {
 
 __global__ __launch_bounds__(256) void head_exact_kernel(dtk_geom g, const float* __restrict__ head,
@@ -335,8 +291,7 @@ __global__ __launch_bounds__(256) void head_exact_kernel(dtk_geom g, const float
 extern "C" int dtk_head_prepare(const float* w1, const float* b1, const float* w2, const float* b2, float* head,
                                 void* stream) {
     DTK_REQUIRE(w1 && b1 && w2 && b2 && head, "dtk_head_prepare: null pointer");
-    hipLaunchKernelGGL(head_prepare_kernel, dim3(1), dim3(64), 0, dtk_stream(stream), w1, b1, w2, b2, head);
-    DTK_LAUNCHED();
+    DTK_LAUNCH("head_prepare", head_prepare_kernel, dim3(1), dim3(64), 0, dtk_stream(stream), w1, b1, w2, b2, head);
     return DTK_OK;
 }
 
@@ -379,15 +334,12 @@ int dtk_track_exact(const dtk_geom* g, const float* feat, const float* norms, co
     const int HW = g->ph * g->pw;
     for (long long m0 = 0; m0 < M; m0 += chunk) {
         const int cnt = (int)((M - m0) < chunk ? (M - m0) : chunk);
-        hipLaunchKernelGGL(row_norms_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, emb, src_row, snorm, (int)m0,
+        DTK_LAUNCH("row_norms", row_norms_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, emb, src_row, snorm, (int)m0,
                            cnt, M, dM, g->C);
-        DTK_LAUNCHED();
-        hipLaunchKernelGGL(corr_exact_kernel, dim3(dtk_cdiv(HW, TN), dtk_cdiv(cnt, TM)), dim3(256), 0, st, *g, feat,
+        DTK_LAUNCH("corr_exact", corr_exact_kernel, dim3(dtk_cdiv(HW, TN), dtk_cdiv(cnt, TM)), dim3(256), 0, st, *g, feat,
                            norms, emb, src_row, tgt, snorm, maps, (int)m0, cnt, M, dM, HWs);
-        DTK_LAUNCHED();
-        hipLaunchKernelGGL(head_exact_kernel, dim3(cnt), dim3(256), lds, st, *g, head, maps, HWs, out_idx, out_xy,
+        DTK_LAUNCH("head_exact", head_exact_kernel, dim3(cnt), dim3(256), lds, st, *g, head, maps, HWs, out_idx, out_xy,
                            (int)m0, cnt, M, dM, normalized);
-        DTK_LAUNCHED();
     }
     return DTK_OK;
 }
@@ -401,8 +353,7 @@ extern "C" int dtk_head_forward(const dtk_geom* g, const float* head, const floa
     DTK_REQUIRE(lds <= 160 * 1024, "dtk_head_forward: token grid %dx%d needs %zu B of LDS (> 160 KiB)", g->ph, g->pw, lds);
     DTK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head_exact_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(head_exact_kernel, dim3(B), dim3(256), lds, dtk_stream(stream), *g, head, maps, g->ph * g->pw,
+    DTK_LAUNCH("head_exact", head_exact_kernel, dim3(B), dim3(256), lds, dtk_stream(stream), *g, head, maps, g->ph * g->pw,
                        (const int32_t*)nullptr, out_xy, 0, B, B, (const int32_t*)nullptr, normalized);
-    DTK_LAUNCHED();
     return DTK_OK;
 }

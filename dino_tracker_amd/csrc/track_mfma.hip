@@ -1,13 +1,673 @@
-// placeholder until the fused path lands
+// track_mfma.hip -- DTK_TRACK_MFMA: the fast path of dtk_track.
+//
+// Per chunk of sources (sorted by target frame):
+//   src16_kernel     s^ = 32 s/|s| -> fp16                                           (A operand)
+//   corr16_kernel    rho~ = relu(<s^, F^>/1024), fp16 MFMA 16x16x32 (fp32 accumulate), 64 sources x 128 cells per
+//                    workgroup, LDS double-buffered, -> fp16 maps in an Infinity-Cache resident staging chunk
+//   head16_kernel    one workgroup per map: approximate max + candidate cells within EPS_C of it, the 3x3/3x3 refiner
+//                    with v_dot2 (fp16 operands, fp32 accumulate) over the whole map for the softmax statistics
+//                    (zmax, Z) -- needed only for the zero-mass fallback test of tracker_head.py:86-94
+//   refine32_kernel  16 consecutive sources per workgroup: candidates re-scored in fp32 -> exact argmax k*;
+//                    fp32 correlation of the union of the 15x15 windows around the k* with the f32-input MFMA
+//                    (16x16x4, bit-exact fmaf chains); fp32 refiner on each window; disk soft-argmax.
+//                    Everything that decides the output (argmax, logits inside the disk) is fp32; the fp16 pass only
+//                    supplies candidates and (zmax, Z), which cancel out of the result unless the fallback fires.
+//   sources whose fp16 pass is inconclusive (more than KC candidates, fallback test within 8x of its threshold)
+//   are appended to a redo list and re-done by the exact path (track_exact.hip) -- device-side count, no host sync.
+#include <limits.h>
 #include "common.h"
-size_t dtk_track_mfma_workspace_bytes(const dtk_geom*, int) { return 0; }
-int dtk_track_mfma(const dtk_geom*, const float*, const float*, const void*, const float*, const float*, const int32_t*,
-                   const int32_t*, const int32_t*, float*, int, const int32_t*, int, void*, size_t, void*) {
-    dtk_set_error("dtk_track(mfma): not built");
-    return DTK_E_INVALID;
+#include "head_common.h"
+
+int dtk_track_exact(const dtk_geom* g, const float* feat, const float* norms, const float* head, const float* emb,
+                    const int32_t* src_row, const int32_t* tgt, const int32_t* out_idx, float* out_xy, int M,
+                    const int32_t* dM, int normalized, void* workspace, size_t workspace_bytes, void* stream);
+size_t dtk_track_exact_workspace_bytes(const dtk_geom* g, int M);
+
+namespace {
+
+typedef _Float16 half_t;
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr float FSCALE = 32.f;            // fp16 operands carry 32 x unit vectors (keeps small components normal)
+constexpr float INV_SCALE2 = 1.f / 1024.f;
+constexpr float EPS_C = 3e-3f;            // candidate window: 2 x (fp16 operand + fp16 storage error bound)
+constexpr int KC = 8;                     // candidates kept per source
+constexpr int CM = 64, CN = 128, CK = 32; // corr16 tile
+constexpr int RB = 8;                     // head16: output rows per block
+constexpr int NB_MAX = 1280;              // refine32: cells of a window-union held in LDS
+constexpr int RD = 5;                     // disk radius in cells supported by refine32 (radius / stride <= 5)
+constexpr int MFMA_CHUNK = 8192;
+
+struct Rec {  // per source, written by head16, read by refine32
+    float amax;
+    int ncand;
+    int cand[KC];
+    float zmax, Z;
+};
+
+__host__ __device__ inline int hw_pad(int HW) { return (HW + CN - 1) / CN * CN; }
+
+// ---- fp16 unit-norm copy of the feature volume ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void feat16_kernel(const float* __restrict__ feat, const float* __restrict__ norms,
+                                                     half_t* __restrict__ f16, int T, int HW, int HWp, int C) {
+    const long long cell = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over T*HWp
+    if (cell >= (long long)T * HWp) return;
+    const int lane = threadIdx.x & 63;
+    const int t = (int)(cell / HWp), c = (int)(cell % HWp);
+    half_t* o = f16 + cell * C;
+    if (c >= HW) {
+        for (int k = lane * 8; k < C; k += 512) *reinterpret_cast<uint4*>(o + k) = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    const float* p = feat + ((size_t)t * HW + c) * C;
+    const float nrm = norms[(size_t)t * HW + c];
+    const float sc = nrm > 1e-30f ? FSCALE / nrm : 0.f;
+    for (int k = lane * 8; k < C; k += 512) {
+        const float4 a = *reinterpret_cast<const float4*>(p + k), b = *reinterpret_cast<const float4*>(p + k + 4);
+        h8 v = {(half_t)(a.x * sc), (half_t)(a.y * sc), (half_t)(a.z * sc), (half_t)(a.w * sc),
+                (half_t)(b.x * sc), (half_t)(b.y * sc), (half_t)(b.z * sc), (half_t)(b.w * sc)};
+        *reinterpret_cast<h8*>(o + k) = v;
+    }
 }
-extern "C" size_t dtk_feat_f16_bytes(const dtk_geom*) { return 0; }
-extern "C" int dtk_make_feat_f16(const dtk_geom*, const float*, const float*, void*, void*) {
-    dtk_set_error("dtk_make_feat_f16: not built");
-    return DTK_E_INVALID;
+
+// ---- sources of a chunk -> fp16 unit vectors; one wave per source ---------------------------------------------------
+__global__ __launch_bounds__(256) void src16_kernel(const float* __restrict__ emb, const int32_t* __restrict__ src_row,
+                                                    half_t* __restrict__ s16, int m0, int count, int M,
+                                                    const int32_t* __restrict__ dM, int C) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= count) return;
+    const int lane = threadIdx.x & 63;
+    const int m = m0 + i;
+    half_t* o = s16 + (size_t)i * C;
+    if (m >= dtk_active(M, dM)) {
+        for (int k = lane * 8; k < C; k += 512) *reinterpret_cast<uint4*>(o + k) = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    const float* p = emb + (size_t)(src_row ? src_row[m] : m) * C;
+    float s = 0.f;
+    for (int k = lane * 4; k < C; k += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(p + k);
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s = sqrtf(wave_sum(s));
+    const float sc = s > 1e-30f ? FSCALE / s : 0.f;
+    for (int k = lane * 8; k < C; k += 512) {
+        const float4 a = *reinterpret_cast<const float4*>(p + k), b = *reinterpret_cast<const float4*>(p + k + 4);
+        h8 v = {(half_t)(a.x * sc), (half_t)(a.y * sc), (half_t)(a.z * sc), (half_t)(a.w * sc),
+                (half_t)(b.x * sc), (half_t)(b.y * sc), (half_t)(b.z * sc), (half_t)(b.w * sc)};
+        *reinterpret_cast<h8*>(o + k) = v;
+    }
+}
+
+// ---- corr16: fp16 MFMA GEMM, 64 sources x 128 cells per workgroup ---------------------------------------------------
+// LDS tiles are [row][32 k] fp16 = 4 x 16-byte pieces per row; piece g of row r lives at r*4 + (g ^ SWZ[(r>>2)&3]),
+// which makes the ds_read_b128 fragment reads (lane = 16*g + r%16) conflict-free.
+__device__ __forceinline__ int swz(int row, int piece) {
+    const int f = (0x1230 >> (((row >> 2) & 3) * 4)) & 3;  // {0,3,2,1}
+    return row * 4 + (piece ^ f);
+}
+
+__global__ __launch_bounds__(256) void corr16_kernel(dtk_geom g, const half_t* __restrict__ f16,
+                                                     const half_t* __restrict__ s16, const int32_t* __restrict__ tgt,
+                                                     half_t* __restrict__ maps, int m0, int count, int M,
+                                                     const int32_t* __restrict__ dM, int HWp) {
+    __shared__ uint4 As[2][CM * 4];
+    __shared__ uint4 Bs[2][CN * 4];
+    __shared__ int s_tgt[CM];
+    __shared__ int s_fr[2];
+    const int active = min(dtk_active(M, dM), m0 + count);
+    const int tile_m0 = m0 + blockIdx.y * CM;
+    if (tile_m0 >= active) return;
+    const int cell0 = blockIdx.x * CN;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < CM) {
+        const int m = tile_m0 + tid;
+        const bool ok = m < active;
+        int f = ok ? min(max(tgt[m], 0), g.T - 1) : -1;
+        s_tgt[tid] = f;
+        int lo = ok ? f : INT_MAX, hi = f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o, WAVE));
+            hi = max(hi, __shfl_xor(hi, o, WAVE));
+        }
+        if (tid == 0) { s_fr[0] = lo; s_fr[1] = hi; }
+    }
+    __syncthreads();
+    const int fmin = s_fr[0], fmax = s_fr[1];
+    const int wr = w >> 1, wc = w & 1;             // wave tile: rows wr*32.., cols wc*64..
+    const int fj = lane & 15, fg = lane >> 4;      // fragment row / k-piece
+    const int lrow = tid >> 2, lpiece = tid & 3;   // loader: row, 16-byte piece
+    const int nk = g.C / CK;
+    const half_t* arow = s16 + (size_t)(tile_m0 - m0 + lrow) * g.C + lpiece * 8;
+    for (int f = fmin; f <= fmax; ++f) {
+        bool mine = false;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mine |= (s_tgt[wr * 32 + fg * 4 + (i & 3) + (i >> 2) * 16] == f);
+        if (!__syncthreads_or(mine)) continue;
+        const half_t* b0 = f16 + ((size_t)f * HWp + cell0 + lrow) * g.C + lpiece * 8;
+        const half_t* b1 = b0 + (size_t)64 * g.C;
+        f4 acc[2][4];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f4{0.f, 0.f, 0.f, 0.f};
+        uint4 ra = *reinterpret_cast<const uint4*>(arow);
+        uint4 rb0 = *reinterpret_cast<const uint4*>(b0), rb1 = *reinterpret_cast<const uint4*>(b1);
+        As[0][swz(lrow, lpiece)] = ra;
+        Bs[0][swz(lrow, lpiece)] = rb0;
+        Bs[0][swz(lrow + 64, lpiece)] = rb1;
+        __syncthreads();
+        int cur = 0;
+        for (int ks = 0; ks < nk; ++ks) {
+            if (ks + 1 < nk) {
+                ra = *reinterpret_cast<const uint4*>(arow + (ks + 1) * CK);
+                rb0 = *reinterpret_cast<const uint4*>(b0 + (ks + 1) * CK);
+                rb1 = *reinterpret_cast<const uint4*>(b1 + (ks + 1) * CK);
+            }
+            h8 af[2], bf[4];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const uint4 v = As[cur][swz(wr * 32 + mi * 16 + fj, fg)];
+                af[mi] = *reinterpret_cast<const h8*>(&v);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const uint4 v = Bs[cur][swz(wc * 64 + ni * 16 + fj, fg)];
+                bf[ni] = *reinterpret_cast<const h8*>(&v);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+            if (ks + 1 < nk) {
+                As[cur ^ 1][swz(lrow, lpiece)] = ra;
+                Bs[cur ^ 1][swz(lrow, lpiece)] = rb0;
+                Bs[cur ^ 1][swz(lrow + 64, lpiece)] = rb1;
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+        // D: lane (fg, fj) holds rows 4*fg + r, column fj of each 16x16 tile
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr * 32 + mi * 16 + fg * 4 + r;
+                if (s_tgt[row] != f) continue;
+                half_t* orow = maps + (size_t)(tile_m0 - m0 + row) * HWp + cell0 + wc * 64 + fj;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) orow[ni * 16] = (half_t)fmaxf(acc[mi][ni][r] * INV_SCALE2, 0.f);
+            }
+    }
+}
+
+// ---- head16: approximate statistics of one map per workgroup ---------------------------------------------------------
+// wpk: packed fp16 weights built by head16_pack_kernel: [0..79] conv1 tap pairs per channel (16 x 5 h2),
+// [80..151] conv2 channel pairs per tap (9 x 8 h2); biases stay fp32 in `head`.
+__global__ void head16_pack_kernel(const float* __restrict__ head, uint32_t* __restrict__ wpk) {
+    const int i = threadIdx.x;
+    auto pack = [](float a, float b) {
+        h2 v = {(half_t)a, (half_t)b};
+        return *reinterpret_cast<uint32_t*>(&v);
+    };
+    if (i < 80) {
+        const int ch = i / 5, p = i % 5;
+        const float a = head[ch * 9 + 2 * p], b = (2 * p + 1 < 9) ? head[ch * 9 + 2 * p + 1] : 0.f;
+        wpk[i] = pack(a, b);
+    } else if (i < 152) {
+        const int tap = (i - 80) / 8, cp = (i - 80) % 8;
+        wpk[i] = pack(head[160 + (2 * cp) * 9 + tap], head[160 + (2 * cp + 1) * 9 + tap]);
+    }
+}
+
+__device__ __forceinline__ h2 as_h2(uint32_t u) { return *reinterpret_cast<h2*>(&u); }
+
+__global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __restrict__ head,
+                                                     const uint32_t* __restrict__ wpk,
+                                                     const half_t* __restrict__ maps, int HWp, Rec* __restrict__ rec,
+                                                     int m0, int count, int M, const int32_t* __restrict__ dM) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int ph = g.ph, pw = g.pw, HW = ph * pw;
+    const int xw = pw + 2;                                   // zero-bordered row pitch
+    const int xs_elems = ((ph + 2) * xw + 7) & ~7;
+    half_t* xs = reinterpret_cast<half_t*>(smem_raw);        // [(ph+2)][(pw+2)]
+    uint4* hb = reinterpret_cast<uint4*>(smem_raw + (size_t)xs_elems * 2);   // [(RB+2)][(pw+2)][2 x uint4]
+    float* red = reinterpret_cast<float*>(hb + (size_t)(RB + 2) * xw * 2);   // 8 floats
+    int* s_cnt = reinterpret_cast<int*>(red + 8);
+    int* s_cand = s_cnt + 1;                                 // KC ints
+    const int i = blockIdx.x;
+    const int m = m0 + i;
+    if (i >= count || m >= dtk_active(M, dM)) return;
+    const int tid = threadIdx.x;
+    const half_t* map = maps + (size_t)i * HWp;
+    for (int c = tid; c < xs_elems; c += 256) xs[c] = (half_t)0.f;
+    for (int c = tid; c < (RB + 2) * xw * 2; c += 256) hb[c] = make_uint4(0, 0, 0, 0);
+    if (tid == 0) *s_cnt = 0;
+    __syncthreads();
+    float amax = 0.f;
+    for (int c = tid; c < HW; c += 256) {
+        const half_t v = map[c];
+        xs[(c / pw + 1) * xw + c % pw + 1] = v;
+        amax = fmaxf(amax, (float)v);
+    }
+    amax = wave_max(amax);
+    if ((tid & 63) == 0) red[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float thr = amax - EPS_C;
+    for (int c = tid; c < HW; c += 256) {
+        const float v = (float)xs[(c / pw + 1) * xw + c % pw + 1];
+        if (v >= thr) {
+            const int slot = atomicAdd(s_cnt, 1);
+            if (slot < KC) s_cand[slot] = c;
+        }
+    }
+
+    const float b2 = head[304];
+    float rm = -INFINITY, rs = 0.f;  // running max / sum of exp for this thread's logits
+    for (int r0 = 0; r0 < ph; r0 += RB) {
+        const int nout = min(RB, ph - r0);
+        __syncthreads();
+        // hidden rows r0-1 .. r0+nout; rows outside the map are zero (conv2's zero padding)
+        for (int idx = tid; idx < (nout + 2) * pw; idx += 256) {
+            const int hr = idx / pw, c = idx - hr * pw;
+            const int row = r0 - 1 + hr;
+            uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
+            if (row >= 0 && row < ph) {
+                const half_t* xp = xs + (row + 1) * xw + (c + 1);
+                const h2 x01 = {xp[-xw - 1], xp[-xw]}, x23 = {xp[-xw + 1], xp[-1]}, x45 = {xp[0], xp[1]},
+                         x67 = {xp[xw - 1], xp[xw]}, x8 = {xp[xw + 1], (half_t)0.f};
+                uint32_t hh[8];
+#pragma unroll
+                for (int cp = 0; cp < 8; ++cp) {
+                    float a[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int ch = 2 * cp + e;
+                        float acc = head[144 + ch];
+                        acc = __builtin_amdgcn_fdot2(as_h2(wpk[ch * 5 + 0]), x01, acc, false);
+                        acc = __builtin_amdgcn_fdot2(as_h2(wpk[ch * 5 + 1]), x23, acc, false);
+                        acc = __builtin_amdgcn_fdot2(as_h2(wpk[ch * 5 + 2]), x45, acc, false);
+                        acc = __builtin_amdgcn_fdot2(as_h2(wpk[ch * 5 + 3]), x67, acc, false);
+                        acc = __builtin_amdgcn_fdot2(as_h2(wpk[ch * 5 + 4]), x8, acc, false);
+                        a[e] = fminf(fmaxf(acc, 0.f), 60000.f);
+                    }
+                    h2 v = {(half_t)a[0], (half_t)a[1]};
+                    hh[cp] = *reinterpret_cast<uint32_t*>(&v);
+                }
+                o0 = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+                o1 = make_uint4(hh[4], hh[5], hh[6], hh[7]);
+            }
+            hb[(hr * xw + c + 1) * 2] = o0;
+            hb[(hr * xw + c + 1) * 2 + 1] = o1;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < nout * pw; idx += 256) {
+            const int ro = idx / pw, c = idx - ro * pw;
+            float acc = b2;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int tap = (dy + 1) * 3 + dx + 1;
+                    const uint4 v0 = hb[((ro + 1 + dy) * xw + c + 1 + dx) * 2];
+                    const uint4 v1 = hb[((ro + 1 + dy) * xw + c + 1 + dx) * 2 + 1];
+                    acc = __builtin_amdgcn_fdot2(as_h2(wpk[80 + tap * 8 + 0]), as_h2(v0.x), acc, false);
+                    acc = __builtin_amdgcn_fdot2(as_h2(wpk[80 + tap * 8 + 1]), as_h2(v0.y), acc, false);
+                    acc = __builtin_amdgcn_fdot2(as_h2(wpk[80 + tap * 8 + 2]), as_h2(v0.z), acc, false);
+                    acc = __builtin_amdgcn_fdot2(as_h2(wpk[80 + tap * 8 + 3]), as_h2(v0.w), acc, false);
+                    acc = __builtin_amdgcn_fdot2(as_h2(wpk[80 + tap * 8 + 4]), as_h2(v1.x), acc, false);
+                    acc = __builtin_amdgcn_fdot2(as_h2(wpk[80 + tap * 8 + 5]), as_h2(v1.y), acc, false);
+                    acc = __builtin_amdgcn_fdot2(as_h2(wpk[80 + tap * 8 + 6]), as_h2(v1.z), acc, false);
+                    acc = __builtin_amdgcn_fdot2(as_h2(wpk[80 + tap * 8 + 7]), as_h2(v1.w), acc, false);
+                }
+            const float mn = fmaxf(rm, acc);
+            rs = rs * expf(rm - mn) + expf(acc - mn);
+            rm = mn;
+        }
+    }
+    // merge the per-thread (max, sum) pairs
+    float zm = wave_max(rm);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = zm;
+    __syncthreads();
+    zm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float zs = rs > 0.f ? rs * expf(rm - zm) : 0.f;
+    zs = wave_sum(zs);
+    __syncthreads();
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = zs;
+    __syncthreads();
+    if (tid == 0) {
+        Rec r;
+        r.amax = amax;
+        r.ncand = *s_cnt;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) r.cand[k] = (k < r.ncand) ? s_cand[k] : 0;
+        r.zmax = zm;
+        r.Z = (red[4] + red[5]) + (red[6] + red[7]);
+        rec[i] = r;
+    }
+}
+
+// ---- refine32: exact fp32 finish for 16 consecutive sources ---------------------------------------------------------
+constexpr int WX = 2 * RD + 5;  // x window side (15)
+constexpr int WH = 2 * RD + 3;  // hidden window side (13)
+constexpr int WZ = 2 * RD + 1;  // logit window side (11)
+
+struct Redo {
+    int32_t* count;
+    int32_t* src_row;
+    int32_t* tgt;
+    int32_t* out_idx;
+};
+
+__global__ __launch_bounds__(256) void refine32_kernel(dtk_geom g, const float* __restrict__ feat,
+                                                       const float* __restrict__ norms, const float* __restrict__ head,
+                                                       const float* __restrict__ emb, const int32_t* __restrict__ src_row,
+                                                       const int32_t* __restrict__ tgt, const int32_t* __restrict__ out_idx,
+                                                       float* __restrict__ out_xy, const Rec* __restrict__ rec, Redo redo,
+                                                       int m0, int count, int M, const int32_t* __restrict__ dM,
+                                                       int normalized) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* win = smem;                          // [16][NB_MAX]
+    float* hbuf = win + 16 * NB_MAX;            // [4][WH*WH][16]
+    float* zbuf = hbuf + 4 * WH * WH * 16;      // [4][WZ*WZ (pad 128)]
+    float* s_sn = zbuf + 4 * 128;               // [16] |s|
+    float* s_tmp = s_sn + 16;                   // [4][2] per-wave result staging
+    int* s_row = reinterpret_cast<int*>(s_tmp + 8);  // [16] emb row
+    int* s_f = s_row + 16;                      // [16] target frame (-1 = inactive / redo)
+    int* s_k = s_f + 16;                        // [16] exact argmax
+    int* s_m = s_k + 16;                        // [16] global source index
+    int* s_grp = s_m + 16;                      // [16] group id
+    int* s_box = s_grp + 16;                    // [16][4] rmin, rmax, cmin, cmax per group
+    int* s_ng = s_box + 64;                     // [1]
+    const int ph = g.ph, pw = g.pw, HW = ph * pw, C = g.C;
+    const int active = min(dtk_active(M, dM), m0 + count);
+    const int tile_m0 = m0 + blockIdx.x * 16;
+    if (tile_m0 >= active) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < 16) {
+        const int m = tile_m0 + tid;
+        const bool ok = m < active;
+        s_m[tid] = m;
+        s_row[tid] = ok ? (src_row ? src_row[m] : m) : (src_row ? src_row[tile_m0] : tile_m0);
+        s_f[tid] = ok ? min(max(tgt[m], 0), g.T - 1) : -1;
+        s_k[tid] = 0;
+    }
+    __syncthreads();
+
+    // |s| and exact re-scoring of the candidates: wave w owns sources 4w .. 4w+3
+    for (int q = 0; q < 4; ++q) {
+        const int s = w * 4 + q;
+        const int f = s_f[s];
+        if (f < 0) continue;  // wave-uniform
+        const float* sp = emb + (size_t)s_row[s] * C;
+        float ss = 0.f;
+        for (int k = lane * 4; k < C; k += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(sp + k);
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        const float sn = sqrtf(wave_sum(ss));
+        const Rec rc = rec[s_m[s] - m0];
+        bool redo_it = rc.ncand > KC || rc.ncand < 1;
+        float best = -1.f;
+        int bi = INT_MAX;
+        if (!redo_it) {
+            for (int k = 0; k < rc.ncand; ++k) {
+                const int cell = min(max(rc.cand[k], 0), HW - 1);
+                const float* fp = feat + ((size_t)f * HW + cell) * C;
+                float d = 0.f;
+                for (int c = lane * 4; c < C; c += 256) {
+                    const float4 a = *reinterpret_cast<const float4*>(sp + c), b = *reinterpret_cast<const float4*>(fp + c);
+                    d += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+                }
+                d = wave_sum(d);
+                const float v = fmaxf(d / fmaxf(sn * norms[(size_t)f * HW + cell], 1e-8f), 0.f);
+                if (v > best || (v == best && cell < bi)) { best = v; bi = cell; }
+            }
+            // a non-positive exact maximum means the relu'd map may be all-zero (argmax 0): let the exact path decide
+            if (!(best > 0.f)) redo_it = true;
+        }
+        if (lane == 0) {
+            s_sn[s] = sn;
+            if (redo_it) {
+                const int slot = atomicAdd(redo.count, 1);
+                redo.src_row[slot] = s_row[s];
+                redo.tgt[slot] = f;
+                redo.out_idx[slot] = out_idx ? out_idx[s_m[s]] : s_m[s];
+                s_f[s] = -1;
+            } else {
+                s_k[s] = bi;
+            }
+        }
+    }
+    __syncthreads();
+
+    // greedy grouping: consecutive sources with the same frame whose window union fits in LDS
+    if (tid == 0) {
+        int ng = 0, cf = -2, r0 = 0, r1 = 0, c0 = 0, c1 = 0;
+        for (int s = 0; s < 16; ++s) {
+            s_grp[s] = -1;
+            if (s_f[s] < 0) continue;
+            const int kr = s_k[s] / pw, kc = s_k[s] % pw;
+            const int a0 = max(kr - (RD + 2), 0), a1 = min(kr + (RD + 2), ph - 1);
+            const int b0 = max(kc - (RD + 2), 0), b1 = min(kc + (RD + 2), pw - 1);
+            bool fits = false;
+            if (ng > 0 && s_f[s] == cf) {
+                const int n0 = min(r0, a0), n1 = max(r1, a1), e0 = min(c0, b0), e1 = max(c1, b1);
+                if ((n1 - n0 + 1) * (e1 - e0 + 1) <= NB_MAX) { r0 = n0; r1 = n1; c0 = e0; c1 = e1; fits = true; }
+            }
+            if (!fits) { ++ng; cf = s_f[s]; r0 = a0; r1 = a1; c0 = b0; c1 = b1; }
+            s_grp[s] = ng - 1;
+            s_box[(ng - 1) * 4 + 0] = r0; s_box[(ng - 1) * 4 + 1] = r1;
+            s_box[(ng - 1) * 4 + 2] = c0; s_box[(ng - 1) * 4 + 3] = c1;
+        }
+        *s_ng = ng;
+    }
+    __syncthreads();
+    const int ng = *s_ng;
+    if (ng == 0) return;
+
+    // A fragments of the f32 MFMA: lane (fg, fj) holds emb[row(fj)][16*kb + 4*fg + i], i = 0..3, for every kb
+    const int fj = lane & 15, fg = lane >> 4;
+    const float* ap = emb + (size_t)s_row[fj] * C + 4 * fg;
+    const float* w1 = head;
+    const float* b1 = head + 144;
+    const float* w2 = head + 160;
+    const float b2 = head[304];
+
+    for (int gi = 0; gi < ng; ++gi) {
+        const int rmin = s_box[gi * 4], rmax = s_box[gi * 4 + 1], cmin = s_box[gi * 4 + 2], cmax = s_box[gi * 4 + 3];
+        const int nc = cmax - cmin + 1, ncells = (rmax - rmin + 1) * nc;
+        int gf = -1;
+        for (int s = 0; s < 16; ++s)
+            if (s_grp[s] == gi) gf = s_f[s];
+        // ---- fp32 correlation of all 16 sources with the cells of the union box (f32-input MFMA 16x16x4) ----
+        for (int nt = w; nt * 16 < ncells; nt += 4) {
+            const int ci = nt * 16 + fj;
+            const int cc = min(ci, ncells - 1);
+            const int cell = (rmin + cc / nc) * pw + cmin + cc % nc;
+            const float* bp = feat + ((size_t)gf * HW + cell) * C + 4 * fg;
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int kb = 0; kb < C / 16; ++kb) {
+                const float4 a = *reinterpret_cast<const float4*>(ap + kb * 16);
+                const float4 b = *reinterpret_cast<const float4*>(bp + kb * 16);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+            }
+            if (ci < ncells) {
+                const float fn = norms[(size_t)gf * HW + cell];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int s = fg * 4 + r;
+                    if (s_grp[s] == gi) win[s * NB_MAX + ci] = fmaxf(acc[r] / fmaxf(s_sn[s] * fn, 1e-8f), 0.f);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- per source: fp32 refiner on the window, disk soft-argmax; wave w owns sources 4w .. 4w+3 ----
+        for (int q = 0; q < 4; ++q) {
+            const int s = w * 4 + q;
+            if (s_grp[s] != gi) continue;  // wave-uniform
+            const int kr = s_k[s] / pw, kc = s_k[s] % pw;
+            const float* xw_ = win + s * NB_MAX;
+            auto xat = [&](int rr, int cc) -> float {
+                return (rr >= 0 && rr < ph && cc >= 0 && cc < pw) ? xw_[(rr - rmin) * nc + (cc - cmin)] : 0.f;
+            };
+            float* hb = hbuf + w * WH * WH * 16;
+            for (int i = lane; i < WH * WH; i += WAVE) {
+                const int hr = kr - (RD + 1) + i / WH, hc = kc - (RD + 1) + i % WH;
+                const bool in = hr >= 0 && hr < ph && hc >= 0 && hc < pw;
+                float x9[9];
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) x9[(dy + 1) * 3 + dx + 1] = in ? xat(hr + dy, hc + dx) : 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 16; ++ch) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) a = fmaf(w1[ch * 9 + t], x9[t], a);
+                    a += b1[ch];
+                    hb[i * 16 + ch] = in ? fmaxf(a, 0.f) : 0.f;
+                }
+            }
+            // (same wave wrote hb; LDS ops of one wave are ordered, but make the compiler keep them so)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float* zb = zbuf + w * 128;
+            for (int i = lane; i < WZ * WZ; i += WAVE) {
+                const int zr = i / WZ, zc = i % WZ;  // hidden-window coords of the centre: (zr+1, zc+1)
+                float a = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 16; ++ch)
+#pragma unroll
+                    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx)
+                            a = fmaf(w2[ch * 9 + (dy + 1) * 3 + dx + 1], hb[((zr + 1 + dy) * WH + zc + 1 + dx) * 16 + ch], a);
+                zb[i] = a + b2;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const Rec rc = rec[s_m[s] - m0];
+            auto zfun = [&](int r, int c) { return zb[(r - (kr - RD)) * WZ + (c - (kc - RD))]; };
+            float sq = 0.f;
+            dtk_disk_softargmax(g, s_k[s], rc.zmax, rc.Z, zfun, normalized, s_tmp + 2 * w, &sq);
+            if (lane == 0) {
+                // the fallback test sq < 1e-8 uses approximate (zmax, Z): redo when it is not clear-cut
+                const bool unclear = (sq > 1.25e-9f && sq < 8e-8f) || !(rc.Z > 0.f) || !(sq == sq);
+                if (unclear) {
+                    const int slot = atomicAdd(redo.count, 1);
+                    redo.src_row[slot] = s_row[s];
+                    redo.tgt[slot] = s_f[s];
+                    redo.out_idx[slot] = out_idx ? out_idx[s_m[s]] : s_m[s];
+                } else {
+                    float* o = out_xy + 2 * (size_t)(out_idx ? out_idx[s_m[s]] : s_m[s]);
+                    o[0] = s_tmp[2 * w];
+                    o[1] = s_tmp[2 * w + 1];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+struct MfmaLayout {
+    size_t s16, maps, rec, wpk, redo_cnt, redo_lists, exact, total;
+    int chunk, HWp;
+};
+
+MfmaLayout mfma_layout(const dtk_geom* g, int M) {
+    MfmaLayout L;
+    L.chunk = M < MFMA_CHUNK ? ((M + CM - 1) / CM * CM) : MFMA_CHUNK;
+    L.HWp = hw_pad(g->ph * g->pw);
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t off = 0;
+    L.s16 = off; off = al(off + (size_t)L.chunk * g->C * 2);
+    L.maps = off; off = al(off + (size_t)L.chunk * L.HWp * 2);
+    L.rec = off; off = al(off + (size_t)L.chunk * sizeof(Rec));
+    L.wpk = off; off = al(off + 152 * 4);
+    L.redo_cnt = off; off = al(off + 16);
+    L.redo_lists = off; off = al(off + (size_t)3 * L.chunk * 4);
+    L.exact = off;
+    L.total = off + dtk_track_exact_workspace_bytes(g, L.chunk);
+    return L;
+}
+
+}  // namespace
+
+size_t dtk_track_mfma_workspace_bytes(const dtk_geom* g, int M) { return mfma_layout(g, M).total; }
+
+extern "C" size_t dtk_feat_f16_bytes(const dtk_geom* g) {
+    if (!g || g->T <= 0 || g->C <= 0) return 0;
+    return (size_t)g->T * hw_pad(g->ph * g->pw) * g->C * 2;
+}
+
+extern "C" int dtk_make_feat_f16(const dtk_geom* g, const float* feat, const float* norms, void* feat_f16, void* stream) {
+    DTK_REQUIRE(g && feat && norms && feat_f16, "dtk_make_feat_f16: null pointer");
+    DTK_REQUIRE(g->C % CK == 0, "dtk_make_feat_f16: C=%d must be a multiple of %d for the MFMA path", g->C, CK);
+    const int HW = g->ph * g->pw, HWp = hw_pad(HW);
+    const long long cells = (long long)g->T * HWp;
+    DTK_LAUNCH("feat16", feat16_kernel, dim3(dtk_cdiv(cells, 4)), dim3(256), 0, dtk_stream(stream), feat, norms,
+               reinterpret_cast<half_t*>(feat_f16), g->T, HW, HWp, g->C);
+    return DTK_OK;
+}
+
+int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, const void* feat_f16, const float* head,
+                   const float* emb, const int32_t* src_row, const int32_t* tgt, const int32_t* out_idx, float* out_xy,
+                   int M, const int32_t* dM, int normalized, void* workspace, size_t workspace_bytes, void* stream) {
+    DTK_REQUIRE(g->C % CK == 0, "dtk_track(mfma): C=%d must be a multiple of %d", g->C, CK);
+    DTK_REQUIRE((int)(g->radius / (float)g->stride) <= RD, "dtk_track(mfma): disk radius %g px > %d cells", g->radius, RD);
+    const MfmaLayout L = mfma_layout(g, M);
+    if (workspace_bytes < L.total) {
+        dtk_set_error("dtk_track(mfma): workspace %zu B < required %zu B", workspace_bytes, L.total);
+        return DTK_E_WORKSPACE;
+    }
+    hipStream_t st = dtk_stream(stream);
+    unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
+    half_t* s16 = reinterpret_cast<half_t*>(ws + L.s16);
+    half_t* maps = reinterpret_cast<half_t*>(ws + L.maps);
+    Rec* rec = reinterpret_cast<Rec*>(ws + L.rec);
+    uint32_t* wpk = reinterpret_cast<uint32_t*>(ws + L.wpk);
+    Redo redo;
+    redo.count = reinterpret_cast<int32_t*>(ws + L.redo_cnt);
+    redo.src_row = reinterpret_cast<int32_t*>(ws + L.redo_lists);
+    redo.tgt = redo.src_row + L.chunk;
+    redo.out_idx = redo.tgt + L.chunk;
+    const int ph = g->ph, pw = g->pw;
+    const size_t lds_head = (size_t)((((ph + 2) * (pw + 2) + 7) & ~7)) * 2 + (size_t)(RB + 2) * (pw + 2) * 32 + 8 * 4 +
+                            (1 + KC) * 4 + 16;
+    const size_t lds_ref = sizeof(float) * (size_t)(16 * NB_MAX + 4 * WH * WH * 16 + 4 * 128 + 16 + 8) +
+                           sizeof(int) * (size_t)(16 * 5 + 64 + 4);
+    DTK_REQUIRE(lds_head <= 160 * 1024, "dtk_track(mfma): token grid %dx%d too large for head16 (%zu B LDS)", ph, pw, lds_head);
+    DTK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_head));
+    DTK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(refine32_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ref));
+    DTK_LAUNCH("head16_pack", head16_pack_kernel, dim3(1), dim3(256), 0, st, head, wpk);
+    const half_t* f16 = reinterpret_cast<const half_t*>(feat_f16);
+    for (long long m0 = 0; m0 < M; m0 += L.chunk) {
+        const int cnt = (int)((M - m0) < L.chunk ? (M - m0) : L.chunk);
+        DTK_LAUNCH("src16", src16_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, emb, src_row, s16, (int)m0, cnt, M,
+                   dM, g->C);
+        DTK_LAUNCH("corr16", corr16_kernel, dim3(L.HWp / CN, dtk_cdiv(cnt, CM)), dim3(256), 0, st, *g, f16, s16, tgt,
+                   maps, (int)m0, cnt, M, dM, L.HWp);
+        DTK_LAUNCH("head16", head16_kernel, dim3(cnt), dim3(256), lds_head, st, *g, head, wpk, maps, L.HWp, rec,
+                   (int)m0, cnt, M, dM);
+        DTK_HIP(hipMemsetAsync(redo.count, 0, sizeof(int32_t), st));
+        DTK_LAUNCH("refine32", refine32_kernel, dim3(dtk_cdiv(cnt, 16)), dim3(256), lds_ref, st, *g, feat, norms, head,
+                   emb, src_row, tgt, out_idx, out_xy, rec, redo, (int)m0, cnt, M, dM, normalized);
+        int rc = dtk_track_exact(g, feat, norms, head, emb, redo.src_row, redo.tgt, redo.out_idx, out_xy, cnt,
+                                 redo.count, normalized, ws + L.exact, workspace_bytes - L.exact, stream);
+        if (rc) return rc;
+    }
+    return DTK_OK;
 }

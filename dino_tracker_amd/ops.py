@@ -148,3 +148,13 @@ def occlusion(green: torch.Tensor, pair_off: torch.Tensor, pair_frame: torch.Ten
                               _p(traj, torch.float32), _p(cs, torch.float32), float(anchor_th), float(cos_th),
                               _p(occ), N, T, _stream()))
     return occ.bool()
+
+
+def profile_enable(on: bool) -> None:
+    check(lib().dtk_profile_enable(int(on)))
+
+
+def profile_collect() -> Dict[str, Tuple[float, int]]:
+    """{kernel name: (total ms, launches)} since profile_enable(True); synchronises."""
+    n = lib().dtk_profile_collect()
+    return {lib().dtk_profile_name(i).decode(): (lib().dtk_profile_ms(i), lib().dtk_profile_launches(i)) for i in range(n)}

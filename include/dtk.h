@@ -49,6 +49,15 @@ typedef struct dtk_geom {
 int dtk_version(void);
 const char* dtk_last_error(void);
 
+/* ---- per-kernel timing (used by bench.py for the roofline figures) -----------------------------------------
+ * dtk_profile_enable(1) makes every kernel launch of this library be bracketed by hipEvents on its stream;
+ * dtk_profile_collect() waits for them and aggregates per kernel name; *_name/_ms/_launches read entry i. */
+int dtk_profile_enable(int on);
+int dtk_profile_collect(void);
+const char* dtk_profile_name(int i);
+double dtk_profile_ms(int i);
+long long dtk_profile_launches(int i);
+
 /* ---- feature volume ------------------------------------------------------------------------------------ */
 /* Reference layout [T][C][ph][pw] (dino_embed_video.pt, models/tracker.py:65-71) -> token-major [T][HW][C]
  * plus per-cell L2 norms [T][HW] (the `.norm(dim=1)` of models/tracker.py:162, hoisted to once per video). */
