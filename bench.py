@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--width", type=int, default=384, help="feature width C (384 = ViT-S/14)")
     ap.add_argument("--method", default="auto", choices=["auto", "exact", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-queries", type=int, default=2, help="queries in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-queries", type=int, default=1, help="queries in the bounded CPU-baseline sample")
     return ap.parse_args()
 
 

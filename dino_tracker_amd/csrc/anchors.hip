@@ -114,6 +114,16 @@ __global__ __launch_bounds__(256) void emit_sources_kernel(const float* __restri
     }
 }
 
+// |G[p][t] - traj[a]|.  Deliberately NOT inlined: the rank-selection below compares values of this function
+// computed at different program points, which must be bit-identical (an inlined copy may contract a*a+b*b into an
+// fma in one place and not in the other, so that an element compares "less than itself").
+__device__ __noinline__ float anchor_dist(const float* __restrict__ green, const float* __restrict__ tr, int p, int a,
+                                          int T, int t) {
+    const float dx = green[((size_t)p * T + t) * 2] - tr[2 * a];
+    const float dy = green[((size_t)p * T + t) * 2 + 1] - tr[2 * a + 1];
+    return sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+}
+
 // one block per query
 __global__ __launch_bounds__(256) void occlusion_kernel(const float* __restrict__ green,
                                                         const int32_t* __restrict__ pair_off,
@@ -131,12 +141,7 @@ __global__ __launch_bounds__(256) void occlusion_kernel(const float* __restrict_
         return;
     }
     const int want = (A - 1) / 2;  // torch.median: lower median
-    auto dist = [&](int k, int t) {
-        const int a = pair_frame[p0 + k];
-        const float dx = green[((size_t)(p0 + k) * T + t) * 2] - tr[2 * a];
-        const float dy = green[((size_t)(p0 + k) * T + t) * 2 + 1] - tr[2 * a + 1];
-        return sqrtf(dx * dx + dy * dy);
-    };
+    auto dist = [&](int k, int t) { return anchor_dist(green, tr, p0 + k, pair_frame[p0 + k], T, t); };
     float tau = -INFINITY;
     for (int t = threadIdx.x; t < T; t += 256) {
         float m = 0.f;
@@ -144,6 +149,7 @@ __global__ __launch_bounds__(256) void occlusion_kernel(const float* __restrict_
             const float dk = dist(k, t);
             int rank = 0;
             for (int k2 = 0; k2 < A; ++k2) {
+                if (k2 == k) continue;
                 const float d2 = dist(k2, t);
                 rank += (d2 < dk || (d2 == dk && k2 < k)) ? 1 : 0;
             }

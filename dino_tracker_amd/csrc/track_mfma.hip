@@ -7,12 +7,13 @@
 //   head16_kernel    one workgroup per map: approximate max + candidate cells within EPS_C of it, the 3x3/3x3 refiner
 //                    with v_dot2 (fp16 operands, fp32 accumulate) over the whole map for the softmax statistics
 //                    (zmax, Z) -- needed only for the zero-mass fallback test of tracker_head.py:86-94
-//   refine32_kernel  16 consecutive sources per workgroup: candidates re-scored in fp32 -> exact argmax k*;
+//   refine_corr      16 consecutive sources per workgroup: candidates re-scored in fp32 -> exact argmax k*;
 //                    fp32 correlation of the union of the 15x15 windows around the k* with the f32-input MFMA
-//                    (16x16x4, bit-exact fmaf chains); fp32 refiner on each window; disk soft-argmax.
+//                    (16x16x4, bit-exact fmaf chains) -> per-source window buffers
+//   refine_head      one wave per source: fp32 refiner on the window; disk soft-argmax.
 //                    Everything that decides the output (argmax, logits inside the disk) is fp32; the fp16 pass only
 //                    supplies candidates and (zmax, Z), which cancel out of the result unless the fallback fires.
-//   sources whose fp16 pass is inconclusive (more than KC candidates, fallback test within 8x of its threshold)
+//   sources whose fp16 pass is inconclusive (more than KC candidates, fallback test within its error band)
 //   are appended to a redo list and re-done by the exact path (track_exact.hip) -- device-side count, no host sync.
 #include <limits.h>
 #include "common.h"
@@ -36,7 +37,7 @@ constexpr float EPS_C = 3e-3f;            // candidate window: 2 x (fp16 operand
 constexpr int KC = 8;                     // candidates kept per source
 constexpr int CM = 64, CN = 128, CK = 32; // corr16 tile
 constexpr int RB = 8;                     // head16: output rows per block
-constexpr int NB_MAX = 1280;              // refine32: cells of a window-union held in LDS
+constexpr int NB_MAX = 1536;              // refine: largest window-union box (cells) correlated as one group
 constexpr int RD = 5;                     // disk radius in cells supported by refine32 (radius / stride <= 5)
 constexpr int MFMA_CHUNK = 8192;
 
@@ -221,6 +222,17 @@ __global__ void head16_pack_kernel(const float* __restrict__ head, uint32_t* __r
     } else if (i < 152) {
         const int tap = (i - 80) / 8, cp = (i - 80) % 8;
         wpk[i] = pack(head[160 + (2 * cp) * 9 + tap], head[160 + (2 * cp + 1) * 9 + tap]);
+    } else if (i == 152) {
+        // bound on |z_fp16pass - z_exact| for any cell: the fp16 pass sees x within DX of the exact relu'd cosine and
+        // rounds weights, x and the hidden activations to fp16 (relative 2^-11 each); x <= 1.
+        const float DX = 2e-3f, U = 1.f / 1024.f;
+        float e = 0.f;
+        for (int ch = 0; ch < 16; ++ch) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int t = 0; t < 9; ++t) { s1 += fabsf(head[ch * 9 + t]); s2 += fabsf(head[160 + ch * 9 + t]); }
+            e += s2 * (s1 * DX + 2.f * U * (fabsf(head[144 + ch]) + s1));
+        }
+        reinterpret_cast<float*>(wpk)[152] = e;
     }
 }
 
@@ -267,6 +279,18 @@ __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __
         }
     }
 
+    // weights live in VGPRs: an opaque per-lane zero keeps the compiler from turning these into scalar loads that
+    // would have to be re-fetched (and waited for on the counter shared with LDS) in every pixel iteration
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    h2 wa[80], wb[72];
+    float bia[16];
+#pragma unroll
+    for (int k = 0; k < 80; ++k) wa[k] = as_h2(wpk[k + vz]);
+#pragma unroll
+    for (int k = 0; k < 72; ++k) wb[k] = as_h2(wpk[80 + k + vz]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bia[k] = head[144 + k + vz];
     const float b2 = head[304];
     float rm = -INFINITY, rs = 0.f;  // running max / sum of exp for this thread's logits
     for (int r0 = 0; r0 < ph; r0 += RB) {
@@ -288,12 +312,12 @@ __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const int ch = 2 * cp + e;
-                        float acc = head[144 + ch];
-                        acc = __builtin_amdgcn_fdot2(as_h2(wpk[ch * 5 + 0]), x01, acc, false);
-                        acc = __builtin_amdgcn_fdot2(as_h2(wpk[ch * 5 + 1]), x23, acc, false);
-                        acc = __builtin_amdgcn_fdot2(as_h2(wpk[ch * 5 + 2]), x45, acc, false);
-                        acc = __builtin_amdgcn_fdot2(as_h2(wpk[ch * 5 + 3]), x67, acc, false);
-                        acc = __builtin_amdgcn_fdot2(as_h2(wpk[ch * 5 + 4]), x8, acc, false);
+                        float acc = bia[ch];
+                        acc = __builtin_amdgcn_fdot2(wa[ch * 5 + 0], x01, acc, false);
+                        acc = __builtin_amdgcn_fdot2(wa[ch * 5 + 1], x23, acc, false);
+                        acc = __builtin_amdgcn_fdot2(wa[ch * 5 + 2], x45, acc, false);
+                        acc = __builtin_amdgcn_fdot2(wa[ch * 5 + 3], x67, acc, false);
+                        acc = __builtin_amdgcn_fdot2(wa[ch * 5 + 4], x8, acc, false);
                         a[e] = fminf(fmaxf(acc, 0.f), 60000.f);
                     }
                     h2 v = {(half_t)a[0], (half_t)a[1]};
@@ -308,7 +332,7 @@ __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __
         __syncthreads();
         for (int idx = tid; idx < nout * pw; idx += 256) {
             const int ro = idx / pw, c = idx - ro * pw;
-            float acc = b2;
+            float a0 = b2, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // four independent accumulation chains
 #pragma unroll
             for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
@@ -316,15 +340,16 @@ __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __
                     const int tap = (dy + 1) * 3 + dx + 1;
                     const uint4 v0 = hb[((ro + 1 + dy) * xw + c + 1 + dx) * 2];
                     const uint4 v1 = hb[((ro + 1 + dy) * xw + c + 1 + dx) * 2 + 1];
-                    acc = __builtin_amdgcn_fdot2(as_h2(wpk[80 + tap * 8 + 0]), as_h2(v0.x), acc, false);
-                    acc = __builtin_amdgcn_fdot2(as_h2(wpk[80 + tap * 8 + 1]), as_h2(v0.y), acc, false);
-                    acc = __builtin_amdgcn_fdot2(as_h2(wpk[80 + tap * 8 + 2]), as_h2(v0.z), acc, false);
-                    acc = __builtin_amdgcn_fdot2(as_h2(wpk[80 + tap * 8 + 3]), as_h2(v0.w), acc, false);
-                    acc = __builtin_amdgcn_fdot2(as_h2(wpk[80 + tap * 8 + 4]), as_h2(v1.x), acc, false);
-                    acc = __builtin_amdgcn_fdot2(as_h2(wpk[80 + tap * 8 + 5]), as_h2(v1.y), acc, false);
-                    acc = __builtin_amdgcn_fdot2(as_h2(wpk[80 + tap * 8 + 6]), as_h2(v1.z), acc, false);
-                    acc = __builtin_amdgcn_fdot2(as_h2(wpk[80 + tap * 8 + 7]), as_h2(v1.w), acc, false);
+                    a0 = __builtin_amdgcn_fdot2(wb[tap * 8 + 0], as_h2(v0.x), a0, false);
+                    a1 = __builtin_amdgcn_fdot2(wb[tap * 8 + 1], as_h2(v0.y), a1, false);
+                    a2 = __builtin_amdgcn_fdot2(wb[tap * 8 + 2], as_h2(v0.z), a2, false);
+                    a3 = __builtin_amdgcn_fdot2(wb[tap * 8 + 3], as_h2(v0.w), a3, false);
+                    a0 = __builtin_amdgcn_fdot2(wb[tap * 8 + 4], as_h2(v1.x), a0, false);
+                    a1 = __builtin_amdgcn_fdot2(wb[tap * 8 + 5], as_h2(v1.y), a1, false);
+                    a2 = __builtin_amdgcn_fdot2(wb[tap * 8 + 6], as_h2(v1.z), a2, false);
+                    a3 = __builtin_amdgcn_fdot2(wb[tap * 8 + 7], as_h2(v1.w), a3, false);
                 }
+            const float acc = (a0 + a1) + (a2 + a3);
             const float mn = fmaxf(rm, acc);
             rs = rs * expf(rm - mn) + expf(acc - mn);
             rm = mn;
@@ -353,10 +378,16 @@ __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __
     }
 }
 
-// ---- refine32: exact fp32 finish for 16 consecutive sources ---------------------------------------------------------
+// ---- refine: exact fp32 finish ------------------------------------------------------------------------------------
+// refine_corr_kernel (16 consecutive sources per workgroup): candidates re-scored in fp32 -> exact argmax k*;
+//   fp32 correlation of every source with the union box of the tile's (2*RD+5)^2 windows on the f32-input MFMA
+//   (16x16x4: bit-exact fmaf chains), scattered into per-source window buffers xwin[m][WX*WX] in global memory.
+//   No LDS tile: occupancy is register-limited and four N-tiles are in flight per wave.
+// refine_head_kernel (one wave per source): fp32 refiner on the window, disk soft-argmax, output or redo.
 constexpr int WX = 2 * RD + 5;  // x window side (15)
 constexpr int WH = 2 * RD + 3;  // hidden window side (13)
 constexpr int WZ = 2 * RD + 1;  // logit window side (11)
+constexpr int NTP = 4;          // N-tiles in flight per wave in refine_corr
 
 struct Redo {
     int32_t* count;
@@ -365,26 +396,17 @@ struct Redo {
     int32_t* out_idx;
 };
 
-__global__ __launch_bounds__(256) void refine32_kernel(dtk_geom g, const float* __restrict__ feat,
-                                                       const float* __restrict__ norms, const float* __restrict__ head,
-                                                       const float* __restrict__ emb, const int32_t* __restrict__ src_row,
-                                                       const int32_t* __restrict__ tgt, const int32_t* __restrict__ out_idx,
-                                                       float* __restrict__ out_xy, const Rec* __restrict__ rec, Redo redo,
-                                                       int m0, int count, int M, const int32_t* __restrict__ dM,
-                                                       int normalized) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* win = smem;                          // [16][NB_MAX]
-    float* hbuf = win + 16 * NB_MAX;            // [4][WH*WH][16]
-    float* zbuf = hbuf + 4 * WH * WH * 16;      // [4][WZ*WZ (pad 128)]
-    float* s_sn = zbuf + 4 * 128;               // [16] |s|
-    float* s_tmp = s_sn + 16;                   // [4][2] per-wave result staging
-    int* s_row = reinterpret_cast<int*>(s_tmp + 8);  // [16] emb row
-    int* s_f = s_row + 16;                      // [16] target frame (-1 = inactive / redo)
-    int* s_k = s_f + 16;                        // [16] exact argmax
-    int* s_m = s_k + 16;                        // [16] global source index
-    int* s_grp = s_m + 16;                      // [16] group id
-    int* s_box = s_grp + 16;                    // [16][4] rmin, rmax, cmin, cmax per group
-    int* s_ng = s_box + 64;                     // [1]
+__global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const float* __restrict__ feat,
+                                                          const float* __restrict__ norms,
+                                                          const float* __restrict__ emb,
+                                                          const int32_t* __restrict__ src_row,
+                                                          const int32_t* __restrict__ tgt,
+                                                          const int32_t* __restrict__ out_idx,
+                                                          const Rec* __restrict__ rec, int32_t* __restrict__ kstar,
+                                                          float* __restrict__ xwin, Redo redo, int m0, int count, int M,
+                                                          const int32_t* __restrict__ dM) {
+    __shared__ float s_sn[16];
+    __shared__ int s_row[16], s_f[16], s_k[16], s_m[16], s_grp[16], s_box[64], s_ng;
     const int ph = g.ph, pw = g.pw, HW = ph * pw, C = g.C;
     const int active = min(dtk_active(M, dM), m0 + count);
     const int tile_m0 = m0 + blockIdx.x * 16;
@@ -440,14 +462,16 @@ __global__ __launch_bounds__(256) void refine32_kernel(dtk_geom g, const float* 
                 redo.tgt[slot] = f;
                 redo.out_idx[slot] = out_idx ? out_idx[s_m[s]] : s_m[s];
                 s_f[s] = -1;
+                kstar[s_m[s] - m0] = -1;
             } else {
                 s_k[s] = bi;
+                kstar[s_m[s] - m0] = bi;
             }
         }
     }
     __syncthreads();
 
-    // greedy grouping: consecutive sources with the same frame whose window union fits in LDS
+    // greedy grouping: consecutive sources with the same frame whose window union stays small
     if (tid == 0) {
         int ng = 0, cf = -2, r0 = 0, r1 = 0, c0 = 0, c1 = 0;
         for (int s = 0; s < 16; ++s) {
@@ -466,122 +490,173 @@ __global__ __launch_bounds__(256) void refine32_kernel(dtk_geom g, const float* 
             s_box[(ng - 1) * 4 + 0] = r0; s_box[(ng - 1) * 4 + 1] = r1;
             s_box[(ng - 1) * 4 + 2] = c0; s_box[(ng - 1) * 4 + 3] = c1;
         }
-        *s_ng = ng;
+        s_ng = ng;
     }
     __syncthreads();
-    const int ng = *s_ng;
-    if (ng == 0) return;
+    const int ng = s_ng;
 
-    // A fragments of the f32 MFMA: lane (fg, fj) holds emb[row(fj)][16*kb + 4*fg + i], i = 0..3, for every kb
+    // A fragments of the f32 MFMA: lane (fg, fj) supplies emb[row(fj)][16*kb + 4*fg + i] as the i-th k-step of block kb
     const int fj = lane & 15, fg = lane >> 4;
     const float* ap = emb + (size_t)s_row[fj] * C + 4 * fg;
+    for (int gi = 0; gi < ng; ++gi) {
+        const int rmin = s_box[gi * 4], rmax = s_box[gi * 4 + 1], cmin = s_box[gi * 4 + 2], cmax = s_box[gi * 4 + 3];
+        const int nc = cmax - cmin + 1, ncells = (rmax - rmin + 1) * nc;
+        const int ntiles = (ncells + 15) / 16;
+        int gf = -1;
+        for (int s = 0; s < 16; ++s)
+            if (s_grp[s] == gi) gf = s_f[s];
+        // my four sources' window origins (rows 4*fg + r of the D fragment)
+        int wr0[4], wc0[4];
+        float sn4[4];
+        bool in_g[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = fg * 4 + r;
+            in_g[r] = s_grp[s] == gi;
+            wr0[r] = s_k[s] / pw - (RD + 2);
+            wc0[r] = s_k[s] % pw - (RD + 2);
+            sn4[r] = s_sn[s];
+        }
+        for (int nt0 = w * NTP; nt0 < ntiles; nt0 += 4 * NTP) {
+            const float* bp[NTP];
+            int cellv[NTP], civ[NTP];
+#pragma unroll
+            for (int u = 0; u < NTP; ++u) {
+                const int ci = (nt0 + u) * 16 + fj;
+                const int cc = min(ci, ncells - 1);
+                civ[u] = ci;
+                cellv[u] = (rmin + cc / nc) * pw + cmin + cc % nc;
+                bp[u] = feat + ((size_t)gf * HW + cellv[u]) * C + 4 * fg;
+            }
+            f4 acc[NTP];
+#pragma unroll
+            for (int u = 0; u < NTP; ++u) acc[u] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+            for (int kb = 0; kb < C / 16; ++kb) {
+                const float4 a = *reinterpret_cast<const float4*>(ap + kb * 16);
+                float4 b[NTP];
+#pragma unroll
+                for (int u = 0; u < NTP; ++u) b[u] = *reinterpret_cast<const float4*>(bp[u] + kb * 16);
+#pragma unroll
+                for (int u = 0; u < NTP; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[u].x, acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < NTP; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[u].y, acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < NTP; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[u].z, acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < NTP; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[u].w, acc[u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < NTP; ++u) {
+                if (civ[u] >= ncells) continue;
+                const int cr = cellv[u] / pw, ccol = cellv[u] % pw;
+                const float fn = norms[(size_t)gf * HW + cellv[u]];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int dr = cr - wr0[r], dc = ccol - wc0[r];
+                    if (in_g[r] && dr >= 0 && dr < WX && dc >= 0 && dc < WX)
+                        xwin[((size_t)(s_m[fg * 4 + r] - m0) * WX + dr) * WX + dc] =
+                            fmaxf(acc[u][r] / fmaxf(sn4[r] * fn, 1e-8f), 0.f);
+                }
+            }
+        }
+    }
+}
+
+// one wave per source
+__global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const float* __restrict__ head,
+                                                          const int32_t* __restrict__ src_row,
+                                                          const int32_t* __restrict__ tgt,
+                                                          const int32_t* __restrict__ out_idx,
+                                                          float* __restrict__ out_xy, const Rec* __restrict__ rec,
+                                                          const int32_t* __restrict__ kstar,
+                                                          const float* __restrict__ xwin,
+                                                          const float* __restrict__ zerr, Redo redo, int m0, int count,
+                                                          int M, const int32_t* __restrict__ dM, int normalized) {
+    __shared__ float s_x[4][WX * WX + 3];
+    __shared__ float s_h[4][WH * WH * 16];
+    __shared__ float s_z[4][WZ * WZ + 7];
+    __shared__ float s_out[4][2];
+    const int ph = g.ph, pw = g.pw;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + w;
+    const int m = m0 + i;
+    if (i >= count || m >= dtk_active(M, dM)) return;  // wave-uniform; no block-level barrier below
+    const int k = kstar[i];
+    if (k < 0) return;  // already queued for the exact path
+    const int kr = k / pw, kc = k % pw;
+    const float* xg = xwin + (size_t)i * WX * WX;
+    float* sx = s_x[w];
+    for (int j = lane; j < WX * WX; j += WAVE) {
+        const int rr = kr - (RD + 2) + j / WX, cc = kc - (RD + 2) + j % WX;
+        sx[j] = (rr >= 0 && rr < ph && cc >= 0 && cc < pw) ? xg[j] : 0.f;  // zero padding of conv1
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     const float* w1 = head;
     const float* b1 = head + 144;
     const float* w2 = head + 160;
     const float b2 = head[304];
-
-    for (int gi = 0; gi < ng; ++gi) {
-        const int rmin = s_box[gi * 4], rmax = s_box[gi * 4 + 1], cmin = s_box[gi * 4 + 2], cmax = s_box[gi * 4 + 3];
-        const int nc = cmax - cmin + 1, ncells = (rmax - rmin + 1) * nc;
-        int gf = -1;
-        for (int s = 0; s < 16; ++s)
-            if (s_grp[s] == gi) gf = s_f[s];
-        // ---- fp32 correlation of all 16 sources with the cells of the union box (f32-input MFMA 16x16x4) ----
-        for (int nt = w; nt * 16 < ncells; nt += 4) {
-            const int ci = nt * 16 + fj;
-            const int cc = min(ci, ncells - 1);
-            const int cell = (rmin + cc / nc) * pw + cmin + cc % nc;
-            const float* bp = feat + ((size_t)gf * HW + cell) * C + 4 * fg;
-            f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-            for (int kb = 0; kb < C / 16; ++kb) {
-                const float4 a = *reinterpret_cast<const float4*>(ap + kb * 16);
-                const float4 b = *reinterpret_cast<const float4*>(bp + kb * 16);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
-            }
-            if (ci < ncells) {
-                const float fn = norms[(size_t)gf * HW + cell];
+    float* hb = s_h[w];
+    for (int j = lane; j < WH * WH; j += WAVE) {
+        const int hy = j / WH, hx = j % WH;  // window coords of the centre in the x window: (hy+1, hx+1)
+        const int hr = kr - (RD + 1) + hy, hc = kc - (RD + 1) + hx;
+        const bool in = hr >= 0 && hr < ph && hc >= 0 && hc < pw;
+        float x9[9];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int s = fg * 4 + r;
-                    if (s_grp[s] == gi) win[s * NB_MAX + ci] = fmaxf(acc[r] / fmaxf(s_sn[s] * fn, 1e-8f), 0.f);
-                }
-            }
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) x9[dy * 3 + dx] = sx[(hy + dy) * WX + hx + dx];
+#pragma unroll
+        for (int ch = 0; ch < 16; ++ch) {
+            float a = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) a = fmaf(w1[ch * 9 + t], x9[t], a);
+            a += b1[ch];
+            hb[j * 16 + ch] = in ? fmaxf(a, 0.f) : 0.f;  // hidden outside the map is zero (conv2's padding)
         }
-        __syncthreads();
-        // ---- per source: fp32 refiner on the window, disk soft-argmax; wave w owns sources 4w .. 4w+3 ----
-        for (int q = 0; q < 4; ++q) {
-            const int s = w * 4 + q;
-            if (s_grp[s] != gi) continue;  // wave-uniform
-            const int kr = s_k[s] / pw, kc = s_k[s] % pw;
-            const float* xw_ = win + s * NB_MAX;
-            auto xat = [&](int rr, int cc) -> float {
-                return (rr >= 0 && rr < ph && cc >= 0 && cc < pw) ? xw_[(rr - rmin) * nc + (cc - cmin)] : 0.f;
-            };
-            float* hb = hbuf + w * WH * WH * 16;
-            for (int i = lane; i < WH * WH; i += WAVE) {
-                const int hr = kr - (RD + 1) + i / WH, hc = kc - (RD + 1) + i % WH;
-                const bool in = hr >= 0 && hr < ph && hc >= 0 && hc < pw;
-                float x9[9];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float* zb = s_z[w];
+    for (int j = lane; j < WZ * WZ; j += WAVE) {
+        const int zy = j / WZ, zx = j % WZ;  // centre in the hidden window: (zy+1, zx+1)
+        float a = 0.f;
 #pragma unroll
-                for (int dy = -1; dy <= 1; ++dy)
+        for (int ch = 0; ch < 16; ++ch)
 #pragma unroll
-                    for (int dx = -1; dx <= 1; ++dx) x9[(dy + 1) * 3 + dx + 1] = in ? xat(hr + dy, hc + dx) : 0.f;
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int ch = 0; ch < 16; ++ch) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) a = fmaf(w1[ch * 9 + t], x9[t], a);
-                    a += b1[ch];
-                    hb[i * 16 + ch] = in ? fmaxf(a, 0.f) : 0.f;
-                }
-            }
-            // (same wave wrote hb; LDS ops of one wave are ordered, but make the compiler keep them so)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            float* zb = zbuf + w * 128;
-            for (int i = lane; i < WZ * WZ; i += WAVE) {
-                const int zr = i / WZ, zc = i % WZ;  // hidden-window coords of the centre: (zr+1, zc+1)
-                float a = 0.f;
-#pragma unroll
-                for (int ch = 0; ch < 16; ++ch)
-#pragma unroll
-                    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                        for (int dx = -1; dx <= 1; ++dx)
-                            a = fmaf(w2[ch * 9 + (dy + 1) * 3 + dx + 1], hb[((zr + 1 + dy) * WH + zc + 1 + dx) * 16 + ch], a);
-                zb[i] = a + b2;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const Rec rc = rec[s_m[s] - m0];
-            auto zfun = [&](int r, int c) { return zb[(r - (kr - RD)) * WZ + (c - (kc - RD))]; };
-            float sq = 0.f;
-            dtk_disk_softargmax(g, s_k[s], rc.zmax, rc.Z, zfun, normalized, s_tmp + 2 * w, &sq);
-            if (lane == 0) {
-                // the fallback test sq < 1e-8 uses approximate (zmax, Z): redo when it is not clear-cut
-                const bool unclear = (sq > 1.25e-9f && sq < 8e-8f) || !(rc.Z > 0.f) || !(sq == sq);
-                if (unclear) {
-                    const int slot = atomicAdd(redo.count, 1);
-                    redo.src_row[slot] = s_row[s];
-                    redo.tgt[slot] = s_f[s];
-                    redo.out_idx[slot] = out_idx ? out_idx[s_m[s]] : s_m[s];
-                } else {
-                    float* o = out_xy + 2 * (size_t)(out_idx ? out_idx[s_m[s]] : s_m[s]);
-                    o[0] = s_tmp[2 * w];
-                    o[1] = s_tmp[2 * w + 1];
-                }
-            }
+                for (int dx = 0; dx < 3; ++dx)
+                    a = fmaf(w2[ch * 9 + dy * 3 + dx], hb[((zy + dy) * WH + zx + dx) * 16 + ch], a);
+        zb[j] = a + b2;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const Rec rc = rec[i];
+    auto zfun = [&](int r, int c) { return zb[(r - (kr - RD)) * WZ + (c - (kc - RD))]; };
+    float sq = 0.f;
+    dtk_disk_softargmax(g, k, rc.zmax, rc.Z, zfun, normalized, s_out[w], &sq);
+    if (lane == 0) {
+        // the fallback test sq < 1e-8 uses the fp16 pass's (zmax, Z), i.e. sq is known up to a factor exp(+-E):
+        // when the test is not clear-cut the exact path decides
+        const float band = expf(fminf(*zerr, 80.f)) * 1.5f;
+        const bool unclear = (sq > 1e-8f / band && sq < 1e-8f * band) || !(rc.Z > 0.f) || !(sq == sq);
+        const int oi = out_idx ? out_idx[m] : m;
+        if (unclear) {
+            const int slot = atomicAdd(redo.count, 1);
+            redo.src_row[slot] = src_row ? src_row[m] : m;
+            redo.tgt[slot] = min(max(tgt[m], 0), g.T - 1);
+            redo.out_idx[slot] = oi;
+        } else {
+            out_xy[2 * (size_t)oi] = s_out[w][0];
+            out_xy[2 * (size_t)oi + 1] = s_out[w][1];
         }
-        __syncthreads();
     }
 }
 
 struct MfmaLayout {
-    size_t s16, maps, rec, wpk, redo_cnt, redo_lists, exact, total;
+    size_t s16, maps, rec, wpk, kstar, xwin, redo_cnt, redo_lists, exact, total;
     int chunk, HWp;
 };
 
@@ -594,7 +669,9 @@ MfmaLayout mfma_layout(const dtk_geom* g, int M) {
     L.s16 = off; off = al(off + (size_t)L.chunk * g->C * 2);
     L.maps = off; off = al(off + (size_t)L.chunk * L.HWp * 2);
     L.rec = off; off = al(off + (size_t)L.chunk * sizeof(Rec));
-    L.wpk = off; off = al(off + 152 * 4);
+    L.wpk = off; off = al(off + 160 * 4);
+    L.kstar = off; off = al(off + (size_t)L.chunk * 4);
+    L.xwin = off; off = al(off + (size_t)L.chunk * WX * WX * 4);
     L.redo_cnt = off; off = al(off + 16);
     L.redo_lists = off; off = al(off + (size_t)3 * L.chunk * 4);
     L.exact = off;
@@ -645,13 +722,11 @@ int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, con
     const int ph = g->ph, pw = g->pw;
     const size_t lds_head = (size_t)((((ph + 2) * (pw + 2) + 7) & ~7)) * 2 + (size_t)(RB + 2) * (pw + 2) * 32 + 8 * 4 +
                             (1 + KC) * 4 + 16;
-    const size_t lds_ref = sizeof(float) * (size_t)(16 * NB_MAX + 4 * WH * WH * 16 + 4 * 128 + 16 + 8) +
-                           sizeof(int) * (size_t)(16 * 5 + 64 + 4);
+    int32_t* kstar = reinterpret_cast<int32_t*>(ws + L.kstar);
+    float* xwin = reinterpret_cast<float*>(ws + L.xwin);
     DTK_REQUIRE(lds_head <= 160 * 1024, "dtk_track(mfma): token grid %dx%d too large for head16 (%zu B LDS)", ph, pw, lds_head);
     DTK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_head));
-    DTK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(refine32_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ref));
     DTK_LAUNCH("head16_pack", head16_pack_kernel, dim3(1), dim3(256), 0, st, head, wpk);
     const half_t* f16 = reinterpret_cast<const half_t*>(feat_f16);
     for (long long m0 = 0; m0 < M; m0 += L.chunk) {
@@ -663,8 +738,11 @@ int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, con
         DTK_LAUNCH("head16", head16_kernel, dim3(cnt), dim3(256), lds_head, st, *g, head, wpk, maps, L.HWp, rec,
                    (int)m0, cnt, M, dM);
         DTK_HIP(hipMemsetAsync(redo.count, 0, sizeof(int32_t), st));
-        DTK_LAUNCH("refine32", refine32_kernel, dim3(dtk_cdiv(cnt, 16)), dim3(256), lds_ref, st, *g, feat, norms, head,
-                   emb, src_row, tgt, out_idx, out_xy, rec, redo, (int)m0, cnt, M, dM, normalized);
+        DTK_LAUNCH("refine_corr", refine_corr_kernel, dim3(dtk_cdiv(cnt, 16)), dim3(256), 0, st, *g, feat, norms, emb,
+                   src_row, tgt, out_idx, rec, kstar, xwin, redo, (int)m0, cnt, M, dM);
+        DTK_LAUNCH("refine_head", refine_head_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, *g, head, src_row, tgt,
+                   out_idx, out_xy, rec, kstar, xwin, reinterpret_cast<const float*>(wpk) + 152, redo, (int)m0, cnt, M, dM,
+                   normalized);
         int rc = dtk_track_exact(g, feat, norms, head, emb, redo.src_row, redo.tgt, redo.out_idx, out_xy, cnt,
                                  redo.count, normalized, ws + L.exact, workspace_bytes - L.exact, stream);
         if (rc) return rc;

@@ -166,6 +166,17 @@ def occlusion_for_query(green: torch.Tensor, traj_xy: torch.Tensor, cs: torch.Te
     return (lower_median(d, 0) > tau) | (cs < cos_th)
 
 
+def occlusion_margins(green: torch.Tensor, traj_xy: torch.Tensor, cs: torch.Tensor, anchor_th: float,
+                      cos_th: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """How far each occlusion decision of occlusion_for_query is from flipping: (|median - tau| in px for frames that
+    are not anchors -- anchors satisfy median <= tau by construction --, |cs - cos_th|).  Test helper."""
+    vis = cs >= anchor_th
+    d = (green - traj_xy[vis][:, None]).norm(dim=-1)
+    med = lower_median(d, 0)
+    tau = lower_median(d[:, vis], 0).max()
+    return (med - tau).abs(), (cs - cos_th).abs()
+
+
 def infer(feats: torch.Tensor, queries: torch.Tensor, head: Dict[str, torch.Tensor], video_h: int, video_w: int,
           anchor_th: float = 0.7, cos_th: float = 0.6, patch: int = 14, stride: int = 7,
           return_aux: bool = False):
