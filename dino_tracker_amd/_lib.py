@@ -43,6 +43,12 @@ SIGNATURES = {
     "dtk_pack_features": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dtk_unpack_features": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dtk_feature_norms": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dtk_delta_dino_packed_floats": (c_size_t, [c_int, c_int]),
+    "dtk_delta_dino_pack": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                    c_void_p, c_void_p]),
+    "dtk_delta_dino_workspace_bytes": (c_size_t, [ctypes.POINTER(Geom)]),
+    "dtk_delta_dino_refine": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_void_p,
+                                      c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "dtk_sample_points": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "dtk_head_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dtk_head_forward": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -1,0 +1,334 @@
+// delta_dino.hip -- P2: refined = dino + align(DeltaDINO(frame))   (models/tracker.py:113-135,
+// models/networks/delta_dino.py:53-61, models/utils.py:7-45), fp32 end to end.
+//
+//   conv5x5_kernel   implicit-GEMM 5x5 convolution (reflect padding, dilation 1 or 2) on the f32-input MFMA
+//                    (32x32x2: exact fmaf chains, 157 TFLOP/s peak), eval-mode BatchNorm folded into a per-channel
+//                    scale/shift, optional ReLU.  Activations are NHWC fp32; one workgroup = 8x8 output pixels x 64
+//                    output channels, K swept in chunks of 8 input channels x 25 taps staged in LDS.
+//   blurpool_kernel  antialiased_cnns.BlurPool(stride 2, filt 4, reflect pad (1,2,1,2)), NHWC.
+//   align_add_kernel bilinear (border, align_corners) resample of the stride-8 CNN map at the ViT token centres,
+//                    added to the token-major DINO features; also emits the per-cell L2 norms.
+#include "common.h"
+
+namespace {
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int CK = 8;        // input channels per LDS chunk
+constexpr int TP = 8;        // output tile is TP x TP pixels
+constexpr int TNC = 64;      // output channels per workgroup
+constexpr int PITCH = 40;    // LDS row pitch of the input patch: 4 tile rows land on 32 distinct banks
+
+__device__ __forceinline__ int reflect(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return min(max(i, 0), n - 1);
+}
+
+// weights: Wk[25][CinP][CoutP] (zero padded), scale/shift[CoutP]
+template <int DIL, bool NCHW_IN>
+__global__ __launch_bounds__(256) void conv5x5_kernel(const float* __restrict__ in, const float* __restrict__ Wk,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      float* __restrict__ out, int H, int W, int Cin, int CinP, int Cout,
+                                                      int CoutP, int relu, int tiles_x) {
+    constexpr int PH = TP + 4 * DIL;  // patch side
+    __shared__ float Xs[CK][PH][PITCH];
+    __shared__ float Ws[25][CK][TNC];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+    const int y0 = ty * TP, x0 = tx * TP;
+    const int n0 = blockIdx.y * TNC;
+    const size_t frame = blockIdx.z;
+    const float* fin = in + frame * (size_t)H * W * Cin;
+    const int msub = w >> 1, nsub = w & 1;
+    const int li = lane & 31, lk = lane >> 5;
+    const int ly = msub * 4 + (li >> 3), lx = li & 7;
+    f16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    for (int c0 = 0; c0 < CinP; c0 += CK) {
+        __syncthreads();
+        // ---- stage the input patch (reflect padding resolved here) ----
+        if (NCHW_IN) {
+            for (int idx = tid; idx < CK * PH * PH; idx += 256) {
+                const int c = idx / (PH * PH), p = idx - c * (PH * PH);
+                const int py = p / PH, px = p - py * PH;
+                const int gy = reflect(y0 - 2 * DIL + py, H), gx = reflect(x0 - 2 * DIL + px, W);
+                Xs[c][py][px] = (c0 + c < Cin) ? fin[((size_t)(c0 + c) * H + gy) * W + gx] : 0.f;
+            }
+        } else {
+            for (int idx = tid; idx < PH * PH * 2; idx += 256) {
+                const int p = idx >> 1, hq = idx & 1;
+                const int py = p / PH, px = p - py * PH;
+                const int gy = reflect(y0 - 2 * DIL + py, H), gx = reflect(x0 - 2 * DIL + px, W);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c0 + hq * 4 < Cin) v = *reinterpret_cast<const float4*>(fin + ((size_t)gy * W + gx) * Cin + c0 + hq * 4);
+                Xs[hq * 4 + 0][py][px] = v.x;
+                Xs[hq * 4 + 1][py][px] = v.y;
+                Xs[hq * 4 + 2][py][px] = v.z;
+                Xs[hq * 4 + 3][py][px] = v.w;
+            }
+        }
+        // ---- stage the weights of this channel chunk: 25 taps x 8 cin x 64 cout ----
+        for (int idx = tid; idx < 25 * CK * (TNC / 4); idx += 256) {
+            const int row = idx / (TNC / 4), q = idx - row * (TNC / 4);  // row = tap*CK + c
+            const int tap = row / CK, c = row - tap * CK;
+            const float4 v = *reinterpret_cast<const float4*>(Wk + ((size_t)tap * CinP + c0 + c) * CoutP + n0 + q * 4);
+            *reinterpret_cast<float4*>(&Ws[tap][c][q * 4]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                const int tap = ky * 5 + kx;
+#pragma unroll
+                for (int s = 0; s < CK / 2; ++s) {
+                    const float a = Xs[2 * s + lk][ly + ky * DIL][lx + kx * DIL];
+                    const float b = Ws[tap][2 * s + lk][nsub * 32 + li];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                }
+            }
+    }
+    // ---- epilogue: D[i][j], j = lane&31 (cout), i = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel of the 32-px sub-tile) ----
+    const int co = n0 + nsub * 32 + li;
+    if (co < Cout) {
+        const float sc = scale[co], sh = shift[co];
+        float* fout = out + frame * (size_t)H * W * Cout;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const int oy = y0 + msub * 4 + (i >> 3), ox = x0 + (i & 7);
+            if (oy < H && ox < W) {
+                float v = acc[r] * sc + sh;
+                if (relu) v = fmaxf(v, 0.f);
+                fout[((size_t)oy * W + ox) * Cout + co] = v;
+            }
+        }
+    }
+}
+
+// NHWC blur-pool: one thread per (output pixel, 4 channels)
+__global__ __launch_bounds__(256) void blurpool_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
+                                                       int Ho, int Wo, int C) {
+    const size_t frame = blockIdx.y;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = C / 4;
+    if (idx >= (long long)Ho * Wo * c4) return;
+    const int cq = (int)(idx % c4);
+    const int p = (int)(idx / c4);
+    const int oy = p / Wo, ox = p - oy * Wo;
+    const float* fin = in + frame * (size_t)H * W * C;
+    const float f[4] = {1.f, 3.f, 3.f, 1.f};
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gy = reflect(2 * oy - 1 + i, H);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gx = reflect(2 * ox - 1 + j, W);
+            const float wgt = f[i] * f[j] * (1.f / 64.f);
+            const float4 v = *reinterpret_cast<const float4*>(fin + ((size_t)gy * W + gx) * C + cq * 4);
+            acc.x = fmaf(wgt, v.x, acc.x);
+            acc.y = fmaf(wgt, v.y, acc.y);
+            acc.z = fmaf(wgt, v.z, acc.z);
+            acc.w = fmaf(wgt, v.w, acc.w);
+        }
+    }
+    *reinterpret_cast<float4*>(out + frame * (size_t)Ho * Wo * C + ((size_t)oy * Wo + ox) * C + cq * 4) = acc;
+}
+
+// one wave per ViT cell: refined = dino + bilinear(cnn), norm
+__global__ __launch_bounds__(256) void align_add_kernel(const float* __restrict__ cnn, const float* __restrict__ dino,
+                                                        float* __restrict__ out, float* __restrict__ norms, int ch, int cw,
+                                                        int ph, int pw, int C, int patch, int vit_stride, int cnn_stride,
+                                                        int nframes) {
+    const long long cell = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int HW = ph * pw;
+    if (cell >= (long long)nframes * HW) return;
+    const int lane = threadIdx.x & 63;
+    const int fr = (int)(cell / HW), k = (int)(cell % HW);
+    const int r = k / pw, c = k % pw;
+    // models/utils.py:30-41: grid = -1 - 1/c_br + 2*pos/c_br, then grid_sample(align_corners, border)
+    const float brx = (float)((cw - 1) * cnn_stride), bry = (float)((ch - 1) * cnn_stride);
+    const float vx = (float)c * (float)vit_stride + (float)patch / 2.f;
+    const float vy = (float)r * (float)vit_stride + (float)patch / 2.f;
+    const float gx = -1.f - (1.f / brx) + (2.f * vx / brx);
+    const float gy = -1.f - (1.f / bry) + (2.f * vy / bry);
+    float ix = ((gx + 1.f) / 2.f) * (float)(cw - 1);
+    float iy = ((gy + 1.f) / 2.f) * (float)(ch - 1);
+    ix = fminf(fmaxf(ix, 0.f), (float)(cw - 1));
+    iy = fminf(fmaxf(iy, 0.f), (float)(ch - 1));
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float fx = ix - x0f, fy = iy - y0f;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const int x1 = min(x0 + 1, cw - 1), y1 = min(y0 + 1, ch - 1);
+    const float* base = cnn + (size_t)fr * ch * cw * C;
+    const float* p00 = base + ((size_t)y0 * cw + x0) * C;
+    const float* p01 = base + ((size_t)y0 * cw + x1) * C;
+    const float* p10 = base + ((size_t)y1 * cw + x0) * C;
+    const float* p11 = base + ((size_t)y1 * cw + x1) * C;
+    const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+    const float* d = dino + cell * C;
+    float* o = out + cell * C;
+    float ss = 0.f;
+    for (int q = lane * 4; q < C; q += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(p00 + q), b = *reinterpret_cast<const float4*>(p01 + q);
+        const float4 e = *reinterpret_cast<const float4*>(p10 + q), f = *reinterpret_cast<const float4*>(p11 + q);
+        const float4 dv = *reinterpret_cast<const float4*>(d + q);
+        float4 v;
+        v.x = dv.x + (a.x * w00 + b.x * w01 + e.x * w10 + f.x * w11);
+        v.y = dv.y + (a.y * w00 + b.y * w01 + e.y * w10 + f.y * w11);
+        v.z = dv.z + (a.z * w00 + b.z * w01 + e.z * w10 + f.z * w11);
+        v.w = dv.w + (a.w * w00 + b.w * w01 + e.w * w10 + f.w * w11);
+        *reinterpret_cast<float4*>(o + q) = v;
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0 && norms) norms[cell] = sqrtf(ss);
+}
+
+// [Cout][Cin][5][5] -> [25][CinP][CoutP]; BN(eval) folded: y = conv*scale + shift
+__global__ void pack_conv_kernel(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ bn_w,
+                                 const float* __restrict__ bn_b, const float* __restrict__ bn_mean,
+                                 const float* __restrict__ bn_var, float eps, int Cin, int Cout, int CinP, int CoutP,
+                                 float* __restrict__ Wk, float* __restrict__ scale, float* __restrict__ shift) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = 25LL * CinP * CoutP;
+    if (idx < total) {
+        const int co = (int)(idx % CoutP);
+        const int ci = (int)((idx / CoutP) % CinP);
+        const int tap = (int)(idx / ((long long)CoutP * CinP));
+        Wk[idx] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * 25 + tap] : 0.f;
+    }
+    if (idx < CoutP) {
+        const int co = (int)idx;
+        if (co < Cout) {
+            const float s = bn_w[co] / sqrtf(bn_var[co] + eps);
+            scale[co] = s;
+            shift[co] = (bias[co] - bn_mean[co]) * s + bn_b[co];
+        } else {
+            scale[co] = 0.f;
+            shift[co] = 0.f;
+        }
+    }
+}
+
+inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+inline int pool_out(int n) { return (n - 1) / 2 + 1; }
+
+struct Plan {
+    int H[4], W[4];       // conv input/output spatial size of layers 0..3
+    int Cin[4], Cout[4];
+    size_t act[4], pool[3];  // float offsets in the workspace (per batch)
+    size_t total_floats;
+};
+
+Plan make_plan(int video_h, int video_w, int C, int fb) {
+    Plan p;
+    const int chans[5] = {3, 64, 128, 256, C};
+    int h = video_h, w = video_w;
+    size_t off = 0;
+    for (int l = 0; l < 4; ++l) {
+        p.H[l] = h; p.W[l] = w; p.Cin[l] = chans[l]; p.Cout[l] = chans[l + 1];
+        p.act[l] = off; off += (size_t)fb * h * w * chans[l + 1];
+        if (l < 3) {
+            h = pool_out(h); w = pool_out(w);
+            p.pool[l] = off; off += (size_t)fb * h * w * chans[l + 1];
+        }
+    }
+    p.total_floats = off;
+    return p;
+}
+
+}  // namespace
+
+extern "C" size_t dtk_delta_dino_packed_floats(int layer, int C) {
+    const int chans[5] = {3, 64, 128, 256, C};
+    if (layer < 0 || layer > 3 || C <= 0) return 0;
+    const int cinp = pad_to(chans[layer], CK), coutp = pad_to(chans[layer + 1], TNC);
+    return (size_t)25 * cinp * coutp + 2 * (size_t)coutp;
+}
+
+extern "C" int dtk_delta_dino_pack(int layer, int C, const float* w, const float* bias, const float* bn_w,
+                                   const float* bn_b, const float* bn_mean, const float* bn_var, float eps, float* packed,
+                                   void* stream) {
+    DTK_REQUIRE(layer >= 0 && layer <= 3 && C > 0 && w && bias && bn_w && bn_b && bn_mean && bn_var && packed,
+                "dtk_delta_dino_pack: bad args");
+    const int chans[5] = {3, 64, 128, 256, C};
+    const int cin = chans[layer], cout = chans[layer + 1];
+    const int cinp = pad_to(cin, CK), coutp = pad_to(cout, TNC);
+    float* Wk = packed;
+    float* scale = packed + (size_t)25 * cinp * coutp;
+    float* shift = scale + coutp;
+    const long long total = 25LL * cinp * coutp;
+    DTK_LAUNCH("dd_pack", pack_conv_kernel, dim3(dtk_cdiv(total, 256)), dim3(256), 0, dtk_stream(stream), w, bias, bn_w,
+               bn_b, bn_mean, bn_var, eps, cin, cout, cinp, coutp, Wk, scale, shift);
+    return DTK_OK;
+}
+
+constexpr int DD_FRAME_BATCH = 8;
+
+extern "C" size_t dtk_delta_dino_workspace_bytes(const dtk_geom* g) {
+    if (!g) return 0;
+    const int fb = g->T < DD_FRAME_BATCH ? g->T : DD_FRAME_BATCH;
+    return make_plan(g->video_h, g->video_w, g->C, fb).total_floats * sizeof(float);
+}
+
+extern "C" int dtk_delta_dino_refine(const dtk_geom* g, const float* video, const float* dino, const float* const* packed,
+                                     float* out, float* norms, int t0, int nframes, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    DTK_REQUIRE(g && video && dino && packed && out && workspace, "dtk_delta_dino_refine: null pointer");
+    DTK_REQUIRE(g->C % 4 == 0, "dtk_delta_dino_refine: C must be a multiple of 4");
+    DTK_REQUIRE(t0 >= 0 && nframes >= 0 && t0 + nframes <= g->T, "dtk_delta_dino_refine: frame range out of bounds");
+    DTK_REQUIRE(g->video_h >= 16 && g->video_w >= 16, "dtk_delta_dino_refine: video too small");
+    const int fb = g->T < DD_FRAME_BATCH ? g->T : DD_FRAME_BATCH;
+    const Plan p = make_plan(g->video_h, g->video_w, g->C, fb);
+    if (workspace_bytes < p.total_floats * sizeof(float)) {
+        dtk_set_error("dtk_delta_dino_refine: workspace %zu B < required %zu B", workspace_bytes,
+                      p.total_floats * sizeof(float));
+        return DTK_E_WORKSPACE;
+    }
+    hipStream_t st = dtk_stream(stream);
+    float* ws = reinterpret_cast<float*>(workspace);
+    const int HW = g->ph * g->pw;
+    for (int f0 = t0; f0 < t0 + nframes; f0 += fb) {
+        const int nf = (t0 + nframes - f0) < fb ? (t0 + nframes - f0) : fb;
+        const float* cur = video + (size_t)f0 * 3 * g->video_h * g->video_w;
+        for (int l = 0; l < 4; ++l) {
+            const int H = p.H[l], W = p.W[l], cin = p.Cin[l], cout = p.Cout[l];
+            const int cinp = pad_to(cin, CK), coutp = pad_to(cout, TNC);
+            const float* Wk = packed[l];
+            const float* scale = Wk + (size_t)25 * cinp * coutp;
+            const float* shift = scale + coutp;
+            const int tiles_x = dtk_cdiv(W, TP), tiles_y = dtk_cdiv(H, TP);
+            dim3 grid(tiles_x * tiles_y, coutp / TNC, nf);
+            float* act = ws + p.act[l];
+            if (l == 0) {
+                DTK_LAUNCH("dd_conv1", (conv5x5_kernel<1, true>), grid, dim3(256), 0, st, cur, Wk, scale, shift, act, H, W,
+                           cin, cinp, cout, coutp, 1, tiles_x);
+            } else if (l < 3) {
+                DTK_LAUNCH("dd_conv23", (conv5x5_kernel<1, false>), grid, dim3(256), 0, st, cur, Wk, scale, shift, act, H,
+                           W, cin, cinp, cout, coutp, 1, tiles_x);
+            } else {
+                DTK_LAUNCH("dd_conv4", (conv5x5_kernel<2, false>), grid, dim3(256), 0, st, cur, Wk, scale, shift, act, H,
+                           W, cin, cinp, cout, coutp, 0, tiles_x);
+            }
+            cur = act;
+            if (l < 3) {
+                const int Ho = pool_out(H), Wo = pool_out(W);
+                float* pl = ws + p.pool[l];
+                const long long n = (long long)Ho * Wo * (cout / 4);
+                DTK_LAUNCH("dd_blurpool", blurpool_kernel, dim3(dtk_cdiv(n, 256), nf), dim3(256), 0, st, act, pl, H, W, Ho,
+                           Wo, cout);
+                cur = pl;
+            }
+        }
+        const long long cells = (long long)nf * HW;
+        DTK_LAUNCH("dd_align_add", align_add_kernel, dim3(dtk_cdiv(cells, 4)), dim3(256), 0, st, cur,
+                   dino + (size_t)f0 * HW * g->C, out + (size_t)f0 * HW * g->C, norms ? norms + (size_t)f0 * HW : nullptr,
+                   p.H[3], p.W[3], g->ph, g->pw, g->C, g->patch, g->stride, 8, nf);
+    }
+    return DTK_OK;
+}

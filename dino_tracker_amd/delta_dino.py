@@ -1,0 +1,61 @@
+"""Host side of P2: packs a DeltaDINO state dict for the HIP convolution kernels and runs the refinement
+(dtk_delta_dino_refine).  Mirrors Tracker.get_refined_embeddings / cache_refined_embeddings (models/tracker.py:113-135)."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import ops
+from ._lib import Geom, check, lib, make_geom
+
+
+def pack_weights(delta_dino, device):
+    """[packed layer 0..3] device tensors; re-packed when any parameter / BN statistic changed."""
+    mods = delta_dino.layers
+    convs = [mods[0], mods[4], mods[8], mods[12]]
+    bns = [mods[1], mods[5], mods[9], mods[13]]
+    key = tuple((t.data_ptr(), t._version) for m in convs + bns for t in list(m.parameters()) + list(m.buffers())) + (str(device),)
+    cache = getattr(delta_dino, "_dtk_packed", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    C = delta_dino.channels[-1]
+    packed = []
+    for l, (cv, bn) in enumerate(zip(convs, bns)):
+        n = int(lib().dtk_delta_dino_packed_floats(l, C))
+        buf = torch.empty(n, dtype=torch.float32, device=device)
+        args = [t.detach().to(device=device, dtype=torch.float32).contiguous()
+                for t in (cv.weight, cv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+        check(lib().dtk_delta_dino_pack(l, C, *[ops._p(a) for a in args], float(bn.eps), ops._p(buf), ops._stream()))
+        packed.append(buf)
+    torch.cuda.current_stream().synchronize()  # the temporaries in `args` die here
+    delta_dino._dtk_packed = (key, packed)
+    return packed
+
+
+def _refine(delta_dino, video: torch.Tensor, dino_thwc: torch.Tensor, g: Geom, want_norms: bool = False):
+    if delta_dino.training:
+        raise RuntimeError("the HIP Delta-DINO path implements eval-mode BatchNorm (inference); call .eval()")
+    packed = pack_weights(delta_dino, dino_thwc.device)
+    ptrs = (ctypes.c_void_p * 4)(*[p.data_ptr() for p in packed])
+    out = torch.empty_like(dino_thwc)
+    norms = torch.empty(dino_thwc.shape[:2], dtype=torch.float32, device=dino_thwc.device) if want_norms else None
+    ws_bytes = int(lib().dtk_delta_dino_workspace_bytes(g))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dino_thwc.device)
+    check(lib().dtk_delta_dino_refine(g, ops._p(video.contiguous(), torch.float32), ops._p(dino_thwc, torch.float32), ptrs,
+                                      ops._p(out), ops._p(norms), 0, g.T, ops._p(ws), ws_bytes, ops._stream()))
+    return out, norms
+
+
+def refine_video_packed(delta_dino, video: torch.Tensor, dino_thwc: torch.Tensor, g: Geom) -> torch.Tensor:
+    """All frames; token-major in, token-major out."""
+    return _refine(delta_dino, video, dino_thwc, g)[0]
+
+
+def refine_frames(delta_dino, frames: torch.Tensor, dino_chw: torch.Tensor, g: Geom) -> torch.Tensor:
+    """Arbitrary frame subset in the reference layout: frames [n,3,H,W], dino [n,C,h,w] -> refined [n,C,h,w]."""
+    n = frames.shape[0]
+    gg = make_geom(n, g.C, g.video_h, g.video_w, g.patch, g.stride, g.radius)
+    thwc, _ = ops.pack_features(dino_chw.to(torch.float32).contiguous())
+    out, _ = _refine(delta_dino, frames.to(torch.float32), thwc, gg)
+    return ops.unpack_features(out, g.ph, g.pw)

@@ -67,6 +67,23 @@ int dtk_unpack_features(const float* thwc, float* chw, int T, int C, int HW, voi
 /* norms only (after refinement wrote thwc in place) */
 int dtk_feature_norms(const float* thwc, float* norms, int T, int C, int HW, void* stream);
 
+/* ---- P2: Delta-DINO refinement (models/tracker.py:113-135; models/networks/delta_dino.py:53-61;
+ *      models/utils.py:7-45), fp32 on the f32-input MFMA ------------------------------------------------------------
+ * dtk_delta_dino_pack: layer l in 0..3 (state-dict keys layers.{4l}.{weight,bias} = conv [Cout][Cin][5][5] and
+ *   layers.{4l+1}.{weight,bias,running_mean,running_var} = BatchNorm2d, eval mode) -> kernel layout
+ *   packed = Wk[25][CinP][CoutP] | scale[CoutP] | shift[CoutP]  (dtk_delta_dino_packed_floats floats).
+ * dtk_delta_dino_refine: for frames t0 .. t0+nframes-1: out[t] = dino[t] + align(CNN(video[t])), token-major, plus
+ *   per-cell norms (may be NULL).  video is [T][3][video_h][video_w] fp32 in [0,1] (data/data_utils.py:79-104),
+ *   packed = 4 device pointers (host array).  BlurPool = antialiased_cnns.BlurPool(stride 2): reflect-pad (1,2,1,2),
+ *   4x4 binomial. */
+size_t dtk_delta_dino_packed_floats(int layer, int C);
+int dtk_delta_dino_pack(int layer, int C, const float* w, const float* bias, const float* bn_w, const float* bn_b,
+                        const float* bn_mean, const float* bn_var, float eps, float* packed, void* stream);
+size_t dtk_delta_dino_workspace_bytes(const dtk_geom* g);
+int dtk_delta_dino_refine(const dtk_geom* g, const float* video, const float* dino, const float* const* packed,
+                          float* out, float* norms, int t0, int nframes, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
 /* ---- K8: bilinear point sampling -------------------------------------------------------------------------
  * Tracker.sample_embeddings (models/tracker.py:96-111 -> utils.py:75-101) for integral frame indices:
  * out[b][:] = bilinear(F[t_idx[b]], (xy[b] - patch/2) / stride), border clamp, align_corners.

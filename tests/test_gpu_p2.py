@@ -1,0 +1,65 @@
+"""-m gpu: Delta-DINO refinement (P2) through the C-ABI vs the reference golden and the oracle.
+Feature-level tolerance: 3e-5 abs on O(1) features (fp32 everywhere; only the summation order differs)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import make_golden as MG
+from dino_tracker_amd import ops, synth
+from oracle import ref_algo as A
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FEAT_TOL = 3e-5
+
+
+def test_refine_matches_reference_golden_and_tracks():
+    from gpu_util import make_inference, make_tracker
+    cfg = MG.CASES["p23_small"]
+    gold = np.load(os.path.join(GOLD, "p23_small.npz"))
+    video, dino, head, queries, delta = MG.build_inputs(cfg)
+    trk = make_tracker(video, dino, head, delta=delta, method=ops.TRACK_MFMA)
+    trk.eval()
+    mi = make_inference(trk, cfg["H"], cfg["W"], cfg["T"])  # runs cache_refined_embeddings() on the HIP path
+    refined = trk.refined_features.cpu().numpy()
+    assert refined.shape == gold["refined"].shape
+    assert np.abs(refined - gold["refined"]).max() < FEAT_TOL
+    assert np.abs(refined - dino.numpy()).mean() > 0.01  # the residual is not trivially zero
+    traj, occ = mi.infer(queries.cuda())
+    assert np.abs(traj.cpu().numpy() - gold["traj"]).max() < 1e-3
+    assert np.array_equal(occ.cpu().numpy(), gold["occ"])
+    # arbitrary frame subset API (Tracker.get_refined_embeddings)
+    sub = torch.tensor([3, 0])
+    r, res = trk.get_refined_embeddings(sub)
+    assert np.abs(r.cpu().numpy() - gold["refined"][[3, 0]]).max() < FEAT_TOL
+    assert np.abs((r - res).cpu().numpy() - dino.numpy()[[3, 0]]).max() < 1e-6
+
+
+@pytest.mark.parametrize("C,H,W", [(384, 476, 854), (32, 98, 126)])
+def test_refine_vs_oracle(C, H, W):
+    from gpu_util import make_tracker
+    T = 2
+    ph, pw = A.feature_grid(H, W)
+    video = synth.synth_video(T, H, W, seed=61)
+    dino = synth.synth_features(T, C, ph, pw, seed=62)
+    delta = synth.synth_delta_dino_weights(C, seed=63)
+    ref = A.refine_features(video, dino, delta)
+    trk = make_tracker(video, dino, synth.synth_head_weights(3), delta=delta)
+    trk.eval()
+    trk.cache_refined_embeddings()
+    got = trk.refined_features.cpu()
+    assert (got - ref).abs().max() < FEAT_TOL
+    feat, norms, _ = trk.features()
+    assert (norms.cpu() - ref.norm(dim=1).reshape(T, -1)).abs().max() < 1e-4
+
+
+def test_training_mode_is_refused():
+    from gpu_util import make_tracker
+    cfg = MG.CASES["p23_small"]
+    video, dino, head, queries, delta = MG.build_inputs(cfg)
+    trk = make_tracker(video, dino, head, delta=delta)
+    trk.train()
+    with pytest.raises(RuntimeError, match="eval-mode"):
+        trk.cache_refined_embeddings()
