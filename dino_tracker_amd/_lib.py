@@ -31,6 +31,19 @@ def make_geom(T: int, C: int, video_h: int, video_w: int, patch: int = 14, strid
     return Geom(T, C, ph, pw, video_h, video_w, patch, stride, radius)
 
 
+class VitLayer(ctypes.Structure):
+    """struct dtk_vit_layer."""
+    _fields_ = [(n, c_void_p) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1", "ln2_w", "ln2_b",
+                                        "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+
+
+class VitModel(ctypes.Structure):
+    """struct dtk_vit_model."""
+    _fields_ = [("D", ctypes.c_int32), ("heads", ctypes.c_int32), ("depth", ctypes.c_int32), ("patch", ctypes.c_int32),
+                ("stride", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("patch_w", c_void_p), ("patch_b", c_void_p),
+                ("cls_pos", c_void_p), ("pos", c_void_p), ("mean_std", c_void_p), ("layers", ctypes.POINTER(VitLayer))]
+
+
 # name -> (restype, argtypes); must list every symbol include/dtk.h declares (tests/test_abi.py checks this)
 SIGNATURES = {
     "dtk_version": (c_int, []),
@@ -43,6 +56,9 @@ SIGNATURES = {
     "dtk_pack_features": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dtk_unpack_features": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dtk_feature_norms": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dtk_vit_workspace_bytes": (c_size_t, [ctypes.POINTER(VitModel), c_int, c_int, c_int]),
+    "dtk_vit_forward": (c_int, [ctypes.POINTER(VitModel), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                c_size_t, c_void_p]),
     "dtk_delta_dino_packed_floats": (c_size_t, [c_int, c_int]),
     "dtk_delta_dino_pack": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                     c_void_p, c_void_p]),

@@ -1,0 +1,513 @@
+// vit.hip -- P1: DINOv2 ViT encoder as driven by VitExtractor (models/extractor.py:41-150, utils.py:33-72):
+// overlapping patch embedding (14x14, stride 7) of ImageNet-normalised frames + interpolated position encoding,
+// `depth` transformer blocks (LN -> QKV -> MHSA -> proj -> LayerScale -> +res; LN -> fc1 -> GELU -> fc2 -> LayerScale
+// -> +res), output = residual stream after the last requested block (no final norm), CLS included.
+//
+//   patch_embed_kernel  exact fp32 implicit GEMM on the f32-input MFMA (K = 3*14*14 = 588), mean/std fused in the load
+//   layernorm_kernel    one wave per token, fp32 statistics, bf16 output
+//   gemm_bf16_kernel    C = A W^T on MFMA 16x16x32 bf16 (fp32 accumulate), 128x128 tiles, LDS double-buffered, with
+//                       fused epilogues: QKV split (Q pre-scaled by log2(e)/sqrt(d), V written transposed), GELU,
+//                       LayerScale + residual add into the fp32 stream
+//   attention_kernel    flash attention, d_head = 64: S^T = K Q^T and O^T = V^T P^T on MFMA 32x32x16 bf16 so that every
+//                       per-query quantity (running max / sum, rescale) is lane-local; K and V^T tiles staged in LDS
+//                       (conflict-free pitches), online softmax in exp2 domain
+// Residual stream fp32, matrix operands bf16 (the reference runs fp32; parity is stated at feature level).
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------------------
+// patch embedding: tokens[f][1 + r*pw + c][:] = W . patch(r,c) + b + pos[r*pw + c];  tokens[f][0] = cls_pos
+// 32 patches x 32 output features per wave (MFMA 32x32x2 f32), 4 waves = 64 patches x 64 features per workgroup
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ frames, const float* __restrict__ Wp,
+                                                          const float* __restrict__ bp, const float* __restrict__ pos,
+                                                          const float* __restrict__ cls_pos,
+                                                          const float* __restrict__ mean_std, float* __restrict__ x,
+                                                          int H, int W, int ph, int pw, int D, int patch, int stride,
+                                                          int S) {
+    const int HW = ph * pw;
+    const int K = 3 * patch * patch;
+    const int frame = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int p0 = blockIdx.x * 64 + (w >> 1) * 32;
+    const int n0 = blockIdx.y * 64 + (w & 1) * 32;
+    const int li = lane & 31, lk = lane >> 5;
+    const float* img = frames + (size_t)frame * 3 * H * W;
+    const int p = min(p0 + li, HW - 1);
+    const int pr = p / pw, pc = p % pw;
+    const int n = min(n0 + li, D - 1);
+    const float* wrow = Wp + (size_t)n * K;  // [D][3][patch][patch]
+    f16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k = lk; k < K; k += 2) {
+        const int ch = k / (patch * patch), rem = k - ch * patch * patch;
+        const int ky = rem / patch, kx = rem - ky * patch;
+        const float px = img[((size_t)ch * H + pr * stride + ky) * W + pc * stride + kx];
+        const float a = (px - mean_std[ch]) / mean_std[3 + ch];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wrow[k], acc, 0, 0, 0);
+    }
+    const int co = n0 + li;
+    if (co < D) {
+        const float b = bp[co];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const int pp = p0 + i;
+            if (pp < HW) x[((size_t)frame * S + 1 + pp) * D + co] = acc[r] + b + pos[(size_t)pp * D + co];
+        }
+    }
+    if (blockIdx.x == 0 && (w >> 1) == 0 && lk == 0 && co < D) x[(size_t)frame * S * D + co] = cls_pos[co];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm: fp32 row -> bf16 row (A operand of the next GEMM); one wave per token
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gam,
+                                                        const float* __restrict__ bet, bf16_t* __restrict__ y,
+                                                        long long rows, int D, float eps) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = x + row * D;
+    float s = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(p + c);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(p + c);
+        const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+        q += (a * a + b * b) + (cc * cc + d * d);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    bf16_t* o = y + row * D;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(p + c);
+        const float4 g = *reinterpret_cast<const float4*>(gam + c), b = *reinterpret_cast<const float4*>(bet + c);
+        bf4 r = {(bf16_t)((v.x - mean) * rstd * g.x + b.x), (bf16_t)((v.y - mean) * rstd * g.y + b.y),
+                 (bf16_t)((v.z - mean) * rstd * g.z + b.z), (bf16_t)((v.w - mean) * rstd * g.w + b.w)};
+        *reinterpret_cast<bf4*>(o + c) = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 GEMM  C[M][N] = A[M][K] . Wt[N][K]^T (+bias) with fused epilogues
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int GM = 128, GN = 128, GK = 32;
+enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2 };
+
+struct GemmEpi {
+    const float* bias;   // [N]
+    // EPI_QKV
+    bf16_t* q;           // [F][heads][Sp][64]
+    bf16_t* k;           // [F][heads][Sp][64]
+    bf16_t* vt;          // [F][heads][64][Sp]
+    int S, Sp, heads, D;
+    float qscale;
+    // EPI_GELU
+    bf16_t* out;         // [M][N]
+    // EPI_RESID
+    float* x;            // [M][N] fp32 residual stream, updated in place
+    const float* gamma;  // [N] LayerScale
+};
+
+__device__ __forceinline__ int gswz(int row, int piece) {
+    const int f = (0x1230 >> (((row >> 2) & 3) * 4)) & 3;  // {0,3,2,1}: conflict-free ds_read_b128 fragments
+    return row * 4 + (piece ^ f);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
+                                                        long long M, int N, int K, GemmEpi e) {
+    __shared__ uint4 As[2][GM * 4];
+    __shared__ uint4 Bs[2][GN * 4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long long m0 = (long long)blockIdx.y * GM;
+    const int n0 = blockIdx.x * GN;
+    const int wr = w >> 1, wc = w & 1;  // wave tile 64 x 64
+    const int fj = lane & 15, fg = lane >> 4;
+    const int lrow = tid >> 2, lpiece = tid & 3;  // loader rows lrow, lrow + 64
+    // clamp loader rows so that ragged M / N never read out of bounds (results of clamped rows are not stored)
+    const long long ar0 = min(m0 + lrow, M - 1), ar1 = min(m0 + lrow + 64, M - 1);
+    const int br0 = min(n0 + lrow, N - 1), br1 = min(n0 + lrow + 64, N - 1);
+    const bf16_t* a0 = A + ar0 * K + lpiece * 8;
+    const bf16_t* a1 = A + ar1 * K + lpiece * 8;
+    const bf16_t* b0 = Wt + (size_t)br0 * K + lpiece * 8;
+    const bf16_t* b1 = Wt + (size_t)br1 * K + lpiece * 8;
+    f4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f4{0.f, 0.f, 0.f, 0.f};
+    uint4 ra0 = *reinterpret_cast<const uint4*>(a0), ra1 = *reinterpret_cast<const uint4*>(a1);
+    uint4 rb0 = *reinterpret_cast<const uint4*>(b0), rb1 = *reinterpret_cast<const uint4*>(b1);
+    As[0][gswz(lrow, lpiece)] = ra0;
+    As[0][gswz(lrow + 64, lpiece)] = ra1;
+    Bs[0][gswz(lrow, lpiece)] = rb0;
+    Bs[0][gswz(lrow + 64, lpiece)] = rb1;
+    __syncthreads();
+    const int nk = K / GK;
+    int cur = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        if (ks + 1 < nk) {
+            ra0 = *reinterpret_cast<const uint4*>(a0 + (ks + 1) * GK);
+            ra1 = *reinterpret_cast<const uint4*>(a1 + (ks + 1) * GK);
+            rb0 = *reinterpret_cast<const uint4*>(b0 + (ks + 1) * GK);
+            rb1 = *reinterpret_cast<const uint4*>(b1 + (ks + 1) * GK);
+        }
+        bf8 af[4], bfr[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const uint4 v = As[cur][gswz(wr * 64 + mi * 16 + fj, fg)];
+            af[mi] = *reinterpret_cast<const bf8*>(&v);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const uint4 v = Bs[cur][gswz(wc * 64 + ni * 16 + fj, fg)];
+            bfr[ni] = *reinterpret_cast<const bf8*>(&v);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+        if (ks + 1 < nk) {
+            As[cur ^ 1][gswz(lrow, lpiece)] = ra0;
+            As[cur ^ 1][gswz(lrow + 64, lpiece)] = ra1;
+            Bs[cur ^ 1][gswz(lrow, lpiece)] = rb0;
+            Bs[cur ^ 1][gswz(lrow + 64, lpiece)] = rb1;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // D fragment: lane (fg, fj) holds rows 4*fg + r (r = 0..3), column fj of each 16x16 tile
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wc * 64 + ni * 16 + fj;
+        if (n >= N) continue;
+        const float bias = e.bias ? e.bias[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const long long mb = m0 + wr * 64 + mi * 16 + fg * 4;
+            if (EPI == EPI_QKV) {
+                const int which = n / e.D, rem = n - which * e.D;
+                const int head = rem >> 6, dh = rem & 63;
+                const int frame = (int)(mb / e.S);  // the 4 rows of a fragment may straddle two frames: handle per row
+                (void)frame;
+                if (which == 2) {
+                    // V transposed: 4 consecutive tokens -> 8 contiguous bytes when they stay inside one frame
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const long long m = mb + r;
+                        if (m < M) {
+                            const int f = (int)(m / e.S), s = (int)(m - (long long)f * e.S);
+                            e.vt[(((size_t)f * e.heads + head) * 64 + dh) * e.Sp + s] = (bf16_t)(acc[mi][ni][r] + bias);
+                        }
+                    }
+                } else {
+                    bf16_t* dst = which == 0 ? e.q : e.k;
+                    const float sc = which == 0 ? e.qscale : 1.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const long long m = mb + r;
+                        if (m < M) {
+                            const int f = (int)(m / e.S), s = (int)(m - (long long)f * e.S);
+                            dst[(((size_t)f * e.heads + head) * e.Sp + s) * 64 + dh] = (bf16_t)((acc[mi][ni][r] + bias) * sc);
+                        }
+                    }
+                }
+            } else if (EPI == EPI_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long m = mb + r;
+                    if (m < M) {
+                        const float v = acc[mi][ni][r] + bias;
+                        e.out[m * N + n] = (bf16_t)(0.5f * v * (1.f + erff(v * 0.70710678118654752f)));
+                    }
+                }
+            } else {
+                const float gm = e.gamma[n];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long m = mb + r;
+                    if (m < M) e.x[m * N + n] += gm * (acc[mi][ni][r] + bias);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// flash attention, d_head = 64.  One workgroup = 128 queries (4 waves x 32) of one (frame, head); KV tiles of 64 keys.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int KP = 72;   // K tile row pitch in bf16 (144 B): ds_read_b128 of 16 rows hits 16 distinct 16-B slots
+constexpr int VP = 68;   // V^T tile row pitch in bf16 (136 B): ds_read_b64 of 32 rows hits 32 distinct 8-B slots
+
+__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kg,
+                                                        const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O, int S,
+                                                        int Sp, int heads, int D) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[2][64 * KP];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[2][64 * VP];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fh = blockIdx.y;  // frame * heads + head
+    const int frame = fh / heads, head = fh - frame * heads;
+    const int q0 = blockIdx.x * 128 + w * 32;
+    const int lq = lane & 31, hi = lane >> 5;
+    const bf16_t* Qb = Q + (size_t)fh * Sp * 64;
+    const bf16_t* Kb = Kg + (size_t)fh * Sp * 64;
+    const bf16_t* Vb = Vt + (size_t)fh * 64 * Sp;
+    // Q^T fragments (B operand): lane (query lq, hi) holds d = 16*ks + 8*hi .. +7 for ks = 0..3
+    bf8 qf[4];
+    {
+        const int qrow = min(q0 + lq, Sp - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf8*>(Qb + (size_t)qrow * 64 + ks * 16 + hi * 8);
+    }
+    f16v o[2];  // O^T accumulators: d-block db: rows d = 32*db + (r&3) + 8*(r>>2) + 4*hi, column = query lq
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const int ntiles = (S + 63) / 64;
+    // loader: thread -> (row, 16-byte piece) x 2 for each of K and V^T
+    const int lr = tid >> 3, lp = tid & 7;  // rows lr, lr + 32; piece lp (8 bf16)
+    uint4 rk0, rk1, rv0, rv1;
+#define ATT_LOAD_TILE(t)                                                                          \
+    do {                                                                                          \
+        const int k0_ = (t) * 64;                                                                 \
+        rk0 = *reinterpret_cast<const uint4*>(Kb + (size_t)(k0_ + lr) * 64 + lp * 8);             \
+        rk1 = *reinterpret_cast<const uint4*>(Kb + (size_t)(k0_ + lr + 32) * 64 + lp * 8);        \
+        rv0 = *reinterpret_cast<const uint4*>(Vb + (size_t)lr * Sp + k0_ + lp * 8);               \
+        rv1 = *reinterpret_cast<const uint4*>(Vb + (size_t)(lr + 32) * Sp + k0_ + lp * 8);        \
+    } while (0)
+#define ATT_STORE_TILE(buf)                                                                       \
+    do {                                                                                          \
+        *reinterpret_cast<uint4*>(&Ks[buf][lr * KP + lp * 8]) = rk0;                              \
+        *reinterpret_cast<uint4*>(&Ks[buf][(lr + 32) * KP + lp * 8]) = rk1;                       \
+        uint2* v0_ = reinterpret_cast<uint2*>(&Vs[buf][lr * VP + lp * 8]);                        \
+        v0_[0] = make_uint2(rv0.x, rv0.y);                                                        \
+        v0_[1] = make_uint2(rv0.z, rv0.w);                                                        \
+        uint2* v1_ = reinterpret_cast<uint2*>(&Vs[buf][(lr + 32) * VP + lp * 8]);                 \
+        v1_[0] = make_uint2(rv1.x, rv1.y);                                                        \
+        v1_[1] = make_uint2(rv1.z, rv1.w);                                                        \
+    } while (0)
+    ATT_LOAD_TILE(0);
+    ATT_STORE_TILE(0);
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) ATT_LOAD_TILE(t + 1);
+        // ---- S^T = K Q^T : two 32-key blocks x four 16-wide d steps ----
+        f16v sc[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[b][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf8 kf = *reinterpret_cast<const bf8*>(&Ks[cur][(b * 32 + lq) * KP + ks * 16 + hi * 8]);
+                sc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[b], 0, 0, 0);
+            }
+        }
+        // keys beyond S (last tile only) are masked out
+        if (t == ntiles - 1 && (S & 63) != 0) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= S) sc[b][r] = -1e30f;
+                }
+        }
+        // ---- online softmax (exp2 domain; Q carries log2(e)/sqrt(d)) : everything per query is lane-local ----
+        float tm = -1e30f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tm = fmaxf(tm, sc[b][r]);
+        tm = fmaxf(tm, __shfl_xor(tm, 32, WAVE));
+        const float m_new = fmaxf(m_run, tm);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float ls = 0.f;
+        bf8 pf[2][2];  // P^T fragments: [key block][16-slot group]
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float p = exp2f(sc[b][8 * j + e] - m_new);
+                    ls += p;
+                    pf[b][j][e] = (bf16_t)p;
+                }
+        l_run = l_run * alpha + ls;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        // ---- O^T += V^T P^T : slot (hi, e) of group (b, j) is key 32b + 16j + 8(e>>2) + 4hi + (e&3) ----
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16_t* vp = &Vs[cur][(db * 32 + lq) * VP + b * 32 + j * 16 + 4 * hi];
+                    const bf4 v0 = *reinterpret_cast<const bf4*>(vp), v1 = *reinterpret_cast<const bf4*>(vp + 8);
+                    const bf8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][j], o[db], 0, 0, 0);
+                }
+        if (t + 1 < ntiles) ATT_STORE_TILE(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, WAVE);
+    const float inv = 1.f / l_tot;
+    const int qi = q0 + lq;
+    if (qi < S) {
+        bf16_t* orow = O + ((size_t)frame * S + qi) * D + head * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int d = db * 32 + 8 * rq + 4 * hi;
+                bf4 v = {(bf16_t)(o[db][4 * rq + 0] * inv), (bf16_t)(o[db][4 * rq + 1] * inv),
+                         (bf16_t)(o[db][4 * rq + 2] * inv), (bf16_t)(o[db][4 * rq + 3] * inv)};
+                *reinterpret_cast<bf4*>(orow + d) = v;
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void zero_kernel(uint4* __restrict__ p, long long n16) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) p[i] = make_uint4(0, 0, 0, 0);
+}
+
+// fp32 tokens [F][S][D] (CLS first) -> token-major features [F][HW][D] (drop CLS)
+__global__ __launch_bounds__(256) void drop_cls_kernel(const float* __restrict__ x, float* __restrict__ out, int S, int D,
+                                                       long long total4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int d4 = D / 4;
+    const long long row = i / d4;  // over F*(S-1)
+    const int c = (int)(i - row * d4);
+    const long long f = row / (S - 1), s = row - f * (S - 1);
+    reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(x)[(f * S + 1 + s) * d4 + c];
+}
+
+struct VitPlan {
+    int S, Sp, FB;
+    size_t x, xn, q, k, vt, ao, hid, total;
+};
+
+VitPlan vit_plan(const dtk_vit_model* m, int ph, int pw, int frames) {
+    VitPlan p;
+    p.S = ph * pw + 1;
+    p.Sp = (p.S + 127) / 128 * 128;
+    p.FB = frames < 8 ? frames : 8;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = 0;
+    const size_t rows = (size_t)p.FB * p.S;
+    p.x = off; off = al(off + rows * m->D * 4);
+    p.xn = off; off = al(off + rows * m->D * 2);
+    p.q = off; off = al(off + (size_t)p.FB * m->heads * p.Sp * 64 * 2);
+    p.k = off; off = al(off + (size_t)p.FB * m->heads * p.Sp * 64 * 2);
+    p.vt = off; off = al(off + (size_t)p.FB * m->heads * p.Sp * 64 * 2);
+    p.ao = off; off = al(off + rows * m->D * 2);
+    p.hid = off; off = al(off + rows * 4 * m->D * 2);
+    p.total = off;
+    return p;
+}
+
+}  // namespace
+
+extern "C" size_t dtk_vit_workspace_bytes(const dtk_vit_model* m, int video_h, int video_w, int frames) {
+    if (!m || frames <= 0) return 0;
+    const int ph = 1 + (video_h - m->patch) / m->stride, pw = 1 + (video_w - m->patch) / m->stride;
+    return vit_plan(m, ph, pw, frames).total;
+}
+
+extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int nframes, int video_h, int video_w,
+                               float* tokens_out, float* feat_out, void* workspace, size_t workspace_bytes, void* stream) {
+    DTK_REQUIRE(m && frames && workspace && (tokens_out || feat_out), "dtk_vit_forward: null pointer");
+    DTK_REQUIRE(m->D > 0 && m->heads > 0 && m->D == m->heads * 64, "dtk_vit_forward: d_head must be 64 (D=%d heads=%d)",
+                m->D, m->heads);
+    DTK_REQUIRE(m->D % 32 == 0 && m->depth >= 0 && m->layers, "dtk_vit_forward: bad model");
+    DTK_REQUIRE(video_h >= m->patch && video_w >= m->patch, "dtk_vit_forward: frame smaller than a patch");
+    const int ph = 1 + (video_h - m->patch) / m->stride, pw = 1 + (video_w - m->patch) / m->stride;
+    const int HW = ph * pw, D = m->D;
+    const VitPlan p = vit_plan(m, ph, pw, nframes);
+    if (workspace_bytes < p.total) {
+        dtk_set_error("dtk_vit_forward: workspace %zu B < required %zu B", workspace_bytes, p.total);
+        return DTK_E_WORKSPACE;
+    }
+    hipStream_t st = dtk_stream(stream);
+    unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
+    float* x = reinterpret_cast<float*>(ws + p.x);
+    bf16_t* xn = reinterpret_cast<bf16_t*>(ws + p.xn);
+    bf16_t* q = reinterpret_cast<bf16_t*>(ws + p.q);
+    bf16_t* k = reinterpret_cast<bf16_t*>(ws + p.k);
+    bf16_t* vt = reinterpret_cast<bf16_t*>(ws + p.vt);
+    bf16_t* ao = reinterpret_cast<bf16_t*>(ws + p.ao);
+    bf16_t* hid = reinterpret_cast<bf16_t*>(ws + p.hid);
+    const int S = p.S, Sp = p.Sp;
+    // Q/K/V^T padding rows (s >= S) must be finite zeros: they are read by the last KV tile
+    {
+        const long long n16 = (long long)((p.ao - p.q) / 16);
+        DTK_LAUNCH("vit_zero", zero_kernel, dim3(dtk_cdiv(n16, 256)), dim3(256), 0, st, reinterpret_cast<uint4*>(q), n16);
+    }
+    for (int f0 = 0; f0 < nframes; f0 += p.FB) {
+        const int nf = (nframes - f0) < p.FB ? (nframes - f0) : p.FB;
+        const long long rows = (long long)nf * S;
+        DTK_LAUNCH("vit_patch_embed", patch_embed_kernel, dim3(dtk_cdiv(HW, 64), dtk_cdiv(D, 64), nf), dim3(256), 0, st,
+                   frames + (size_t)f0 * 3 * video_h * video_w, m->patch_w, m->patch_b, m->pos, m->cls_pos, m->mean_std, x,
+                   video_h, video_w, ph, pw, D, m->patch, m->stride, S);
+        for (int l = 0; l < m->depth; ++l) {
+            const dtk_vit_layer& L = m->layers[l];
+            GemmEpi e{};
+            DTK_LAUNCH("vit_layernorm", layernorm_kernel, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x, L.ln1_w, L.ln1_b, xn,
+                       rows, D, m->ln_eps);
+            e.bias = L.qkv_b; e.q = q; e.k = k; e.vt = vt; e.S = S; e.Sp = Sp; e.heads = m->heads; e.D = D;
+            e.qscale = 0.125f * 1.4426950408889634f;
+            DTK_LAUNCH("vit_gemm_qkv", (gemm_bf16_kernel<EPI_QKV>), dim3(dtk_cdiv(3 * D, GN), dtk_cdiv(rows, GM)), dim3(256),
+                       0, st, xn, reinterpret_cast<const bf16_t*>(L.qkv_w), rows, 3 * D, D, e);
+            DTK_LAUNCH("vit_attention", attention_kernel, dim3(dtk_cdiv(S, 128), nf * m->heads), dim3(256), 0, st, q, k, vt,
+                       ao, S, Sp, m->heads, D);
+            e = GemmEpi{};
+            e.bias = L.proj_b; e.x = x; e.gamma = L.ls1;
+            DTK_LAUNCH("vit_gemm_proj", (gemm_bf16_kernel<EPI_RESID>), dim3(dtk_cdiv(D, GN), dtk_cdiv(rows, GM)), dim3(256), 0,
+                       st, ao, reinterpret_cast<const bf16_t*>(L.proj_w), rows, D, D, e);
+            DTK_LAUNCH("vit_layernorm", layernorm_kernel, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x, L.ln2_w, L.ln2_b, xn,
+                       rows, D, m->ln_eps);
+            e = GemmEpi{};
+            e.bias = L.fc1_b; e.out = hid;
+            DTK_LAUNCH("vit_gemm_fc1", (gemm_bf16_kernel<EPI_GELU>), dim3(dtk_cdiv(4 * D, GN), dtk_cdiv(rows, GM)), dim3(256),
+                       0, st, xn, reinterpret_cast<const bf16_t*>(L.fc1_w), rows, 4 * D, D, e);
+            e = GemmEpi{};
+            e.bias = L.fc2_b; e.x = x; e.gamma = L.ls2;
+            DTK_LAUNCH("vit_gemm_fc2", (gemm_bf16_kernel<EPI_RESID>), dim3(dtk_cdiv(D, GN), dtk_cdiv(rows, GM)), dim3(256), 0,
+                       st, hid, reinterpret_cast<const bf16_t*>(L.fc2_w), rows, D, 4 * D, e);
+        }
+        if (tokens_out)
+            DTK_HIP(hipMemcpyAsync(tokens_out + (size_t)f0 * S * D, x, (size_t)rows * D * sizeof(float),
+                                   hipMemcpyDeviceToDevice, st));
+        if (feat_out) {
+            const long long total4 = (long long)nf * HW * (D / 4);
+            DTK_LAUNCH("vit_drop_cls", drop_cls_kernel, dim3(dtk_cdiv(total4, 256)), dim3(256), 0, st, x,
+                       feat_out + (size_t)f0 * HW * D, S, D, total4);
+        }
+    }
+    return DTK_OK;
+}

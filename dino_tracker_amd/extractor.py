@@ -1,0 +1,170 @@
+"""VitExtractor -- the reference's models/extractor.py:16-274 API on the HIP ViT encoder (dtk_vit_forward).
+
+The reference obtains the network through torch.hub (models/extractor.py:26), which needs the network.  Here the
+weights are a plain state dict in upstream facebookresearch/dinov2 naming (`patch_embed.proj.weight`,
+`blocks.{i}.attn.qkv.weight`, `blocks.{i}.ls1.gamma`, ...), taken from, in order:
+  1. the `state_dict=` argument,
+  2. the file named by $DTK_DINOV2_WEIGHTS (e.g. the official dinov2_vits14_pretrain.pth),
+  3. a seeded random initialisation if `random_seed=` is given (synthetic benchmarks / parity tests).
+Anything else raises: there is no silent fallback.
+Only the `tokens` facet (block outputs, models/extractor.py:137-150) is implemented on the device; the q/k/v/attn
+facet getters keep their signatures and raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import VitLayer, VitModel, check, lib
+from .synth import VIT_CONFIGS, make_vit_weights
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+class VitExtractor(nn.Module):
+    BLOCK_KEY, ATTN_KEY, PATCH_IMD_KEY, QKV_KEY = "block", "attn", "patch_imd", "qkv"
+    KEY_LIST = [BLOCK_KEY, ATTN_KEY, PATCH_IMD_KEY, QKV_KEY]
+
+    def __init__(self, model_name, stride, device, state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                 random_seed: Optional[int] = None):
+        super().__init__()
+        if model_name not in VIT_CONFIGS:
+            raise NotImplementedError(f"{model_name}: the HIP encoder covers dinov2_vit{{s,b,l}}14 (d_head 64)")
+        self.model_name, self.stride, self.device = model_name, stride, device
+        self.cfg = VIT_CONFIGS[model_name]
+        if state_dict is None and os.environ.get("DTK_DINOV2_WEIGHTS"):
+            state_dict = torch.load(os.environ["DTK_DINOV2_WEIGHTS"], map_location="cpu")
+        if state_dict is None and random_seed is not None:
+            state_dict = make_vit_weights(model_name, seed=random_seed)
+        if state_dict is None:
+            raise RuntimeError("no DINOv2 weights: pass state_dict=, set $DTK_DINOV2_WEIGHTS to a checkpoint in "
+                               "upstream naming, or ask for random_seed= explicitly (torch.hub needs the network)")
+        self.n_layers = self.get_n_layers()
+        self._sd = {k: v.detach().to(device=device, dtype=torch.float32).contiguous() for k, v in state_dict.items()
+                    if k.startswith(("cls_token", "pos_embed", "patch_embed.", "blocks."))}
+        self._keep = []      # device tensors referenced by the C structs
+        self._layers = None  # ctypes array
+        self._pos_cache = {}
+        self._build_layers()
+
+    # ---- weights -> C structs -----------------------------------------------------------------------------------
+    def _build_layers(self):
+        depth = self.cfg["depth"]
+        arr = (VitLayer * depth)()
+        sd = self._sd
+
+        def f32(name):
+            t = sd[name].contiguous()
+            self._keep.append(t)
+            return t.data_ptr()
+
+        def b16(name):
+            t = sd[name].to(torch.bfloat16).contiguous()
+            self._keep.append(t)
+            return t.data_ptr()
+
+        for i in range(depth):
+            p = f"blocks.{i}."
+            L = arr[i]
+            L.ln1_w, L.ln1_b = f32(p + "norm1.weight"), f32(p + "norm1.bias")
+            L.qkv_w, L.qkv_b = b16(p + "attn.qkv.weight"), f32(p + "attn.qkv.bias")
+            L.proj_w, L.proj_b = b16(p + "attn.proj.weight"), f32(p + "attn.proj.bias")
+            L.ls1 = f32(p + "ls1.gamma")
+            L.ln2_w, L.ln2_b = f32(p + "norm2.weight"), f32(p + "norm2.bias")
+            L.fc1_w, L.fc1_b = b16(p + "mlp.fc1.weight"), f32(p + "mlp.fc1.bias")
+            L.fc2_w, L.fc2_b = b16(p + "mlp.fc2.weight"), f32(p + "mlp.fc2.bias")
+            L.ls2 = f32(p + "ls2.gamma")
+        self._layers = arr
+
+    def _pos_embed(self, ph: int, pw: int):
+        """models/extractor.py:57-85 (`_fix_pos_enc`): bicubic, align_corners=False, scale_factor with the +0.1 fudge,
+        recompute_scale_factor=False; frame independent, so computed once per grid size (torch, one-off)."""
+        key = (ph, pw)
+        if key not in self._pos_cache:
+            pe = self._sd["pos_embed"]
+            n = int(math.sqrt(pe.shape[1] - 1))
+            d = pe.shape[-1]
+            grid = pe[:, 1:].reshape(1, n, n, d).permute(0, 3, 1, 2)
+            grid = F.interpolate(grid, scale_factor=((ph + 0.1) / n, (pw + 0.1) / n), mode="bicubic",
+                                 align_corners=False, recompute_scale_factor=False)
+            assert grid.shape[-2] == ph and grid.shape[-1] == pw
+            pos = grid.permute(0, 2, 3, 1).reshape(ph * pw, d).contiguous()
+            cls_pos = (self._sd["cls_token"].reshape(-1) + pe[0, 0]).contiguous()
+            self._pos_cache[key] = (pos, cls_pos)
+        return self._pos_cache[key]
+
+    # ---- forward ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode(self, frames: torch.Tensor, layer: Optional[int] = None, normalize: bool = True, want: str = "feat"):
+        """frames [n,3,H,W] fp32 -> `feat`: token-major [n, ph*pw, D] (CLS dropped) or `tokens`: [n, 1+ph*pw, D].
+        normalize=True applies the ImageNet mean/std inside the patch-embedding kernel (utils.py:46,55)."""
+        frames = frames.to(self.device, torch.float32).contiguous()
+        n, _, H, W = frames.shape
+        layer = self.n_layers - 1 if layer is None else layer
+        if not 0 <= layer < self.n_layers:
+            raise ValueError(f"layer {layer} out of range")
+        patch = self.get_patch_size()
+        ph, pw = 1 + (H - patch) // self.stride, 1 + (W - patch) // self.stride
+        pos, cls_pos = self._pos_embed(ph, pw)
+        ms = torch.tensor((IMAGENET_MEAN + IMAGENET_STD) if normalize else (0.0, 0.0, 0.0, 1.0, 1.0, 1.0),
+                          dtype=torch.float32, device=self.device)
+        D = self.cfg["dim"]
+        m = VitModel(D, self.cfg["heads"], layer + 1, patch, self.stride, 1e-6, self._sd["patch_embed.proj.weight"].data_ptr(),
+                     self._sd["patch_embed.proj.bias"].data_ptr(), cls_pos.data_ptr(), pos.data_ptr(), ms.data_ptr(),
+                     ctypes.cast(self._layers, ctypes.POINTER(VitLayer)))
+        ws_bytes = int(lib().dtk_vit_workspace_bytes(m, H, W, n))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+        S = ph * pw + 1
+        tokens = torch.empty((n, S, D), dtype=torch.float32, device=self.device) if want == "tokens" else None
+        feat = torch.empty((n, ph * pw, D), dtype=torch.float32, device=self.device) if want == "feat" else None
+        check(lib().dtk_vit_forward(m, ops._p(frames), n, H, W, ops._p(tokens), ops._p(feat), ops._p(ws), ws_bytes,
+                                    ops._stream()))
+        torch.cuda.current_stream().synchronize()  # `ms`, `ws` must outlive the launches
+        return tokens if want == "tokens" else feat
+
+    def get_feature_from_input(self, input_img, layers: List[int]):  # models/extractor.py:137-150
+        """input_img [B,3,H,W] ALREADY ImageNet-normalised (as the reference's caller does) -> mean over `layers` of
+        the block outputs, [B, 1+ph*pw, D]."""
+        outs = [self.encode(input_img, layer=l, normalize=False, want="tokens") for l in layers]
+        return torch.stack(outs).mean(dim=0)
+
+    def _facet_unavailable(self, *a, **k):
+        raise NotImplementedError("only the `tokens` facet runs on the HIP encoder (SURVEY.md 8a row a4)")
+
+    get_qkv_feature_from_input = get_attn_feature_from_input = _facet_unavailable
+    get_keys_from_input = get_queries_from_input = get_values_from_input = _facet_unavailable
+    get_keys_self_sim_from_input = _facet_unavailable
+
+    # ---- static model facts (models/extractor.py:168-222) ----------------------------------------------------------
+    def get_patch_size(self):
+        return 8 if "8" in self.model_name else 14
+
+    def get_width_patch_num(self, input_img_shape):
+        b, c, h, w = input_img_shape
+        return 1 + (w - self.get_patch_size()) // self.stride
+
+    def get_height_patch_num(self, input_img_shape):
+        b, c, h, w = input_img_shape
+        return 1 + (h - self.get_patch_size()) // self.stride
+
+    def get_patch_num(self, input_img_shape):
+        return 1 + self.get_height_patch_num(input_img_shape) * self.get_width_patch_num(input_img_shape)
+
+    def get_n_layers(self):
+        return self.cfg["depth"]
+
+    def get_head_num(self):
+        return self.cfg["heads"]
+
+    @staticmethod
+    def get_embedding_dim(model_name=None):
+        # the reference defines this name twice (instance method shadowed by the static one, :207-222)
+        return VIT_CONFIGS[model_name]["dim"]

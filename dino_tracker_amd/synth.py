@@ -102,3 +102,46 @@ def grid_queries(nx: int, ny: int, h: int = 476, w: int = 854, t: int = 0, margi
     ys = torch.linspace(margin, h - 1 - margin, ny)
     yy, xx = torch.meshgrid(ys, xs, indexing="ij")
     return torch.stack([xx.reshape(-1), yy.reshape(-1), torch.full((nx * ny,), float(t))], dim=1)
+
+
+VIT_CONFIGS = {  # models/extractor.py:183-222
+    "dinov2_vits14": dict(dim=384, depth=12, heads=6),
+    "dinov2_vitb14": dict(dim=768, depth=12, heads=12),
+    "dinov2_vitl14": dict(dim=1024, depth=24, heads=16),
+}
+
+
+def make_vit_weights(model_name: str, seed: int = 2, pos_grid: int = 37, patch: int = 14) -> Dict[str, torch.Tensor]:
+    """Seeded random weights with upstream's parameter names (no checkpoint exists in this environment)."""
+    cfg = VIT_CONFIGS[model_name]
+    d, depth = cfg["dim"], cfg["depth"]
+    g = torch.Generator().manual_seed(seed)
+
+    def tn(*shape, std=0.02):
+        return torch.randn(*shape, generator=g) * std
+
+    sd = {
+        "cls_token": tn(1, 1, d, std=1e-6 * 1e4),
+        "pos_embed": tn(1, 1 + pos_grid * pos_grid, d),
+        "patch_embed.proj.weight": tn(d, 3, patch, patch, std=0.05),
+        "patch_embed.proj.bias": tn(d),
+    }
+    for i in range(depth):
+        p = f"blocks.{i}."
+        sd[p + "norm1.weight"] = 1.0 + tn(d, std=0.1)
+        sd[p + "norm1.bias"] = tn(d, std=0.05)
+        sd[p + "attn.qkv.weight"] = tn(3 * d, d, std=0.04)
+        sd[p + "attn.qkv.bias"] = tn(3 * d)
+        sd[p + "attn.proj.weight"] = tn(d, d, std=0.04)
+        sd[p + "attn.proj.bias"] = tn(d)
+        sd[p + "ls1.gamma"] = 1.0 + tn(d, std=0.1)  # upstream hub models: init_values=1.0
+        sd[p + "norm2.weight"] = 1.0 + tn(d, std=0.1)
+        sd[p + "norm2.bias"] = tn(d, std=0.05)
+        sd[p + "mlp.fc1.weight"] = tn(4 * d, d, std=0.04)
+        sd[p + "mlp.fc1.bias"] = tn(4 * d)
+        sd[p + "mlp.fc2.weight"] = tn(d, 4 * d, std=0.03)
+        sd[p + "mlp.fc2.bias"] = tn(d)
+        sd[p + "ls2.gamma"] = 1.0 + tn(d, std=0.1)
+    return sd
+
+

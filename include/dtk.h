@@ -67,6 +67,44 @@ int dtk_unpack_features(const float* thwc, float* chw, int T, int C, int HW, voi
 /* norms only (after refinement wrote thwc in place) */
 int dtk_feature_norms(const float* thwc, float* norms, int T, int C, int HW, void* stream);
 
+/* ---- P1: DINOv2 ViT encoder as driven by VitExtractor (models/extractor.py:23-150, utils.py:33-72) -----------------
+ * Host-side structs of DEVICE pointers.  Matrix weights are bf16 in nn.Linear layout [out][in]; vectors are fp32.
+ * Upstream facebookresearch/dinov2 parameter names are given for each field (blocks.{i}.*). */
+typedef struct dtk_vit_layer {
+    const float *ln1_w, *ln1_b;   /* norm1.weight / .bias */
+    const void* qkv_w;            /* attn.qkv.weight  bf16 [3D][D] */
+    const float* qkv_b;           /* attn.qkv.bias    [3D] */
+    const void* proj_w;           /* attn.proj.weight bf16 [D][D] */
+    const float* proj_b;          /* attn.proj.bias */
+    const float* ls1;             /* ls1.gamma */
+    const float *ln2_w, *ln2_b;   /* norm2.* */
+    const void* fc1_w;            /* mlp.fc1.weight bf16 [4D][D] */
+    const float* fc1_b;
+    const void* fc2_w;            /* mlp.fc2.weight bf16 [D][4D] */
+    const float* fc2_b;
+    const float* ls2;             /* ls2.gamma */
+} dtk_vit_layer;
+
+typedef struct dtk_vit_model {
+    int32_t D, heads;             /* d_head = D / heads must be 64 (ViT-S/B/L) */
+    int32_t depth;                /* number of blocks to run = hooked layer + 1 (models/extractor.py:137-150) */
+    int32_t patch, stride;        /* 14, 7 (models/extractor.py:41-55) */
+    float ln_eps;                 /* 1e-6 */
+    const float* patch_w;         /* patch_embed.proj.weight fp32 [D][3][patch][patch] */
+    const float* patch_b;         /* patch_embed.proj.bias */
+    const float* cls_pos;         /* cls_token + pos_embed[0]  [D] */
+    const float* pos;             /* interpolated patch position encoding [ph*pw][D] (models/extractor.py:57-85) */
+    const float* mean_std;        /* ImageNet mean[3], std[3] (utils.py:46) */
+    const dtk_vit_layer* layers;  /* HOST array of `depth` entries */
+} dtk_vit_model;
+
+/* frames [n][3][video_h][video_w] fp32 in [0,1] -> block output of layer depth-1 (before the final norm):
+ * tokens_out [n][1 + ph*pw][D] (CLS first; what get_feature_from_input returns) and/or
+ * feat_out   [n][ph*pw][D]     (CLS dropped: the token-major feature volume of this library).  Either may be NULL. */
+size_t dtk_vit_workspace_bytes(const dtk_vit_model* m, int video_h, int video_w, int frames);
+int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int nframes, int video_h, int video_w,
+                    float* tokens_out, float* feat_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- P2: Delta-DINO refinement (models/tracker.py:113-135; models/networks/delta_dino.py:53-61;
  *      models/utils.py:7-45), fp32 on the f32-input MFMA ------------------------------------------------------------
  * dtk_delta_dino_pack: layer l in 0..3 (state-dict keys layers.{4l}.{weight,bias} = conv [Cout][Cin][5][5] and

@@ -271,40 +271,6 @@ VIT_CONFIGS = {  # models/extractor.py:183-222
 }
 
 
-def make_vit_weights(model_name: str, seed: int = 2, pos_grid: int = 37, patch: int = 14) -> Dict[str, torch.Tensor]:
-    """Seeded random weights with upstream's parameter names (no checkpoint exists in this environment)."""
-    cfg = VIT_CONFIGS[model_name]
-    d, depth = cfg["dim"], cfg["depth"]
-    g = torch.Generator().manual_seed(seed)
-
-    def tn(*shape, std=0.02):
-        return torch.randn(*shape, generator=g) * std
-
-    sd = {
-        "cls_token": tn(1, 1, d, std=1e-6 * 1e4),
-        "pos_embed": tn(1, 1 + pos_grid * pos_grid, d),
-        "patch_embed.proj.weight": tn(d, 3, patch, patch, std=0.05),
-        "patch_embed.proj.bias": tn(d),
-    }
-    for i in range(depth):
-        p = f"blocks.{i}."
-        sd[p + "norm1.weight"] = 1.0 + tn(d, std=0.1)
-        sd[p + "norm1.bias"] = tn(d, std=0.05)
-        sd[p + "attn.qkv.weight"] = tn(3 * d, d, std=0.04)
-        sd[p + "attn.qkv.bias"] = tn(3 * d)
-        sd[p + "attn.proj.weight"] = tn(d, d, std=0.04)
-        sd[p + "attn.proj.bias"] = tn(d)
-        sd[p + "ls1.gamma"] = 1.0 + tn(d, std=0.1)  # upstream hub models: init_values=1.0
-        sd[p + "norm2.weight"] = 1.0 + tn(d, std=0.1)
-        sd[p + "norm2.bias"] = tn(d, std=0.05)
-        sd[p + "mlp.fc1.weight"] = tn(4 * d, d, std=0.04)
-        sd[p + "mlp.fc1.bias"] = tn(4 * d)
-        sd[p + "mlp.fc2.weight"] = tn(d, 4 * d, std=0.03)
-        sd[p + "mlp.fc2.bias"] = tn(d)
-        sd[p + "ls2.gamma"] = 1.0 + tn(d, std=0.1)
-    return sd
-
-
 def vit_pos_embed(sd: Dict[str, torch.Tensor], h0: int, w0: int) -> torch.Tensor:
     """models/extractor.py:57-85 (`_fix_pos_enc`).  NB the upstream caller passes (x, w:=H, h:=W) so the reference's
     local `w0` is the token-ROW count and `h0` the token-COLUMN count; here h0/w0 are rows/cols directly.

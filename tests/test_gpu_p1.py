@@ -1,0 +1,79 @@
+"""-m gpu: DINOv2 ViT encoder (P1) through the C-ABI vs the fp32 oracle restatement (seeded random weights).
+The device path uses bf16 matrix operands (fp32 accumulate / residual stream), the oracle fp32, so parity is stated
+at feature level: per-token cosine similarity >= 0.999 and relative Frobenius error <= 2e-2."""
+import pytest
+import torch
+
+from dino_tracker_amd import synth
+from dino_tracker_amd.extractor import VitExtractor
+from oracle import ref_algo as A
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(got, ref, cos_min=0.999, rel_max=2e-2):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    cos = torch.nn.functional.cosine_similarity(got, ref, dim=-1)
+    rel = (got - ref).norm() / ref.norm()
+    assert cos.min() >= cos_min, (cos.min().item(), rel.item())
+    assert rel <= rel_max, (cos.min().item(), rel.item())
+    return cos.min().item(), rel.item()
+
+
+@pytest.fixture(scope="module")
+def vits():
+    sd = synth.make_vit_weights("dinov2_vits14", seed=2)
+    return sd, VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd)
+
+
+@pytest.mark.parametrize("layer", [0, 3, 11])
+def test_small_frames_all_depths(vits, layer):
+    sd, ex = vits
+    video = synth.synth_video(3, 140, 210, seed=71)  # 19 x 29 tokens; 3 frames in one batch
+    feat = ex.encode(video, layer=layer)
+    assert feat.shape == (3, 19 * 29, 384)
+    for t in range(3):
+        ref = A.vit_tokens(video[t:t + 1], sd, "dinov2_vits14", layer=layer).permute(1, 2, 0).reshape(-1, 384)
+        _check(feat[t], ref)
+
+
+def test_full_resolution_first_blocks(vits):
+    """476 x 854 -> 8107 patch tokens + CLS (not a multiple of the 64-key tile: exercises the masked tail)."""
+    sd, ex = vits
+    video = synth.synth_video(1, 476, 854, seed=72)
+    feat = ex.encode(video, layer=1)
+    ref = A.vit_tokens(video, sd, "dinov2_vits14", layer=1).permute(1, 2, 0).reshape(-1, 384)
+    _check(feat[0], ref)
+
+
+def test_get_feature_from_input_includes_cls(vits):
+    sd, ex = vits
+    video = synth.synth_video(1, 98, 126, seed=73)
+    m = torch.tensor(A.IMAGENET_MEAN).view(1, 3, 1, 1)
+    s = torch.tensor(A.IMAGENET_STD).view(1, 3, 1, 1)
+    tok = ex.get_feature_from_input(((video - m) / s).cuda(), layers=[2])
+    assert tok.shape == (1, 1 + 13 * 17, 384)
+    ref = A.vit_tokens(video, sd, "dinov2_vits14", layer=2).permute(1, 2, 0).reshape(-1, 384)
+    _check(tok[0, 1:], ref)
+    assert torch.isfinite(tok[0, 0]).all() and tok[0, 0].abs().sum() > 0
+
+
+def test_get_dino_features_video_contract(vits):
+    from dino_tracker_amd.utils import get_dino_features_video
+    sd, _ = vits
+    video = synth.synth_video(2, 98, 126, seed=74)
+    out = get_dino_features_video(video.cuda(), model_name="dinov2_vits14", facet="tokens", stride=7, layer=1,
+                                  device="cuda:0", state_dict=sd)
+    assert out.device.type == "cpu" and out.shape == (2, 384, 13, 17)  # utils.py:53,67: T x C x ph x pw on the CPU
+    ref = A.vit_tokens(video[1:2], sd, "dinov2_vits14", layer=1)
+    _check(out[1].permute(1, 2, 0).reshape(-1, 384), ref.permute(1, 2, 0).reshape(-1, 384))
+
+
+def test_vitb_width(vits):
+    """ViT-B/14 (D = 768, 12 heads) shares the kernels."""
+    sd = synth.make_vit_weights("dinov2_vitb14", seed=5)
+    ex = VitExtractor("dinov2_vitb14", stride=7, device="cuda:0", state_dict=sd)
+    video = synth.synth_video(1, 98, 126, seed=75)
+    feat = ex.encode(video, layer=1)
+    ref = A.vit_tokens(video, sd, "dinov2_vitb14", layer=1).permute(1, 2, 0).reshape(-1, 768)
+    _check(feat[0], ref)
