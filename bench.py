@@ -35,6 +35,12 @@ def parse():
     ap.add_argument("--queries", type=int, default=1024)
     ap.add_argument("--width", type=int, default=384, help="feature width C (384 = ViT-S/14)")
     ap.add_argument("--method", default="auto", choices=["auto", "exact", "mfma"])
+    ap.add_argument("--stages", default="extract,refine,track",
+                    help="comma list of extract (ViT), refine (Delta-DINO), track (ModelInference.infer); stages that "
+                         "are left out are computed once outside the timed region")
+    ap.add_argument("--features", default="vit", choices=["vit", "synthetic"],
+                    help="vit: features come from the (random-weight) ViT on the synthetic video; synthetic: the "
+                         "feature-level generator with dense anchors (worst case for the tracker stage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=1, help="queries in the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -67,19 +73,38 @@ def main():
     if method is None:
         method = ops.TRACK_MFMA if ops.feat_f16_bytes(__import__("dino_tracker_amd")._lib.make_geom(T, C, H, W)) > 0 else ops.TRACK_EXACT
 
-    # per-rank synthetic video at the feature level (SURVEY.md 8d "north-star" generator): dense anchors
-    feats = synth.synth_features(T, C, 67, 121, seed=1000 + rank)
+    stages = [x for x in args.stages.split(",") if x]
+    from dino_tracker_amd.extractor import VitExtractor
+    from dino_tracker_amd.tracker import Tracker
+    from dino_tracker_amd._lib import make_geom
+    model_name = {384: "dinov2_vits14", 768: "dinov2_vitb14", 1024: "dinov2_vitl14"}[C]
+    # per-rank synthetic inputs: translating-texture video, seeded random weights
+    video = synth.synth_video(T, H, W, seed=2000 + rank).to(dev)
     head = synth.synth_head_weights(3)
+    delta = synth.synth_delta_dino_weights(C, seed=4)
     queries = synth.grid_queries(nx, ny, H, W, 0).to(dev)
-    trk = gpu_util.make_tracker(torch.zeros(T, 3, H, W), feats, head, method=method)
-    mi = ModelInference(trk, RangeNormalizer((W, H, T), device=dev), 0.7, 0.6)
+    ex = VitExtractor(model_name, stride=7, device=dev, random_seed=2)
+    if args.features == "vit":
+        feats0 = ex.encode(video)
+    else:
+        feats0 = synth.synth_features(T, C, 67, 121, seed=1000 + rank).to(dev).permute(0, 2, 3, 1).reshape(T, 67 * 121, C).contiguous()
+        stages = [x for x in stages if x != "extract"]
+    trk = Tracker(video=video, dino_features=feats0, dino_patch_size=14, stride=7, device=dev, track_method=method)
+    trk.tracker_head.load_state_dict(head)
+    trk.delta_dino.load_state_dict(delta)
+    trk.to(dev).eval()
+    mi = ModelInference(trk, RangeNormalizer((W, H, T), device=dev), 0.7, 0.6)  # caches refined features once
 
     gather_buf = None
 
     def step():
         nonlocal gather_buf
-        traj, occ = mi.infer(queries)
-        if world > 1:
+        if "extract" in stages:
+            trk.set_video(video, ex.encode(video))        # P1: ViT-S/14 block-11 tokens, stride 7
+        if "refine" in stages or "extract" in stages:
+            trk.cache_refined_embeddings()                # P2: dino + Delta-DINO(video)
+        traj, occ = mi.infer(queries) if "track" in stages else (None, None)   # P3
+        if world > 1 and traj is not None:
             import torch.distributed as dist
             payload = torch.cat([traj.reshape(-1), occ.reshape(-1).float()])
             if rank == 0:
@@ -116,23 +141,42 @@ def main():
     ops.profile_enable(False)
     roofline = None
     if prof:
+        HW, S = 67 * 121, 67 * 121 + 1
+        depth = 12 if C in (384, 768) else 24
+        f_delta = 2.0 * (406504 * 4800 + 101626 * 204800 + 25466 * 819200 + 6420 * 6400 * C)
+        # ALGORITHMIC flops of one step per kernel, and the peak that bounds it (TFLOP/s, dense)
+        algo = {
+            "vit_attention": (4.0 * S * S * C * depth * T, MFMA_F16_PEAK_TF),
+            "vit_gemm_qkv": (2.0 * S * C * 3 * C * depth * T, MFMA_F16_PEAK_TF),
+            "vit_gemm_proj": (2.0 * S * C * C * depth * T, MFMA_F16_PEAK_TF),
+            "vit_gemm_fc1": (2.0 * S * C * 4 * C * depth * T, MFMA_F16_PEAK_TF),
+            "vit_gemm_fc2": (2.0 * S * C * 4 * C * depth * T, MFMA_F16_PEAK_TF),
+            "vit_patch_embed": (2.0 * HW * 588 * C * T, F32_PEAK_TF),
+            "dd_conv1": (2.0 * 406504 * 4800 * T, F32_PEAK_TF),
+            "dd_conv23": (2.0 * (101626 * 204800 + 25466 * 819200) * T, F32_PEAK_TF),
+            "dd_conv4": (2.0 * 6420 * 6400 * C * T, F32_PEAK_TF),
+            "corr16": (2.0 * HW * C * maps, MFMA_F16_PEAK_TF),
+            "corr_exact": (2.0 * HW * C * maps, F32_PEAK_TF),
+            "head16": (576.0 * HW * maps, 2 * F32_PEAK_TF),       # v_dot2_f32_f16: 2 MACs per lane-op
+            "head_exact": (576.0 * HW * maps, F32_PEAK_TF),
+            "refine_corr": (2.0 * 225 * C * maps, F32_PEAK_TF),   # (2*RD+5)^2 window cells per map
+            "refine_head": (2.0 * (169 + 121) * 144 * maps, F32_PEAK_TF),
+        }
         dom = max(prof, key=lambda k: prof[k][0])
         ms, launches = prof[dom]
-        HW = 67 * 121
-        per_map_flops = {"corr_exact": 2.0 * HW * C, "corr16": 2.0 * HW * C, "head_exact": 576.0 * HW,
-                         "head16": 576.0 * HW}
-        peak = {"corr_exact": F32_PEAK_TF, "head_exact": F32_PEAK_TF, "corr16": MFMA_F16_PEAK_TF,
-                "head16": F32_PEAK_TF}
-        if dom in per_map_flops:
-            achieved = per_map_flops[dom] * maps / (ms * 1e-3) / 1e12
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak[dom],
-                        "unit": "TFLOP/s", "frac": round(achieved / peak[dom], 4), "traffic": None,
-                        "avg_launch_ms": round(ms / max(launches, 1), 4), "launches": launches}
+        if dom in algo:
+            fl, peak = algo[dom]
+            achieved = fl / (ms * 1e-3) / 1e12
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
+                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None}
         else:
             roofline = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": None, "traffic": None, "avg_launch_ms": round(ms / max(launches, 1), 4),
-                        "launches": launches}
-        roofline["kernel_ms"] = {k: round(v[0], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:8]}
+                        "frac": None, "traffic": None}
+        roofline["avg_launch_ms"] = round(ms / max(launches, 1), 4)
+        roofline["launches"] = launches
+        roofline["kernel_ms"] = {k: round(v[0], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]}
+        roofline["kernel_tflops"] = {k: round(algo[k][0] / (prof[k][0] * 1e-3) / 1e12, 1) for k in prof
+                                     if k in algo and prof[k][0] > 0}
 
     # ---- CPU baseline: the oracle (torch fp32 port of the reference algorithm) on a bounded sample --------------
     cpu = None
@@ -142,7 +186,8 @@ def main():
         sel = torch.linspace(0, N - 1, nq).long()
         q_cpu = queries.cpu()[sel]
         c0 = time.perf_counter()
-        _, _, cs_cpu, _ = A.infer(feats, q_cpu, head, H, W, return_aux=True)
+        feats_cpu = trk.refined_features.cpu()
+        _, _, cs_cpu, _ = A.infer(feats_cpu, q_cpu, head, H, W, return_aux=True)
         cdt = time.perf_counter() - c0
         cpu = {"value": round(nq * T / cdt, 3), "unit": "query-points*frames/s", "cores": torch.get_num_threads(),
                "kind": "port",
@@ -159,7 +204,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"854x480x{T} synthetic video (model res 854x476, 67x121 tokens, C={C}), {N} grid "
                                    f"queries, one video per GPU",
-                       "stages": ["track: ModelInference.infer on cached refined features"],
+                       "stages": stages, "features": args.features,
                        "track_method": "exact" if method == ops.TRACK_EXACT else "mfma",
                        "anchor_pairs": pairs, "correlation_maps_per_step": maps, "parallelism": f"video-parallel x{world}"},
             "roofline": roofline, "cpu_baseline": cpu,

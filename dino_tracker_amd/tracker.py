@@ -32,7 +32,10 @@ def load_pre_trained_model(pre_trained_sd, target_model):
 class Tracker(nn.Module):
     def __init__(self, video=None, ckpt_path="", dino_embed_path="", dino_patch_size=14, stride=7, device="cuda:0",
                  cyc_n_frames=4, cyc_batch_size_per_frame=256, cyc_fg_points_ratio=0.7, cyc_thresh=4,
-                 track_method: Optional[int] = None):
+                 track_method: Optional[int] = None, dino_features: Optional[torch.Tensor] = None):
+        """Reference signature (models/tracker.py:18-30) plus two optional extensions: `track_method`
+        (ops.TRACK_MFMA default / ops.TRACK_EXACT) and `dino_features`, a device-resident token-major
+        [T, ph*pw, C] volume handed over by the extractor instead of the dino_embed_video.pt round trip."""
         super().__init__()
         self.stride = stride
         self.dino_patch_size = dino_patch_size
@@ -42,7 +45,8 @@ class Tracker(nn.Module):
         self.cyc_n_frames, self.cyc_batch_size_per_frame = cyc_n_frames, cyc_batch_size_per_frame
         self.cyc_fg_points_ratio, self.cyc_thresh = cyc_fg_points_ratio, cyc_thresh
         self.video = video
-        self.track_method = ops.TRACK_EXACT if track_method is None else track_method
+        self.track_method = ops.TRACK_MFMA if track_method is None else track_method
+        self._dino_features_arg = dino_features
 
         self._dino = None          # token-major raw embeddings  [T][HW][C]
         self._dino_norms = None
@@ -53,38 +57,68 @@ class Tracker(nn.Module):
         self._refined_chw = None   # lazily unpacked view for callers reading `.refined_features`
         self._workspace = None
 
+        self._dino_chw = None
         self.load_dino_embed_video()
         t, c, h, w = self.video.shape
-        emb_c = self.dino_embed_video.shape[1]
+        emb_c = self._dino.shape[2]
         self.delta_dino = DeltaDINO(channels=[3, 64, 128, 256, emb_c], vit_stride=self.stride).to(device)
         self.tracker_head = TrackerHead(use_cnn_refiner=True, patch_size=dino_patch_size, step_h=stride, step_w=stride,
                                         video_h=h, video_w=w).to(device)
         self.range_normalizer = RangeNormalizer(shapes=(w, h, t), device=device)
         self.geom = make_geom(t, emb_c, h, w, dino_patch_size, stride, float(self.tracker_head.argmax_radius))
-        eh, ew = self.dino_embed_video.shape[-2:]
-        if (eh, ew) != (self.geom.ph, self.geom.pw) or self.dino_embed_video.shape[0] != t:
-            raise RuntimeError(f"dino embeddings {tuple(self.dino_embed_video.shape)} do not match video "
+        if self._dino.shape[1] != self.geom.ph * self.geom.pw or self._dino.shape[0] != t:
+            raise RuntimeError(f"dino embeddings {tuple(self._dino.shape)} (T, tokens, C) do not match video "
                                f"{tuple(self.video.shape)} at patch {dino_patch_size} stride {stride}")
+        if emb_c % 32 != 0 and self.track_method == ops.TRACK_MFMA:
+            self.track_method = ops.TRACK_EXACT  # the MFMA path needs C % 32 == 0
 
     # ---- embeddings ------------------------------------------------------------------------------------
     @torch.no_grad()
     def load_dino_embed_video(self):
-        """tracker.py:64-71: T x C x h x w tensor written by preprocessing/save_dino_embed_video.py."""
+        """tracker.py:64-71: the T x C x h x w tensor written by preprocessing/save_dino_embed_video.py, kept
+        token-major on the device; or the in-memory volume passed as `dino_features`."""
+        if self._dino_features_arg is not None:
+            self._dino = self._dino_features_arg.to(self.device, torch.float32).contiguous()
+            self._dino_norms = ops.feature_norms(self._dino)
+            self._dino_features_arg = None
+            return
         assert os.path.exists(self.dino_embed_path)
-        self.dino_embed_video = torch.load(self.dino_embed_path, map_location=self.device).to(torch.float32).contiguous()
+        chw = torch.load(self.dino_embed_path, map_location=self.device).to(torch.float32).contiguous()
+        self._dino, self._dino_norms = ops.pack_features(chw)
 
-    def set_dino_embed_video(self, emb: torch.Tensor):
-        """In-memory hand-off from the extractor (no .pt round trip)."""
-        self.dino_embed_video = emb.to(self.device, torch.float32).contiguous()
-        self._dino = self._dino_norms = self._dino_f16 = None
+    @torch.no_grad()
+    def set_video(self, video: torch.Tensor, dino_features: torch.Tensor):
+        """Re-target this tracker (weights kept) at another video of the same geometry: `video` [T,3,H,W] and its
+        token-major DINO volume [T, ph*pw, C] straight from the extractor.  Drops every cached derived tensor."""
+        if tuple(video.shape[1:]) != tuple(self.video.shape[1:]) or video.shape[0] != self.geom.T:
+            raise RuntimeError("set_video: geometry differs; build a new Tracker")
+        if tuple(dino_features.shape) != (self.geom.T, self.geom.ph * self.geom.pw, self.geom.C):
+            raise RuntimeError(f"set_video: dino_features {tuple(dino_features.shape)} != (T, tokens, C)")
+        self.video = video
+        self._dino = dino_features.to(self.device, torch.float32).contiguous()
+        self._dino_norms = ops.feature_norms(self._dino)
+        self._dino_chw = self._dino_f16 = None
+        self.refined_features = None
+
+    @property
+    def dino_embed_video(self):
+        """T x C x h x w view for callers of the reference attribute (unpacked on first use)."""
+        if self._dino_chw is None:
+            self._dino_chw = ops.unpack_features(self._dino, self.geom.ph, self.geom.pw)
+        return self._dino_chw
+
+    @dino_embed_video.setter
+    def dino_embed_video(self, emb):
+        emb = emb.to(self.device, torch.float32).contiguous()
+        self._dino, self._dino_norms = ops.pack_features(emb)
+        self._dino_chw = None
+        self._dino_f16 = None
 
     def _packed_dino(self):
-        if self._dino is None:
-            self._dino, self._dino_norms = ops.pack_features(self.dino_embed_video)
         return self._dino, self._dino_norms
 
     def get_dino_embed_video(self, frames_set_t):
-        return self.dino_embed_video[frames_set_t.to(self.dino_embed_video.device).long()]
+        return self.dino_embed_video[frames_set_t.to(self.device).long()]
 
     @property
     def refined_features(self):
@@ -141,7 +175,7 @@ class Tracker(nn.Module):
     def get_refined_embeddings(self, frames_set_t, return_raw_embeddings=False):
         """tracker.py:113-129 for an arbitrary frame subset (T' x C x h x w tensors, reference layout)."""
         from .delta_dino import refine_frames
-        idx = frames_set_t.to(self.dino_embed_video.device).long()
+        idx = frames_set_t.to(self.device).long()
         dino = self.dino_embed_video[idx].contiguous()
         refined = refine_frames(self.delta_dino, self.video[idx].contiguous(), dino, self.geom)
         residual = refined - dino
@@ -158,15 +192,13 @@ class Tracker(nn.Module):
         self._refined_norms = ops.feature_norms(self._refined)
         self._refined_f16 = None
         self._refined_chw = None
-        if move_dino_to_cpu:
-            self.dino_embed_video = self.dino_embed_video.to("cpu")
+        # move_dino_to_cpu was a memory knob of the reference (two fp32 copies of the volume); the raw volume stays
+        # on the device here because Tracker.forward(use_raw_features=True) reads it in place.
 
     def uncache_refined_embeddings(self, move_dino_to_gpu=False):
         self.refined_features = None
         torch.cuda.empty_cache()
         gc.collect()
-        if move_dino_to_gpu:
-            self.dino_embed_video = self.dino_embed_video.to(self.device)
 
     # ---- checkpoints (tracker.py:144-156) ------------------------------------------------------------------
     def save_weights(self, iter):
