@@ -16,6 +16,7 @@
 //   sources whose fp16 pass is inconclusive (more than KC candidates, fallback test within its error band)
 //   are appended to a redo list and re-done by the exact path (track_exact.hip) -- device-side count, no host sync.
 #include <limits.h>
+#include <stdlib.h>
 #include "common.h"
 #include "head_common.h"
 
@@ -39,7 +40,8 @@ constexpr int CM = 64, CN = 128, CK = 32; // corr16 tile
 constexpr int RB = 8;                     // head16: output rows per block
 constexpr int NB_MAX = 1536;              // refine: largest window-union box (cells) correlated as one group
 constexpr int RD = 5;                     // disk radius in cells supported by refine32 (radius / stride <= 5)
-constexpr int MFMA_CHUNK = 8192;
+constexpr int MFMA_CHUNK = 16384;
+constexpr int MFMA_SUPER = 262144;
 
 struct Rec {  // per source, written by head16, read by refine32
     float amax;
@@ -238,142 +240,191 @@ __global__ void head16_pack_kernel(const float* __restrict__ head, uint32_t* __r
 
 __device__ __forceinline__ h2 as_h2(uint32_t u) { return *reinterpret_cast<h2*>(&u); }
 
+// head16_kernel: one workgroup per map.  The map sits in LDS as fp16 with a zero border; besides the approximate maximum
+// and the candidate cells, the whole refiner runs on the matrix cores without ever staging the hidden activations:
+//   conv1 as GEMM1 (MFMA 16x16x16 f16):  h^T[16 ch][16 px] = W1[16 ch][K = 3 rows x (3 taps + pad) | bias] . X[K][16 px]
+//   D of GEMM1 (lane (g, j): channels 4g..4g+3 of pixel j) IS the B fragment of
+//   conv2 as GEMM2:  P[(dy, dx)][16 px] = W2[taps][16 ch] . relu(h)^T   (per-pixel 16 -> 9 projection)
+//   z[row r+dy'][col c] = sum_dx P[(dy, dx)][c + dx]: the dx sum is two DPP row shifts, the dy sum is carried in one
+//   accumulator per 16-lane group: the group <-> output-row assignment rotates with the row (three static A2 variants),
+//   so each lane group finishes one output row every third step and no data ever moves between groups.
+// Work item = (14-column segment, quarter of the rows); 36 items over the 4 waves.
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+template <int DPP>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), DPP, 0xF, 0xF, true));
+}
+
+struct HeadLane {  // per-lane constants of the chained GEMMs
+    h4 a1;         // W1 fragment
+    h4 a2[3];      // W2 fragment per phase
+    float keep[3]; // 0 where this lane's group starts a new output row at that phase, else 1
+    int done[3];   // 1 where this lane's group completes an output row at that phase
+};
+
+__device__ __forceinline__ void head_step(const HeadLane& L, int v, bool row_ok, bool can_complete, const half_t* xp,
+                                          unsigned hmask, float& acc, float& zst) {
+    float V = 0.f;
+    if (row_ok) {
+        // B1: k = 4g + i: rows r'-1+g (g < 3), taps dx = i-1 (i < 3); g = 3: the constant (1,0,0,0) for the bias
+        // three 2-byte LDS reads straight into packed halves (the address is only 2-byte aligned: a merged
+        // ds_read_b32 would be a misaligned access); loads and their wait live in one asm statement (the compiler does
+        // not count asm loads)
+        unsigned xlo, xhi;
+        asm volatile(
+            "v_mov_b32 %1, 0\n\t"
+            "ds_read_u16_d16 %0, %2\n\t"
+            "ds_read_u16_d16_hi %0, %2 offset:2\n\t"
+            "ds_read_u16_d16 %1, %2 offset:4\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(xlo), "=&v"(xhi)
+            : "v"((unsigned)(size_t)xp)
+            : "memory");
+        const h2 x01 = __builtin_bit_cast(h2, xlo), x2 = __builtin_bit_cast(h2, xhi);
+        const h4 b1 = {x01[0], x01[1], x2[0], x2[1]};
+        f4 d1 = {0.f, 0.f, 0.f, 0.f};
+        d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(L.a1, b1, d1, 0, 0, 0);
+        // fp16 (round-to-zero pack never overflows to inf) + packed relu; hidden activations outside the map are zero
+        // (conv2's zero padding)
+        const h2 zero2 = {(half_t)0.f, (half_t)0.f};
+        h2 lo = __builtin_elementwise_max(__builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(d1[0], d1[1])), zero2);
+        h2 hi = __builtin_elementwise_max(__builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(d1[2], d1[3])), zero2);
+        unsigned ulo = __builtin_bit_cast(unsigned, lo) & hmask, uhi = __builtin_bit_cast(unsigned, hi) & hmask;
+        lo = __builtin_bit_cast(h2, ulo);
+        hi = __builtin_bit_cast(h2, uhi);
+        const h4 b2 = {lo[0], lo[1], hi[0], hi[1]};
+        f4 d2 = {0.f, 0.f, 0.f, 0.f};
+        d2 = __builtin_amdgcn_mfma_f32_16x16x16f16(L.a2[v], b2, d2, 0, 0, 0);
+        // sum over dx: P[dx=-1] of the pixel to the left, P[dx=0] here, P[dx=+1] of the pixel to the right
+        V = dpp_f<0x111>(d2[0]) + d2[1] + dpp_f<0x101>(d2[2]);
+    }
+    acc = fmaf(acc, L.keep[v], V);
+    if (can_complete) zst = L.done[v] ? acc : zst;
+}
+
 __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __restrict__ head,
                                                      const uint32_t* __restrict__ wpk,
                                                      const half_t* __restrict__ maps, int HWp, Rec* __restrict__ rec,
-                                                     int m0, int count, int M, const int32_t* __restrict__ dM) {
+                                                     int m0, int count, int M, const int32_t* __restrict__ dM, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int ph = g.ph, pw = g.pw, HW = ph * pw;
-    const int xw = pw + 2;                                   // zero-bordered row pitch
-    const int xs_elems = ((ph + 2) * xw + 7) & ~7;
-    half_t* xs = reinterpret_cast<half_t*>(smem_raw);        // [(ph+2)][(pw+2)]
-    uint4* hb = reinterpret_cast<uint4*>(smem_raw + (size_t)xs_elems * 2);   // [(RB+2)][(pw+2)][2 x uint4]
-    float* red = reinterpret_cast<float*>(hb + (size_t)(RB + 2) * xw * 2);   // 8 floats
-    int* s_cnt = reinterpret_cast<int*>(red + 8);
-    int* s_cand = s_cnt + 1;                                 // KC ints
+    const int xw = pw + 4;                                  // 2 zero columns on each side
+    const int xs_elems = (ph + 2) * xw + 32;                // + slack: edge segments read a little past a row
+    half_t* xs = reinterpret_cast<half_t*>(smem_raw);       // [(ph+2)][(pw+4)], row -1 and row ph are zero
+    half_t* cst = xs + ((xs_elems + 7) & ~7);               // {1, 0, 0, 0}: the bias column of B1
+    float* red = reinterpret_cast<float*>(cst + 8);         // 16 floats
+    int* s_cnt = reinterpret_cast<int*>(red + 16);
+    int* s_cand = s_cnt + 1;                                // KC ints
     const int i = blockIdx.x;
     const int m = m0 + i;
     if (i >= count || m >= dtk_active(M, dM)) return;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const half_t* map = maps + (size_t)i * HWp;
-    for (int c = tid; c < xs_elems; c += 256) xs[c] = (half_t)0.f;
-    for (int c = tid; c < (RB + 2) * xw * 2; c += 256) hb[c] = make_uint4(0, 0, 0, 0);
+    for (int c = tid; c < ((xs_elems + 7) & ~7); c += 256) xs[c] = (half_t)0.f;
+    if (tid < 8) cst[tid] = (half_t)(tid == 0 ? 1.f : 0.f);
     if (tid == 0) *s_cnt = 0;
     __syncthreads();
     float amax = 0.f;
     for (int c = tid; c < HW; c += 256) {
         const half_t v = map[c];
-        xs[(c / pw + 1) * xw + c % pw + 1] = v;
+        xs[(c / pw + 1) * xw + c % pw + 2] = v;
         amax = fmaxf(amax, (float)v);
     }
     amax = wave_max(amax);
-    if ((tid & 63) == 0) red[tid >> 6] = amax;
+    if (lane == 0) red[w] = amax;
     __syncthreads();
     amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     const float thr = amax - EPS_C;
-    for (int c = tid; c < HW; c += 256) {
-        const float v = (float)xs[(c / pw + 1) * xw + c % pw + 1];
+    for (int c = tid; c < ((dbg & 64) ? 0 : HW); c += 256) {
+        const float v = (float)xs[(c / pw + 1) * xw + c % pw + 2];
         if (v >= thr) {
             const int slot = atomicAdd(s_cnt, 1);
             if (slot < KC) s_cand[slot] = c;
         }
     }
 
-    // weights live in VGPRs: an opaque per-lane zero keeps the compiler from turning these into scalar loads that
-    // would have to be re-fetched (and waited for on the counter shared with LDS) in every pixel iteration
-    int vz;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
-    h2 wa[80], wb[72];
-    float bia[16];
+    // ---- per-lane constants ----
+    const int lg = lane >> 4, lj = lane & 15;
+    HeadLane L;
+    {
+        // A1[m = ch lj][k = 4*lg + i]
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        if (lg < 3) {
 #pragma unroll
-    for (int k = 0; k < 80; ++k) wa[k] = as_h2(wpk[k + vz]);
-#pragma unroll
-    for (int k = 0; k < 72; ++k) wb[k] = as_h2(wpk[80 + k + vz]);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) bia[k] = head[144 + k + vz];
-    const float b2 = head[304];
-    float rm = -INFINITY, rs = 0.f;  // running max / sum of exp for this thread's logits
-    for (int r0 = 0; r0 < ph; r0 += RB) {
-        const int nout = min(RB, ph - r0);
-        __syncthreads();
-        // hidden rows r0-1 .. r0+nout; rows outside the map are zero (conv2's zero padding)
-        for (int idx = tid; idx < (nout + 2) * pw; idx += 256) {
-            const int hr = idx / pw, c = idx - hr * pw;
-            const int row = r0 - 1 + hr;
-            uint4 o0 = make_uint4(0, 0, 0, 0), o1 = o0;
-            if (row >= 0 && row < ph) {
-                const half_t* xp = xs + (row + 1) * xw + (c + 1);
-                const h2 x01 = {xp[-xw - 1], xp[-xw]}, x23 = {xp[-xw + 1], xp[-1]}, x45 = {xp[0], xp[1]},
-                         x67 = {xp[xw - 1], xp[xw]}, x8 = {xp[xw + 1], (half_t)0.f};
-                uint32_t hh[8];
-#pragma unroll
-                for (int cp = 0; cp < 8; ++cp) {
-                    float a[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int ch = 2 * cp + e;
-                        float acc = bia[ch];
-                        acc = __builtin_amdgcn_fdot2(wa[ch * 5 + 0], x01, acc, false);
-                        acc = __builtin_amdgcn_fdot2(wa[ch * 5 + 1], x23, acc, false);
-                        acc = __builtin_amdgcn_fdot2(wa[ch * 5 + 2], x45, acc, false);
-                        acc = __builtin_amdgcn_fdot2(wa[ch * 5 + 3], x67, acc, false);
-                        acc = __builtin_amdgcn_fdot2(wa[ch * 5 + 4], x8, acc, false);
-                        a[e] = fminf(fmaxf(acc, 0.f), 60000.f);
-                    }
-                    h2 v = {(half_t)a[0], (half_t)a[1]};
-                    hh[cp] = *reinterpret_cast<uint32_t*>(&v);
-                }
-                o0 = make_uint4(hh[0], hh[1], hh[2], hh[3]);
-                o1 = make_uint4(hh[4], hh[5], hh[6], hh[7]);
-            }
-            hb[(hr * xw + c + 1) * 2] = o0;
-            hb[(hr * xw + c + 1) * 2 + 1] = o1;
+            for (int q = 0; q < 3; ++q) a[q] = head[lj * 9 + lg * 3 + q];  // tap (dy = lg-1, dx = q-1)
+        } else {
+            a[0] = head[144 + lj];
         }
-        __syncthreads();
-        for (int idx = tid; idx < nout * pw; idx += 256) {
-            const int ro = idx / pw, c = idx - ro * pw;
-            float a0 = b2, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // four independent accumulation chains
+        L.a1 = h4{(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]};
+        // A2_v[m = lj][k = ch 4*lg + i]: m = 4*gm + t <-> (dy of group gm at phase v, dx = t-1)
+        const int gm = lj >> 2, t = lj & 3;
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
+        for (int v = 0; v < 3; ++v) {
+            float b[4] = {0.f, 0.f, 0.f, 0.f};
+            if (gm < 3 && t < 3) {
+                const int dy = (gm == (v + 1) % 3) ? -1 : ((gm == v) ? 0 : 1);
 #pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int tap = (dy + 1) * 3 + dx + 1;
-                    const uint4 v0 = hb[((ro + 1 + dy) * xw + c + 1 + dx) * 2];
-                    const uint4 v1 = hb[((ro + 1 + dy) * xw + c + 1 + dx) * 2 + 1];
-                    a0 = __builtin_amdgcn_fdot2(wb[tap * 8 + 0], as_h2(v0.x), a0, false);
-                    a1 = __builtin_amdgcn_fdot2(wb[tap * 8 + 1], as_h2(v0.y), a1, false);
-                    a2 = __builtin_amdgcn_fdot2(wb[tap * 8 + 2], as_h2(v0.z), a2, false);
-                    a3 = __builtin_amdgcn_fdot2(wb[tap * 8 + 3], as_h2(v0.w), a3, false);
-                    a0 = __builtin_amdgcn_fdot2(wb[tap * 8 + 4], as_h2(v1.x), a0, false);
-                    a1 = __builtin_amdgcn_fdot2(wb[tap * 8 + 5], as_h2(v1.y), a1, false);
-                    a2 = __builtin_amdgcn_fdot2(wb[tap * 8 + 6], as_h2(v1.z), a2, false);
-                    a3 = __builtin_amdgcn_fdot2(wb[tap * 8 + 7], as_h2(v1.w), a3, false);
-                }
-            const float acc = (a0 + a1) + (a2 + a3);
-            const float mn = fmaxf(rm, acc);
-            rs = rs * expf(rm - mn) + expf(acc - mn);
-            rm = mn;
+                for (int q = 0; q < 4; ++q) b[q] = head[160 + (4 * lg + q) * 9 + (dy + 1) * 3 + t];
+            }
+            L.a2[v] = h4{(half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+            L.keep[v] = (lg == (v + 1) % 3) ? 0.f : 1.f;
+            L.done[v] = (lg == (v + 2) % 3) ? 1 : 0;
         }
     }
-    // merge the per-thread (max, sum) pairs
+    const float b2 = head[304];
+    const int nq = (pw + 13) / 14;
+    float rm = -1e30f, rs = 0.f;  // this lane's running (max, sum of exp) over the logits it completed
+    __syncthreads();
+    const int wu = __builtin_amdgcn_readfirstlane(w);  // provably wave-uniform: the row loop below becomes scalar control flow
+    for (int item = wu; item < ((dbg & 32) ? 0 : nq * 4); item += 4) {
+        const int q = item >> 2, rq = item & 3;
+        const int ra = (ph * rq) >> 2, rb = (ph * (rq + 1)) >> 2;
+        const int cj = 14 * q - 1 + lj;                               // this lane's pixel column
+        const unsigned hmask = (cj >= 0 && cj < pw) ? 0xFFFFFFFFu : 0u;
+        const bool zok = lg < 3 && lj >= 1 && lj <= 14 && cj < pw;
+        // B1 source: lanes of group g < 3 read row r'-1+g at columns cj-1..cj+1; group 3 reads the constant
+        const half_t* xp = (lg < 3) ? xs + (ra - 1 - 1 + lg + 1) * xw + (cj - 1 + 2) : cst;
+        const int xstep = (lg < 3) ? xw : 0;
+        float acc = 0.f, zst = -1e30f;
+        const int nsteps = rb - ra + 2;
+        for (int u0 = 0; u0 < nsteps; u0 += 3) {
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const int u = u0 + v;
+                if (u < nsteps) {
+                    const int r = ra - 1 + u;
+                    head_step(L, v, r >= 0 && r < ph, u >= 2, xp, hmask, acc, zst);
+                    xp += xstep;
+                }
+            }
+            // fold the (up to three) output rows completed in this round into the running softmax statistics
+            const float z = (zok && zst > -1e29f) ? zst + b2 : -1e30f;
+            const float mn = fmaxf(rm, z);
+            rs = rs * expf(rm - mn) + ((z > -1e29f) ? expf(z - mn) : 0.f);
+            rm = mn;
+            zst = -1e30f;
+        }
+    }
+    // merge the per-lane (max, sum) pairs
     float zm = wave_max(rm);
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = zm;
-    __syncthreads();
-    zm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float zs = rs > 0.f ? rs * expf(rm - zm) : 0.f;
+    float zs = rs * expf(rm - zm);
     zs = wave_sum(zs);
     __syncthreads();
-    if ((tid & 63) == 0) red[4 + (tid >> 6)] = zs;
+    if (lane == 0) { red[w] = zm; red[4 + w] = zs; }
     __syncthreads();
     if (tid == 0) {
+        const float zmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float Z = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Z += red[4 + k] * expf(red[k] - zmax);
         Rec r;
         r.amax = amax;
         r.ncand = *s_cnt;
 #pragma unroll
         for (int k = 0; k < KC; ++k) r.cand[k] = (k < r.ncand) ? s_cand[k] : 0;
-        r.zmax = zm;
-        r.Z = (red[4] + red[5]) + (red[6] + red[7]);
+        r.zmax = zmax;
+        r.Z = Z;
         rec[i] = r;
     }
 }
@@ -388,6 +439,8 @@ constexpr int WX = 2 * RD + 5;  // x window side (15)
 constexpr int WH = 2 * RD + 3;  // hidden window side (13)
 constexpr int WZ = 2 * RD + 1;  // logit window side (11)
 constexpr int NTP = 4;          // N-tiles in flight per wave in refine_corr
+
+__device__ unsigned long long g_dbg[4];  // development counters: tiles, groups, union-box cells, blocks
 
 struct Redo {
     int32_t* count;
@@ -404,7 +457,7 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const floa
                                                           const int32_t* __restrict__ out_idx,
                                                           const Rec* __restrict__ rec, int32_t* __restrict__ kstar,
                                                           float* __restrict__ xwin, Redo redo, int m0, int count, int M,
-                                                          const int32_t* __restrict__ dM) {
+                                                          const int32_t* __restrict__ dM, int dbg) {
     __shared__ float s_sn[16];
     __shared__ int s_row[16], s_f[16], s_k[16], s_m[16], s_grp[16], s_box[64], s_ng;
     const int ph = g.ph, pw = g.pw, HW = ph * pw, C = g.C;
@@ -439,7 +492,8 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const floa
         float best = -1.f;
         int bi = INT_MAX;
         if (!redo_it) {
-            for (int k = 0; k < rc.ncand; ++k) {
+            const int ncd = (dbg & 2) ? 1 : rc.ncand;
+            for (int k = 0; k < ncd; ++k) {
                 const int cell = min(max(rc.cand[k], 0), HW - 1);
                 const float* fp = feat + ((size_t)f * HW + cell) * C;
                 float d = 0.f;
@@ -494,14 +548,30 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const floa
     }
     __syncthreads();
     const int ng = s_ng;
+    if ((dbg & 16) && tid == 0) {
+        atomicAdd(&g_dbg[0], 1ULL);
+        atomicAdd(&g_dbg[1], (unsigned long long)ng);
+        for (int gi = 0; gi < ng; ++gi) {
+            const int ncl = (s_box[gi * 4 + 1] - s_box[gi * 4] + 1) * (s_box[gi * 4 + 3] - s_box[gi * 4 + 2] + 1);
+            atomicAdd(&g_dbg[2], (unsigned long long)ncl);
+            atomicAdd(&g_dbg[3], (unsigned long long)((ncl + 63) / 64));
+        }
+    }
 
-    // A fragments of the f32 MFMA: lane (fg, fj) supplies emb[row(fj)][16*kb + 4*fg + i] as the i-th k-step of block kb
+    // ---- fp32 correlation of all 16 sources with the cells of each group's union box ------------------------------
+    // f32-input MFMA 16x16x4; A (16 sources) and B (64 cells per block, one 16-cell N-tile per wave) are staged through
+    // LDS in 32-float K chunks with coalesced 128-byte row segments, double-buffered.  Row pitch 34 floats makes the
+    // fragment reads (lane (fg, fj) reads [row fj][4*kk + fg]) conflict-free.
+    constexpr int RP = 34;
+    __shared__ __attribute__((aligned(16))) float As[2][16 * RP];
+    __shared__ __attribute__((aligned(16))) float Bs[2][64 * RP];
     const int fj = lane & 15, fg = lane >> 4;
-    const float* ap = emb + (size_t)s_row[fj] * C + 4 * fg;
-    for (int gi = 0; gi < ng; ++gi) {
+    const int lrow = tid >> 3, lk4 = (tid & 7) * 4;  // loader: row (cell or source), 4-float piece
+    const float* arow = emb + (size_t)s_row[lrow & 15] * C + lk4;
+    const int nkc = C / 32;
+    for (int gi = 0; gi < ((dbg & 1) ? 0 : ng); ++gi) {
         const int rmin = s_box[gi * 4], rmax = s_box[gi * 4 + 1], cmin = s_box[gi * 4 + 2], cmax = s_box[gi * 4 + 3];
         const int nc = cmax - cmin + 1, ncells = (rmax - rmin + 1) * nc;
-        const int ntiles = (ncells + 15) / 16;
         int gf = -1;
         for (int s = 0; s < 16; ++s)
             if (s_grp[s] == gi) gf = s_f[s];
@@ -517,46 +587,63 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const floa
             wc0[r] = s_k[s] % pw - (RD + 2);
             sn4[r] = s_sn[s];
         }
-        for (int nt0 = w * NTP; nt0 < ntiles; nt0 += 4 * NTP) {
-            const float* bp[NTP];
-            int cellv[NTP], civ[NTP];
+        const float* fbase = feat + (size_t)gf * HW * C;
+        for (int blk = 0; blk < ncells; blk += 64) {
+            // loader cells of this thread (clamped: results of padded cells are never stored)
+            const int l0 = min(blk + lrow, ncells - 1), l1 = min(blk + lrow + 32, ncells - 1);
+            const float* b0 = fbase + (size_t)((rmin + l0 / nc) * pw + cmin + l0 % nc) * C + lk4;
+            const float* b1 = fbase + (size_t)((rmin + l1 / nc) * pw + cmin + l1 % nc) * C + lk4;
+            float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb0, rb1;
+            if (tid < 128) ra = *reinterpret_cast<const float4*>(arow);
+            rb0 = *reinterpret_cast<const float4*>(b0);
+            rb1 = *reinterpret_cast<const float4*>(b1);
+            __syncthreads();  // previous block / group finished reading LDS
+#define RC_STORE(buf)                                                                                  \
+    do {                                                                                               \
+        if (tid < 128) {                                                                               \
+            float2* pa = reinterpret_cast<float2*>(&As[buf][lrow * RP + lk4]);                         \
+            pa[0] = make_float2(ra.x, ra.y);                                                           \
+            pa[1] = make_float2(ra.z, ra.w);                                                           \
+        }                                                                                              \
+        float2* pb0 = reinterpret_cast<float2*>(&Bs[buf][lrow * RP + lk4]);                            \
+        pb0[0] = make_float2(rb0.x, rb0.y);                                                            \
+        pb0[1] = make_float2(rb0.z, rb0.w);                                                            \
+        float2* pb1 = reinterpret_cast<float2*>(&Bs[buf][(lrow + 32) * RP + lk4]);                     \
+        pb1[0] = make_float2(rb1.x, rb1.y);                                                            \
+        pb1[1] = make_float2(rb1.z, rb1.w);                                                            \
+    } while (0)
+            RC_STORE(0);
+            __syncthreads();
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+            int cur = 0;
+            for (int kc = 0; kc < nkc; ++kc) {
+                if (kc + 1 < nkc && !(dbg & 8)) {
+                    if (tid < 128) ra = *reinterpret_cast<const float4*>(arow + (kc + 1) * 32);
+                    rb0 = *reinterpret_cast<const float4*>(b0 + (kc + 1) * 32);
+                    rb1 = *reinterpret_cast<const float4*>(b1 + (kc + 1) * 32);
+                }
+                const float* ap = &As[cur][fj * RP + fg];
+                const float* bp = &Bs[cur][(w * 16 + fj) * RP + fg];
+                if (!(dbg & 4)) {
 #pragma unroll
-            for (int u = 0; u < NTP; ++u) {
-                const int ci = (nt0 + u) * 16 + fj;
-                const int cc = min(ci, ncells - 1);
-                civ[u] = ci;
-                cellv[u] = (rmin + cc / nc) * pw + cmin + cc % nc;
-                bp[u] = feat + ((size_t)gf * HW + cellv[u]) * C + 4 * fg;
+                    for (int kk = 0; kk < 8; ++kk)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * 4], bp[kk * 4], acc, 0, 0, 0);
+                }
+                if (kc + 1 < nkc) RC_STORE(cur ^ 1);
+                __syncthreads();
+                cur ^= 1;
             }
-            f4 acc[NTP];
-#pragma unroll
-            for (int u = 0; u < NTP; ++u) acc[u] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-            for (int kb = 0; kb < C / 16; ++kb) {
-                const float4 a = *reinterpret_cast<const float4*>(ap + kb * 16);
-                float4 b[NTP];
-#pragma unroll
-                for (int u = 0; u < NTP; ++u) b[u] = *reinterpret_cast<const float4*>(bp[u] + kb * 16);
-#pragma unroll
-                for (int u = 0; u < NTP; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[u].x, acc[u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < NTP; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[u].y, acc[u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < NTP; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[u].z, acc[u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < NTP; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[u].w, acc[u], 0, 0, 0);
-            }
-#pragma unroll
-            for (int u = 0; u < NTP; ++u) {
-                if (civ[u] >= ncells) continue;
-                const int cr = cellv[u] / pw, ccol = cellv[u] % pw;
-                const float fn = norms[(size_t)gf * HW + cellv[u]];
+#undef RC_STORE
+            const int ci = blk + w * 16 + fj;
+            if (ci < ncells) {
+                const int cr = rmin + ci / nc, ccol = cmin + ci % nc;
+                const float fn = norms[(size_t)gf * HW + cr * pw + ccol];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int dr = cr - wr0[r], dc = ccol - wc0[r];
                     if (in_g[r] && dr >= 0 && dr < WX && dc >= 0 && dc < WX)
                         xwin[((size_t)(s_m[fg * 4 + r] - m0) * WX + dr) * WX + dc] =
-                            fmaxf(acc[u][r] / fmaxf(sn4[r] * fn, 1e-8f), 0.f);
+                            fmaxf(acc[r] / fmaxf(sn4[r] * fn, 1e-8f), 0.f);
                 }
             }
         }
@@ -657,23 +744,26 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
 
 struct MfmaLayout {
     size_t s16, maps, rec, wpk, kstar, xwin, redo_cnt, redo_lists, exact, total;
-    int chunk, HWp;
+    int chunk;   // sources per corr16/head16 launch: their fp16 maps stay Infinity-Cache resident
+    int super;   // sources per refine / redo round: large, so that uneven tiles balance across the chip
+    int HWp;
 };
 
 MfmaLayout mfma_layout(const dtk_geom* g, int M) {
     MfmaLayout L;
     L.chunk = M < MFMA_CHUNK ? ((M + CM - 1) / CM * CM) : MFMA_CHUNK;
+    L.super = M < MFMA_SUPER ? ((M + CM - 1) / CM * CM) : MFMA_SUPER;
     L.HWp = hw_pad(g->ph * g->pw);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t off = 0;
     L.s16 = off; off = al(off + (size_t)L.chunk * g->C * 2);
     L.maps = off; off = al(off + (size_t)L.chunk * L.HWp * 2);
-    L.rec = off; off = al(off + (size_t)L.chunk * sizeof(Rec));
+    L.rec = off; off = al(off + (size_t)L.super * sizeof(Rec));
     L.wpk = off; off = al(off + 160 * 4);
-    L.kstar = off; off = al(off + (size_t)L.chunk * 4);
-    L.xwin = off; off = al(off + (size_t)L.chunk * WX * WX * 4);
+    L.kstar = off; off = al(off + (size_t)L.super * 4);
+    L.xwin = off; off = al(off + (size_t)L.super * WX * WX * 4);
     L.redo_cnt = off; off = al(off + 16);
-    L.redo_lists = off; off = al(off + (size_t)3 * L.chunk * 4);
+    L.redo_lists = off; off = al(off + (size_t)3 * L.super * 4);
     L.exact = off;
     L.total = off + dtk_track_exact_workspace_bytes(g, L.chunk);
     return L;
@@ -682,6 +772,14 @@ MfmaLayout mfma_layout(const dtk_geom* g, int M) {
 }  // namespace
 
 size_t dtk_track_mfma_workspace_bytes(const dtk_geom* g, int M) { return mfma_layout(g, M).total; }
+
+// development aid (not part of dtk.h): read and reset the refine_corr counters enabled by DTK_DEBUG & 16
+extern "C" int dtk_debug_counters(unsigned long long* out4) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    DTK_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_dbg), sizeof(z)));
+    DTK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)));
+    return DTK_OK;
+}
 
 extern "C" size_t dtk_feat_f16_bytes(const dtk_geom* g) {
     if (!g || g->T <= 0 || g->C <= 0) return 0;
@@ -709,6 +807,8 @@ int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, con
         return DTK_E_WORKSPACE;
     }
     hipStream_t st = dtk_stream(stream);
+    const char* dbg_env = getenv("DTK_DEBUG");
+    const int dbg = dbg_env ? atoi(dbg_env) : 0;
     unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
     half_t* s16 = reinterpret_cast<half_t*>(ws + L.s16);
     half_t* maps = reinterpret_cast<half_t*>(ws + L.maps);
@@ -717,11 +817,10 @@ int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, con
     Redo redo;
     redo.count = reinterpret_cast<int32_t*>(ws + L.redo_cnt);
     redo.src_row = reinterpret_cast<int32_t*>(ws + L.redo_lists);
-    redo.tgt = redo.src_row + L.chunk;
-    redo.out_idx = redo.tgt + L.chunk;
+    redo.tgt = redo.src_row + L.super;
+    redo.out_idx = redo.tgt + L.super;
     const int ph = g->ph, pw = g->pw;
-    const size_t lds_head = (size_t)((((ph + 2) * (pw + 2) + 7) & ~7)) * 2 + (size_t)(RB + 2) * (pw + 2) * 32 + 8 * 4 +
-                            (1 + KC) * 4 + 16;
+    const size_t lds_head = (size_t)((((ph + 2) * (pw + 4) + 32 + 7) & ~7)) * 2 + 16 + 16 * 4 + (1 + KC) * 4 + 16;
     int32_t* kstar = reinterpret_cast<int32_t*>(ws + L.kstar);
     float* xwin = reinterpret_cast<float*>(ws + L.xwin);
     DTK_REQUIRE(lds_head <= 160 * 1024, "dtk_track(mfma): token grid %dx%d too large for head16 (%zu B LDS)", ph, pw, lds_head);
@@ -729,21 +828,25 @@ int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, con
                                 (int)lds_head));
     DTK_LAUNCH("head16_pack", head16_pack_kernel, dim3(1), dim3(256), 0, st, head, wpk);
     const half_t* f16 = reinterpret_cast<const half_t*>(feat_f16);
-    for (long long m0 = 0; m0 < M; m0 += L.chunk) {
-        const int cnt = (int)((M - m0) < L.chunk ? (M - m0) : L.chunk);
-        DTK_LAUNCH("src16", src16_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, emb, src_row, s16, (int)m0, cnt, M,
-                   dM, g->C);
-        DTK_LAUNCH("corr16", corr16_kernel, dim3(L.HWp / CN, dtk_cdiv(cnt, CM)), dim3(256), 0, st, *g, f16, s16, tgt,
-                   maps, (int)m0, cnt, M, dM, L.HWp);
-        DTK_LAUNCH("head16", head16_kernel, dim3(cnt), dim3(256), lds_head, st, *g, head, wpk, maps, L.HWp, rec,
-                   (int)m0, cnt, M, dM);
+    for (long long s0 = 0; s0 < M; s0 += L.super) {
+        const int scnt = (int)((M - s0) < L.super ? (M - s0) : L.super);
+        for (long long m0 = s0; m0 < s0 + scnt; m0 += L.chunk) {
+            const int cnt = (int)((s0 + scnt - m0) < L.chunk ? (s0 + scnt - m0) : L.chunk);
+            DTK_LAUNCH("src16", src16_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, emb, src_row, s16, (int)m0, cnt,
+                       M, dM, g->C);
+            DTK_LAUNCH("corr16", corr16_kernel, dim3(L.HWp / CN, dtk_cdiv(cnt, CM)), dim3(256), 0, st, *g, f16, s16, tgt,
+                       maps, (int)m0, cnt, M, dM, L.HWp);
+            DTK_LAUNCH("head16", head16_kernel, dim3(cnt), dim3(256), lds_head, st, *g, head, wpk, maps, L.HWp,
+                       rec + (m0 - s0), (int)m0, cnt, M, dM, dbg);
+        }
         DTK_HIP(hipMemsetAsync(redo.count, 0, sizeof(int32_t), st));
-        DTK_LAUNCH("refine_corr", refine_corr_kernel, dim3(dtk_cdiv(cnt, 16)), dim3(256), 0, st, *g, feat, norms, emb,
-                   src_row, tgt, out_idx, rec, kstar, xwin, redo, (int)m0, cnt, M, dM);
-        DTK_LAUNCH("refine_head", refine_head_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, *g, head, src_row, tgt,
-                   out_idx, out_xy, rec, kstar, xwin, reinterpret_cast<const float*>(wpk) + 152, redo, (int)m0, cnt, M, dM,
-                   normalized);
-        int rc = dtk_track_exact(g, feat, norms, head, emb, redo.src_row, redo.tgt, redo.out_idx, out_xy, cnt,
+        DTK_LAUNCH("refine_corr", refine_corr_kernel, dim3(dtk_cdiv(scnt, 16)), dim3(256), 0, st, *g, feat, norms, emb,
+                   src_row, tgt, out_idx, rec, kstar, xwin, redo, (int)s0, scnt, M, dM, dbg);
+        DTK_LAUNCH("refine_head", refine_head_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, *g, head, src_row, tgt,
+                   out_idx, out_xy, rec, kstar, xwin, reinterpret_cast<const float*>(wpk) + 152, redo, (int)s0, scnt, M,
+                   dM, normalized);
+        // inconclusive sources of this round: the exact path, with the device-side count (kernels of empty rounds exit)
+        int rc = dtk_track_exact(g, feat, norms, head, emb, redo.src_row, redo.tgt, redo.out_idx, out_xy, scnt,
                                  redo.count, normalized, ws + L.exact, workspace_bytes - L.exact, stream);
         if (rc) return rc;
     }
