@@ -83,7 +83,10 @@ def main():
     head = synth.synth_head_weights(3)
     delta = synth.synth_delta_dino_weights(C, seed=4)
     queries = synth.grid_queries(nx, ny, H, W, 0).to(dev)
-    ex = VitExtractor(model_name, stride=7, device=dev, random_seed=2)
+    # no DINOv2 checkpoint exists offline: seeded random weights of the named architecture; LayerScale mean 0.1 keeps
+    # the untrained encoder from collapsing all tokens onto one vector (synth.make_vit_weights)
+    ex = VitExtractor(model_name, stride=7, device=dev,
+                      state_dict=synth.make_vit_weights(model_name, seed=2, layerscale=0.1))
     if args.features == "vit":
         feats0 = ex.encode(video)
     else:
@@ -105,11 +108,8 @@ def main():
             trk.cache_refined_embeddings()                # P2: dino + Delta-DINO(video)
         traj, occ = mi.infer(queries) if "track" in stages else (None, None)   # P3
         if world > 1 and traj is not None:
-            import torch.distributed as dist
-            payload = torch.cat([traj.reshape(-1), occ.reshape(-1).float()])
-            if rank == 0:
-                gather_buf = [torch.empty_like(payload) for _ in range(world)]
-            dist.gather(payload, gather_buf if rank == 0 else None, dst=0)
+            from dino_tracker_amd import sharding
+            gather_buf = sharding.gather_results(traj, occ, N, T, dev)  # RCCL gather of the results only
         return traj, occ
 
     def barrier():

@@ -23,6 +23,43 @@ from .dataset import RangeNormalizer
 from .tracker import Tracker
 
 
+# ---- per-query helpers of the reference module (models/model_inference.py:8-74), kept for API parity ----------------
+def generate_trajectory_input(query_point, video, start_t=None, end_t=None):
+    """(source_points, source_frame_indices, target_frame_indices, frames_set_t) for Tracker.forward: the query repeated
+    for frames [start_t, end_t), frame set = [t_query, start_t .. end_t-1]."""
+    start_t = 0 if start_t is None else start_t
+    end_t = video.shape[0] if end_t is None else end_t
+    rest = end_t - start_t
+    dev = video.device
+    source_points = query_point.unsqueeze(0).repeat(rest, 1)
+    frames_set_t = torch.cat([query_point[2:3].to(dev), torch.arange(start_t, end_t, device=dev).to(query_point.dtype)]).int()
+    source_frame_indices = torch.zeros(rest, dtype=torch.long, device=dev)
+    target_frame_indices = torch.arange(rest, dtype=torch.long, device=dev) + 1
+    return source_points, source_frame_indices, target_frame_indices, frames_set_t
+
+
+@torch.no_grad()
+def generate_trajectory(query_point, video, model, range_normalizer, dst_range=(-1, 1), use_raw_features=False,
+                        batch_size=None):
+    """rest x 3 (x, y, t) for one query, through Tracker.forward (models/model_inference.py:37-57)."""
+    batch_size = video.shape[0] if batch_size is None else batch_size
+    out = []
+    for start_t in range(0, video.shape[0], batch_size):
+        end_t = min(start_t + batch_size, video.shape[0])
+        inp = generate_trajectory_input(query_point, video, start_t, end_t)
+        coords = range_normalizer.unnormalize(model(inp, use_raw_features=use_raw_features), dims=[0, 1], src=dst_range)
+        out.append(torch.cat([coords, inp[-1][1:].to(torch.float32).unsqueeze(1)], dim=1))
+    return torch.cat(out, dim=0)
+
+
+@torch.no_grad()
+def generate_trajectories(query_points, video, model, range_normalizer, dst_range=(-1, 1), use_raw_features=False,
+                          batch_size=None):
+    """N x rest x 3; per-query loop like the reference (ModelInference.compute_trajectories is the batched path)."""
+    return torch.stack([generate_trajectory(q, video, model, range_normalizer, dst_range, use_raw_features, batch_size)
+                        for q in query_points.to(dtype=torch.float32)])
+
+
 class ModelInference(torch.nn.Module):
     def __init__(self, model: Tracker, range_normalizer: RangeNormalizer,
                  anchor_cosine_similarity_threshold: float = 0.5, cosine_similarity_threshold: float = 0.5) -> None:

@@ -111,8 +111,12 @@ VIT_CONFIGS = {  # models/extractor.py:183-222
 }
 
 
-def make_vit_weights(model_name: str, seed: int = 2, pos_grid: int = 37, patch: int = 14) -> Dict[str, torch.Tensor]:
-    """Seeded random weights with upstream's parameter names (no checkpoint exists in this environment)."""
+def make_vit_weights(model_name: str, seed: int = 2, pos_grid: int = 37, patch: int = 14,
+                     layerscale: float = 1.0) -> Dict[str, torch.Tensor]:
+    """Seeded random weights with upstream's parameter names (no checkpoint exists in this environment).
+    `layerscale` is the mean of the LayerScale gammas: 1.0 is the hub models' init_values; with untrained attention
+    (near-uniform averaging) that makes every token collapse onto a common vector, unlike trained DINOv2 features,
+    so the benchmark uses a small value that keeps the residual stream dominated by the patch content."""
     cfg = VIT_CONFIGS[model_name]
     d, depth = cfg["dim"], cfg["depth"]
     g = torch.Generator().manual_seed(seed)
@@ -134,14 +138,14 @@ def make_vit_weights(model_name: str, seed: int = 2, pos_grid: int = 37, patch: 
         sd[p + "attn.qkv.bias"] = tn(3 * d)
         sd[p + "attn.proj.weight"] = tn(d, d, std=0.04)
         sd[p + "attn.proj.bias"] = tn(d)
-        sd[p + "ls1.gamma"] = 1.0 + tn(d, std=0.1)  # upstream hub models: init_values=1.0
+        sd[p + "ls1.gamma"] = layerscale * (1.0 + tn(d, std=0.1))  # upstream hub models: init_values=1.0
         sd[p + "norm2.weight"] = 1.0 + tn(d, std=0.1)
         sd[p + "norm2.bias"] = tn(d, std=0.05)
         sd[p + "mlp.fc1.weight"] = tn(4 * d, d, std=0.04)
         sd[p + "mlp.fc1.bias"] = tn(4 * d)
         sd[p + "mlp.fc2.weight"] = tn(d, 4 * d, std=0.03)
         sd[p + "mlp.fc2.bias"] = tn(d)
-        sd[p + "ls2.gamma"] = 1.0 + tn(d, std=0.1)
+        sd[p + "ls2.gamma"] = layerscale * (1.0 + tn(d, std=0.1))
     return sd
 
 

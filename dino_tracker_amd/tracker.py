@@ -23,6 +23,9 @@ from .dataset import RangeNormalizer
 from .networks import DeltaDINO, TrackerHead
 
 
+EPS = 1e-08  # models/tracker.py:14
+
+
 def load_pre_trained_model(pre_trained_sd, target_model):
     """models/utils.py:71-76."""
     target_model.load_state_dict(dict(pre_trained_sd))
