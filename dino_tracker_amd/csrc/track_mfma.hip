@@ -37,8 +37,7 @@ constexpr float INV_SCALE2 = 1.f / 1024.f;
 constexpr float EPS_C = 3e-3f;            // candidate window: 2 x (fp16 operand + fp16 storage error bound)
 constexpr int KC = 8;                     // candidates kept per source
 constexpr int CM = 64, CN = 128, CK = 32; // corr16 tile
-constexpr int RB = 8;                     // head16: output rows per block
-constexpr int NB_MAX = 1536;              // refine: largest window-union box (cells) correlated as one group
+constexpr int NB_MAX = 1024;              // refine: largest window-union box (cells) correlated as one group
 constexpr int RD = 5;                     // disk radius in cells supported by refine32 (radius / stride <= 5)
 constexpr int MFMA_CHUNK = 16384;
 constexpr int MFMA_SUPER = 262144;
@@ -438,7 +437,6 @@ __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __
 constexpr int WX = 2 * RD + 5;  // x window side (15)
 constexpr int WH = 2 * RD + 3;  // hidden window side (13)
 constexpr int WZ = 2 * RD + 1;  // logit window side (11)
-constexpr int NTP = 4;          // N-tiles in flight per wave in refine_corr
 
 __device__ unsigned long long g_dbg[4];  // development counters: tiles, groups, union-box cells, blocks
 
@@ -449,83 +447,179 @@ struct Redo {
     int32_t* out_idx;
 };
 
+// spatial sort key of an argmax cell: 8-row bands, column-major inside a band, so that sources that are consecutive in
+// key order have nearly coincident windows
+__device__ __forceinline__ int cell_key(int cell, int pw) {
+    const int r = cell / pw, c = cell - r * pw;
+    return (r >> 3) * (8 * pw) + c * 8 + (r & 7);
+}
+
+// one wave per source: |s|, exact fp32 re-scoring of the candidates -> k*, histogram of (frame, cell key)
+__global__ __launch_bounds__(256) void rescore_kernel(dtk_geom g, const float* __restrict__ feat,
+                                                      const float* __restrict__ norms, const float* __restrict__ emb,
+                                                      const int32_t* __restrict__ src_row, const int32_t* __restrict__ tgt,
+                                                      const int32_t* __restrict__ out_idx, const Rec* __restrict__ rec,
+                                                      int32_t* __restrict__ kstar, float* __restrict__ snorm,
+                                                      int32_t* __restrict__ hist, int HWk, Redo redo, int m0, int count,
+                                                      int M, const int32_t* __restrict__ dM, int dbg) {
+    const int HW = g.ph * g.pw, C = g.C;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int m = m0 + i;
+    if (i >= count) return;
+    if (m >= dtk_active(M, dM)) {
+        if (lane == 0) kstar[i] = -1;
+        return;
+    }
+    const int row = src_row ? src_row[m] : m;
+    const int f = min(max(tgt[m], 0), g.T - 1);
+    const float* sp = emb + (size_t)row * C;
+    float ss = 0.f;
+    for (int k = lane * 4; k < C; k += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(sp + k);
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    const float sn = sqrtf(wave_sum(ss));
+    const Rec rc = rec[i];
+    bool redo_it = rc.ncand > KC || rc.ncand < 1;
+    float best = -1.f;
+    int bi = INT_MAX;
+    if (!redo_it) {
+        const int ncd = (dbg & 2) ? 1 : rc.ncand;
+        for (int k = 0; k < ncd; ++k) {
+            const int cell = min(max(rc.cand[k], 0), HW - 1);
+            const float* fp = feat + ((size_t)f * HW + cell) * C;
+            float d = 0.f;
+            for (int c = lane * 4; c < C; c += 256) {
+                const float4 a = *reinterpret_cast<const float4*>(sp + c), b = *reinterpret_cast<const float4*>(fp + c);
+                d += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+            }
+            d = wave_sum(d);
+            const float v = fmaxf(d / fmaxf(sn * norms[(size_t)f * HW + cell], 1e-8f), 0.f);
+            if (v > best || (v == best && cell < bi)) { best = v; bi = cell; }
+        }
+        // a non-positive exact maximum means the relu'd map may be all-zero (argmax 0): let the exact path decide
+        if (!(best > 0.f)) redo_it = true;
+    }
+    if (lane == 0) {
+        snorm[i] = sn;
+        if (redo_it) {
+            const int slot = atomicAdd(redo.count, 1);
+            redo.src_row[slot] = row;
+            redo.tgt[slot] = f;
+            redo.out_idx[slot] = out_idx ? out_idx[m] : m;
+            kstar[i] = -1;
+        } else {
+            kstar[i] = bi;
+            atomicAdd(&hist[(size_t)f * HWk + cell_key(bi, g.pw)], 1);
+        }
+    }
+}
+
+// ---- exclusive scan of the key histogram (n up to T * HWk): block sums -> scan of block sums -> final -------------
+constexpr int SCAN_PER_BLOCK = 1024;
+__global__ __launch_bounds__(256) void scan_blocksum_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ bsum, int n) {
+    __shared__ int red[4];
+    const int base = blockIdx.x * SCAN_PER_BLOCK;
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = base + j * 256 + threadIdx.x;
+        s += idx < n ? in[idx] : 0;
+    }
+    s = wave_sum_i(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ int block_incl_scan(int v, int* lds4, int* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, WAVE);
+        if (lane >= o) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) lds4[w] = x;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < w; ++k) base += lds4[k];
+    *total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+    return x + base;
+}
+__global__ __launch_bounds__(256) void scan_top_kernel(int32_t* __restrict__ bsum, int nb, int32_t* __restrict__ total_out) {
+    __shared__ int lds4[4];
+    int carry = 0;
+    for (int i0 = 0; i0 < nb; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        const int v = i < nb ? bsum[i] : 0;
+        int total;
+        const int incl = block_incl_scan(v, lds4, &total);
+        if (i < nb) bsum[i] = carry + incl - v;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+__global__ __launch_bounds__(256) void scan_final_kernel(const int32_t* __restrict__ in, const int32_t* __restrict__ boff,
+                                                         int32_t* __restrict__ out, int n) {
+    __shared__ int lds4[4];
+    const int base = blockIdx.x * SCAN_PER_BLOCK;
+    int carry = boff[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = base + j * 256 + threadIdx.x;
+        const int v = idx < n ? in[idx] : 0;
+        int total;
+        const int incl = block_incl_scan(v, lds4, &total);
+        if (idx < n) out[idx] = carry + incl - v;
+        carry += total;
+    }
+}
+// perm[offset[key] + arrival] = source; arrival order inside a key is irrelevant (results do not depend on tile mates)
+__global__ __launch_bounds__(256) void scatter_kernel(dtk_geom g, const int32_t* __restrict__ tgt,
+                                                      const int32_t* __restrict__ kstar, const int32_t* __restrict__ off,
+                                                      int32_t* __restrict__ cursor, int32_t* __restrict__ perm, int HWk,
+                                                      int m0, int count) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const int k = kstar[i];
+    if (k < 0) return;
+    const int f = min(max(tgt[m0 + i], 0), g.T - 1);
+    const size_t key = (size_t)f * HWk + cell_key(k, g.pw);
+    perm[off[key] + atomicAdd(&cursor[key], 1)] = i;
+}
+
 __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const float* __restrict__ feat,
                                                           const float* __restrict__ norms,
                                                           const float* __restrict__ emb,
                                                           const int32_t* __restrict__ src_row,
                                                           const int32_t* __restrict__ tgt,
-                                                          const int32_t* __restrict__ out_idx,
-                                                          const Rec* __restrict__ rec, int32_t* __restrict__ kstar,
-                                                          float* __restrict__ xwin, Redo redo, int m0, int count, int M,
-                                                          const int32_t* __restrict__ dM, int dbg) {
+                                                          const int32_t* __restrict__ kstar,
+                                                          const float* __restrict__ snorm,
+                                                          const int32_t* __restrict__ perm,
+                                                          const int32_t* __restrict__ nvalid,
+                                                          float* __restrict__ xwin, int m0, int dbg) {
     __shared__ float s_sn[16];
     __shared__ int s_row[16], s_f[16], s_k[16], s_m[16], s_grp[16], s_box[64], s_ng;
     const int ph = g.ph, pw = g.pw, HW = ph * pw, C = g.C;
-    const int active = min(dtk_active(M, dM), m0 + count);
-    const int tile_m0 = m0 + blockIdx.x * 16;
-    if (tile_m0 >= active) return;
+    const int nv = *nvalid;
+    const int t0 = blockIdx.x * 16;
+    if (t0 >= nv) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid < 16) {
-        const int m = tile_m0 + tid;
-        const bool ok = m < active;
+        const bool ok = t0 + tid < nv;
+        const int i = perm[ok ? t0 + tid : t0];  // index inside the round
+        const int m = m0 + i;
         s_m[tid] = m;
-        s_row[tid] = ok ? (src_row ? src_row[m] : m) : (src_row ? src_row[tile_m0] : tile_m0);
+        s_row[tid] = src_row ? src_row[m] : m;
         s_f[tid] = ok ? min(max(tgt[m], 0), g.T - 1) : -1;
-        s_k[tid] = 0;
+        s_k[tid] = kstar[i];
+        s_sn[tid] = snorm[i];
     }
     __syncthreads();
 
-    // |s| and exact re-scoring of the candidates: wave w owns sources 4w .. 4w+3
-    for (int q = 0; q < 4; ++q) {
-        const int s = w * 4 + q;
-        const int f = s_f[s];
-        if (f < 0) continue;  // wave-uniform
-        const float* sp = emb + (size_t)s_row[s] * C;
-        float ss = 0.f;
-        for (int k = lane * 4; k < C; k += 256) {
-            const float4 v = *reinterpret_cast<const float4*>(sp + k);
-            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-        }
-        const float sn = sqrtf(wave_sum(ss));
-        const Rec rc = rec[s_m[s] - m0];
-        bool redo_it = rc.ncand > KC || rc.ncand < 1;
-        float best = -1.f;
-        int bi = INT_MAX;
-        if (!redo_it) {
-            const int ncd = (dbg & 2) ? 1 : rc.ncand;
-            for (int k = 0; k < ncd; ++k) {
-                const int cell = min(max(rc.cand[k], 0), HW - 1);
-                const float* fp = feat + ((size_t)f * HW + cell) * C;
-                float d = 0.f;
-                for (int c = lane * 4; c < C; c += 256) {
-                    const float4 a = *reinterpret_cast<const float4*>(sp + c), b = *reinterpret_cast<const float4*>(fp + c);
-                    d += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
-                }
-                d = wave_sum(d);
-                const float v = fmaxf(d / fmaxf(sn * norms[(size_t)f * HW + cell], 1e-8f), 0.f);
-                if (v > best || (v == best && cell < bi)) { best = v; bi = cell; }
-            }
-            // a non-positive exact maximum means the relu'd map may be all-zero (argmax 0): let the exact path decide
-            if (!(best > 0.f)) redo_it = true;
-        }
-        if (lane == 0) {
-            s_sn[s] = sn;
-            if (redo_it) {
-                const int slot = atomicAdd(redo.count, 1);
-                redo.src_row[slot] = s_row[s];
-                redo.tgt[slot] = f;
-                redo.out_idx[slot] = out_idx ? out_idx[s_m[s]] : s_m[s];
-                s_f[s] = -1;
-                kstar[s_m[s] - m0] = -1;
-            } else {
-                s_k[s] = bi;
-                kstar[s_m[s] - m0] = bi;
-            }
-        }
-    }
-    __syncthreads();
-
-    // greedy grouping: consecutive sources with the same frame whose window union stays small
+    // greedy grouping: consecutive (key-sorted) sources with the same frame whose window union stays small
     if (tid == 0) {
         int ng = 0, cf = -2, r0 = 0, r1 = 0, c0 = 0, c1 = 0;
         for (int s = 0; s < 16; ++s) {
@@ -743,7 +837,8 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
 }
 
 struct MfmaLayout {
-    size_t s16, maps, rec, wpk, kstar, xwin, redo_cnt, redo_lists, exact, total;
+    size_t s16, maps, rec, wpk, kstar, xwin, snorm, perm, hist, off, cursor, bsum, nvalid, redo_cnt, redo_lists, exact, total;
+    int HWk, nkeys, nblocks;
     int chunk;   // sources per corr16/head16 launch: their fp16 maps stay Infinity-Cache resident
     int super;   // sources per refine / redo round: large, so that uneven tiles balance across the chip
     int HWp;
@@ -762,6 +857,16 @@ MfmaLayout mfma_layout(const dtk_geom* g, int M) {
     L.wpk = off; off = al(off + 160 * 4);
     L.kstar = off; off = al(off + (size_t)L.super * 4);
     L.xwin = off; off = al(off + (size_t)L.super * WX * WX * 4);
+    L.HWk = (g->ph + 7) / 8 * 8 * g->pw;
+    L.nkeys = g->T * L.HWk;
+    L.nblocks = (L.nkeys + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
+    L.snorm = off; off = al(off + (size_t)L.super * 4);
+    L.perm = off; off = al(off + (size_t)L.super * 4);
+    L.hist = off; off = al(off + (size_t)L.nkeys * 4);     // hist and cursor are contiguous: one memset
+    L.cursor = off; off = al(off + (size_t)L.nkeys * 4);
+    L.off = off; off = al(off + (size_t)(L.nkeys + 1) * 4);
+    L.bsum = off; off = al(off + (size_t)(L.nblocks + 1) * 4);
+    L.nvalid = off; off = al(off + 16);
     L.redo_cnt = off; off = al(off + 16);
     L.redo_lists = off; off = al(off + (size_t)3 * L.super * 4);
     L.exact = off;
@@ -840,8 +945,23 @@ int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, con
                        rec + (m0 - s0), (int)m0, cnt, M, dM, dbg);
         }
         DTK_HIP(hipMemsetAsync(redo.count, 0, sizeof(int32_t), st));
+        DTK_HIP(hipMemsetAsync(ws + L.hist, 0, L.cursor + (size_t)L.nkeys * 4 - L.hist, st));
+        int32_t* hist = reinterpret_cast<int32_t*>(ws + L.hist);
+        int32_t* cursor = reinterpret_cast<int32_t*>(ws + L.cursor);
+        int32_t* koff = reinterpret_cast<int32_t*>(ws + L.off);
+        int32_t* bsum = reinterpret_cast<int32_t*>(ws + L.bsum);
+        int32_t* nvalid = reinterpret_cast<int32_t*>(ws + L.nvalid);
+        float* snorm = reinterpret_cast<float*>(ws + L.snorm);
+        int32_t* perm = reinterpret_cast<int32_t*>(ws + L.perm);
+        DTK_LAUNCH("rescore", rescore_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, *g, feat, norms, emb, src_row, tgt,
+                   out_idx, rec, kstar, snorm, hist, L.HWk, redo, (int)s0, scnt, M, dM, dbg);
+        DTK_LAUNCH("key_scan", scan_blocksum_kernel, dim3(L.nblocks), dim3(256), 0, st, hist, bsum, L.nkeys);
+        DTK_LAUNCH("key_scan", scan_top_kernel, dim3(1), dim3(256), 0, st, bsum, L.nblocks, nvalid);
+        DTK_LAUNCH("key_scan", scan_final_kernel, dim3(L.nblocks), dim3(256), 0, st, hist, bsum, koff, L.nkeys);
+        DTK_LAUNCH("key_scatter", scatter_kernel, dim3(dtk_cdiv(scnt, 256)), dim3(256), 0, st, *g, tgt, kstar, koff, cursor,
+                   perm, L.HWk, (int)s0, scnt);
         DTK_LAUNCH("refine_corr", refine_corr_kernel, dim3(dtk_cdiv(scnt, 16)), dim3(256), 0, st, *g, feat, norms, emb,
-                   src_row, tgt, out_idx, rec, kstar, xwin, redo, (int)s0, scnt, M, dM, dbg);
+                   src_row, tgt, kstar, snorm, perm, nvalid, xwin, (int)s0, dbg);
         DTK_LAUNCH("refine_head", refine_head_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, *g, head, src_row, tgt,
                    out_idx, out_xy, rec, kstar, xwin, reinterpret_cast<const float*>(wpk) + 152, redo, (int)s0, scnt, M,
                    dM, normalized);
