@@ -49,22 +49,29 @@ struct Rec {  // per source, written by head16, read by refine32
     float zmax, Z;
 };
 
-__host__ __device__ inline int hw_pad(int HW) { return (HW + CN - 1) / CN * CN; }
+// fp16 path geometry: every map row is padded to PWP = a multiple of the 128-cell GEMM tile, so that an N-tile is (part
+// of) ONE map row and the output tile can be stored with 16-byte pieces; a stored map is [(ph+2) rows][XW cols] with
+// 8 zero columns left of the cells (16-byte alignment) and >= 8 zero columns to their right.
+__host__ __device__ inline int pw_pad(int pw) { return (pw + CN - 1) / CN * CN; }
+__host__ __device__ inline int map_xw(int pw) { return pw_pad(pw) + 16; }
+__host__ __device__ inline int hw_pad(int ph, int pw) { return ph * pw_pad(pw); }
 
 // ---- fp16 unit-norm copy of the feature volume ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void feat16_kernel(const float* __restrict__ feat, const float* __restrict__ norms,
-                                                     half_t* __restrict__ f16, int T, int HW, int HWp, int C) {
-    const long long cell = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over T*HWp
+                                                     half_t* __restrict__ f16, int T, int ph, int pw, int PWP, int C) {
+    const long long cell = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over T * ph * PWP padded cells
+    const int HWp = ph * PWP, HW = ph * pw;
     if (cell >= (long long)T * HWp) return;
     const int lane = threadIdx.x & 63;
-    const int t = (int)(cell / HWp), c = (int)(cell % HWp);
+    const int t = (int)(cell / HWp), pc = (int)(cell % HWp);
+    const int r = pc / PWP, c = pc - r * PWP;
     half_t* o = f16 + cell * C;
-    if (c >= HW) {
+    if (c >= pw) {
         for (int k = lane * 8; k < C; k += 512) *reinterpret_cast<uint4*>(o + k) = make_uint4(0, 0, 0, 0);
         return;
     }
-    const float* p = feat + ((size_t)t * HW + c) * C;
-    const float nrm = norms[(size_t)t * HW + c];
+    const float* p = feat + ((size_t)t * HW + r * pw + c) * C;
+    const float nrm = norms[(size_t)t * HW + r * pw + c];
     const float sc = nrm > 1e-30f ? FSCALE / nrm : 0.f;
     for (int k = lane * 8; k < C; k += 512) {
         const float4 a = *reinterpret_cast<const float4*>(p + k), b = *reinterpret_cast<const float4*>(p + k + 4);
@@ -111,18 +118,35 @@ __device__ __forceinline__ int swz(int row, int piece) {
     return row * 4 + (piece ^ f);
 }
 
-__global__ __launch_bounds__(256) void corr16_kernel(dtk_geom g, const half_t* __restrict__ f16,
+__global__ __launch_bounds__(256) void corr16_tiled_kernel(dtk_geom g, const half_t* __restrict__ f16,
                                                      const half_t* __restrict__ s16, const int32_t* __restrict__ tgt,
                                                      half_t* __restrict__ maps, int m0, int count, int M,
-                                                     const int32_t* __restrict__ dM, int HWp) {
-    __shared__ uint4 As[2][CM * 4];
-    __shared__ uint4 Bs[2][CN * 4];
+                                                     const int32_t* __restrict__ dM, int HWp, int MP, int dbg) {
+    __shared__ uint4 smem_ab[2 * (CM + CN) * 4];  // 24 KB: A/B double buffers; reused as the 64 x 128 fp16 output tile
+    uint4 (*As)[CM * 4] = reinterpret_cast<uint4 (*)[CM * 4]>(smem_ab);
+    uint4 (*Bs)[CN * 4] = reinterpret_cast<uint4 (*)[CN * 4]>(smem_ab + 2 * CM * 4);
+    half_t* Ts = reinterpret_cast<half_t*>(smem_ab);  // [CM][CN + 8]
+    constexpr int TP16 = CN + 8;
     __shared__ int s_tgt[CM];
     __shared__ int s_fr[2];
     const int active = min(dtk_active(M, dM), m0 + count);
-    const int tile_m0 = m0 + blockIdx.y * CM;
+    // block -> (source tile, N-tile): workgroup L runs on XCD L % 8 (observed dispatch order; speed only).  Each XCD gets
+    // the source tiles mt = 8*j + xcd and walks the N-tiles in panels of 8, so that its private L2 holds one B panel
+    // (8 x 96 KB at C = 384) plus its share of the A tiles instead of streaming the whole frame per source tile.
+    const int NT = HWp / CN, MT = (count + CM - 1) / CM;
+    int bx, by;
+    {
+        const int L = blockIdx.x, xcd = L & 7, k = L >> 3;
+        const int mt_per = (MT + 7) >> 3;                     // source tiles per XCD
+        const int per_panel = mt_per * 8;                     // (source tile, N-tile-in-panel) pairs per panel per XCD
+        const int p = k / per_panel, rem = k - p * per_panel;
+        by = (rem >> 3) * 8 + xcd;
+        bx = p * 8 + (rem & 7);
+        if (by >= MT || bx >= NT) return;
+    }
+    const int tile_m0 = m0 + by * CM;
     if (tile_m0 >= active) return;
-    const int cell0 = blockIdx.x * CN;
+    const int cell0 = bx * CN;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid < CM) {
         const int m = tile_m0 + tid;
@@ -193,17 +217,33 @@ __global__ __launch_bounds__(256) void corr16_kernel(dtk_geom g, const half_t* _
             __syncthreads();
             cur ^= 1;
         }
-        // D: lane (fg, fj) holds rows 4*fg + r, column fj of each 16x16 tile
+        // D: lane (fg, fj) holds rows 4*fg + r, column fj of each 16x16 tile.  The tile is transposed through LDS and
+        // stored as 16-byte pieces: an N-tile is 128 consecutive columns of ONE map row (padded cells are zero), and maps
+        // are written in the layout head16 copies into LDS verbatim (zero border, written once per call by a memset).
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = wr * 32 + mi * 16 + fg * 4 + r;
-                if (s_tgt[row] != f) continue;
-                half_t* orow = maps + (size_t)(tile_m0 - m0 + row) * HWp + cell0 + wc * 64 + fj;
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) orow[ni * 16] = (half_t)fmaxf(acc[mi][ni][r] * INV_SCALE2, 0.f);
+                for (int ni = 0; ni < 4; ++ni)
+                    Ts[row * TP16 + wc * 64 + ni * 16 + fj] = (half_t)fmaxf(acc[mi][ni][r] * INV_SCALE2, 0.f);
             }
+        __syncthreads();
+        {
+            const int PWP = pw_pad(g.pw);
+            const int mr = cell0 / PWP, mc = cell0 - mr * PWP;
+            const size_t po = (size_t)(mr + 1) * map_xw(g.pw) + 8 + mc;
+            const int piece = tid & 15, r0 = tid >> 4;
+#pragma unroll
+            for (int rr = 0; rr < CM; rr += 16) {
+                const int row = rr + r0;
+                if (s_tgt[row] == f && !(dbg & 256))
+                    *reinterpret_cast<uint4*>(maps + (size_t)(tile_m0 - m0 + row) * MP + po + piece * 8) =
+                        *reinterpret_cast<const uint4*>(Ts + row * TP16 + piece * 8);
+            }
+        }
+        __syncthreads();  // the next frame of a mixed tile restages As/Bs
     }
 }
 
@@ -308,7 +348,7 @@ __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __
                                                      int m0, int count, int M, const int32_t* __restrict__ dM, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int ph = g.ph, pw = g.pw, HW = ph * pw;
-    const int xw = pw + 4;                                  // 2 zero columns on each side
+    const int xw = map_xw(pw);                              // 8 zero columns left, >= 8 right
     const int xs_elems = (ph + 2) * xw + 32;                // + slack: edge segments read a little past a row
     half_t* xs = reinterpret_cast<half_t*>(smem_raw);       // [(ph+2)][(pw+4)], row -1 and row ph are zero
     half_t* cst = xs + ((xs_elems + 7) & ~7);               // {1, 0, 0, 0}: the bias column of B1
@@ -319,27 +359,40 @@ __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __
     const int m = m0 + i;
     if (i >= count || m >= dtk_active(M, dM)) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const half_t* map = maps + (size_t)i * HWp;
-    for (int c = tid; c < ((xs_elems + 7) & ~7); c += 256) xs[c] = (half_t)0.f;
+    // the map arrives in the padded layout (HWp here is its pitch): a straight 16-byte copy into LDS
+    const int n16 = ((xs_elems + 7) & ~7) / 8;
+    const uint4* map16 = reinterpret_cast<const uint4*>(maps + (size_t)i * HWp);
+    uint4* xs16 = reinterpret_cast<uint4*>(xs);
     if (tid < 8) cst[tid] = (half_t)(tid == 0 ? 1.f : 0.f);
     if (tid == 0) *s_cnt = 0;
-    __syncthreads();
-    float amax = 0.f;
-    for (int c = tid; c < HW; c += 256) {
-        const half_t v = map[c];
-        xs[(c / pw + 1) * xw + c % pw + 2] = v;
-        amax = fmaxf(amax, (float)v);
+    h2 mx2 = {(half_t)0.f, (half_t)0.f};
+    for (int c = tid; c < n16; c += 256) {
+        const uint4 v = map16[c];
+        xs16[c] = v;
+        mx2 = __builtin_elementwise_max(mx2, __builtin_elementwise_max(
+                  __builtin_elementwise_max(as_h2(v.x), as_h2(v.y)), __builtin_elementwise_max(as_h2(v.z), as_h2(v.w))));
     }
+    float amax = fmaxf((float)mx2[0], (float)mx2[1]);
     amax = wave_max(amax);
     if (lane == 0) red[w] = amax;
     __syncthreads();
     amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     const float thr = amax - EPS_C;
-    for (int c = tid; c < ((dbg & 64) ? 0 : HW); c += 256) {
-        const float v = (float)xs[(c / pw + 1) * xw + c % pw + 2];
-        if (v >= thr) {
-            const int slot = atomicAdd(s_cnt, 1);
-            if (slot < KC) s_cand[slot] = c;
+    const half_t thr_h = (half_t)fmaxf(thr - 1e-3f, -1.f);  // coarse fp16 pre-filter, exact test below
+    for (int c = tid; c < ((dbg & 64) ? 0 : n16); c += 256) {
+        const uint4 v = xs16[c];
+        const h2 m4 = __builtin_elementwise_max(__builtin_elementwise_max(as_h2(v.x), as_h2(v.y)),
+                                                __builtin_elementwise_max(as_h2(v.z), as_h2(v.w)));
+        if (m4[0] < thr_h && m4[1] < thr_h) continue;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int pidx = c * 8 + e;
+            const int pr = pidx / xw, pc = pidx - pr * xw;
+            if (pr < 1 || pr > ph || pc < 8 || pc >= pw + 8) continue;  // border zeros are not cells
+            if ((float)xs[pidx] >= thr) {
+                const int slot = atomicAdd(s_cnt, 1);
+                if (slot < KC) s_cand[slot] = (pr - 1) * pw + (pc - 8);
+            }
         }
     }
 
@@ -383,7 +436,7 @@ __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __
         const unsigned hmask = (cj >= 0 && cj < pw) ? 0xFFFFFFFFu : 0u;
         const bool zok = lg < 3 && lj >= 1 && lj <= 14 && cj < pw;
         // B1 source: lanes of group g < 3 read row r'-1+g at columns cj-1..cj+1; group 3 reads the constant
-        const half_t* xp = (lg < 3) ? xs + (ra - 1 - 1 + lg + 1) * xw + (cj - 1 + 2) : cst;
+        const half_t* xp = (lg < 3) ? xs + (ra - 1 - 1 + lg + 1) * xw + (cj - 1 + 8) : cst;
         const int xstep = (lg < 3) ? xw : 0;
         float acc = 0.f, zst = -1e30f;
         const int nsteps = rb - ra + 2;
@@ -400,7 +453,7 @@ __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __
             // fold the (up to three) output rows completed in this round into the running softmax statistics
             const float z = (zok && zst > -1e29f) ? zst + b2 : -1e30f;
             const float mn = fmaxf(rm, z);
-            rs = rs * expf(rm - mn) + ((z > -1e29f) ? expf(z - mn) : 0.f);
+            rs = rs * __expf(rm - mn) + ((z > -1e29f) ? __expf(z - mn) : 0.f);  // approximate pass: fast exp
             rm = mn;
             zst = -1e30f;
         }
@@ -839,6 +892,7 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
 struct MfmaLayout {
     size_t s16, maps, rec, wpk, kstar, xwin, snorm, perm, hist, off, cursor, bsum, nvalid, redo_cnt, redo_lists, exact, total;
     int HWk, nkeys, nblocks;
+    int MP;      // pitch (in halves) of one padded fp16 map: (ph+2) x (pw+4) + slack, multiple of 8
     int chunk;   // sources per corr16/head16 launch: their fp16 maps stay Infinity-Cache resident
     int super;   // sources per refine / redo round: large, so that uneven tiles balance across the chip
     int HWp;
@@ -848,11 +902,12 @@ MfmaLayout mfma_layout(const dtk_geom* g, int M) {
     MfmaLayout L;
     L.chunk = M < MFMA_CHUNK ? ((M + CM - 1) / CM * CM) : MFMA_CHUNK;
     L.super = M < MFMA_SUPER ? ((M + CM - 1) / CM * CM) : MFMA_SUPER;
-    L.HWp = hw_pad(g->ph * g->pw);
+    L.HWp = hw_pad(g->ph, g->pw);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t off = 0;
     L.s16 = off; off = al(off + (size_t)L.chunk * g->C * 2);
-    L.maps = off; off = al(off + (size_t)L.chunk * L.HWp * 2);
+    L.MP = ((g->ph + 2) * map_xw(g->pw) + 32 + 7) & ~7;
+    L.maps = off; off = al(off + (size_t)L.chunk * L.MP * 2);
     L.rec = off; off = al(off + (size_t)L.super * sizeof(Rec));
     L.wpk = off; off = al(off + 160 * 4);
     L.kstar = off; off = al(off + (size_t)L.super * 4);
@@ -888,16 +943,16 @@ extern "C" int dtk_debug_counters(unsigned long long* out4) {
 
 extern "C" size_t dtk_feat_f16_bytes(const dtk_geom* g) {
     if (!g || g->T <= 0 || g->C <= 0) return 0;
-    return (size_t)g->T * hw_pad(g->ph * g->pw) * g->C * 2;
+    return (size_t)g->T * hw_pad(g->ph, g->pw) * g->C * 2;
 }
 
 extern "C" int dtk_make_feat_f16(const dtk_geom* g, const float* feat, const float* norms, void* feat_f16, void* stream) {
     DTK_REQUIRE(g && feat && norms && feat_f16, "dtk_make_feat_f16: null pointer");
     DTK_REQUIRE(g->C % CK == 0, "dtk_make_feat_f16: C=%d must be a multiple of %d for the MFMA path", g->C, CK);
-    const int HW = g->ph * g->pw, HWp = hw_pad(HW);
+    const int HWp = hw_pad(g->ph, g->pw);
     const long long cells = (long long)g->T * HWp;
     DTK_LAUNCH("feat16", feat16_kernel, dim3(dtk_cdiv(cells, 4)), dim3(256), 0, dtk_stream(stream), feat, norms,
-               reinterpret_cast<half_t*>(feat_f16), g->T, HW, HWp, g->C);
+               reinterpret_cast<half_t*>(feat_f16), g->T, g->ph, g->pw, pw_pad(g->pw), g->C);
     return DTK_OK;
 }
 
@@ -925,13 +980,14 @@ int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, con
     redo.tgt = redo.src_row + L.super;
     redo.out_idx = redo.tgt + L.super;
     const int ph = g->ph, pw = g->pw;
-    const size_t lds_head = (size_t)((((ph + 2) * (pw + 4) + 32 + 7) & ~7)) * 2 + 16 + 16 * 4 + (1 + KC) * 4 + 16;
+    const size_t lds_head = (size_t)((((ph + 2) * map_xw(pw) + 32 + 7) & ~7)) * 2 + 16 + 16 * 4 + (1 + KC) * 4 + 16;
     int32_t* kstar = reinterpret_cast<int32_t*>(ws + L.kstar);
     float* xwin = reinterpret_cast<float*>(ws + L.xwin);
     DTK_REQUIRE(lds_head <= 160 * 1024, "dtk_track(mfma): token grid %dx%d too large for head16 (%zu B LDS)", ph, pw, lds_head);
     DTK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_head));
     DTK_LAUNCH("head16_pack", head16_pack_kernel, dim3(1), dim3(256), 0, st, head, wpk);
+    DTK_HIP(hipMemsetAsync(maps, 0, (size_t)L.chunk * L.MP * 2, st));  // zero borders of the padded maps
     const half_t* f16 = reinterpret_cast<const half_t*>(feat_f16);
     for (long long s0 = 0; s0 < M; s0 += L.super) {
         const int scnt = (int)((M - s0) < L.super ? (M - s0) : L.super);
@@ -939,9 +995,13 @@ int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, con
             const int cnt = (int)((s0 + scnt - m0) < L.chunk ? (s0 + scnt - m0) : L.chunk);
             DTK_LAUNCH("src16", src16_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, emb, src_row, s16, (int)m0, cnt,
                        M, dM, g->C);
-            DTK_LAUNCH("corr16", corr16_kernel, dim3(L.HWp / CN, dtk_cdiv(cnt, CM)), dim3(256), 0, st, *g, f16, s16, tgt,
-                       maps, (int)m0, cnt, M, dM, L.HWp);
-            DTK_LAUNCH("head16", head16_kernel, dim3(cnt), dim3(256), lds_head, st, *g, head, wpk, maps, L.HWp,
+            {
+                const int MT = dtk_cdiv(cnt, CM), NT = L.HWp / CN;
+                const int blocks = 8 * ((MT + 7) / 8) * 8 * ((NT + 7) / 8);
+                DTK_LAUNCH("corr16", corr16_tiled_kernel, dim3(blocks), dim3(256), 0, st, *g, f16, s16, tgt, maps, (int)m0,
+                           cnt, M, dM, L.HWp, L.MP, dbg);
+            }
+            DTK_LAUNCH("head16", head16_kernel, dim3(cnt), dim3(256), lds_head, st, *g, head, wpk, maps, L.MP,
                        rec + (m0 - s0), (int)m0, cnt, M, dM, dbg);
         }
         DTK_HIP(hipMemsetAsync(redo.count, 0, sizeof(int32_t), st));
