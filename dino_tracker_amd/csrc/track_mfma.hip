@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
                                                           const float* __restrict__ zerr, Redo redo, int m0, int count,
                                                           int M, const int32_t* __restrict__ dM, int normalized) {
     __shared__ float s_x[4][WX * WX + 3];
-    __shared__ float s_h[4][WH * WH * 16];
+    __shared__ __attribute__((aligned(16))) float s_h[4][WH * WH * 16];
     __shared__ float s_z[4][WZ * WZ + 7];
     __shared__ float s_out[4][2];
     const int ph = g.ph, pw = g.pw;
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
 #pragma unroll
             for (int t = 0; t < 9; ++t) a = fmaf(w1[ch * 9 + t], x9[t], a);
             a += b1[ch];
-            hb[j * 16 + ch] = in ? fmaxf(a, 0.f) : 0.f;  // hidden outside the map is zero (conv2's padding)
+            hb[ch * (WH * WH) + j] = in ? fmaxf(a, 0.f) : 0.f;  // channel planes; hidden outside the map is zero
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -855,15 +855,17 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
     float* zb = s_z[w];
     for (int j = lane; j < WZ * WZ; j += WAVE) {
         const int zy = j / WZ, zx = j % WZ;  // centre in the hidden window: (zy+1, zx+1)
-        float a = 0.f;
+        // one fmaf chain per output like the exact path (fp32 result depends on the summation order only at the
+        // 1e-7 level; four interleaved chains keep the VALU busy instead of waiting on a 144-long dependency)
+        float a4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ch = 0; ch < 16; ++ch)
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx)
-                    a = fmaf(w2[ch * 9 + dy * 3 + dx], hb[((zy + dy) * WH + zx + dx) * 16 + ch], a);
-        zb[j] = a + b2;
+                    a4[ch & 3] = fmaf(w2[ch * 9 + dy * 3 + dx], hb[ch * (WH * WH) + (zy + dy) * WH + zx + dx], a4[ch & 3]);
+        zb[j] = ((a4[0] + a4[1]) + (a4[2] + a4[3])) + b2;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -925,7 +927,10 @@ MfmaLayout mfma_layout(const dtk_geom* g, int M) {
     L.redo_cnt = off; off = al(off + 16);
     L.redo_lists = off; off = al(off + (size_t)3 * L.super * 4);
     L.exact = off;
-    L.total = off + dtk_track_exact_workspace_bytes(g, L.chunk);
+    // staging of the exact path for re-done sources: large, so that a refine round costs a handful of (mostly empty)
+    // exact-path launches instead of hundreds
+    const int redo_rows = L.super < 65536 ? L.super : 65536;
+    L.total = off + (size_t)redo_rows * (((size_t)g->ph * g->pw + 63) / 64 * 64 + 1) * sizeof(float);
     return L;
 }
 
