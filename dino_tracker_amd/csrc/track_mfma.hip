@@ -302,23 +302,25 @@ struct HeadLane {  // per-lane constants of the chained GEMMs
     int done[3];   // 1 where this lane's group completes an output row at that phase
 };
 
-__device__ __forceinline__ void head_step(const HeadLane& L, int v, bool row_ok, bool can_complete, const half_t* xp,
-                                          unsigned hmask, float& acc, float& zst) {
+// OFF: byte offset of the segment relative to xp (the second segment of a pair sits 14 columns = 28 bytes to the right);
+// `edge`: the segment touches a map border, so hidden activations of out-of-map columns must be zeroed (hmask)
+template <int OFF>
+__device__ __forceinline__ void head_step(const HeadLane& L, int v, bool row_ok, bool can_complete, bool edge,
+                                          const half_t* xp, unsigned hmask, int done_v, float& acc, float& zst) {
     float V = 0.f;
     if (row_ok) {
-        // B1: k = 4g + i: rows r'-1+g (g < 3), taps dx = i-1 (i < 3); g = 3: the constant (1,0,0,0) for the bias
-        // three 2-byte LDS reads straight into packed halves (the address is only 2-byte aligned: a merged
-        // ds_read_b32 would be a misaligned access); loads and their wait live in one asm statement (the compiler does
-        // not count asm loads)
+        // B1: k = 4g + i: rows r'-1+g (g < 3), taps dx = i-1 (i < 3); g = 3: the constant (1,0,0,0) for the bias.
+        // Three 2-byte LDS reads straight into packed halves (the address is only 2-byte aligned: a merged ds_read_b32
+        // would be a misaligned access); loads and their wait live in one asm statement (the compiler does not count
+        // asm loads)
         unsigned xlo, xhi;
         asm volatile(
-            "v_mov_b32 %1, 0\n\t"
-            "ds_read_u16_d16 %0, %2\n\t"
-            "ds_read_u16_d16_hi %0, %2 offset:2\n\t"
-            "ds_read_u16_d16 %1, %2 offset:4\n\t"
+            "ds_read_u16_d16 %0, %2 offset:%3\n\t"
+            "ds_read_u16_d16_hi %0, %2 offset:%4\n\t"
+            "ds_read_u16 %1, %2 offset:%5\n\t"
             "s_waitcnt lgkmcnt(0)"
             : "=&v"(xlo), "=&v"(xhi)
-            : "v"((unsigned)(size_t)xp)
+            : "v"((unsigned)(size_t)xp), "i"(OFF), "i"(OFF + 2), "i"(OFF + 4)
             : "memory");
         const h2 x01 = __builtin_bit_cast(h2, xlo), x2 = __builtin_bit_cast(h2, xhi);
         const h4 b1 = {x01[0], x01[1], x2[0], x2[1]};
@@ -329,9 +331,10 @@ __device__ __forceinline__ void head_step(const HeadLane& L, int v, bool row_ok,
         const h2 zero2 = {(half_t)0.f, (half_t)0.f};
         h2 lo = __builtin_elementwise_max(__builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(d1[0], d1[1])), zero2);
         h2 hi = __builtin_elementwise_max(__builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(d1[2], d1[3])), zero2);
-        unsigned ulo = __builtin_bit_cast(unsigned, lo) & hmask, uhi = __builtin_bit_cast(unsigned, hi) & hmask;
-        lo = __builtin_bit_cast(h2, ulo);
-        hi = __builtin_bit_cast(h2, uhi);
+        if (edge) {
+            lo = __builtin_bit_cast(h2, __builtin_bit_cast(unsigned, lo) & hmask);
+            hi = __builtin_bit_cast(h2, __builtin_bit_cast(unsigned, hi) & hmask);
+        }
         const h4 b2 = {lo[0], lo[1], hi[0], hi[1]};
         f4 d2 = {0.f, 0.f, 0.f, 0.f};
         d2 = __builtin_amdgcn_mfma_f32_16x16x16f16(L.a2[v], b2, d2, 0, 0, 0);
@@ -339,7 +342,7 @@ __device__ __forceinline__ void head_step(const HeadLane& L, int v, bool row_ok,
         V = dpp_f<0x111>(d2[0]) + d2[1] + dpp_f<0x101>(d2[2]);
     }
     acc = fmaf(acc, L.keep[v], V);
-    if (can_complete) zst = L.done[v] ? acc : zst;
+    if (can_complete) zst = done_v ? acc : zst;
 }
 
 __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __restrict__ head,
@@ -351,8 +354,8 @@ __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __
     const int xw = map_xw(pw);                              // 8 zero columns left, >= 8 right
     const int xs_elems = (ph + 2) * xw + 32;                // + slack: edge segments read a little past a row
     half_t* xs = reinterpret_cast<half_t*>(smem_raw);       // [(ph+2)][(pw+4)], row -1 and row ph are zero
-    half_t* cst = xs + ((xs_elems + 7) & ~7);               // {1, 0, 0, 0}: the bias column of B1
-    float* red = reinterpret_cast<float*>(cst + 8);         // 16 floats
+    half_t* cst = xs + ((xs_elems + 7) & ~7);               // {1,0,0,..} at +0 and +14: the bias column of B1
+    float* red = reinterpret_cast<float*>(cst + 32);        // 16 floats
     int* s_cnt = reinterpret_cast<int*>(red + 16);
     int* s_cand = s_cnt + 1;                                // KC ints
     const int i = blockIdx.x;
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __
     const int n16 = ((xs_elems + 7) & ~7) / 8;
     const uint4* map16 = reinterpret_cast<const uint4*>(maps + (size_t)i * HWp);
     uint4* xs16 = reinterpret_cast<uint4*>(xs);
-    if (tid < 8) cst[tid] = (half_t)(tid == 0 ? 1.f : 0.f);
+    if (tid < 32) cst[tid] = (half_t)((tid == 0 || tid == 14) ? 1.f : 0.f);
     if (tid == 0) *s_cnt = 0;
     h2 mx2 = {(half_t)0.f, (half_t)0.f};
     for (int c = tid; c < n16; c += 256) {
@@ -398,6 +401,7 @@ __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __
 
     // ---- per-lane constants ----
     const int lg = lane >> 4, lj = lane & 15;
+    constexpr float LOG2E = 1.4426950408889634f;
     HeadLane L;
     {
         // A1[m = ch lj][k = 4*lg + i]
@@ -417,28 +421,40 @@ __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __
             if (gm < 3 && t < 3) {
                 const int dy = (gm == (v + 1) % 3) ? -1 : ((gm == v) ? 0 : 1);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) b[q] = head[160 + (4 * lg + q) * 9 + (dy + 1) * 3 + t];
+                for (int q = 0; q < 4; ++q) b[q] = LOG2E * head[160 + (4 * lg + q) * 9 + (dy + 1) * 3 + t];
             }
             L.a2[v] = h4{(half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
             L.keep[v] = (lg == (v + 1) % 3) ? 0.f : 1.f;
             L.done[v] = (lg == (v + 2) % 3) ? 1 : 0;
         }
     }
-    const float b2 = head[304];
+    const float LOG2E_ = 1.4426950408889634f;
+    const float b2 = LOG2E_ * head[304];   // logits are carried in log2 units: exp2 is one instruction
     const int nq = (pw + 13) / 14;
     float rm = -1e30f, rs = 0.f;  // this lane's running (max, sum of exp) over the logits it completed
     __syncthreads();
     const int wu = __builtin_amdgcn_readfirstlane(w);  // provably wave-uniform: the row loop below becomes scalar control flow
-    for (int item = wu; item < ((dbg & 32) ? 0 : nq * 4); item += 4) {
-        const int q = item >> 2, rq = item & 3;
+    // work item = (pair of 14-column segments, quarter of the rows); the two segments of a pair are advanced in lock-step
+    const int npair = (nq + 1) >> 1;
+    for (int item = wu; item < ((dbg & 32) ? 0 : npair * 4); item += 4) {
+        const int qa = (item >> 2) * 2, qb = qa + 1, rq = item & 3;
+        const bool has_b = qb < nq;  // wave-uniform
+        const bool edge_a = qa == 0 || qa == nq - 1, edge_b = qb == nq - 1;
         const int ra = (ph * rq) >> 2, rb = (ph * (rq + 1)) >> 2;
-        const int cj = 14 * q - 1 + lj;                               // this lane's pixel column
-        const unsigned hmask = (cj >= 0 && cj < pw) ? 0xFFFFFFFFu : 0u;
-        const bool zok = lg < 3 && lj >= 1 && lj <= 14 && cj < pw;
-        // B1 source: lanes of group g < 3 read row r'-1+g at columns cj-1..cj+1; group 3 reads the constant
-        const half_t* xp = (lg < 3) ? xs + (ra - 1 - 1 + lg + 1) * xw + (cj - 1 + 8) : cst;
+        const int cja = 14 * qa - 1 + lj, cjb = cja + 14;             // this lane's pixel column in either segment
+        const unsigned hma = (cja >= 0 && cja < pw) ? 0xFFFFFFFFu : 0u, hmb = (cjb < pw) ? 0xFFFFFFFFu : 0u;
+        const bool zoka = lg < 3 && lj >= 1 && lj <= 14 && cja < pw, zokb = has_b && lg < 3 && lj >= 1 && lj <= 14 && cjb < pw;
+        int dna[3], dnb[3];  // completion masks: only valid output pixels ever reach the statistics
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            dna[v] = (L.done[v] && zoka) ? 1 : 0;
+            dnb[v] = (L.done[v] && zokb) ? 1 : 0;
+        }
+        // B1 source: lanes of group g < 3 read row r'-1+g at columns cj-1..cj+1 (segment b: +28 bytes); group 3 reads
+        // the constant
+        const half_t* xp = (lg < 3) ? xs + (ra - 1 - 1 + lg + 1) * xw + (cja - 1 + 8) : cst;
         const int xstep = (lg < 3) ? xw : 0;
-        float acc = 0.f, zst = -1e30f;
+        float acca = 0.f, zsta = -1e30f, accb = 0.f, zstb = -1e30f;
         const int nsteps = rb - ra + 2;
         for (int u0 = 0; u0 < nsteps; u0 += 3) {
 #pragma unroll
@@ -446,18 +462,29 @@ __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __
                 const int u = u0 + v;
                 if (u < nsteps) {
                     const int r = ra - 1 + u;
-                    head_step(L, v, r >= 0 && r < ph, u >= 2, xp, hmask, acc, zst);
+                    head_step<0>(L, v, r >= 0 && r < ph, u >= 2, edge_a, xp, hma, dna[v], acca, zsta);
+                    if (has_b) head_step<28>(L, v, r >= 0 && r < ph, u >= 2, edge_b, xp, hmb, dnb[v], accb, zstb);
                     xp += xstep;
                 }
             }
-            // fold the (up to three) output rows completed in this round into the running softmax statistics
-            const float z = (zok && zst > -1e29f) ? zst + b2 : -1e30f;
-            const float mn = fmaxf(rm, z);
-            rs = rs * __expf(rm - mn) + ((z > -1e29f) ? __expf(z - mn) : 0.f);  // approximate pass: fast exp
-            rm = mn;
-            zst = -1e30f;
+            // fold the output rows completed in this round into the running statistics (log2 domain, deferred maximum:
+            // the running reference rm only moves when a logit exceeds it by more than 8, so the common path is
+            // two subtractions, two exp2 and two adds; an untouched zst of -1e30 contributes exp2(-inf) = 0)
+            const float za = zsta + b2, zb_ = zstb + b2;
+            const float zmx = fmaxf(za, zb_);
+            if (__any(zmx > rm + 8.f)) {
+                asm volatile("; rescale (rare)" ::: "memory");  // keeps this a real branch instead of selects
+                const float mn = fmaxf(rm, zmx);
+                rs *= __builtin_amdgcn_exp2f(rm - mn);
+                rm = mn;
+            }
+            rs += __builtin_amdgcn_exp2f(za - rm) + __builtin_amdgcn_exp2f(zb_ - rm);  // raw v_exp_f32: exp2(-huge) = 0
+            zsta = -1e30f;
+            zstb = -1e30f;
         }
     }
+    // back to natural units: zmax = rm * ln 2; the sum is unit-free
+    rm = (rm > -1e29f) ? rm * 0.6931471805599453f : rm;
     // merge the per-lane (max, sum) pairs
     float zm = wave_max(rm);
     float zs = rs * expf(rm - zm);
@@ -985,7 +1012,7 @@ int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, con
     redo.tgt = redo.src_row + L.super;
     redo.out_idx = redo.tgt + L.super;
     const int ph = g->ph, pw = g->pw;
-    const size_t lds_head = (size_t)((((ph + 2) * map_xw(pw) + 32 + 7) & ~7)) * 2 + 16 + 16 * 4 + (1 + KC) * 4 + 16;
+    const size_t lds_head = (size_t)((((ph + 2) * map_xw(pw) + 32 + 7) & ~7)) * 2 + 64 + 16 * 4 + (1 + KC) * 4 + 16;
     int32_t* kstar = reinterpret_cast<int32_t*>(ws + L.kstar);
     float* xwin = reinterpret_cast<float*>(ws + L.xwin);
     DTK_REQUIRE(lds_head <= 160 * 1024, "dtk_track(mfma): token grid %dx%d too large for head16 (%zu B LDS)", ph, pw, lds_head);
