@@ -274,10 +274,74 @@ __global__ void head16_pack_kernel(const float* __restrict__ head, uint32_t* __r
             e += s2 * (s1 * DX + 2.f * U * (fabsf(head[144 + ch]) + s1));
         }
         reinterpret_cast<float*>(wpk)[152] = e;
+    } else if (i >= 160 && i < 176) {
+        // constants of the upper bound z_ub(a) = b2 + sum_ch [ W2p relu(b1 + P1 a) + W2n relu(b1 + N1 a) ] of the refiner
+        // output over ANY map with values in [0, a]: P1/N1 = positive / negative tap sums of conv1, W2p/W2n of conv2
+        const int ch = i - 160;
+        float p1 = 0.f, n1 = 0.f, p2 = 0.f, n2 = 0.f;
+        for (int t = 0; t < 9; ++t) {
+            const float a = head[ch * 9 + t], b = head[160 + ch * 9 + t];
+            p1 += fmaxf(a, 0.f); n1 += fminf(a, 0.f);
+            p2 += fmaxf(b, 0.f); n2 += fminf(b, 0.f);
+        }
+        float* cf = reinterpret_cast<float*>(wpk) + 160;
+        cf[ch] = p1; cf[16 + ch] = n1; cf[32 + ch] = p2; cf[48 + ch] = n2;
     }
 }
 
 __device__ __forceinline__ h2 as_h2(uint32_t u) { return *reinterpret_cast<h2*>(&u); }
+
+// peak16_kernel (fast mode): one wave per map -- approximate maximum and candidate cells only.  The softmax statistics of
+// the whole map are not needed when refine_head can certify that the zero-mass fallback cannot fire (see there).
+__global__ __launch_bounds__(256) void peak16_kernel(dtk_geom g, const half_t* __restrict__ maps, int MP,
+                                                     Rec* __restrict__ rec, int m0, int count, int M,
+                                                     const int32_t* __restrict__ dM) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= count || m0 + i >= dtk_active(M, dM)) return;
+    const int ph = g.ph, pw = g.pw, xw = map_xw(pw);
+    const int n16 = ((ph + 2) * xw + 7) / 8;
+    const uint4* map16 = reinterpret_cast<const uint4*>(maps + (size_t)i * MP);
+    h2 mx2 = {(half_t)0.f, (half_t)0.f};
+    for (int c = lane; c < n16; c += WAVE) {
+        const uint4 v = map16[c];
+        mx2 = __builtin_elementwise_max(mx2, __builtin_elementwise_max(
+                  __builtin_elementwise_max(as_h2(v.x), as_h2(v.y)), __builtin_elementwise_max(as_h2(v.z), as_h2(v.w))));
+    }
+    const float amax = wave_max(fmaxf((float)mx2[0], (float)mx2[1]));
+    const float thr = amax - EPS_C;
+    const half_t thr_h = (half_t)fmaxf(thr - 1e-3f, -1.f);
+    int ncand = 0, mine[KC];
+    const half_t* mh = maps + (size_t)i * MP;
+    for (int c = lane; c < n16; c += WAVE) {
+        const uint4 v = map16[c];
+        const h2 m4 = __builtin_elementwise_max(__builtin_elementwise_max(as_h2(v.x), as_h2(v.y)),
+                                                __builtin_elementwise_max(as_h2(v.z), as_h2(v.w)));
+        if (m4[0] < thr_h && m4[1] < thr_h) continue;
+        for (int e = 0; e < 8; ++e) {
+            const int pidx = c * 8 + e;
+            const int pr = pidx / xw, pc = pidx - pr * xw;
+            if (pr < 1 || pr > ph || pc < 8 || pc >= pw + 8) continue;  // border zeros are not cells
+            if ((float)mh[pidx] >= thr) {
+                if (ncand < KC) mine[ncand] = (pr - 1) * pw + (pc - 8);
+                ++ncand;
+            }
+        }
+    }
+    // wave-wide compaction of the per-lane candidate lists (order is irrelevant)
+    int total = ncand, base = 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(total, o, WAVE);
+        if (lane >= o) total += y;
+    }
+    base = total - ncand;
+    const int all = __shfl(total, 63, WAVE);
+    Rec* r = rec + i;
+    for (int k = 0; k < ncand && k < KC; ++k)
+        if (base + k < KC) r->cand[base + k] = mine[k];
+    if (lane == 0) { r->amax = amax; r->ncand = all; r->zmax = 0.f; r->Z = -1.f; }
+}
 
 // head16_kernel: one workgroup per map.  The map sits in LDS as fp16 with a zero border; besides the approximate maximum
 // and the candidate cells, the whole refiner runs on the matrix cores without ever staging the hidden activations:
@@ -832,8 +896,9 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
                                                           float* __restrict__ out_xy, const Rec* __restrict__ rec,
                                                           const int32_t* __restrict__ kstar,
                                                           const float* __restrict__ xwin,
-                                                          const float* __restrict__ zerr, Redo redo, int m0, int count,
-                                                          int M, const int32_t* __restrict__ dM, int normalized) {
+                                                          const float* __restrict__ zerr, Redo redo, Redo uncert,
+                                                          int fast, int m0, int count, int M,
+                                                          const int32_t* __restrict__ dM, int normalized) {
     __shared__ float s_x[4][WX * WX + 3];
     __shared__ __attribute__((aligned(16))) float s_h[4][WH * WH * 16];
     __shared__ float s_z[4][WZ * WZ + 7];
@@ -898,6 +963,50 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
     __builtin_amdgcn_wave_barrier();
     const Rec rc = rec[i];
     auto zfun = [&](int r, int c) { return zb[(r - (kr - RD)) * WZ + (c - (kc - RD))]; };
+    if (fast) {
+        // Certificate that the zero-mass fallback (tracker_head.py:86-94) cannot fire, without the map's softmax
+        // statistics: the masked mass is at least exp(zw)/(HW exp(z_ub)), zw = largest exact logit inside the disk (the
+        // arg-max cell is always inside), z_ub = bound of the refiner output over any map with values in [0, amax].
+        // If that exceeds the 1e-8 threshold the result is the plain ratio, in which the statistics cancel.
+        float zw = -INFINITY;
+        {
+            const float half = (float)(g.patch / 2);
+            for (int j = lane; j < WZ * WZ; j += WAVE) {
+                const int r = kr - RD + j / WZ, c = kc - RD + j % WZ;
+                if (r < 0 || r >= ph || c < 0 || c >= pw) continue;
+                const float dx = (float)((c - kc) * g.stride), dy = (float)((r - kr) * g.stride);
+                (void)half;
+                if (sqrtf(dx * dx + dy * dy) <= g.radius) zw = fmaxf(zw, zb[j]);
+            }
+            zw = wave_max(zw);
+        }
+        const float* cf = zerr + 8;  // = wpk + 160: P1, N1, W2p, W2n per channel
+        const float amx = fminf(rc.amax + 2e-3f, 1.f);
+        float zub = 0.f;
+        if (lane < 16) {
+            const float bb = head[144 + lane];
+            zub = cf[32 + lane] * fmaxf(bb + cf[lane] * amx, 0.f) + cf[48 + lane] * fmaxf(bb + cf[16 + lane] * amx, 0.f);
+        }
+        zub = wave_sum(zub) + head[304];
+        const bool certified = (zub - zw) < (18.42f - 0.1f - logf((float)(ph * pw)));
+        if (!certified) {
+            if (lane == 0) {
+                const int slot = atomicAdd(uncert.count, 1);
+                uncert.src_row[slot] = src_row ? src_row[m] : m;
+                uncert.tgt[slot] = min(max(tgt[m], 0), g.T - 1);
+                uncert.out_idx[slot] = out_idx ? out_idx[m] : m;
+            }
+            return;
+        }
+        float sq = 0.f;
+        dtk_disk_softargmax(g, k, zw, 1.f, zfun, normalized, s_out[w], &sq);  // sq >= 1: the fallback branch is dead
+        if (lane == 0) {
+            const int oi = out_idx ? out_idx[m] : m;
+            out_xy[2 * (size_t)oi] = s_out[w][0];
+            out_xy[2 * (size_t)oi + 1] = s_out[w][1];
+        }
+        return;
+    }
     float sq = 0.f;
     dtk_disk_softargmax(g, k, rc.zmax, rc.Z, zfun, normalized, s_out[w], &sq);
     if (lane == 0) {
@@ -920,7 +1029,8 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
 
 struct MfmaLayout {
     size_t s16, maps, rec, wpk, kstar, xwin, snorm, perm, hist, off, cursor, bsum, nvalid, redo_cnt, redo_lists, exact, total;
-    int HWk, nkeys, nblocks;
+    int HWk, nkeys, nblocks, cap;
+    size_t unc_lists;
     int MP;      // pitch (in halves) of one padded fp16 map: (ph+2) x (pw+4) + slack, multiple of 8
     int chunk;   // sources per corr16/head16 launch: their fp16 maps stay Infinity-Cache resident
     int super;   // sources per refine / redo round: large, so that uneven tiles balance across the chip
@@ -938,7 +1048,7 @@ MfmaLayout mfma_layout(const dtk_geom* g, int M) {
     L.MP = ((g->ph + 2) * map_xw(g->pw) + 32 + 7) & ~7;
     L.maps = off; off = al(off + (size_t)L.chunk * L.MP * 2);
     L.rec = off; off = al(off + (size_t)L.super * sizeof(Rec));
-    L.wpk = off; off = al(off + 160 * 4);
+    L.wpk = off; off = al(off + 256 * 4);
     L.kstar = off; off = al(off + (size_t)L.super * 4);
     L.xwin = off; off = al(off + (size_t)L.super * WX * WX * 4);
     L.HWk = (g->ph + 7) / 8 * 8 * g->pw;
@@ -951,8 +1061,10 @@ MfmaLayout mfma_layout(const dtk_geom* g, int M) {
     L.off = off; off = al(off + (size_t)(L.nkeys + 1) * 4);
     L.bsum = off; off = al(off + (size_t)(L.nblocks + 1) * 4);
     L.nvalid = off; off = al(off + 16);
-    L.redo_cnt = off; off = al(off + 16);
-    L.redo_lists = off; off = al(off + (size_t)3 * L.super * 4);
+    L.cap = (M + CM - 1) / CM * CM;                            // redo / uncertified lists can hold every source
+    L.redo_cnt = off; off = al(off + 16);                     // [0] redo count, [1] uncertified count
+    L.redo_lists = off; off = al(off + (size_t)3 * L.cap * 4);
+    L.unc_lists = off; off = al(off + (size_t)3 * L.cap * 4);
     L.exact = off;
     // staging of the exact path for re-done sources: large, so that a refine round costs a handful of (mostly empty)
     // exact-path launches instead of hundreds
@@ -988,6 +1100,77 @@ extern "C" int dtk_make_feat_f16(const dtk_geom* g, const float* feat, const flo
     return DTK_OK;
 }
 
+namespace {
+
+struct SrcLists {
+    const int32_t *src_row, *tgt, *out_idx;
+};
+
+// One pass of the MFMA pipeline over `count` sources (exact count, known on the host).
+//   fast = true : corr16 -> peak16 -> rescore/sort/refine_corr -> refine_head with the no-fallback certificate;
+//                 sources it cannot certify go to `uncert`, sources the fp16 pass cannot decide go to `redo`
+//   fast = false: corr16 -> head16 (whole-map refiner statistics on the matrix cores) -> ... -> refine_head with the
+//                 statistics; undecidable sources go to `redo`
+int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const float* feat, const float* norms,
+               const half_t* f16, const float* head, const float* emb, SrcLists in, float* out_xy, int count,
+               int normalized, bool fast, Redo redo, Redo uncert, size_t lds_head, hipStream_t st, int dbg) {
+    half_t* s16 = reinterpret_cast<half_t*>(ws + L.s16);
+    half_t* maps = reinterpret_cast<half_t*>(ws + L.maps);
+    Rec* rec = reinterpret_cast<Rec*>(ws + L.rec);
+    uint32_t* wpk = reinterpret_cast<uint32_t*>(ws + L.wpk);
+    int32_t* kstar = reinterpret_cast<int32_t*>(ws + L.kstar);
+    float* xwin = reinterpret_cast<float*>(ws + L.xwin);
+    int32_t* hist = reinterpret_cast<int32_t*>(ws + L.hist);
+    int32_t* cursor = reinterpret_cast<int32_t*>(ws + L.cursor);
+    int32_t* koff = reinterpret_cast<int32_t*>(ws + L.off);
+    int32_t* bsum = reinterpret_cast<int32_t*>(ws + L.bsum);
+    int32_t* nvalid = reinterpret_cast<int32_t*>(ws + L.nvalid);
+    float* snorm = reinterpret_cast<float*>(ws + L.snorm);
+    int32_t* perm = reinterpret_cast<int32_t*>(ws + L.perm);
+    const int32_t* nodm = nullptr;
+    const int M = count;
+    for (long long s0 = 0; s0 < M; s0 += L.super) {
+        const int scnt = (int)((M - s0) < L.super ? (M - s0) : L.super);
+        for (long long m0 = s0; m0 < s0 + scnt; m0 += L.chunk) {
+            const int cnt = (int)((s0 + scnt - m0) < L.chunk ? (s0 + scnt - m0) : L.chunk);
+            DTK_LAUNCH("src16", src16_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, emb, in.src_row, s16, (int)m0, cnt, M,
+                       nodm, g->C);
+            {
+                const int MT = dtk_cdiv(cnt, CM), NT = L.HWp / CN;
+                const int blocks = 8 * ((MT + 7) / 8) * 8 * ((NT + 7) / 8);
+                DTK_LAUNCH("corr16", corr16_tiled_kernel, dim3(blocks), dim3(256), 0, st, *g, f16, s16, in.tgt, maps, (int)m0,
+                           cnt, M, nodm, L.HWp, L.MP, dbg);
+            }
+            if (fast) {
+                DTK_LAUNCH("peak16", peak16_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, *g, maps, L.MP, rec + (m0 - s0),
+                           (int)m0, cnt, M, nodm);
+            } else {
+                DTK_LAUNCH("head16", head16_kernel, dim3(cnt), dim3(256), lds_head, st, *g, head, wpk, maps, L.MP,
+                           rec + (m0 - s0), (int)m0, cnt, M, nodm, dbg);
+            }
+        }
+        DTK_HIP(hipMemsetAsync(ws + L.hist, 0, L.cursor + (size_t)L.nkeys * 4 - L.hist, st));
+        DTK_LAUNCH("rescore", rescore_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, *g, feat, norms, emb, in.src_row,
+                   in.tgt, in.out_idx, rec, kstar, snorm, hist, L.HWk, redo, (int)s0, scnt, M, nodm, dbg);
+        DTK_LAUNCH("key_scan", scan_blocksum_kernel, dim3(L.nblocks), dim3(256), 0, st, hist, bsum, L.nkeys);
+        DTK_LAUNCH("key_scan", scan_top_kernel, dim3(1), dim3(256), 0, st, bsum, L.nblocks, nvalid);
+        DTK_LAUNCH("key_scan", scan_final_kernel, dim3(L.nblocks), dim3(256), 0, st, hist, bsum, koff, L.nkeys);
+        DTK_LAUNCH("key_scatter", scatter_kernel, dim3(dtk_cdiv(scnt, 256)), dim3(256), 0, st, *g, in.tgt, kstar, koff, cursor,
+                   perm, L.HWk, (int)s0, scnt);
+        DTK_LAUNCH("refine_corr", refine_corr_kernel, dim3(dtk_cdiv(scnt, 16)), dim3(256), 0, st, *g, feat, norms, emb,
+                   in.src_row, in.tgt, kstar, snorm, perm, nvalid, xwin, (int)s0, dbg);
+        DTK_LAUNCH("refine_head", refine_head_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, *g, head, in.src_row, in.tgt,
+                   in.out_idx, out_xy, rec, kstar, xwin, reinterpret_cast<const float*>(wpk) + 152, redo, uncert,
+                   fast ? 1 : 0, (int)s0, scnt, M, nodm, normalized);
+    }
+    return DTK_OK;
+}
+
+}  // namespace
+
+// NOTE: unlike the rest of the library this entry synchronises `stream` (up to three times): the sizes of its second
+// and third phase (sources that need the whole-map refiner statistics; sources re-done on the exact path) are only
+// known on the device, and launching worst-case grids for them costs more than the round trips.
 int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, const void* feat_f16, const float* head,
                    const float* emb, const int32_t* src_row, const int32_t* tgt, const int32_t* out_idx, float* out_xy,
                    int M, const int32_t* dM, int normalized, void* workspace, size_t workspace_bytes, void* stream) {
@@ -1002,64 +1185,50 @@ int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, con
     const char* dbg_env = getenv("DTK_DEBUG");
     const int dbg = dbg_env ? atoi(dbg_env) : 0;
     unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
-    half_t* s16 = reinterpret_cast<half_t*>(ws + L.s16);
-    half_t* maps = reinterpret_cast<half_t*>(ws + L.maps);
-    Rec* rec = reinterpret_cast<Rec*>(ws + L.rec);
-    uint32_t* wpk = reinterpret_cast<uint32_t*>(ws + L.wpk);
-    Redo redo;
-    redo.count = reinterpret_cast<int32_t*>(ws + L.redo_cnt);
+    int count = M;
+    if (dM) {  // data-dependent number of sources (anchor stage): read it instead of launching worst-case grids
+        int32_t v = 0;
+        DTK_HIP(hipMemcpyAsync(&v, dM, sizeof(v), hipMemcpyDeviceToHost, st));
+        DTK_HIP(hipStreamSynchronize(st));
+        count = v < M ? (v < 0 ? 0 : v) : M;
+    }
+    if (count == 0) return DTK_OK;
+    int32_t* counters = reinterpret_cast<int32_t*>(ws + L.redo_cnt);
+    Redo redo, uncert;
+    redo.count = counters;
     redo.src_row = reinterpret_cast<int32_t*>(ws + L.redo_lists);
-    redo.tgt = redo.src_row + L.super;
-    redo.out_idx = redo.tgt + L.super;
+    redo.tgt = redo.src_row + L.cap;
+    redo.out_idx = redo.tgt + L.cap;
+    uncert.count = counters + 1;
+    uncert.src_row = reinterpret_cast<int32_t*>(ws + L.unc_lists);
+    uncert.tgt = uncert.src_row + L.cap;
+    uncert.out_idx = uncert.tgt + L.cap;
     const int ph = g->ph, pw = g->pw;
     const size_t lds_head = (size_t)((((ph + 2) * map_xw(pw) + 32 + 7) & ~7)) * 2 + 64 + 16 * 4 + (1 + KC) * 4 + 16;
-    int32_t* kstar = reinterpret_cast<int32_t*>(ws + L.kstar);
-    float* xwin = reinterpret_cast<float*>(ws + L.xwin);
     DTK_REQUIRE(lds_head <= 160 * 1024, "dtk_track(mfma): token grid %dx%d too large for head16 (%zu B LDS)", ph, pw, lds_head);
     DTK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_head));
-    DTK_LAUNCH("head16_pack", head16_pack_kernel, dim3(1), dim3(256), 0, st, head, wpk);
-    DTK_HIP(hipMemsetAsync(maps, 0, (size_t)L.chunk * L.MP * 2, st));  // zero borders of the padded maps
+    DTK_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(int32_t), st));
+    DTK_LAUNCH("head16_pack", head16_pack_kernel, dim3(1), dim3(256), 0, st, head, reinterpret_cast<uint32_t*>(ws + L.wpk));
+    DTK_HIP(hipMemsetAsync(ws + L.maps, 0, (size_t)L.chunk * L.MP * 2, st));  // zero borders of the padded maps
     const half_t* f16 = reinterpret_cast<const half_t*>(feat_f16);
-    for (long long s0 = 0; s0 < M; s0 += L.super) {
-        const int scnt = (int)((M - s0) < L.super ? (M - s0) : L.super);
-        for (long long m0 = s0; m0 < s0 + scnt; m0 += L.chunk) {
-            const int cnt = (int)((s0 + scnt - m0) < L.chunk ? (s0 + scnt - m0) : L.chunk);
-            DTK_LAUNCH("src16", src16_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, emb, src_row, s16, (int)m0, cnt,
-                       M, dM, g->C);
-            {
-                const int MT = dtk_cdiv(cnt, CM), NT = L.HWp / CN;
-                const int blocks = 8 * ((MT + 7) / 8) * 8 * ((NT + 7) / 8);
-                DTK_LAUNCH("corr16", corr16_tiled_kernel, dim3(blocks), dim3(256), 0, st, *g, f16, s16, tgt, maps, (int)m0,
-                           cnt, M, dM, L.HWp, L.MP, dbg);
-            }
-            DTK_LAUNCH("head16", head16_kernel, dim3(cnt), dim3(256), lds_head, st, *g, head, wpk, maps, L.MP,
-                       rec + (m0 - s0), (int)m0, cnt, M, dM, dbg);
-        }
-        DTK_HIP(hipMemsetAsync(redo.count, 0, sizeof(int32_t), st));
-        DTK_HIP(hipMemsetAsync(ws + L.hist, 0, L.cursor + (size_t)L.nkeys * 4 - L.hist, st));
-        int32_t* hist = reinterpret_cast<int32_t*>(ws + L.hist);
-        int32_t* cursor = reinterpret_cast<int32_t*>(ws + L.cursor);
-        int32_t* koff = reinterpret_cast<int32_t*>(ws + L.off);
-        int32_t* bsum = reinterpret_cast<int32_t*>(ws + L.bsum);
-        int32_t* nvalid = reinterpret_cast<int32_t*>(ws + L.nvalid);
-        float* snorm = reinterpret_cast<float*>(ws + L.snorm);
-        int32_t* perm = reinterpret_cast<int32_t*>(ws + L.perm);
-        DTK_LAUNCH("rescore", rescore_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, *g, feat, norms, emb, src_row, tgt,
-                   out_idx, rec, kstar, snorm, hist, L.HWk, redo, (int)s0, scnt, M, dM, dbg);
-        DTK_LAUNCH("key_scan", scan_blocksum_kernel, dim3(L.nblocks), dim3(256), 0, st, hist, bsum, L.nkeys);
-        DTK_LAUNCH("key_scan", scan_top_kernel, dim3(1), dim3(256), 0, st, bsum, L.nblocks, nvalid);
-        DTK_LAUNCH("key_scan", scan_final_kernel, dim3(L.nblocks), dim3(256), 0, st, hist, bsum, koff, L.nkeys);
-        DTK_LAUNCH("key_scatter", scatter_kernel, dim3(dtk_cdiv(scnt, 256)), dim3(256), 0, st, *g, tgt, kstar, koff, cursor,
-                   perm, L.HWk, (int)s0, scnt);
-        DTK_LAUNCH("refine_corr", refine_corr_kernel, dim3(dtk_cdiv(scnt, 16)), dim3(256), 0, st, *g, feat, norms, emb,
-                   src_row, tgt, kstar, snorm, perm, nvalid, xwin, (int)s0, dbg);
-        DTK_LAUNCH("refine_head", refine_head_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, *g, head, src_row, tgt,
-                   out_idx, out_xy, rec, kstar, xwin, reinterpret_cast<const float*>(wpk) + 152, redo, (int)s0, scnt, M,
-                   dM, normalized);
-        // inconclusive sources of this round: the exact path, with the device-side count (kernels of empty rounds exit)
-        int rc = dtk_track_exact(g, feat, norms, head, emb, redo.src_row, redo.tgt, redo.out_idx, out_xy, scnt,
-                                 redo.count, normalized, ws + L.exact, workspace_bytes - L.exact, stream);
+    const bool fast_ok = !(dbg & 512);
+    int rc = mfma_phase(g, L, ws, feat, norms, f16, head, emb, SrcLists{src_row, tgt, out_idx}, out_xy, count, normalized,
+                        fast_ok, redo, uncert, lds_head, st, dbg);
+    if (rc) return rc;
+    int32_t hc[2] = {0, 0};
+    DTK_HIP(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, st));
+    DTK_HIP(hipStreamSynchronize(st));
+    if (hc[1] > 0) {  // sources without a no-fallback certificate: whole-map statistics
+        rc = mfma_phase(g, L, ws, feat, norms, f16, head, emb, SrcLists{uncert.src_row, uncert.tgt, uncert.out_idx}, out_xy,
+                        hc[1], normalized, false, redo, uncert, lds_head, st, dbg);
+        if (rc) return rc;
+        DTK_HIP(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, st));
+        DTK_HIP(hipStreamSynchronize(st));
+    }
+    if (hc[0] > 0) {  // sources the fp16 pass could not decide: the exact fp32 path
+        rc = dtk_track_exact(g, feat, norms, head, emb, redo.src_row, redo.tgt, redo.out_idx, out_xy, hc[0], nullptr,
+                             normalized, ws + L.exact, workspace_bytes - L.exact, stream);
         if (rc) return rc;
     }
     return DTK_OK;
