@@ -337,9 +337,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) tm = fmaxf(tm, sc[b][r]);
         tm = fmaxf(tm, __shfl_xor(tm, 32, WAVE));
-        const float m_new = fmaxf(m_run, tm);
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
+        // deferred maximum: the running reference only moves (and O, l are only rescaled) when some query of the wave
+        // sees a score more than 8 above it, so P stays <= 2^8 and the common path has no rescale
+        if (!__all(tm <= m_run + 8.f)) {
+            asm volatile("; rescale" ::: "memory");
+            const float m_new = fmaxf(m_run, tm);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // raw v_exp_f32 (exp2f() adds range handling)
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
         float ls = 0.f;
         bf8 pf[2][2];  // P^T fragments: [key block][16-slot group]
 #pragma unroll
@@ -348,15 +358,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float p = exp2f(sc[b][8 * j + e] - m_new);
+                    const float p = __builtin_amdgcn_exp2f(sc[b][8 * j + e] - m_run);
                     ls += p;
                     pf[b][j][e] = (bf16_t)p;
                 }
-        l_run = l_run * alpha + ls;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        l_run += ls;
         // ---- O^T += V^T P^T : slot (hi, e) of group (b, j) is key 32b + 16j + 8(e>>2) + 4hi + (e&3) ----
 #pragma unroll
         for (int db = 0; db < 2; ++db)

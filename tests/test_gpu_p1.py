@@ -77,3 +77,17 @@ def test_vitb_width(vits):
     feat = ex.encode(video, layer=1)
     ref = A.vit_tokens(video, sd, "dinov2_vitb14", layer=1).permute(1, 2, 0).reshape(-1, 768)
     _check(feat[0], ref)
+
+
+def test_attention_large_logits_force_rescale():
+    """Online-softmax deferred-maximum branch: with 6x larger q/k projections the scores spread over tens of log2
+    units, so the running maximum is overtaken by more than 8 many times along the key sweep (with the default weights
+    the rescale only happens on the first tile).  The first block's output must still match the fp32 oracle."""
+    sd = {k: v.clone() for k, v in synth.make_vit_weights("dinov2_vits14", seed=9).items()}
+    d = 384
+    sd["blocks.0.attn.qkv.weight"][:2 * d] *= 6.0  # q and k rows
+    ex = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd)
+    video = synth.synth_video(1, 238, 322, seed=76)  # 33 x 45 = 1485 tokens: 24 key tiles
+    feat = ex.encode(video, layer=0)
+    ref = A.vit_tokens(video, sd, "dinov2_vits14", layer=0).permute(1, 2, 0).reshape(-1, d)
+    _check(feat[0], ref, cos_min=0.998, rel_max=3e-2)
