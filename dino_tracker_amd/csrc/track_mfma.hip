@@ -118,10 +118,21 @@ __device__ __forceinline__ int swz(int row, int piece) {
     return row * 4 + (piece ^ f);
 }
 
+// PEAKS = false: the fp16 maps are stored (whole-map refiner statistics follow in head16).
+// PEAKS = true : nothing of the correlation volume leaves the chip: per (source, N-tile) only a 12-byte record is kept --
+//                the two largest values of the tile with their cells and the number of cells within EPS_C of the
+//                tile maximum -- from which select_kernel derives the approximate maximum and the candidate cells.
+struct TileRec {
+    float v1, v2;
+    uint32_t idx;  // i1 | i2 << 8 | count << 16  (columns inside the tile; count saturates at 255)
+};
+
+template <bool PEAKS>
 __global__ __launch_bounds__(256) void corr16_tiled_kernel(dtk_geom g, const half_t* __restrict__ f16,
                                                      const half_t* __restrict__ s16, const int32_t* __restrict__ tgt,
-                                                     half_t* __restrict__ maps, int m0, int count, int M,
-                                                     const int32_t* __restrict__ dM, int HWp, int MP, int dbg) {
+                                                     half_t* __restrict__ maps, TileRec* __restrict__ trec, int m0,
+                                                     int count, int M, const int32_t* __restrict__ dM, int HWp, int MP,
+                                                     int dbg) {
     __shared__ uint4 smem_ab[2 * (CM + CN) * 4];  // 24 KB: A/B double buffers; reused as the 64 x 128 fp16 output tile
     uint4 (*As)[CM * 4] = reinterpret_cast<uint4 (*)[CM * 4]>(smem_ab);
     uint4 (*Bs)[CN * 4] = reinterpret_cast<uint4 (*)[CN * 4]>(smem_ab + 2 * CM * 4);
@@ -230,9 +241,9 @@ __global__ __launch_bounds__(256) void corr16_tiled_kernel(dtk_geom g, const hal
                     Ts[row * TP16 + wc * 64 + ni * 16 + fj] = (half_t)fmaxf(acc[mi][ni][r] * INV_SCALE2, 0.f);
             }
         __syncthreads();
-        {
-            const int PWP = pw_pad(g.pw);
-            const int mr = cell0 / PWP, mc = cell0 - mr * PWP;
+        const int PWP = pw_pad(g.pw);
+        const int mr = cell0 / PWP, mc = cell0 - mr * PWP;
+        if (!PEAKS) {
             const size_t po = (size_t)(mr + 1) * map_xw(g.pw) + 8 + mc;
             const int piece = tid & 15, r0 = tid >> 4;
 #pragma unroll
@@ -241,6 +252,57 @@ __global__ __launch_bounds__(256) void corr16_tiled_kernel(dtk_geom g, const hal
                 if (s_tgt[row] == f && !(dbg & 256))
                     *reinterpret_cast<uint4*>(maps + (size_t)(tile_m0 - m0 + row) * MP + po + piece * 8) =
                         *reinterpret_cast<const uint4*>(Ts + row * TP16 + piece * 8);
+            }
+        } else {
+            // four threads per source row, 32 cells each: top-2 with positions, then the band count
+            const int row = tid >> 2, qd = tid & 3;
+            const half_t* tr = Ts + row * TP16 + qd * 32;
+            float v1 = -1.f, v2 = -1.f;
+            int i1 = 0, i2 = 0;
+            const int ncol = g.pw - mc - qd * 32;  // cells of this quarter that exist (padded columns are not cells)
+#pragma unroll
+            for (int p8 = 0; p8 < 4; ++p8) {
+                const uint4 u = *reinterpret_cast<const uint4*>(tr + p8 * 8);
+                const h8 hv = *reinterpret_cast<const h8*>(&u);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = (p8 * 8 + e < ncol) ? (float)hv[e] : -1.f;
+                    const int ci = qd * 32 + p8 * 8 + e;
+                    if (v > v1) { v2 = v1; i2 = i1; v1 = v; i1 = ci; }
+                    else if (v > v2) { v2 = v; i2 = ci; }
+                }
+            }
+            // merge the four quarters (lanes tid^1, tid^2 hold the other quarters of the same row)
+#pragma unroll
+            for (int o = 1; o <= 2; o <<= 1) {
+                const float w1 = __shfl_xor(v1, o, WAVE), w2 = __shfl_xor(v2, o, WAVE);
+                const int j1 = __shfl_xor(i1, o, WAVE), j2 = __shfl_xor(i2, o, WAVE);
+                // top-2 of {v1, v2, w1, w2}; ties resolved towards the lower column
+                const bool a_first = v1 > w1 || (v1 == w1 && i1 < j1);
+                const float n1 = a_first ? v1 : w1;
+                const int m1 = a_first ? i1 : j1;
+                const float c1 = a_first ? v2 : v1, c2 = a_first ? w1 : w2;  // runners-up of either side
+                const int d1 = a_first ? i2 : i1, d2 = a_first ? j1 : j2;
+                const bool c_first = c1 > c2 || (c1 == c2 && d1 < d2);
+                v1 = n1; i1 = m1;
+                v2 = c_first ? c1 : c2; i2 = c_first ? d1 : d2;
+            }
+            int cnt = 0;
+            const float band = v1 - EPS_C;
+#pragma unroll
+            for (int p8 = 0; p8 < 4; ++p8) {
+                const uint4 u = *reinterpret_cast<const uint4*>(tr + p8 * 8);
+                const h8 hv = *reinterpret_cast<const h8*>(&u);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cnt += (p8 * 8 + e < ncol && (float)hv[e] >= band) ? 1 : 0;
+            }
+            cnt += __shfl_xor(cnt, 1, WAVE);
+            cnt += __shfl_xor(cnt, 2, WAVE);
+            if (qd == 0 && s_tgt[row] == f) {
+                TileRec r;
+                r.v1 = v1; r.v2 = v2;
+                r.idx = (uint32_t)i1 | ((uint32_t)i2 << 8) | ((uint32_t)min(cnt, 255) << 16);
+                trec[(size_t)(tile_m0 - m0 + row) * (HWp / CN) + bx] = r;
             }
         }
         __syncthreads();  // the next frame of a mixed tile restages As/Bs
@@ -291,54 +353,47 @@ __global__ void head16_pack_kernel(const float* __restrict__ head, uint32_t* __r
 
 __device__ __forceinline__ h2 as_h2(uint32_t u) { return *reinterpret_cast<h2*>(&u); }
 
-// peak16_kernel (fast mode): one wave per map -- approximate maximum and candidate cells only.  The softmax statistics of
-// the whole map are not needed when refine_head can certify that the zero-mass fallback cannot fire (see there).
-__global__ __launch_bounds__(256) void peak16_kernel(dtk_geom g, const half_t* __restrict__ maps, int MP,
+// select_kernel (fast mode): one wave per source -- approximate maximum and candidate cells from the per-tile records of
+// corr16<PEAKS>.  A tile whose maximum lies within EPS_C of the global one but that holds more than two cells in its own
+// band may hide further candidates: such a source is marked as overflowing and is re-done by the exact path.
+__global__ __launch_bounds__(256) void select_kernel(dtk_geom g, const TileRec* __restrict__ trec, int ntiles,
                                                      Rec* __restrict__ rec, int m0, int count, int M,
                                                      const int32_t* __restrict__ dM) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= count || m0 + i >= dtk_active(M, dM)) return;
-    const int ph = g.ph, pw = g.pw, xw = map_xw(pw);
-    const int n16 = ((ph + 2) * xw + 7) / 8;
-    const uint4* map16 = reinterpret_cast<const uint4*>(maps + (size_t)i * MP);
-    h2 mx2 = {(half_t)0.f, (half_t)0.f};
-    for (int c = lane; c < n16; c += WAVE) {
-        const uint4 v = map16[c];
-        mx2 = __builtin_elementwise_max(mx2, __builtin_elementwise_max(
-                  __builtin_elementwise_max(as_h2(v.x), as_h2(v.y)), __builtin_elementwise_max(as_h2(v.z), as_h2(v.w))));
-    }
-    const float amax = wave_max(fmaxf((float)mx2[0], (float)mx2[1]));
+    const int PWP = pw_pad(g.pw);
+    const TileRec* tr = trec + (size_t)i * ntiles;
+    float amax = 0.f;
+    for (int t = lane; t < ntiles; t += WAVE) amax = fmaxf(amax, tr[t].v1);
+    amax = wave_max(amax);
     const float thr = amax - EPS_C;
-    const half_t thr_h = (half_t)fmaxf(thr - 1e-3f, -1.f);
-    int ncand = 0, mine[KC];
-    const half_t* mh = maps + (size_t)i * MP;
-    for (int c = lane; c < n16; c += WAVE) {
-        const uint4 v = map16[c];
-        const h2 m4 = __builtin_elementwise_max(__builtin_elementwise_max(as_h2(v.x), as_h2(v.y)),
-                                                __builtin_elementwise_max(as_h2(v.z), as_h2(v.w)));
-        if (m4[0] < thr_h && m4[1] < thr_h) continue;
-        for (int e = 0; e < 8; ++e) {
-            const int pidx = c * 8 + e;
-            const int pr = pidx / xw, pc = pidx - pr * xw;
-            if (pr < 1 || pr > ph || pc < 8 || pc >= pw + 8) continue;  // border zeros are not cells
-            if ((float)mh[pidx] >= thr) {
-                if (ncand < KC) mine[ncand] = (pr - 1) * pw + (pc - 8);
-                ++ncand;
-            }
+    int ncand = 0, mine[4];
+    bool overflow = false;
+    for (int t = lane; t < ntiles; t += WAVE) {
+        const TileRec r = tr[t];
+        if (r.v1 < thr) continue;
+        const int cell0 = t * CN, mr = cell0 / PWP, mc = cell0 - mr * PWP;
+        const int c1 = r.idx & 255, c2 = (r.idx >> 8) & 255, cnt = r.idx >> 16;
+        if (ncand < 4) mine[ncand] = mr * g.pw + mc + c1;
+        ++ncand;
+        if (r.v2 >= thr) {
+            if (ncand < 4) mine[ncand] = mr * g.pw + mc + c2;
+            ++ncand;
         }
+        if (cnt > 2) overflow = true;
     }
-    // wave-wide compaction of the per-lane candidate lists (order is irrelevant)
-    int total = ncand, base = 0;
+    int total = ncand;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const int y = __shfl_up(total, o, WAVE);
         if (lane >= o) total += y;
     }
-    base = total - ncand;
-    const int all = __shfl(total, 63, WAVE);
+    const int base = total - ncand;
+    int all = __shfl(total, 63, WAVE);
+    if (__any(overflow)) all = KC + 1;
     Rec* r = rec + i;
-    for (int k = 0; k < ncand && k < KC; ++k)
+    for (int k = 0; k < ncand && k < 4; ++k)
         if (base + k < KC) r->cand[base + k] = mine[k];
     if (lane == 0) { r->amax = amax; r->ncand = all; r->zmax = 0.f; r->Z = -1.f; }
 }
@@ -1030,7 +1085,7 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
 struct MfmaLayout {
     size_t s16, maps, rec, wpk, kstar, xwin, snorm, perm, hist, off, cursor, bsum, nvalid, redo_cnt, redo_lists, exact, total;
     int HWk, nkeys, nblocks, cap;
-    size_t unc_lists;
+    size_t unc_lists, trec;
     int MP;      // pitch (in halves) of one padded fp16 map: (ph+2) x (pw+4) + slack, multiple of 8
     int chunk;   // sources per corr16/head16 launch: their fp16 maps stay Infinity-Cache resident
     int super;   // sources per refine / redo round: large, so that uneven tiles balance across the chip
@@ -1048,6 +1103,7 @@ MfmaLayout mfma_layout(const dtk_geom* g, int M) {
     L.MP = ((g->ph + 2) * map_xw(g->pw) + 32 + 7) & ~7;
     L.maps = off; off = al(off + (size_t)L.chunk * L.MP * 2);
     L.rec = off; off = al(off + (size_t)L.super * sizeof(Rec));
+    L.trec = off; off = al(off + (size_t)L.chunk * (L.HWp / CN) * sizeof(TileRec));
     L.wpk = off; off = al(off + 256 * 4);
     L.kstar = off; off = al(off + (size_t)L.super * 4);
     L.xwin = off; off = al(off + (size_t)L.super * WX * WX * 4);
@@ -1138,13 +1194,18 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
             {
                 const int MT = dtk_cdiv(cnt, CM), NT = L.HWp / CN;
                 const int blocks = 8 * ((MT + 7) / 8) * 8 * ((NT + 7) / 8);
-                DTK_LAUNCH("corr16", corr16_tiled_kernel, dim3(blocks), dim3(256), 0, st, *g, f16, s16, in.tgt, maps, (int)m0,
-                           cnt, M, nodm, L.HWp, L.MP, dbg);
+                TileRec* trec = reinterpret_cast<TileRec*>(ws + L.trec);
+                if (fast) {
+                    DTK_LAUNCH("corr16_peaks", corr16_tiled_kernel<true>, dim3(blocks), dim3(256), 0, st, *g, f16, s16, in.tgt,
+                               maps, trec, (int)m0, cnt, M, nodm, L.HWp, L.MP, dbg);
+                    DTK_LAUNCH("select", select_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, *g, trec, NT, rec + (m0 - s0),
+                               (int)m0, cnt, M, nodm);
+                } else {
+                    DTK_LAUNCH("corr16", corr16_tiled_kernel<false>, dim3(blocks), dim3(256), 0, st, *g, f16, s16, in.tgt,
+                               maps, trec, (int)m0, cnt, M, nodm, L.HWp, L.MP, dbg);
+                }
             }
-            if (fast) {
-                DTK_LAUNCH("peak16", peak16_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, *g, maps, L.MP, rec + (m0 - s0),
-                           (int)m0, cnt, M, nodm);
-            } else {
+            if (!fast) {
                 DTK_LAUNCH("head16", head16_kernel, dim3(cnt), dim3(256), lds_head, st, *g, head, wpk, maps, L.MP,
                            rec + (m0 - s0), (int)m0, cnt, M, nodm, dbg);
             }
