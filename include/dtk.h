@@ -146,8 +146,11 @@ int dtk_head_forward(const dtk_geom* g, const float* head, const float* maps, fl
  * and out_xy[out_idx[m]] = (x, y) in PIXELS (model_inference.py:52 already applied), or normalised to [-1,1]
  * if normalized != 0 (the value Tracker.forward returns, tracker.py:303-325).
  * src_row / out_idx may be NULL (identity).  Any order of tgt is correct; sources sorted by tgt run fastest.
- * `method`: DTK_TRACK_EXACT = fp32 everywhere (correlation volume staged through `workspace`);
- *           DTK_TRACK_MFMA  = fused fp16-MFMA sweep + fp32 window refinement (volume never leaves the CU).
+ * `method`: DTK_TRACK_EXACT = fp32 everywhere (correlation volume staged through `workspace`), fully asynchronous;
+ *           DTK_TRACK_MFMA  = fp16-MFMA correlation reduced on chip to peak records + fp32 window refinement;
+ *                             sources that need the whole-map refiner statistics / the exact path are handled in a
+ *                             second / third phase whose sizes are read back: this method SYNCHRONISES `stream`
+ *                             up to three times per call.
  * `dM` (device int32*, may be NULL): if given, the number of sources is min(M, *dM) read on device -- lets the
  * anchor stage run without a host sync on the data-dependent anchor count. */
 #define DTK_TRACK_EXACT 0
@@ -158,8 +161,8 @@ int dtk_track(const dtk_geom* g, const float* feat, const float* norms, const vo
               const int32_t* out_idx, float* out_xy, int M, const int32_t* dM, int normalized, int method,
               void* workspace, size_t workspace_bytes, void* stream);
 
-/* fp16 unit-norm copy of the feature volume consumed by DTK_TRACK_MFMA: f16[t][cell][c] = F/|F| (cells padded
- * to a multiple of 16 per frame with zeros; C must be a multiple of 32). */
+/* fp16 unit-norm copy of the feature volume consumed by DTK_TRACK_MFMA: f16[t][row][col][c] = 32 F/|F| with every map
+ * row padded with zero cells to a multiple of 128 columns (an N-tile of the GEMM is one map row); C % 32 == 0. */
 size_t dtk_feat_f16_bytes(const dtk_geom* g);
 int dtk_make_feat_f16(const dtk_geom* g, const float* feat, const float* norms, void* feat_f16, void* stream);
 
