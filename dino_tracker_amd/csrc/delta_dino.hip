@@ -109,6 +109,237 @@ __global__ __launch_bounds__(256) void conv5x5_kernel(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// split-fp16 convolution (layers 2-4): every fp32 operand is carried as hi + lo fp16 halves (x = xh + xl exactly to
+// 2^-22 relative), and a product is three matrix-core products  xh.wh + xh.wl + xl.wh  accumulated in fp32 -- fp32-grade
+// results (each fp16 x fp16 product is exact in fp32; the dropped xl.wl term is 2^-22 relative) at a third of the fp16
+// MFMA rate instead of the 1/16 of the f32-input MFMA.  Activations live as two NHWC fp16 planes, weights as two planes in
+// [cout tile][cin chunk][tap][64 cout][16 cin] (pre-scaled by 2^8 so that the lo halves stay normal numbers).
+// Workgroup = 16 x 16 output pixels x 64 output channels; wave = 4 x 16 pixels x 64 channels (2 M-tiles x 2 N-tiles of
+// 32x32x16: 8 ds_read_b128 feed 12 MFMAs).
+// LDS rows of 16 cin (32 B) sit at a 48-byte pitch: the ds_read_b128 fragment reads of 32 lanes are conflict-free.
+// ---------------------------------------------------------------------------------------------------------------
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+constexpr int SK = 16;             // cin per chunk
+constexpr int SPT = 24;            // LDS pitch of one 16-cin row in halves (48 B)
+constexpr int STY = 16, STX = 16;  // pixel tile
+constexpr float WSCALE = 256.f;
+
+template <int DIL>
+struct SplitCfg {
+    static constexpr int PY = STY + 4 * DIL, PX = STX + 4 * DIL;
+    static constexpr int PXP = 24;  // row stride of 24 px * 48 B = 128 mod 256 B: two patch rows read conflict-free
+    static constexpr int X_HALVES = PY * PXP * SPT;
+    static constexpr int W_HALVES = 5 * 64 * SPT;
+    static constexpr size_t LDS_BYTES = (size_t)(2 * X_HALVES + 2 * W_HALVES) * sizeof(half_t);
+    static_assert(PX <= PXP, "patch wider than the padded LDS row");
+};
+
+template <int DIL, bool OUT_SPLIT>
+__global__ __launch_bounds__(256) void conv5x5_split_kernel(const half_t* __restrict__ in_hi, const half_t* __restrict__ in_lo,
+                                                            const half_t* __restrict__ Wh, const half_t* __restrict__ Wl,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            half_t* __restrict__ out_hi, half_t* __restrict__ out_lo,
+                                                            float* __restrict__ out_f32, int H, int W, int Cin, int Cout,
+                                                            int relu, int tiles_x) {
+    typedef SplitCfg<DIL> Cfg;
+    constexpr int PY = Cfg::PY, PX = Cfg::PX, PXP = Cfg::PXP;
+    extern __shared__ __attribute__((aligned(16))) half_t smem_s[];
+    half_t* Xh = smem_s;                       // [PY][PXP][SPT]
+    half_t* Xl = Xh + Cfg::X_HALVES;
+    half_t* Wsh = Xl + Cfg::X_HALVES;          // [5 taps][64 cout][SPT]
+    half_t* Wsl = Wsh + Cfg::W_HALVES;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+    const int y0 = ty * STY, x0 = tx * STX;
+    const int ct = blockIdx.y;                 // 64-cout tile
+    const size_t frame = blockIdx.z;
+    const half_t* fh = in_hi + frame * (size_t)H * W * Cin;
+    const half_t* fl = in_lo + frame * (size_t)H * W * Cin;
+    const int li = lane & 31, hi = lane >> 5;
+    const int ly = w * 4 + (li >> 3), lx = li & 7;   // M-tile m covers columns m*8 .. m*8+7 of the wave's 4 rows
+    const int nck = Cin / SK;
+    f16v acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    for (int ck = 0; ck < nck; ++ck) {
+        __syncthreads();
+        // input patch, both planes: PY*PX pixels x 2 pieces of 8 cin
+        for (int idx = tid; idx < PY * PX * 4; idx += 256) {
+            const int plane = idx & 1, piece = (idx >> 1) & 1, p = idx >> 2;
+            const int py = p / PX, px = p - py * PX;
+            const int gy = reflect(y0 - 2 * DIL + py, H), gx = reflect(x0 - 2 * DIL + px, W);
+            const half_t* src = (plane ? fl : fh) + ((size_t)gy * W + gx) * Cin + ck * SK + piece * 8;
+            *reinterpret_cast<uint4*>((plane ? Xl : Xh) + (py * PXP + px) * SPT + piece * 8) =
+                *reinterpret_cast<const uint4*>(src);
+        }
+        for (int ky = 0; ky < 5; ++ky) {
+            if (ky) __syncthreads();
+            // weights of this tap row: 5 taps x 64 cout x 2 pieces, both planes
+            const size_t wbase = ((((size_t)ct * nck + ck) * 25) + ky * 5) * 64 * SK;
+            for (int idx = tid; idx < 5 * 64 * 4; idx += 256) {
+                const int plane = idx & 1, piece = (idx >> 1) & 1, rowi = idx >> 2;  // rowi = tap*64 + cout
+                const half_t* src = (plane ? Wl : Wh) + wbase + (size_t)rowi * SK + piece * 8;
+                *reinterpret_cast<uint4*>((plane ? Wsl : Wsh) + rowi * SPT + piece * 8) = *reinterpret_cast<const uint4*>(src);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                h8 xh[2], xl[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int p = (ly + ky * DIL) * PXP + m * 8 + lx + kx * DIL;
+                    xh[m] = *reinterpret_cast<const h8*>(Xh + p * SPT + hi * 8);
+                    xl[m] = *reinterpret_cast<const h8*>(Xl + p * SPT + hi * 8);
+                }
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int wr = (kx * 64 + n * 32 + li) * SPT + hi * 8;
+                    const h8 wh = *reinterpret_cast<const h8*>(Wsh + wr);
+                    const h8 wl = *reinterpret_cast<const h8*>(Wsl + wr);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[m], wh, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[m], wl, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[m], wh, acc[m][n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // D[i][j]: j = lane&31 (cout), i = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel of the M-tile's 4 x 8 block)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int co = ct * 64 + n * 32 + li;
+        if (co >= Cout) continue;
+        const float sc = scale[co], sh = shift[co];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int oy = y0 + w * 4 + (i >> 3), ox = x0 + m * 8 + (i & 7);
+                if (oy < H && ox < W) {
+                    float v = (acc[m][n][r] * (1.f / WSCALE)) * sc + sh;
+                    if (relu) v = fmaxf(v, 0.f);
+                    const size_t o = frame * (size_t)H * W * Cout + ((size_t)oy * W + ox) * Cout + co;
+                    if (OUT_SPLIT) {
+                        const half_t vh = (half_t)v;
+                        out_hi[o] = vh;
+                        out_lo[o] = (half_t)(v - (float)vh);
+                    } else {
+                        out_f32[o] = v;
+                    }
+                }
+            }
+    }
+}
+
+// NHWC blur-pool on split planes: one thread per (output pixel, 8 channels)
+__global__ __launch_bounds__(256) void blurpool_split_kernel(const half_t* __restrict__ in_hi, const half_t* __restrict__ in_lo,
+                                                             half_t* __restrict__ out_hi, half_t* __restrict__ out_lo, int H,
+                                                             int W, int Ho, int Wo, int C) {
+    const size_t frame = blockIdx.y;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c8 = C / 8;
+    if (idx >= (long long)Ho * Wo * c8) return;
+    const int cq = (int)(idx % c8);
+    const int p = (int)(idx / c8);
+    const int oy = p / Wo, ox = p - oy * Wo;
+    const half_t* fh = in_hi + frame * (size_t)H * W * C;
+    const half_t* fl = in_lo + frame * (size_t)H * W * C;
+    const float f[4] = {1.f, 3.f, 3.f, 1.f};
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gy = reflect(2 * oy - 1 + i, H);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gx = reflect(2 * ox - 1 + j, W);
+            const float wgt = f[i] * f[j] * (1.f / 64.f);
+            const size_t o = ((size_t)gy * W + gx) * C + cq * 8;
+            const uint4 uh = *reinterpret_cast<const uint4*>(fh + o), ul = *reinterpret_cast<const uint4*>(fl + o);
+            const h8 vh = *reinterpret_cast<const h8*>(&uh), vl = *reinterpret_cast<const h8*>(&ul);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(wgt, (float)vh[e] + (float)vl[e], acc[e]);
+        }
+    }
+    h8 oh, ol;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        oh[e] = (half_t)acc[e];
+        ol[e] = (half_t)(acc[e] - (float)oh[e]);
+    }
+    const size_t oo = frame * (size_t)Ho * Wo * C + ((size_t)oy * Wo + ox) * C + cq * 8;
+    *reinterpret_cast<h8*>(out_hi + oo) = oh;
+    *reinterpret_cast<h8*>(out_lo + oo) = ol;
+}
+
+// NHWC blur-pool of the fp32 first-layer output, written as split planes: one thread per (output pixel, 4 channels)
+__global__ __launch_bounds__(256) void blurpool_to_split_kernel(const float* __restrict__ in, half_t* __restrict__ out_hi,
+                                                                half_t* __restrict__ out_lo, int H, int W, int Ho, int Wo,
+                                                                int C) {
+    const size_t frame = blockIdx.y;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = C / 4;
+    if (idx >= (long long)Ho * Wo * c4) return;
+    const int cq = (int)(idx % c4);
+    const int p = (int)(idx / c4);
+    const int oy = p / Wo, ox = p - oy * Wo;
+    const float* fin = in + frame * (size_t)H * W * C;
+    const float f[4] = {1.f, 3.f, 3.f, 1.f};
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gy = reflect(2 * oy - 1 + i, H);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gx = reflect(2 * ox - 1 + j, W);
+            const float wgt = f[i] * f[j] * (1.f / 64.f);
+            const float4 v = *reinterpret_cast<const float4*>(fin + ((size_t)gy * W + gx) * C + cq * 4);
+            acc[0] = fmaf(wgt, v.x, acc[0]);
+            acc[1] = fmaf(wgt, v.y, acc[1]);
+            acc[2] = fmaf(wgt, v.z, acc[2]);
+            acc[3] = fmaf(wgt, v.w, acc[3]);
+        }
+    }
+    typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+    h4v oh, ol;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        oh[e] = (half_t)acc[e];
+        ol[e] = (half_t)(acc[e] - (float)oh[e]);
+    }
+    const size_t oo = frame * (size_t)Ho * Wo * C + ((size_t)oy * Wo + ox) * C + cq * 4;
+    *reinterpret_cast<h4v*>(out_hi + oo) = oh;
+    *reinterpret_cast<h4v*>(out_lo + oo) = ol;
+}
+
+// [Cout][Cin][5][5] fp32 -> split planes [cout tile][cin chunk][25][64][16] of w * 2^8
+__global__ void pack_split_kernel(const float* __restrict__ w, int Cin, int Cout, half_t* __restrict__ Wh, half_t* __restrict__ Wl) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int nck = Cin / SK, nct = (Cout + 63) / 64;
+    const long long total = (long long)nct * nck * 25 * 64 * SK;
+    if (idx >= total) return;
+    const int ci_l = (int)(idx % SK);
+    const int co_l = (int)((idx / SK) % 64);
+    const int tap = (int)((idx / (SK * 64)) % 25);
+    const int ck = (int)((idx / (SK * 64 * 25)) % nck);
+    const int ct = (int)(idx / ((long long)SK * 64 * 25 * nck));
+    const int co = ct * 64 + co_l, ci = ck * SK + ci_l;
+    const float v = (co < Cout) ? w[((size_t)co * Cin + ci) * 25 + tap] * WSCALE : 0.f;
+    const half_t h = (half_t)v;
+    Wh[idx] = h;
+    Wl[idx] = (half_t)(v - (float)h);
+}
+
 // NHWC blur-pool: one thread per (output pixel, 4 channels)
 __global__ __launch_bounds__(256) void blurpool_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
                                                        int Ho, int Wo, int C) {
@@ -242,13 +473,23 @@ Plan make_plan(int video_h, int video_w, int C, int fb) {
     return p;
 }
 
+inline size_t f32_packed_floats(int cinp, int coutp) { return (size_t)25 * cinp * coutp + 2 * (size_t)coutp; }
+// halves in ONE split weight plane == floats taken by the two planes together
+inline size_t split_plane_halves(int cin, int cout) { return (size_t)((cout + 63) / 64) * (cin / SK) * 25 * 64 * SK; }
+
+// DTK_DEBUG bit 1024: run layers 2-4 on the fp32-input MFMA kernel instead of the split-fp16 one
+inline bool dd_force_f32() {
+    static const int v = [] { const char* e = getenv("DTK_DEBUG"); return e ? atoi(e) : 0; }();
+    return (v & 1024) != 0;
+}
+
 }  // namespace
 
 extern "C" size_t dtk_delta_dino_packed_floats(int layer, int C) {
     const int chans[5] = {3, 64, 128, 256, C};
     if (layer < 0 || layer > 3 || C <= 0) return 0;
     const int cinp = pad_to(chans[layer], CK), coutp = pad_to(chans[layer + 1], TNC);
-    return (size_t)25 * cinp * coutp + 2 * (size_t)coutp;
+    return f32_packed_floats(cinp, coutp) + (layer ? split_plane_halves(chans[layer], chans[layer + 1]) : 0);
 }
 
 extern "C" int dtk_delta_dino_pack(int layer, int C, const float* w, const float* bias, const float* bn_w,
@@ -265,6 +506,12 @@ extern "C" int dtk_delta_dino_pack(int layer, int C, const float* w, const float
     const long long total = 25LL * cinp * coutp;
     DTK_LAUNCH("dd_pack", pack_conv_kernel, dim3(dtk_cdiv(total, 256)), dim3(256), 0, dtk_stream(stream), w, bias, bn_w,
                bn_b, bn_mean, bn_var, eps, cin, cout, cinp, coutp, Wk, scale, shift);
+    if (layer) {
+        half_t* Wh = reinterpret_cast<half_t*>(packed + f32_packed_floats(cinp, coutp));
+        const size_t nh = split_plane_halves(cin, cout);
+        DTK_LAUNCH("dd_pack", pack_split_kernel, dim3(dtk_cdiv((long long)nh, 256)), dim3(256), 0, dtk_stream(stream), w, cin,
+                   cout, Wh, Wh + nh);
+    }
     return DTK_OK;
 }
 
@@ -293,35 +540,76 @@ extern "C" int dtk_delta_dino_refine(const dtk_geom* g, const float* video, cons
     hipStream_t st = dtk_stream(stream);
     float* ws = reinterpret_cast<float*>(workspace);
     const int HW = g->ph * g->pw;
+    static const bool lds_ok = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5x5_split_kernel<1, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitCfg<1>::LDS_BYTES) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5x5_split_kernel<2, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitCfg<2>::LDS_BYTES) == hipSuccess;
+    }();
+    DTK_REQUIRE(lds_ok, "dtk_delta_dino_refine: cannot reserve LDS for the split-fp16 convolution");
     for (int f0 = t0; f0 < t0 + nframes; f0 += fb) {
         const int nf = (t0 + nframes - f0) < fb ? (t0 + nframes - f0) : fb;
         const float* cur = video + (size_t)f0 * 3 * g->video_h * g->video_w;
+        const bool split = !dd_force_f32();
         for (int l = 0; l < 4; ++l) {
             const int H = p.H[l], W = p.W[l], cin = p.Cin[l], cout = p.Cout[l];
             const int cinp = pad_to(cin, CK), coutp = pad_to(cout, TNC);
             const float* Wk = packed[l];
             const float* scale = Wk + (size_t)25 * cinp * coutp;
             const float* shift = scale + coutp;
-            const int tiles_x = dtk_cdiv(W, TP), tiles_y = dtk_cdiv(H, TP);
-            dim3 grid(tiles_x * tiles_y, coutp / TNC, nf);
             float* act = ws + p.act[l];
-            if (l == 0) {
-                DTK_LAUNCH("dd_conv1", (conv5x5_kernel<1, true>), grid, dim3(256), 0, st, cur, Wk, scale, shift, act, H, W,
-                           cin, cinp, cout, coutp, 1, tiles_x);
-            } else if (l < 3) {
-                DTK_LAUNCH("dd_conv23", (conv5x5_kernel<1, false>), grid, dim3(256), 0, st, cur, Wk, scale, shift, act, H,
-                           W, cin, cinp, cout, coutp, 1, tiles_x);
+            // split activations: hi plane in the first half of the fp32-sized slot, lo plane in the second
+            const size_t in_n = (size_t)nf * H * W * cin, out_n = (size_t)nf * H * W * cout;
+            if (l == 0 || !split) {
+                const int tiles_x = dtk_cdiv(W, TP), tiles_y = dtk_cdiv(H, TP);
+                dim3 grid(tiles_x * tiles_y, coutp / TNC, nf);
+                if (l == 0) {
+                    DTK_LAUNCH("dd_conv1", (conv5x5_kernel<1, true>), grid, dim3(256), 0, st, cur, Wk, scale, shift, act, H,
+                               W, cin, cinp, cout, coutp, 1, tiles_x);
+                } else if (l < 3) {
+                    DTK_LAUNCH("dd_conv23", (conv5x5_kernel<1, false>), grid, dim3(256), 0, st, cur, Wk, scale, shift, act,
+                               H, W, cin, cinp, cout, coutp, 1, tiles_x);
+                } else {
+                    DTK_LAUNCH("dd_conv4", (conv5x5_kernel<2, false>), grid, dim3(256), 0, st, cur, Wk, scale, shift, act, H,
+                               W, cin, cinp, cout, coutp, 0, tiles_x);
+                }
             } else {
-                DTK_LAUNCH("dd_conv4", (conv5x5_kernel<2, false>), grid, dim3(256), 0, st, cur, Wk, scale, shift, act, H,
-                           W, cin, cinp, cout, coutp, 0, tiles_x);
+                const half_t* Wh = reinterpret_cast<const half_t*>(Wk + f32_packed_floats(cinp, coutp));
+                const half_t* Wl = Wh + split_plane_halves(cin, cout);
+                const half_t* ih = reinterpret_cast<const half_t*>(cur);
+                half_t* oh = reinterpret_cast<half_t*>(act);
+                const int tiles_x = dtk_cdiv(W, STX), tiles_y = dtk_cdiv(H, STY);
+                dim3 grid(tiles_x * tiles_y, (cout + 63) / 64, nf);
+                if (l < 3) {
+                    DTK_LAUNCH("dd_conv23", (conv5x5_split_kernel<1, true>), grid, dim3(256), SplitCfg<1>::LDS_BYTES, st, ih,
+                               ih + in_n, Wh, Wl, scale, shift, oh, oh + out_n, (float*)nullptr, H, W, cin, cout, 1, tiles_x);
+                } else {
+                    DTK_LAUNCH("dd_conv4", (conv5x5_split_kernel<2, false>), grid, dim3(256), SplitCfg<2>::LDS_BYTES, st, ih,
+                               ih + in_n, Wh, Wl, scale, shift, (half_t*)nullptr, (half_t*)nullptr, act, H, W, cin, cout, 0,
+                               tiles_x);
+                }
             }
             cur = act;
             if (l < 3) {
                 const int Ho = pool_out(H), Wo = pool_out(W);
                 float* pl = ws + p.pool[l];
-                const long long n = (long long)Ho * Wo * (cout / 4);
-                DTK_LAUNCH("dd_blurpool", blurpool_kernel, dim3(dtk_cdiv(n, 256), nf), dim3(256), 0, st, act, pl, H, W, Ho,
-                           Wo, cout);
+                const size_t pool_n = (size_t)nf * Ho * Wo * cout;
+                if (!split) {
+                    const long long n = (long long)Ho * Wo * (cout / 4);
+                    DTK_LAUNCH("dd_blurpool", blurpool_kernel, dim3(dtk_cdiv(n, 256), nf), dim3(256), 0, st, act, pl, H, W,
+                               Ho, Wo, cout);
+                } else if (l == 0) {
+                    const long long n = (long long)Ho * Wo * (cout / 4);
+                    half_t* ph_ = reinterpret_cast<half_t*>(pl);
+                    DTK_LAUNCH("dd_blurpool", blurpool_to_split_kernel, dim3(dtk_cdiv(n, 256), nf), dim3(256), 0, st, act,
+                               ph_, ph_ + pool_n, H, W, Ho, Wo, cout);
+                } else {
+                    const long long n = (long long)Ho * Wo * (cout / 8);
+                    const half_t* ah = reinterpret_cast<const half_t*>(act);
+                    half_t* ph_ = reinterpret_cast<half_t*>(pl);
+                    DTK_LAUNCH("dd_blurpool", blurpool_split_kernel, dim3(dtk_cdiv(n, 256), nf), dim3(256), 0, st, ah,
+                               ah + out_n, ph_, ph_ + pool_n, H, W, Ho, Wo, cout);
+                }
                 cur = pl;
             }
         }
