@@ -76,7 +76,8 @@ def main():
     stages = [x for x in args.stages.split(",") if x]
     from dino_tracker_amd.extractor import VitExtractor
     from dino_tracker_amd.tracker import Tracker
-    from dino_tracker_amd._lib import make_geom
+    import ctypes
+    from dino_tracker_amd._lib import lib, make_geom
     model_name = {384: "dinov2_vits14", 768: "dinov2_vitb14", 1024: "dinov2_vitl14"}[C]
     # per-rank synthetic inputs: translating-texture video, seeded random weights
     video = synth.synth_video(T, H, W, seed=2000 + rank).to(dev)
@@ -196,6 +197,14 @@ def main():
                          f"resident; {cdt:.1f}s"}
 
     if rank == 0:
+        if int(os.environ.get("DTK_DEBUG", "0")) & 4096:
+            dc = (ctypes.c_ulonglong * 4)()
+            lib().dtk_debug_counters(dc)
+            print("redo reasons [overflow, none, nonpositive, -]:", list(dc), file=sys.stderr)
+        tc = (ctypes.c_int * 3)()
+        track_counts = None
+        if hasattr(lib(), "dtk_debug_track_counts") and lib().dtk_debug_track_counts(tc) == 0:
+            track_counts = {"sources": tc[0], "whole_map_tier": tc[1], "exact_tier": tc[2]}  # last dtk_track call
         out = {
             "metric": "query-points*frames/s", "value": round(world * N * T * args.steps / dt, 1),
             "unit": "query-points*frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -206,7 +215,8 @@ def main():
                                    f"queries, one video per GPU",
                        "stages": stages, "features": args.features,
                        "track_method": "exact" if method == ops.TRACK_EXACT else "mfma",
-                       "anchor_pairs": pairs, "correlation_maps_per_step": maps, "parallelism": f"video-parallel x{world}"},
+                       "anchor_pairs": pairs, "correlation_maps_per_step": maps, "anchor_track_tiers": track_counts,
+                       "parallelism": f"video-parallel x{world}"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

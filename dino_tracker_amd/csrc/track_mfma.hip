@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void feat16_kernel(const float* __restrict__ f
 // ---- sources of a chunk -> fp16 unit vectors; one wave per source ---------------------------------------------------
 __global__ __launch_bounds__(256) void src16_kernel(const float* __restrict__ emb, const int32_t* __restrict__ src_row,
                                                     half_t* __restrict__ s16, int m0, int count, int M,
-                                                    const int32_t* __restrict__ dM, int C) {
+                                                    const int32_t* __restrict__ dM, int C, float scale) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= count) return;
     const int lane = threadIdx.x & 63;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void src16_kernel(const float* __restrict__ em
         s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
     s = sqrtf(wave_sum(s));
-    const float sc = s > 1e-30f ? FSCALE / s : 0.f;
+    const float sc = s > 1e-30f ? scale / s : 0.f;
     for (int k = lane * 8; k < C; k += 512) {
         const float4 a = *reinterpret_cast<const float4*>(p + k), b = *reinterpret_cast<const float4*>(p + k + 4);
         h8 v = {(half_t)(a.x * sc), (half_t)(a.y * sc), (half_t)(a.z * sc), (half_t)(a.w * sc),
@@ -398,6 +398,242 @@ __global__ __launch_bounds__(256) void select_kernel(dtk_geom g, const TileRec* 
     if (lane == 0) { r->amax = amax; r->ncand = all; r->zmax = 0.f; r->Z = -1.f; }
 }
 
+// ---- corr_peaks (fast mode, C = 384): source-stationary correlation + candidate selection in one kernel ---------------
+// A workgroup owns 256 sources of one target frame (a wave 64 of them) for the whole frame: the sources sit in registers
+// as the B operand of the 32x32x16 MFMA (24 k-steps x 2 column tiles = 192 VGPRs), the frame's cells stream through a
+// triple-buffered 24 KB LDS tile of 32 cells filled by LDS-DMA (global_load_lds_dwordx4, no staging registers) and are
+// read once per wave as the A operand: one ds_read_b128 feeds two MFMAs, half the LDS traffic per flop of the tiled
+// kernel, and no correlation value ever leaves the registers.  In D a lane holds ONE source and 16 cells, so the
+// running top-4 of a source is lane-local: each value gets its 13-bit (step, register) position OR-ed into the low
+// mantissa bits (costs 2^-10 relative, covered by TRUNC_C in the candidate band) and is pushed through three v_med3 and
+// one v_max.  The cell <-> MFMA row assignment puts the cells on a checkerboard over the two lane halves, so a peak and
+// its neighbours split evenly between the two top-4 lists of a source.  The epilogue of step n-1 is
+// independent of the MFMAs of step n and is interleaved with them by the scheduler (one wave per SIMD: 512 VGPRs).
+constexpr int PK_SRC = 256;               // sources per workgroup
+constexpr int PK_CELLS = 32;              // cells per step
+constexpr int PK_IDX_BITS = 13;           // position tag: step << 4 | accumulator register
+constexpr int PK_VAL_BITS = 17;           // sources carry 2^12 x, cells 2^5 x unit vectors: the accumulator is 2^17 rho
+constexpr float PK_SRC_SCALE = 4096.f;
+constexpr int PK_TOP = 5;                 // list length per lane half
+// candidate band of the fused pass: two fp16 operand roundings bound |rho16 - rho| by 2^-10 (Cauchy-Schwarz over the
+// relative errors), so the exact arg-max cell is within 2 x 2^-10 of the fp16 maximum; + fp32 accumulation and the
+// truncation to PK_VAL_BITS
+constexpr float EPS_PK = 2.1e-3f;
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// LDS-DMA of 16 bytes per lane: LDS destination = wave-uniform `lds_dst` + 16 * lane, source = the lane's own pointer plus
+// a literal byte offset.  Issued from asm so that the compiler does not serialise it against the ds_reads of the OTHER
+// buffer with a vmcnt(0) of its own; completion is awaited explicitly (glds_wait) before the barrier that publishes
+// the tile.  M0 carries the LDS base and is restored (the compiler reserves it).
+// (No immediate offset: the instruction offset would be added to the LDS address as well as to the global one.)
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+template <int N>
+__device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+// sorted top-N insertion on signed integers: one v_med3_i32 per list entry and a v_max_i32 for the head
+__device__ __forceinline__ int med3_i32(int a, int b, int c) {
+    int d;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+template <int N>
+__device__ __forceinline__ void top_push(int (&v)[N], int x) {
+#pragma unroll
+    for (int k = N - 1; k > 0; --k) v[k] = med3_i32(v[k - 1], v[k], x);
+    v[0] = max(v[0], x);
+}
+// value -> key: fixed point (the accumulator already is 2^17 rho; negative values stay negative and never enter a list
+// that starts at zero) shifted above the position tag.  The wave-uniform tag sits in an SGPR.
+__device__ __forceinline__ int make_key(float x, int tag) {
+    int d;
+    const int xi = (int)x;  // v_cvt_i32_f32
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(xi), "n"(PK_IDX_BITS), "s"(tag));
+    return d;
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_t* __restrict__ f16,
+                                                         const half_t* __restrict__ s16, const int32_t* __restrict__ tgt,
+                                                         Rec* __restrict__ rec, int m0, int count, int HWp) {
+    constexpr int C = KS * 16;
+    constexpr int TILE_BYTES = PK_CELLS * C * 2;
+    __shared__ __attribute__((aligned(1024))) unsigned char cells[3][TILE_BYTES];
+    __shared__ int s_fr[8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int src0 = blockIdx.x * PK_SRC + w * 64;  // first source of this wave (index inside the launch)
+    // target frames of this lane's two sources; frame range of the workgroup
+    int tf[2];
+    {
+        int lo = INT_MAX, hi = -1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int i = src0 + t * 32 + j;
+            tf[t] = i < count ? min(max(tgt[m0 + i], 0), g.T - 1) : -1;
+            if (tf[t] >= 0) { lo = min(lo, tf[t]); hi = max(hi, tf[t]); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o, WAVE));
+            hi = max(hi, __shfl_xor(hi, o, WAVE));
+        }
+        if (lane == 0) { s_fr[w] = lo; s_fr[4 + w] = hi; }
+    }
+    // the sources: B operand, lane (j, h) holds source j, k = 16 ks + 8 h .. + 7
+    h8 bs[2][KS];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int i = src0 + t * 32 + j;
+        const half_t* sp = s16 + (size_t)min(i, count - 1) * C + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            uint4 u = *reinterpret_cast<const uint4*>(sp + ks * 16);
+            if (i >= count) u = make_uint4(0, 0, 0, 0);
+            bs[t][ks] = *reinterpret_cast<const h8*>(&u);
+        }
+    }
+    __syncthreads();
+    const int fmin = min(min(s_fr[0], s_fr[1]), min(s_fr[2], s_fr[3]));
+    const int fmax = max(max(s_fr[4], s_fr[5]), max(s_fr[6], s_fr[7]));
+    // loader: wave w fills k-steps w*KS/4 .. of the tile; lane l' fetches cell c(l' & 31), k-half l' >> 5, where MFMA row
+    // i = 8a + 4p + b carries cell 8a + 2b + p
+    // (on odd map rows the two halves swap: a peak's vertical neighbours split between the lists as well)
+    const int lcell = 8 * (j >> 3) + 2 * (j & 3) + ((j >> 2) & 1);
+    const int lcell_odd = lcell ^ 1;
+    const int tiles_per_row = pw_pad(g.pw) / PK_CELLS;
+    constexpr int LQ = KS / 4;
+    const unsigned lds_base = (unsigned)(size_t)&cells[0][0];
+    const int NT = HWp / PK_CELLS;
+    const int band = (int)(EPS_PK * (float)(1 << PK_VAL_BITS)) << PK_IDX_BITS;
+    for (int f = fmin; f <= fmax; ++f) {
+        const half_t* gl = f16 + ((size_t)f * HWp + lcell) * C + (w * LQ) * 16 + h * 8;
+        const half_t* gl_odd = f16 + ((size_t)f * HWp + lcell_odd) * C + (w * LQ) * 16 + h * 8;
+        auto issue = [&](int n, int buf) {
+            const half_t* gp = (((n / tiles_per_row) & 1) ? gl_odd : gl) + (size_t)n * PK_CELLS * C;
+#pragma unroll
+            for (int q = 0; q < LQ; ++q) glds16(gp + q * 16, lds_base + buf * TILE_BYTES + (w * LQ + q) * 1024);
+        };
+        int v[2][PK_TOP];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int k = 0; k < PK_TOP; ++k) v[t][k] = 0;
+        // one step: the MFMAs of the tile in `buf` into accN, interleaved one-to-one with the top-4 updates of the
+        // previous tile's accP (step index np): a 32-cycle MFMA covers the five VALU instructions of one value
+        auto step = [&](int buf, f16v (&accN)[2], const f16v (&accP)[2], int np) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accN[t][r] = 0.f;
+            const unsigned char* base = &cells[buf][lane * 16];
+            const int ib = np << 4;
+            h8 a[3];
+            a[0] = *reinterpret_cast<const h8*>(base);
+            a[1] = *reinterpret_cast<const h8*>(base + 1024);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 2 < KS) a[(ks + 2) % 3] = *reinterpret_cast<const h8*>(base + (ks + 2) * 1024);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    accN[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks % 3], bs[t][ks], accN[t], 0, 0, 0);
+                    // the 32 values of the previous tile are spread evenly over the 2 KS MFMAs
+                    const int q = ks * 2 + t;
+#pragma unroll
+                    for (int e = q * 32 / (2 * KS); e < (q + 1) * 32 / (2 * KS); ++e)
+                        top_push(v[e & 1], make_key(accP[e & 1][e >> 1], ib | (e >> 1)));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        auto epi = [&](const f16v (&acc)[2], int np) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) top_push(v[t], make_key(acc[t][r], (np << 4) | r));
+        };
+        f16v accA[2], accB[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accB[t][r] = 0.f;
+        // three LDS buffers, tiles requested two steps ahead (an L2 miss takes longer than one step): at the end of step
+        // n the tile of step n+1 must have landed while the LQ requests of step n+2 stay in flight -> vmcnt(LQ).  Tiles past
+        // the end are clamped to the last one (never read), which keeps that count uniform.
+        issue(0, 0);
+        issue(min(1, NT - 1), 1);
+        glds_wait<LQ>();
+        __syncthreads();
+        int n = 0, b0 = 0;  // b0 = n % 3
+        for (; n + 1 < NT; n += 2) {
+            const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+            issue(min(n + 2, NT - 1), b2);
+            step(b0, accA, accB, max(n - 1, 0));  // first step: accB = 0, pushes zeros
+            glds_wait<LQ>();
+            __syncthreads();
+            issue(min(n + 3, NT - 1), b0);
+            step(b1, accB, accA, n);
+            glds_wait<LQ>();
+            __syncthreads();
+            b0 = b2;
+        }
+        if (n < NT) {  // NT odd: one more tile
+            step(b0, accA, accB, max(n - 1, 0));
+            epi(accA, n);
+        } else {
+            epi(accB, n - 1);
+        }
+        glds_wait<0>();
+        __syncthreads();  // every wave is done with the buffers before the next frame restages them
+        // merge the two lane halves of each source and write its record
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            int o[PK_TOP];
+#pragma unroll
+            for (int k = 0; k < PK_TOP; ++k) o[k] = __shfl(v[t][k], lane ^ 32, WAVE);
+            const int i = src0 + t * 32 + j;
+            if (h == 0 && tf[t] == f) {
+                const int amax_i = max(v[t][0], o[0]);
+                const int thr = amax_i - band;
+                int nc = 0;
+                Rec* rr = rec + i;
+                const int PWP = pw_pad(g.pw);
+#pragma unroll
+                for (int k = 0; k < 2 * PK_TOP; ++k) {
+                    const int xi = k < PK_TOP ? v[t][k] : o[k - PK_TOP];
+                    if (xi >= thr) {
+                        const int tag = xi & ((1 << PK_IDX_BITS) - 1);
+                        const int r = tag & 15, st = tag >> 4;
+                        const int pc = st * PK_CELLS + 8 * (r >> 2) + 2 * (r & 3) +
+                                       ((k < PK_TOP ? 0 : 1) ^ ((st / tiles_per_row) & 1));
+                        const int row = pc / PWP, col = pc - row * PWP;
+                        if (nc < KC) rr->cand[nc] = row * g.pw + min(col, g.pw - 1);
+                        ++nc;
+                    }
+                }
+                // a last list entry inside the band may hide a further one; a maximum inside the band of zero decides nothing
+                if (v[t][PK_TOP - 1] >= thr || o[PK_TOP - 1] >= thr || thr <= 0) nc = KC + 1;
+                const float amax = (float)(amax_i >> PK_IDX_BITS) * (1.f / (float)(1 << PK_VAL_BITS));
+                rr->amax = amax;
+                rr->ncand = nc;
+                rr->zmax = 0.f;
+                rr->Z = -1.f;
+            }
+        }
+    }
+}
+
 // head16_kernel: one workgroup per map.  The map sits in LDS as fp16 with a zero border; besides the approximate maximum
 // and the candidate cells, the whole refiner runs on the matrix cores without ever staging the hidden activations:
 //   conv1 as GEMM1 (MFMA 16x16x16 f16):  h^T[16 ch][16 px] = W1[16 ch][K = 3 rows x (3 taps + pad) | bias] . X[K][16 px]
@@ -637,7 +873,6 @@ constexpr int WX = 2 * RD + 5;  // x window side (15)
 constexpr int WH = 2 * RD + 3;  // hidden window side (13)
 constexpr int WZ = 2 * RD + 1;  // logit window side (11)
 
-__device__ unsigned long long g_dbg[4];  // development counters: tiles, groups, union-box cells, blocks
 
 struct Redo {
     int32_t* count;
@@ -652,6 +887,8 @@ __device__ __forceinline__ int cell_key(int cell, int pw) {
     const int r = cell / pw, c = cell - r * pw;
     return (r >> 3) * (8 * pw) + c * 8 + (r & 7);
 }
+
+__device__ unsigned long long g_dbg[4];  // development counters (DTK_DEBUG & 16: refine_corr boxes; & 4096: redo reasons)
 
 // one wave per source: |s|, exact fp32 re-scoring of the candidates -> k*, histogram of (frame, cell key)
 __global__ __launch_bounds__(256) void rescore_kernel(dtk_geom g, const float* __restrict__ feat,
@@ -700,6 +937,8 @@ __global__ __launch_bounds__(256) void rescore_kernel(dtk_geom g, const float* _
         // a non-positive exact maximum means the relu'd map may be all-zero (argmax 0): let the exact path decide
         if (!(best > 0.f)) redo_it = true;
     }
+    if ((dbg & 4096) && lane == 0 && redo_it)
+        atomicAdd(&g_dbg[rc.ncand > KC ? 0 : (rc.ncand < 1 ? 1 : 2)], 1ULL);
     if (lane == 0) {
         snorm[i] = sn;
         if (redo_it) {
@@ -1099,7 +1338,7 @@ MfmaLayout mfma_layout(const dtk_geom* g, int M) {
     L.HWp = hw_pad(g->ph, g->pw);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t off = 0;
-    L.s16 = off; off = al(off + (size_t)L.chunk * g->C * 2);
+    L.s16 = off; off = al(off + (size_t)L.super * g->C * 2);  // corr_peaks converts a whole super-chunk at once
     L.MP = ((g->ph + 2) * map_xw(g->pw) + 32 + 7) & ~7;
     L.maps = off; off = al(off + (size_t)L.chunk * L.MP * 2);
     L.rec = off; off = al(off + (size_t)L.super * sizeof(Rec));
@@ -1138,6 +1377,13 @@ extern "C" int dtk_debug_counters(unsigned long long* out4) {
     unsigned long long z[4] = {0, 0, 0, 0};
     DTK_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_dbg), sizeof(z)));
     DTK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)));
+    return DTK_OK;
+}
+
+// development aid (not part of dtk.h): sources / uncertified / re-done counts of the last dtk_track(mfma) call
+static int g_last_track[3] = {0, 0, 0};
+extern "C" int dtk_debug_track_counts(int* out3) {
+    for (int i = 0; i < 3; ++i) out3[i] = g_last_track[i];
     return DTK_OK;
 }
 
@@ -1187,10 +1433,18 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
     const int M = count;
     for (long long s0 = 0; s0 < M; s0 += L.super) {
         const int scnt = (int)((M - s0) < L.super ? (M - s0) : L.super);
-        for (long long m0 = s0; m0 < s0 + scnt; m0 += L.chunk) {
+        // source-stationary fused correlation + selection (C = 384, position tags of 13 bits)
+        const bool peaks = fast && g->C == 384 && L.HWp / PK_CELLS <= (1 << (PK_IDX_BITS - 4)) && !(dbg & 2048);
+        if (peaks) {
+            DTK_LAUNCH("src16", src16_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, emb, in.src_row, s16, (int)s0, scnt, M,
+                       nodm, g->C, PK_SRC_SCALE);
+            DTK_LAUNCH("corr_peaks", corr_peaks_kernel<24>, dim3(dtk_cdiv(scnt, PK_SRC)), dim3(256), 0, st, *g, f16, s16,
+                       in.tgt, rec, (int)s0, scnt, L.HWp);
+        }
+        for (long long m0 = s0; m0 < s0 + scnt && !peaks; m0 += L.chunk) {
             const int cnt = (int)((s0 + scnt - m0) < L.chunk ? (s0 + scnt - m0) : L.chunk);
             DTK_LAUNCH("src16", src16_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, emb, in.src_row, s16, (int)m0, cnt, M,
-                       nodm, g->C);
+                       nodm, g->C, FSCALE);
             {
                 const int MT = dtk_cdiv(cnt, CM), NT = L.HWp / CN;
                 const int blocks = 8 * ((MT + 7) / 8) * 8 * ((NT + 7) / 8);
@@ -1280,6 +1534,7 @@ int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, con
     int32_t hc[2] = {0, 0};
     DTK_HIP(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, st));
     DTK_HIP(hipStreamSynchronize(st));
+    g_last_track[0] = count; g_last_track[1] = hc[1]; g_last_track[2] = hc[0];
     if (hc[1] > 0) {  // sources without a no-fallback certificate: whole-map statistics
         rc = mfma_phase(g, L, ws, feat, norms, f16, head, emb, SrcLists{uncert.src_row, uncert.tgt, uncert.out_idx}, out_xy,
                         hc[1], normalized, false, redo, uncert, lds_head, st, dbg);
@@ -1287,6 +1542,7 @@ int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, con
         DTK_HIP(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, st));
         DTK_HIP(hipStreamSynchronize(st));
     }
+    g_last_track[2] = hc[0];
     if (hc[0] > 0) {  // sources the fp16 pass could not decide: the exact fp32 path
         rc = dtk_track_exact(g, feat, norms, head, emb, redo.src_row, redo.tgt, redo.out_idx, out_xy, hc[0], nullptr,
                              normalized, ws + L.exact, workspace_bytes - L.exact, stream);
