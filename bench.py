@@ -134,7 +134,7 @@ def main():
         dt = float(tmax.item())
 
     # ---- per-kernel profile pass (separate from the timed region) ------------------------------------------
-    pairs = int(mi.last_counts[0])
+    pairs = int(mi.last_counts[0]) if hasattr(mi, "last_counts") else 0
     maps = N * T + pairs * T
     ops.profile_enable(True)
     step()
@@ -175,7 +175,7 @@ def main():
                         "frac": None, "traffic": None}
         roofline["avg_launch_ms"] = round(ms / max(launches, 1), 4)
         roofline["launches"] = launches
-        roofline["kernel_ms"] = {k: round(v[0], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]}
+        roofline["kernel_ms"] = {k: round(v[0], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("DTK_BENCH_KERNELS", "12"))]}
         roofline["kernel_tflops"] = {k: round(algo[k][0] / (prof[k][0] * 1e-3) / 1e12, 1) for k in prof
                                      if k in algo and prof[k][0] > 0}
 

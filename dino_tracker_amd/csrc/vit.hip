@@ -12,6 +12,8 @@
 //                       per-query quantity (running max / sum, rescale) is lane-local; K and V^T tiles staged in LDS
 //                       (conflict-free pitches), online softmax in exp2 domain
 // Residual stream fp32, matrix operands bf16 (the reference runs fp32; parity is stated at feature level).
+#include <stdlib.h>
+#include <utility>
 #include "common.h"
 
 namespace {
@@ -70,33 +72,51 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------------------
 // LayerNorm: fp32 row -> bf16 row (A operand of the next GEMM); one wave per token
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gam,
-                                                        const float* __restrict__ bet, bf16_t* __restrict__ y,
-                                                        long long rows, int D, float eps) {
+__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, const float* __restrict__ delta,
+                                                        const float* __restrict__ gam, const float* __restrict__ bet,
+                                                        bf16_t* __restrict__ y, long long rows, int D, float eps) {
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
-    const float* p = x + row * D;
+    float* p = x + row * D;
+    // the row stays in registers (D <= 1024: four float4 per lane); a pending residual update (the LayerScale'd output of
+    // the previous projection / MLP, written by the GEMM epilogue) is applied here: x += delta
+    float4 v[4];
     float s = 0.f;
-    for (int c = lane * 4; c < D; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(p + c);
-        s += (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < D) {
+            v[it] = *reinterpret_cast<const float4*>(p + c);
+            if (delta) {
+                const float4 d = *reinterpret_cast<const float4*>(delta + row * D + c);
+                v[it].x += d.x; v[it].y += d.y; v[it].z += d.z; v[it].w += d.w;
+                *reinterpret_cast<float4*>(p + c) = v[it];
+            }
+            s += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+        }
     }
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
-    for (int c = lane * 4; c < D; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(p + c);
-        const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
-        q += (a * a + b * b) + (cc * cc + d * d);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        if (lane * 4 + it * 256 < D) {
+            const float a = v[it].x - mean, b = v[it].y - mean, cc = v[it].z - mean, d = v[it].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (!y) return;  // final residual update only
     bf16_t* o = y + row * D;
-    for (int c = lane * 4; c < D; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(p + c);
-        const float4 g = *reinterpret_cast<const float4*>(gam + c), b = *reinterpret_cast<const float4*>(bet + c);
-        bf4 r = {(bf16_t)((v.x - mean) * rstd * g.x + b.x), (bf16_t)((v.y - mean) * rstd * g.y + b.y),
-                 (bf16_t)((v.z - mean) * rstd * g.z + b.z), (bf16_t)((v.w - mean) * rstd * g.w + b.w)};
-        *reinterpret_cast<bf4*>(o + c) = r;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < D) {
+            const float4 g = *reinterpret_cast<const float4*>(gam + c), b = *reinterpret_cast<const float4*>(bet + c);
+            bf4 r = {(bf16_t)((v[it].x - mean) * rstd * g.x + b.x), (bf16_t)((v[it].y - mean) * rstd * g.y + b.y),
+                     (bf16_t)((v[it].z - mean) * rstd * g.z + b.z), (bf16_t)((v[it].w - mean) * rstd * g.w + b.w)};
+            *reinterpret_cast<bf4*>(o + c) = r;
+        }
     }
 }
 
@@ -104,7 +124,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // bf16 GEMM  C[M][N] = A[M][K] . Wt[N][K]^T (+bias) with fused epilogues
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int GM = 128, GN = 128, GK = 32;
-enum { EPI_QKV = 0, EPI_GELU = 1, EPI_RESID = 2 };
+enum { EPI_QKV = 0, EPI_GELU = 1, EPI_DELTA = 2 };
 
 struct GemmEpi {
     const float* bias;   // [N]
@@ -116,8 +136,9 @@ struct GemmEpi {
     float qscale;
     // EPI_GELU
     bf16_t* out;         // [M][N]
-    // EPI_RESID
-    float* x;            // [M][N] fp32 residual stream, updated in place
+    // EPI_DELTA
+    int no_store;        // development: skip the stores of the weight-stationary kernel (DTK_DEBUG & 65536)
+    float* delta;        // [M][N] fp32: gamma * (A W^T + bias), added to the residual stream by the next LayerNorm
     const float* gamma;  // [N] LayerScale
 };
 
@@ -240,11 +261,213 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const long long m = mb + r;
-                    if (m < M) e.x[m * N + n] += gm * (acc[mi][ni][r] + bias);
+                    if (m < M) e.delta[m * N + n] = gm * (acc[mi][ni][r] + bias);
                 }
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight-stationary GEMM for K = 384 (QKV, attention projection and fc1 of ViT-S): C[M][N] = A[M][384] . Wt[N][384]^T
+//
+// A workgroup of two waves owns 128 output features for a chunk of token tiles; a wave keeps its 64 weight rows in
+// registers for the whole chunk (A operand of MFMA 32x32x16 bf16: 24 k-steps x 2 row tiles = 192 VGPRs) and the tokens
+// stream through a triple-buffered LDS tile of 32 tokens (24 KB) filled by LDS-DMA two steps ahead, read once per wave
+// as the B operand: one ds_read_b128 feeds two MFMAs and there is no K loop with barriers -- one barrier per 32 tokens.
+// The weight rows are permuted over the MFMA rows so that in D a lane (token j, half h) holds 16 CONSECUTIVE output
+// features (n0 + 32 t + 16 h + r): the epilogue of the previous tile (bias, GELU / Q scale / LayerScale, conversion,
+// 16-byte stores) is issued between the MFMAs of the current one.  Two workgroups share a CU (one wave per SIMD).
+// Measured alternatives (all slower on MI355X): staging the outputs through LDS for whole-line stores, one output
+// feature per lane (2-byte stores), 4 tokens x 256 B per DMA request, register-staged tiles instead of LDS-DMA.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int WS_KS = 24, WS_K = 16 * WS_KS, WS_ROWS = 32, WS_COLS = 128;
+constexpr int WS_TILE_BYTES = WS_ROWS * WS_K * 2;
+constexpr int WS_LQ = WS_KS / 2;  // LDS-DMA requests per wave per tile
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void ws_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+template <int N>
+__device__ __forceinline__ void ws_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+// GELU(x) = x Phi(x) with erf(s / sqrt 2) ~ s P(s^2) on |s| <= 4.25 (odd minimax polynomial, 9 coefficients, |err| < 2e-5;
+// |GELU error| < 6e-5 everywhere, far below the bf16 rounding of the result); two values per packed fp32 instruction
+__device__ __forceinline__ f2 gelu2(f2 x) {
+    const f2 c = {4.25f, 4.25f};
+    const f2 sx = __builtin_elementwise_min(__builtin_elementwise_max(x, -c), c);
+    const f2 u = sx * sx;
+    f2 p = {1.112979639e-10f, 1.112979639e-10f};
+    p = __builtin_elementwise_fma(p, u, f2{-1.065557687e-08f, -1.065557687e-08f});
+    p = __builtin_elementwise_fma(p, u, f2{4.510875158e-07f, 4.510875158e-07f});
+    p = __builtin_elementwise_fma(p, u, f2{-1.125288873e-05f, -1.125288873e-05f});
+    p = __builtin_elementwise_fma(p, u, f2{1.868377149e-04f, 1.868377149e-04f});
+    p = __builtin_elementwise_fma(p, u, f2{-2.217123518e-03f, -2.217123518e-03f});
+    p = __builtin_elementwise_fma(p, u, f2{1.963194646e-02f, 1.963194646e-02f});
+    p = __builtin_elementwise_fma(p, u, f2{-1.326889843e-01f, -1.326889843e-01f});
+    p = __builtin_elementwise_fma(p, u, f2{7.978046536e-01f, 7.978046536e-01f});
+    const f2 one = {1.f, 1.f};
+    const f2 e = __builtin_elementwise_min(__builtin_elementwise_max(sx * p, -one), one);
+    const f2 hx = x * f2{0.5f, 0.5f};
+    return __builtin_elementwise_fma(hx, e, hx);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(128) void gemm_ws_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
+                                                      long long M, int N, GemmEpi e, int tiles_per_chunk) {
+    __shared__ __attribute__((aligned(1024))) unsigned char toks[3][WS_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) float s_bias[2][64], s_gamma[2][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * WS_COLS + w * 64;
+    const long long total_tiles = (M + WS_ROWS - 1) / WS_ROWS;
+    const long long tile0 = (long long)blockIdx.y * tiles_per_chunk;
+    if (tile0 >= total_tiles) return;
+    const int NT = (int)((total_tiles - tile0) < tiles_per_chunk ? (total_tiles - tile0) : tiles_per_chunk);
+    // weights: MFMA row i of row tile t carries output feature n0 + 32 t + nl(i), nl chosen so that D row
+    // (r & 3) + 8 (r >> 2) + 4 h  <->  feature 16 h + r
+    const int nl = (j & 3) + 4 * (j >> 3) + 16 * ((j >> 2) & 1);
+    bf8 wf[2][WS_KS];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int row = min(n0 + t * 32 + nl, N - 1);
+        const bf16_t* wp = Wt + (size_t)row * WS_K + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < WS_KS; ++ks) wf[t][ks] = *reinterpret_cast<const bf8*>(wp + ks * 16);
+    }
+    {
+        const int n = min(n0 + lane, N - 1);
+        s_bias[w][lane] = e.bias ? e.bias[n] : 0.f;
+        s_gamma[w][lane] = (EPI == EPI_DELTA) ? e.gamma[n] : 1.f;
+    }
+    // QKV: a 64-feature group is one head of q, k or v
+    const int which = (EPI == EPI_QKV) ? n0 / e.D : 0;
+    const int head = (EPI == EPI_QKV) ? (n0 - which * e.D) >> 6 : 0;
+    const float qsc = (EPI == EPI_QKV && which == 0) ? e.qscale : 1.f;
+    // this lane's token of the tile whose epilogue runs next, as (frame, position) for the QKV layouts
+    long long m_ep = tile0 * WS_ROWS + j;
+    int f_ep = 0, s_ep = 0;
+    if (EPI == EPI_QKV) { f_ep = (int)(m_ep / e.S); s_ep = (int)(m_ep - (long long)f_ep * e.S); }
+    const unsigned lds_base = (unsigned)(size_t)&toks[0][0];
+    auto issue = [&](int n, int buf) {
+        const long long m = min((tile0 + n) * WS_ROWS + j, M - 1);
+        const bf16_t* gp = A + m * WS_K + (w * WS_LQ) * 16 + h * 8;
+#pragma unroll
+        for (int q = 0; q < WS_LQ; ++q) ws_glds16(gp + q * 16, lds_base + buf * WS_TILE_BYTES + (w * WS_LQ + q) * 1024);
+    };
+    // epilogue of 8 values (row tile t, half hv of this lane's 16 features): features nb .. nb + 7
+    auto epi8 = [&](const f16v (&acc)[2], int t, int hv) {
+        const int fl = 32 * t + 16 * h + 8 * hv;  // feature offset inside the wave's 64
+        const int nb = n0 + fl;
+        const float4 b0 = *reinterpret_cast<const float4*>(&s_bias[w][fl]), b1 = *reinterpret_cast<const float4*>(&s_bias[w][fl + 4]);
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = acc[t][8 * hv + r];
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        const bool ok = m_ep < M && nb < N && !e.no_store;
+        if (EPI == EPI_GELU) {
+            bf8 o;
+#pragma unroll
+            for (int r = 0; r < 8; r += 2) {
+                const f2 g = gelu2(f2{v[r], v[r + 1]});
+                o[r] = (bf16_t)g[0];
+                o[r + 1] = (bf16_t)g[1];
+            }
+            if (ok) *reinterpret_cast<bf8*>(e.out + m_ep * N + nb) = o;
+        } else if (EPI == EPI_DELTA) {
+            const float4 g0 = *reinterpret_cast<const float4*>(&s_gamma[w][fl]), g1 = *reinterpret_cast<const float4*>(&s_gamma[w][fl + 4]);
+            if (ok) {
+                float* dp = e.delta + m_ep * N + nb;
+                *reinterpret_cast<float4*>(dp) = make_float4(v[0] * g0.x, v[1] * g0.y, v[2] * g0.z, v[3] * g0.w);
+                *reinterpret_cast<float4*>(dp + 4) = make_float4(v[4] * g1.x, v[5] * g1.y, v[6] * g1.z, v[7] * g1.w);
+            }
+        } else {
+            const int dh = fl;  // 0..63 inside the head
+            if (which == 2) {
+                // V^T[f][head][dh][s]: consecutive lanes are consecutive tokens
+                if (ok) {
+                    bf16_t* vp = e.vt + (((size_t)f_ep * e.heads + head) * 64 + dh) * e.Sp + s_ep;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) vp[(size_t)r * e.Sp] = (bf16_t)v[r];
+                }
+            } else {
+                bf8 o;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) o[r] = (bf16_t)(v[r] * qsc);
+                bf16_t* dst = which == 0 ? e.q : e.k;
+                if (ok) *reinterpret_cast<bf8*>(dst + (((size_t)f_ep * e.heads + head) * e.Sp + s_ep) * 64 + dh) = o;
+            }
+        }
+    };
+    auto advance = [&]() {  // the epilogue moves on to the next tile
+        m_ep += WS_ROWS;
+        if (EPI == EPI_QKV) {
+            s_ep += WS_ROWS;
+            if (s_ep >= e.S) { s_ep -= e.S; ++f_ep; }
+        }
+    };
+    // one step: MFMAs of the tile in `buf` into accN, with the four epilogue pieces of the previous tile (accP) in between
+    auto step = [&](int buf, f16v (&accN)[2], const f16v (&accP)[2], bool have_prev) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accN[t][r] = 0.f;
+        const unsigned char* base = &toks[0][0] + buf * WS_TILE_BYTES + lane * 16;
+        bf8 b[3];
+        b[0] = *reinterpret_cast<const bf8*>(base);
+        b[1] = *reinterpret_cast<const bf8*>(base + 1024);
+#pragma unroll
+        for (int ks = 0; ks < WS_KS; ++ks) {
+            if (ks + 2 < WS_KS) b[(ks + 2) % 3] = *reinterpret_cast<const bf8*>(base + (ks + 2) * 1024);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                accN[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][ks], b[ks % 3], accN[t], 0, 0, 0);
+            if (have_prev && ks % 6 == 1) epi8(accP, (ks / 6) >> 1, (ks / 6) & 1);
+        }
+        if (have_prev) advance();
+    };
+    f16v accA[2], accB[2];
+    // three LDS buffers, tiles requested two steps ahead.  The wait at the end of a step must prove that the tile of the
+    // next step has landed: loads retire in order among themselves and the stores of the epilogue only add to the
+    // count, so vmcnt(LQ) -- the requests of the tile after next -- is sufficient, if conservative.
+    issue(0, 0);
+    issue(min(1, NT - 1), 1);
+    ws_wait<WS_LQ>();
+    __syncthreads();
+    int n = 0, b0 = 0;
+    for (; n + 1 < NT; n += 2) {
+        const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+        issue(min(n + 2, NT - 1), b2);
+        step(b0, accA, accB, n > 0);
+        ws_wait<WS_LQ>();
+        __syncthreads();
+        issue(min(n + 3, NT - 1), b0);
+        step(b1, accB, accA, true);
+        ws_wait<WS_LQ>();
+        __syncthreads();
+        b0 = b2;
+    }
+    if (n < NT) {  // NT odd: one more tile, then its own epilogue
+        step(b0, accA, accB, n > 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) epi8(accA, u >> 1, u & 1);
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) epi8(accB, u >> 1, u & 1);
+    }
+    ws_wait<0>();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -413,16 +636,20 @@ __global__ __launch_bounds__(256) void drop_cls_kernel(const float* __restrict__
     reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(x)[(f * S + 1 + s) * d4 + c];
 }
 
+// frames per pass of the encoder: large batches give the weight-stationary GEMMs long token chunks per workgroup
+// (their weights are loaded once per chunk); 30 frames of 67x121 tokens need ~2.6 GB of workspace
+constexpr int VIT_FRAME_BATCH = 30;
+
 struct VitPlan {
     int S, Sp, FB;
-    size_t x, xn, q, k, vt, ao, hid, total;
+    size_t x, xn, q, k, vt, ao, hid, delta, total;
 };
 
 VitPlan vit_plan(const dtk_vit_model* m, int ph, int pw, int frames) {
     VitPlan p;
     p.S = ph * pw + 1;
     p.Sp = (p.S + 127) / 128 * 128;
-    p.FB = frames < 8 ? frames : 8;
+    p.FB = frames < VIT_FRAME_BATCH ? frames : VIT_FRAME_BATCH;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t off = 0;
     const size_t rows = (size_t)p.FB * p.S;
@@ -433,6 +660,7 @@ VitPlan vit_plan(const dtk_vit_model* m, int ph, int pw, int frames) {
     p.vt = off; off = al(off + (size_t)p.FB * m->heads * p.Sp * 64 * 2);
     p.ao = off; off = al(off + rows * m->D * 2);
     p.hid = off; off = al(off + rows * 4 * m->D * 2);
+    p.delta = off; off = al(off + rows * m->D * 4);
     p.total = off;
     return p;
 }
@@ -468,6 +696,7 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
     bf16_t* vt = reinterpret_cast<bf16_t*>(ws + p.vt);
     bf16_t* ao = reinterpret_cast<bf16_t*>(ws + p.ao);
     bf16_t* hid = reinterpret_cast<bf16_t*>(ws + p.hid);
+    float* delta = reinterpret_cast<float*>(ws + p.delta);
     const int S = p.S, Sp = p.Sp;
     // Q/K/V^T padding rows (s >= S) must be finite zeros: they are read by the last KV tile
     {
@@ -480,32 +709,65 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
         DTK_LAUNCH("vit_patch_embed", patch_embed_kernel, dim3(dtk_cdiv(HW, 64), dtk_cdiv(D, 64), nf), dim3(256), 0, st,
                    frames + (size_t)f0 * 3 * video_h * video_w, m->patch_w, m->patch_b, m->pos, m->cls_pos, m->mean_std, x,
                    video_h, video_w, ph, pw, D, m->patch, m->stride, S);
+        // K = 384 GEMMs run weight-stationary; everything else (fc2, wider models) on the tiled kernel.  The residual
+        // updates (LayerScale'd projection / MLP outputs) are written as `delta` and added by the next LayerNorm.
+        const bool ws_ok = D == WS_K;
+        static const int dbg_ns = [] { const char* v = getenv("DTK_DEBUG"); return v ? (atoi(v) >> 16) & 3 : 0; }();
+        auto ws_grid = [&](int N) {  // one resident round: two workgroups per CU
+            const int colwg = dtk_cdiv(N, WS_COLS);
+            const int chunks = 512 / colwg > 0 ? 512 / colwg : 1;
+            const long long tiles = dtk_cdiv(rows, WS_ROWS);
+            const int tpc = (int)dtk_cdiv(tiles, chunks);
+            return std::make_pair(dim3(colwg, (unsigned)dtk_cdiv(tiles, tpc)), tpc);
+        };
         for (int l = 0; l < m->depth; ++l) {
             const dtk_vit_layer& L = m->layers[l];
             GemmEpi e{};
-            DTK_LAUNCH("vit_layernorm", layernorm_kernel, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x, L.ln1_w, L.ln1_b, xn,
-                       rows, D, m->ln_eps);
+            DTK_LAUNCH("vit_layernorm", layernorm_kernel, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x,
+                       l ? delta : (const float*)nullptr, L.ln1_w, L.ln1_b, xn, rows, D, m->ln_eps);
             e.bias = L.qkv_b; e.q = q; e.k = k; e.vt = vt; e.S = S; e.Sp = Sp; e.heads = m->heads; e.D = D;
             e.qscale = 0.125f * 1.4426950408889634f;
-            DTK_LAUNCH("vit_gemm_qkv", (gemm_bf16_kernel<EPI_QKV>), dim3(dtk_cdiv(3 * D, GN), dtk_cdiv(rows, GM)), dim3(256),
-                       0, st, xn, reinterpret_cast<const bf16_t*>(L.qkv_w), rows, 3 * D, D, e);
+            e.no_store = dbg_ns;
+            if (ws_ok) {
+                const auto gr = ws_grid(3 * D);
+                DTK_LAUNCH("vit_gemm_qkv", (gemm_ws_kernel<EPI_QKV>), gr.first, dim3(128), 0, st, xn,
+                           reinterpret_cast<const bf16_t*>(L.qkv_w), rows, 3 * D, e, gr.second);
+            } else {
+                DTK_LAUNCH("vit_gemm_qkv", (gemm_bf16_kernel<EPI_QKV>), dim3(dtk_cdiv(3 * D, GN), dtk_cdiv(rows, GM)),
+                           dim3(256), 0, st, xn, reinterpret_cast<const bf16_t*>(L.qkv_w), rows, 3 * D, D, e);
+            }
             DTK_LAUNCH("vit_attention", attention_kernel, dim3(dtk_cdiv(S, 128), nf * m->heads), dim3(256), 0, st, q, k, vt,
                        ao, S, Sp, m->heads, D);
             e = GemmEpi{};
-            e.bias = L.proj_b; e.x = x; e.gamma = L.ls1;
-            DTK_LAUNCH("vit_gemm_proj", (gemm_bf16_kernel<EPI_RESID>), dim3(dtk_cdiv(D, GN), dtk_cdiv(rows, GM)), dim3(256), 0,
-                       st, ao, reinterpret_cast<const bf16_t*>(L.proj_w), rows, D, D, e);
-            DTK_LAUNCH("vit_layernorm", layernorm_kernel, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x, L.ln2_w, L.ln2_b, xn,
-                       rows, D, m->ln_eps);
+            e.bias = L.proj_b; e.delta = delta; e.gamma = L.ls1; e.no_store = dbg_ns;
+            if (ws_ok) {
+                const auto gr = ws_grid(D);
+                DTK_LAUNCH("vit_gemm_proj", (gemm_ws_kernel<EPI_DELTA>), gr.first, dim3(128), 0, st, ao,
+                           reinterpret_cast<const bf16_t*>(L.proj_w), rows, D, e, gr.second);
+            } else {
+                DTK_LAUNCH("vit_gemm_proj", (gemm_bf16_kernel<EPI_DELTA>), dim3(dtk_cdiv(D, GN), dtk_cdiv(rows, GM)), dim3(256),
+                           0, st, ao, reinterpret_cast<const bf16_t*>(L.proj_w), rows, D, D, e);
+            }
+            DTK_LAUNCH("vit_layernorm", layernorm_kernel, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x, (const float*)delta,
+                       L.ln2_w, L.ln2_b, xn, rows, D, m->ln_eps);
             e = GemmEpi{};
-            e.bias = L.fc1_b; e.out = hid;
-            DTK_LAUNCH("vit_gemm_fc1", (gemm_bf16_kernel<EPI_GELU>), dim3(dtk_cdiv(4 * D, GN), dtk_cdiv(rows, GM)), dim3(256),
-                       0, st, xn, reinterpret_cast<const bf16_t*>(L.fc1_w), rows, 4 * D, D, e);
+            e.bias = L.fc1_b; e.out = hid; e.no_store = dbg_ns;
+            if (ws_ok) {
+                const auto gr = ws_grid(4 * D);
+                DTK_LAUNCH("vit_gemm_fc1", (gemm_ws_kernel<EPI_GELU>), gr.first, dim3(128), 0, st, xn,
+                           reinterpret_cast<const bf16_t*>(L.fc1_w), rows, 4 * D, e, gr.second);
+            } else {
+                DTK_LAUNCH("vit_gemm_fc1", (gemm_bf16_kernel<EPI_GELU>), dim3(dtk_cdiv(4 * D, GN), dtk_cdiv(rows, GM)),
+                           dim3(256), 0, st, xn, reinterpret_cast<const bf16_t*>(L.fc1_w), rows, 4 * D, D, e);
+            }
             e = GemmEpi{};
-            e.bias = L.fc2_b; e.x = x; e.gamma = L.ls2;
-            DTK_LAUNCH("vit_gemm_fc2", (gemm_bf16_kernel<EPI_RESID>), dim3(dtk_cdiv(D, GN), dtk_cdiv(rows, GM)), dim3(256), 0,
+            e.bias = L.fc2_b; e.delta = delta; e.gamma = L.ls2;
+            DTK_LAUNCH("vit_gemm_fc2", (gemm_bf16_kernel<EPI_DELTA>), dim3(dtk_cdiv(D, GN), dtk_cdiv(rows, GM)), dim3(256), 0,
                        st, hid, reinterpret_cast<const bf16_t*>(L.fc2_w), rows, D, 4 * D, e);
         }
+        if (m->depth > 0)  // the last MLP's residual update
+            DTK_LAUNCH("vit_layernorm", layernorm_kernel, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x, (const float*)delta,
+                       (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, rows, D, m->ln_eps);
         if (tokens_out)
             DTK_HIP(hipMemcpyAsync(tokens_out + (size_t)f0 * S * D, x, (size_t)rows * D * sizeof(float),
                                    hipMemcpyDeviceToDevice, st));
