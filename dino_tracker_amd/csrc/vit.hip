@@ -359,13 +359,27 @@ __global__ __launch_bounds__(128) void gemm_ws_kernel(const bf16_t* __restrict__
     long long m_ep = tile0 * WS_ROWS + j;
     int f_ep = 0, s_ep = 0;
     if (EPI == EPI_QKV) { f_ep = (int)(m_ep / e.S); s_ep = (int)(m_ep - (long long)f_ep * e.S); }
+    // token tiles: a DMA request fetches 4 tokens x 256 contiguous bytes (8 cache lines; one token row per lane would be
+    // 32).  Region (g, c) of 1 KB holds tokens 4g .. 4g+3, pieces 16c .. 16c+15 (piece = 8 k values); piece pp of token
+    // tt sits at slot ((pp + g) & 15) * 4 + tt, which keeps the fragment reads of 16 consecutive lanes conflict-free
     const unsigned lds_base = (unsigned)(size_t)&toks[0][0];
+    const int l_tt = lane & 3, l_pp = lane >> 2;
     auto issue = [&](int n, int buf) {
-        const long long m = min((tile0 + n) * WS_ROWS + j, M - 1);
-        const bf16_t* gp = A + m * WS_K + (w * WS_LQ) * 16 + h * 8;
 #pragma unroll
-        for (int q = 0; q < WS_LQ; ++q) ws_glds16(gp + q * 16, lds_base + buf * WS_TILE_BYTES + (w * WS_LQ + q) * 1024);
+        for (int gg = 0; gg < 4; ++gg) {
+            const int g = 4 * w + gg;
+            const long long m = min((tile0 + n) * WS_ROWS + 4 * g + l_tt, M - 1);
+            const bf16_t* gp = A + m * WS_K + ((l_pp - g) & 15) * 8;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                ws_glds16(gp + c * 128, __builtin_amdgcn_readfirstlane(lds_base + buf * WS_TILE_BYTES + (g * 3 + c) * 1024));
+        }
     };
+    // B-operand fragment of k-step ks for lane (token j, half h): piece 2 ks + h -> region column c = ks >> 3
+    unsigned frag_off[8];
+#pragma unroll
+    for (int k8 = 0; k8 < 8; ++k8)
+        frag_off[k8] = (unsigned)((j >> 2) * 3 * 1024 + ((((2 * k8 + h + (j >> 2)) & 15) * 4 + (j & 3)) * 16));
     // epilogue of 8 values (row tile t, half hv of this lane's 16 features): features nb .. nb + 7
     auto epi8 = [&](const f16v (&acc)[2], int t, int hv) {
         const int fl = 32 * t + 16 * h + 8 * hv;  // feature offset inside the wave's 64
@@ -424,13 +438,14 @@ __global__ __launch_bounds__(128) void gemm_ws_kernel(const bf16_t* __restrict__
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) accN[t][r] = 0.f;
-        const unsigned char* base = &toks[0][0] + buf * WS_TILE_BYTES + lane * 16;
+        const unsigned char* base = &toks[0][0] + buf * WS_TILE_BYTES;
         bf8 b[3];
-        b[0] = *reinterpret_cast<const bf8*>(base);
-        b[1] = *reinterpret_cast<const bf8*>(base + 1024);
+        b[0] = *reinterpret_cast<const bf8*>(base + frag_off[0]);
+        b[1] = *reinterpret_cast<const bf8*>(base + frag_off[1]);
 #pragma unroll
         for (int ks = 0; ks < WS_KS; ++ks) {
-            if (ks + 2 < WS_KS) b[(ks + 2) % 3] = *reinterpret_cast<const bf8*>(base + (ks + 2) * 1024);
+            if (ks + 2 < WS_KS)
+                b[(ks + 2) % 3] = *reinterpret_cast<const bf8*>(base + frag_off[(ks + 2) & 7] + ((ks + 2) >> 3) * 1024);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
                 accN[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][ks], b[ks % 3], accN[t], 0, 0, 0);
