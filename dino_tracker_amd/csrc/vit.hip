@@ -281,9 +281,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 // Measured alternatives (all slower on MI355X): staging the outputs through LDS for whole-line stores, one output
 // feature per lane (2-byte stores), 4 tokens x 256 B per DMA request, register-staged tiles instead of LDS-DMA.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int WS_KS = 24, WS_K = 16 * WS_KS, WS_ROWS = 32, WS_COLS = 128;
+constexpr int WS_KS = 24, WS_K = 16 * WS_KS, WS_ROWS = 32, WS_COLS = 256;
 constexpr int WS_TILE_BYTES = WS_ROWS * WS_K * 2;
-constexpr int WS_LQ = WS_KS / 2;  // LDS-DMA requests per wave per tile
+constexpr int WS_LQ = WS_KS / 4;  // LDS-DMA requests per wave per tile
+constexpr int WS_PITCH = 144;                    // staging row pitch: 128 B of payload + 16 (conflict-free 16-B accesses)
+constexpr int WS_UNIT_BYTES = WS_ROWS * WS_PITCH;  // staging unit: 32 rows x 128 B (64 bf16 or 32 fp32 outputs)
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void ws_glds16(const void* gsrc, unsigned lds_dst) {
@@ -323,10 +325,11 @@ __device__ __forceinline__ f2 gelu2(f2 x) {
 }
 
 template <int EPI>
-__global__ __launch_bounds__(128) void gemm_ws_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
+__global__ __launch_bounds__(256) void gemm_ws_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
                                                       long long M, int N, GemmEpi e, int tiles_per_chunk) {
     __shared__ __attribute__((aligned(1024))) unsigned char toks[3][WS_TILE_BYTES];
-    __shared__ __attribute__((aligned(16))) float s_bias[2][64], s_gamma[2][64];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[4][2][WS_UNIT_BYTES];  // per wave: two staging units
+    __shared__ __attribute__((aligned(16))) float s_bias[4][64], s_gamma[4][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -352,8 +355,8 @@ __global__ __launch_bounds__(128) void gemm_ws_kernel(const bf16_t* __restrict__
         s_gamma[w][lane] = (EPI == EPI_DELTA) ? e.gamma[n] : 1.f;
     }
     // QKV: a 64-feature group is one head of q, k or v
-    const int which = (EPI == EPI_QKV) ? n0 / e.D : 0;
-    const int head = (EPI == EPI_QKV) ? (n0 - which * e.D) >> 6 : 0;
+    const int which = (EPI == EPI_QKV) ? min(n0, N - 1) / e.D : 0;  // (the last column group of N = 1152 / 384 has idle waves)
+    const int head = (EPI == EPI_QKV) ? (min(n0, N - 1) - which * e.D) >> 6 : 0;
     const float qsc = (EPI == EPI_QKV && which == 0) ? e.qscale : 1.f;
     // this lane's token of the tile whose epilogue runs next, as (frame, position) for the QKV layouts
     long long m_ep = tile0 * WS_ROWS + j;
@@ -366,8 +369,8 @@ __global__ __launch_bounds__(128) void gemm_ws_kernel(const bf16_t* __restrict__
     const int l_tt = lane & 3, l_pp = lane >> 2;
     auto issue = [&](int n, int buf) {
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-            const int g = 4 * w + gg;
+        for (int gg = 0; gg < 2; ++gg) {
+            const int g = 2 * w + gg;
             const long long m = min((tile0 + n) * WS_ROWS + 4 * g + l_tt, M - 1);
             const bf16_t* gp = A + m * WS_K + ((l_pp - g) & 15) * 8;
 #pragma unroll
@@ -399,14 +402,14 @@ __global__ __launch_bounds__(128) void gemm_ws_kernel(const bf16_t* __restrict__
                 o[r] = (bf16_t)g[0];
                 o[r + 1] = (bf16_t)g[1];
             }
+            // (staging the GELU output for whole-line stores measured slower than these scattered 16-byte stores)
             if (ok) *reinterpret_cast<bf8*>(e.out + m_ep * N + nb) = o;
         } else if (EPI == EPI_DELTA) {
             const float4 g0 = *reinterpret_cast<const float4*>(&s_gamma[w][fl]), g1 = *reinterpret_cast<const float4*>(&s_gamma[w][fl + 4]);
-            if (ok) {
-                float* dp = e.delta + m_ep * N + nb;
-                *reinterpret_cast<float4*>(dp) = make_float4(v[0] * g0.x, v[1] * g0.y, v[2] * g0.z, v[3] * g0.w);
-                *reinterpret_cast<float4*>(dp + 4) = make_float4(v[4] * g1.x, v[5] * g1.y, v[6] * g1.z, v[7] * g1.w);
-            }
+            // fp32: row tile t fills unit t (32 features = 128 B per row)
+            float* dp = reinterpret_cast<float*>(&stage[w][t][0] + j * WS_PITCH + (16 * h + 8 * hv) * 4);
+            *reinterpret_cast<float4*>(dp) = make_float4(v[0] * g0.x, v[1] * g0.y, v[2] * g0.z, v[3] * g0.w);
+            *reinterpret_cast<float4*>(dp + 4) = make_float4(v[4] * g1.x, v[5] * g1.y, v[6] * g1.z, v[7] * g1.w);
         } else {
             const int dh = fl;  // 0..63 inside the head
             if (which == 2) {
@@ -420,9 +423,40 @@ __global__ __launch_bounds__(128) void gemm_ws_kernel(const bf16_t* __restrict__
                 bf8 o;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) o[r] = (bf16_t)(v[r] * qsc);
-                bf16_t* dst = which == 0 ? e.q : e.k;
-                if (ok) *reinterpret_cast<bf8*>(dst + (((size_t)f_ep * e.heads + head) * e.Sp + s_ep) * 64 + dh) = o;
+                *reinterpret_cast<bf8*>(&stage[w][0][0] + j * WS_PITCH + fl * 2) = o;
             }
+        }
+    };
+    // staged rows -> global memory with 8 lanes per 128-byte output row (whole lines).  (mt_fl, f0_fl, s0_fl): first
+    // token of the staged tile and its (frame, position)
+    long long mt_fl = tile0 * WS_ROWS;
+    int f0_fl = 0, s0_fl = 0;
+    if (EPI == EPI_QKV) { f0_fl = (int)(mt_fl / e.S); s0_fl = (int)(mt_fl - (long long)f0_fl * e.S); }
+    auto flush = [&]() {
+        if (EPI != EPI_GELU && n0 < N && !e.no_store && !(EPI == EPI_QKV && which == 2)) {
+#pragma unroll
+            for (int u = 0; u < (EPI == EPI_DELTA ? 2 : 1); ++u) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int row = 8 * p + (lane >> 3), piece = lane & 7;
+                    const uint4 val = *reinterpret_cast<const uint4*>(&stage[w][u][0] + row * WS_PITCH + piece * 16);
+                    if (mt_fl + row < M) {
+                        if (EPI == EPI_DELTA) {
+                            *reinterpret_cast<uint4*>(e.delta + (mt_fl + row) * N + n0 + 32 * u + piece * 4) = val;
+                        } else {
+                            int f = f0_fl, sp = s0_fl + row;  // a tile crosses at most one frame end
+                            if (sp >= e.S) { sp -= e.S; ++f; }
+                            bf16_t* dst = which == 0 ? e.q : e.k;
+                            *reinterpret_cast<uint4*>(dst + (((size_t)f * e.heads + head) * e.Sp + sp) * 64 + piece * 8) = val;
+                        }
+                    }
+                }
+            }
+        }
+        mt_fl += WS_ROWS;
+        if (EPI == EPI_QKV) {
+            s0_fl += WS_ROWS;
+            if (s0_fl >= e.S) { s0_fl -= e.S; ++f0_fl; }
         }
     };
     auto advance = [&]() {  // the epilogue moves on to the next tile
@@ -433,7 +467,7 @@ __global__ __launch_bounds__(128) void gemm_ws_kernel(const bf16_t* __restrict__
         }
     };
     // one step: MFMAs of the tile in `buf` into accN, with the four epilogue pieces of the previous tile (accP) in between
-    auto step = [&](int buf, f16v (&accN)[2], const f16v (&accP)[2], bool have_prev) {
+    auto step = [&](int buf, f16v (&accN)[2], const f16v (&accP)[2], bool have_prev, bool have_flush) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -449,7 +483,9 @@ __global__ __launch_bounds__(128) void gemm_ws_kernel(const bf16_t* __restrict__
 #pragma unroll
             for (int t = 0; t < 2; ++t)
                 accN[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][ks], b[ks % 3], accN[t], 0, 0, 0);
-            if (have_prev && ks % 6 == 1) epi8(accP, (ks / 6) >> 1, (ks / 6) & 1);
+            // the tile staged during the previous step leaves first: its stores have the whole step to retire
+            if (have_flush && ks == 0) flush();
+            if (have_prev && ks % 6 == 2) epi8(accP, (ks / 6) >> 1, (ks / 6) & 1);
         }
         if (have_prev) advance();
     };
@@ -465,23 +501,26 @@ __global__ __launch_bounds__(128) void gemm_ws_kernel(const bf16_t* __restrict__
     for (; n + 1 < NT; n += 2) {
         const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
         issue(min(n + 2, NT - 1), b2);
-        step(b0, accA, accB, n > 0);
+        step(b0, accA, accB, n > 0, n > 1);
         ws_wait<WS_LQ>();
         __syncthreads();
         issue(min(n + 3, NT - 1), b0);
-        step(b1, accB, accA, true);
+        step(b1, accB, accA, true, n > 0);
         ws_wait<WS_LQ>();
         __syncthreads();
         b0 = b2;
     }
-    if (n < NT) {  // NT odd: one more tile, then its own epilogue
-        step(b0, accA, accB, n > 0);
+    if (n < NT) {  // NT odd: one more tile
+        step(b0, accA, accB, n > 0, n > 1);
+        if (n > 0) flush();
 #pragma unroll
         for (int u = 0; u < 4; ++u) epi8(accA, u >> 1, u & 1);
     } else {
+        if (n > 1) flush();
 #pragma unroll
         for (int u = 0; u < 4; ++u) epi8(accB, u >> 1, u & 1);
     }
+    flush();
     ws_wait<0>();
 }
 
@@ -728,9 +767,9 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
         // updates (LayerScale'd projection / MLP outputs) are written as `delta` and added by the next LayerNorm.
         const bool ws_ok = D == WS_K;
         static const int dbg_ns = [] { const char* v = getenv("DTK_DEBUG"); return v ? (atoi(v) >> 16) & 3 : 0; }();
-        auto ws_grid = [&](int N) {  // one resident round: two workgroups per CU
+        auto ws_grid = [&](int N) {  // one resident round: one workgroup per CU
             const int colwg = dtk_cdiv(N, WS_COLS);
-            const int chunks = 512 / colwg > 0 ? 512 / colwg : 1;
+            const int chunks = 256 / colwg > 0 ? 256 / colwg : 1;
             const long long tiles = dtk_cdiv(rows, WS_ROWS);
             const int tpc = (int)dtk_cdiv(tiles, chunks);
             return std::make_pair(dim3(colwg, (unsigned)dtk_cdiv(tiles, tpc)), tpc);
@@ -745,7 +784,7 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
             e.no_store = dbg_ns;
             if (ws_ok) {
                 const auto gr = ws_grid(3 * D);
-                DTK_LAUNCH("vit_gemm_qkv", (gemm_ws_kernel<EPI_QKV>), gr.first, dim3(128), 0, st, xn,
+                DTK_LAUNCH("vit_gemm_qkv", (gemm_ws_kernel<EPI_QKV>), gr.first, dim3(256), 0, st, xn,
                            reinterpret_cast<const bf16_t*>(L.qkv_w), rows, 3 * D, e, gr.second);
             } else {
                 DTK_LAUNCH("vit_gemm_qkv", (gemm_bf16_kernel<EPI_QKV>), dim3(dtk_cdiv(3 * D, GN), dtk_cdiv(rows, GM)),
@@ -757,7 +796,7 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
             e.bias = L.proj_b; e.delta = delta; e.gamma = L.ls1; e.no_store = dbg_ns;
             if (ws_ok) {
                 const auto gr = ws_grid(D);
-                DTK_LAUNCH("vit_gemm_proj", (gemm_ws_kernel<EPI_DELTA>), gr.first, dim3(128), 0, st, ao,
+                DTK_LAUNCH("vit_gemm_proj", (gemm_ws_kernel<EPI_DELTA>), gr.first, dim3(256), 0, st, ao,
                            reinterpret_cast<const bf16_t*>(L.proj_w), rows, D, e, gr.second);
             } else {
                 DTK_LAUNCH("vit_gemm_proj", (gemm_bf16_kernel<EPI_DELTA>), dim3(dtk_cdiv(D, GN), dtk_cdiv(rows, GM)), dim3(256),
@@ -769,7 +808,7 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
             e.bias = L.fc1_b; e.out = hid; e.no_store = dbg_ns;
             if (ws_ok) {
                 const auto gr = ws_grid(4 * D);
-                DTK_LAUNCH("vit_gemm_fc1", (gemm_ws_kernel<EPI_GELU>), gr.first, dim3(128), 0, st, xn,
+                DTK_LAUNCH("vit_gemm_fc1", (gemm_ws_kernel<EPI_GELU>), gr.first, dim3(256), 0, st, xn,
                            reinterpret_cast<const bf16_t*>(L.fc1_w), rows, 4 * D, e, gr.second);
             } else {
                 DTK_LAUNCH("vit_gemm_fc1", (gemm_bf16_kernel<EPI_GELU>), dim3(dtk_cdiv(4 * D, GN), dtk_cdiv(rows, GM)),
