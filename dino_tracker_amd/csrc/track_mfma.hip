@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __
                                                      const half_t* __restrict__ maps, int HWp, Rec* __restrict__ rec,
                                                      int m0, int count, int M, const int32_t* __restrict__ dM, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int ph = g.ph, pw = g.pw, HW = ph * pw;
+    const int ph = g.ph, pw = g.pw;
     const int xw = map_xw(pw);                              // 8 zero columns left, >= 8 right
     const int xs_elems = (ph + 2) * xw + 32;                // + slack: edge segments read a little past a row
     half_t* xs = reinterpret_cast<half_t*>(smem_raw);       // [(ph+2)][(pw+4)], row -1 and row ph are zero
@@ -1233,7 +1233,8 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
                                                           int fast, int m0, int count, int M,
                                                           const int32_t* __restrict__ dM, int normalized) {
     __shared__ float s_x[4][WX * WX + 3];
-    __shared__ __attribute__((aligned(16))) float s_h[4][WH * WH * 16];
+    constexpr int PN = (WH * WH + 15) / 16 * 16;  // cells per tap plane
+    __shared__ float s_p[4][9 * PN];
     __shared__ float s_z[4][WZ * WZ + 7];
     __shared__ float s_out[4][2];
     const int ph = g.ph, pw = g.pw;
@@ -1252,27 +1253,52 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const float* w1 = head;
-    const float* b1 = head + 144;
-    const float* w2 = head + 160;
+    // ---- the refiner on the matrix cores (f32-input MFMA 16x16x4: fp32 products, fp32 accumulation), 16 hidden cells
+    // per pass:
+    //   GEMM1  H^T[16 ch][16 px] = W1e[16 ch][12] . Xe[12][16 px]     k = tap 0..8, k = 9: bias row (1.0), 10, 11: zero
+    //   GEMM2  P[tap][16 px]     = W2[tap][16 ch] . relu(H^T)         (taps 9..15 of the 16 rows are zero)
+    // D of GEMM1 -- lane (g, j): channels 4g + r of cell j -- feeds GEMM2 as its B operand when k-step kp is given the
+    // channels {4g' + kp}: lane group g' then simply supplies its register kp.  The per-tap planes go to LDS and
+    //   z[zy][zx] = b2 + sum_tap P[tap][(zy + dy) * WH + zx + dx]
+    // is nine LDS reads per logit instead of 144.
     const float b2 = head[304];
-    float* hb = s_h[w];
-    for (int j = lane; j < WH * WH; j += WAVE) {
-        const int hy = j / WH, hx = j % WH;  // window coords of the centre in the x window: (hy+1, hx+1)
+    const int gq = lane >> 4, jq = lane & 15;
+    float a1[3], a2[4], xconst[3];
+    int xoff[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        const int kk = 4 * ks + gq;
+        a1[ks] = kk < 9 ? head[jq * 9 + kk] : (kk == 9 ? head[144 + jq] : 0.f);
+        xoff[ks] = kk < 9 ? (kk / 3) * WX + (kk % 3) : -1;
+        xconst[ks] = kk == 9 ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int kp = 0; kp < 4; ++kp) a2[kp] = jq < 9 ? head[160 + (4 * gq + kp) * 9 + jq] : 0.f;
+    float* Pb = s_p[w];
+#pragma unroll 1
+    for (int grp = 0; grp < (WH * WH + 15) / 16; ++grp) {
+        const int p = grp * 16 + jq;  // hidden cell of this lane's column
+        const int pc = min(p, WH * WH - 1);
+        const int hy = pc / WH, hx = pc - hy * WH;  // window coords of its centre in the x window: (hy+1, hx+1)
         const int hr = kr - (RD + 1) + hy, hc = kc - (RD + 1) + hx;
         const bool in = hr >= 0 && hr < ph && hc >= 0 && hc < pw;
-        float x9[9];
+        const float* xb = sx + hy * WX + hx;
+        f4 d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int ks = 0; ks < 3; ++ks) {
+            const float xv = xoff[ks] >= 0 ? xb[xoff[ks]] : xconst[ks];
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], xv, d1, 0, 0, 0);
+        }
+        f4 d2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) x9[dy * 3 + dx] = sx[(hy + dy) * WX + hx + dx];
+        for (int kp = 0; kp < 4; ++kp) {
+            const float hv = in ? fmaxf(d1[kp], 0.f) : 0.f;  // hidden outside the map is zero (conv2's padding)
+            d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[kp], hv, d2, 0, 0, 0);
+        }
 #pragma unroll
-        for (int ch = 0; ch < 16; ++ch) {
-            float a = 0.f;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) a = fmaf(w1[ch * 9 + t], x9[t], a);
-            a += b1[ch];
-            hb[ch * (WH * WH) + j] = in ? fmaxf(a, 0.f) : 0.f;  // channel planes; hidden outside the map is zero
+        for (int r = 0; r < 4; ++r) {
+            const int tap = 4 * gq + r;
+            if (tap < 9 && p < WH * WH) Pb[tap * PN + p] = d2[r];
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1280,17 +1306,12 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
     float* zb = s_z[w];
     for (int j = lane; j < WZ * WZ; j += WAVE) {
         const int zy = j / WZ, zx = j % WZ;  // centre in the hidden window: (zy+1, zx+1)
-        // one fmaf chain per output like the exact path (fp32 result depends on the summation order only at the
-        // 1e-7 level; four interleaved chains keep the VALU busy instead of waiting on a 144-long dependency)
-        float a4[4] = {0.f, 0.f, 0.f, 0.f};
+        float a = 0.f;
 #pragma unroll
-        for (int ch = 0; ch < 16; ++ch)
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
-                    a4[ch & 3] = fmaf(w2[ch * 9 + dy * 3 + dx], hb[ch * (WH * WH) + (zy + dy) * WH + zx + dx], a4[ch & 3]);
-        zb[j] = ((a4[0] + a4[1]) + (a4[2] + a4[3])) + b2;
+            for (int dx = 0; dx < 3; ++dx) a += Pb[(dy * 3 + dx) * PN + (zy + dy) * WH + zx + dx];
+        zb[j] = a + b2;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
