@@ -240,6 +240,115 @@ __global__ __launch_bounds__(256) void conv5x5_split_kernel(const half_t* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// first layer (3 -> 64 channels) on the split-fp16 MFMA as well.  The frame is first rewritten as two NHWC planes with
+// 4 channels per pixel (hi / lo halves, channel 3 = 0): 8 bytes per pixel and plane, so that the K index
+// k = tap * 4 + channel (25 taps -> K = 100, padded to 112 = 7 k-steps of 16) makes every 8-wide A fragment two
+// neighbouring taps = two 8-byte LDS reads, with no im2col gather.  The 64 x 112 weights (two planes) live in
+// registers for the lifetime of a workgroup.  A = pixels (rows), B = output channels (columns): in D a lane holds one
+// channel of 16 pixels and a store instruction writes 128 contiguous bytes (32 channels) of two pixels.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int C1_KS = 7;             // k-steps of 16: K = 112 >= 25 taps x 4 channels
+constexpr int C1_K = 16 * C1_KS;
+constexpr int C1_TY = 16, C1_TX = 8;  // output tile; wave = 4 rows x 8 columns
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void video_split4_kernel(const float* __restrict__ video, h4v* __restrict__ hi_,
+                                                           h4v* __restrict__ lo_, int H, int W, long long npix) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // over frames * H * W
+    if (i >= npix) return;
+    const long long f = i / ((long long)H * W), p = i - f * (long long)H * W;
+    const float* fr = video + f * 3 * (long long)H * W + p;
+    h4v h, l;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = fr[(long long)c * H * W];
+        h[c] = (half_t)v;
+        l[c] = (half_t)(v - (float)h[c]);
+    }
+    h[3] = (half_t)0.f;
+    l[3] = (half_t)0.f;
+    hi_[i] = h;
+    lo_[i] = l;
+}
+
+// [64][3][5][5] fp32 -> split planes [64 cout][112 k] of w * 2^8, k = tap * 4 + channel
+__global__ void pack_conv1_split_kernel(const float* __restrict__ w, half_t* __restrict__ Wh, half_t* __restrict__ Wl) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 64 * C1_K) return;
+    const int co = idx / C1_K, k = idx - co * C1_K;
+    const int tap = k >> 2, c = k & 3;
+    const float v = (tap < 25 && c < 3) ? w[((size_t)co * 3 + c) * 25 + tap] * WSCALE : 0.f;
+    const half_t h = (half_t)v;
+    Wh[idx] = h;
+    Wl[idx] = (half_t)(v - (float)h);
+}
+
+__global__ __launch_bounds__(256) void conv1_split_kernel(const h4v* __restrict__ in_hi, const h4v* __restrict__ in_lo,
+                                                          const half_t* __restrict__ Wh, const half_t* __restrict__ Wl,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          float* __restrict__ out, int H, int W, int tiles_x) {
+    constexpr int PY = C1_TY + 4, PX = C1_TX + 4;
+    __shared__ h4v Xh[PY * PX], Xl[PY * PX];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+    const int y0 = ty * C1_TY, x0 = tx * C1_TX;
+    const size_t frame = blockIdx.z;
+    const int li = lane & 31, hh = lane >> 5;
+    // weights: B operand, lane (cout li of column tile n, half hh) holds k = 16 ks + 8 hh .. + 7
+    h8 wh[2][C1_KS], wl[2][C1_KS];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int ks = 0; ks < C1_KS; ++ks) {
+            const size_t o = (size_t)(n * 32 + li) * C1_K + ks * 16 + hh * 8;
+            wh[n][ks] = *reinterpret_cast<const h8*>(Wh + o);
+            wl[n][ks] = *reinterpret_cast<const h8*>(Wl + o);
+        }
+    const h4v* fh = in_hi + frame * (size_t)H * W;
+    const h4v* fl = in_lo + frame * (size_t)H * W;
+    for (int idx = tid; idx < PY * PX; idx += 256) {
+        const int py = idx / PX, px = idx - py * PX;
+        const size_t g = (size_t)reflect(y0 - 2 + py, H) * W + reflect(x0 - 2 + px, W);
+        Xh[idx] = fh[g];
+        Xl[idx] = fl[g];
+    }
+    __syncthreads();
+    const int ly = w * 4 + (li >> 3), lx = li & 7;  // this lane's pixel (row of the A operand)
+    f16v acc[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < C1_KS; ++ks) {
+        // the 8 k values of this lane: taps t0 = 2 (2 ks + hh) and t0 + 1 (taps >= 25 carry zero weights: any valid pixel)
+        const int t0 = min(4 * ks + 2 * hh, 24), t1 = min(4 * ks + 2 * hh + 1, 24);
+        const int p0 = (ly + t0 / 5) * PX + lx + t0 % 5, p1 = (ly + t1 / 5) * PX + lx + t1 % 5;
+        const h4v a0 = Xh[p0], a1 = Xh[p1], b0 = Xl[p0], b1 = Xl[p1];
+        const h8 xh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        const h8 xl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh[n][ks], acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl[n][ks], acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh[n][ks], acc[n], 0, 0, 0);
+        }
+    }
+    // D[i][j]: j = lane & 31 (cout), i = (r&3) + 8 (r>>2) + 4 hh (pixel of the wave's 4 x 8 block); BN fold + ReLU
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int co = n * 32 + li;
+        const float sc = scale[co] * (1.f / WSCALE), sh = shift[co];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const int oy = y0 + w * 4 + (i >> 3), ox = x0 + (i & 7);
+            if (oy < H && ox < W) out[(frame * (size_t)H * W + (size_t)oy * W + ox) * 64 + co] = fmaxf(acc[n][r] * sc + sh, 0.f);
+        }
+    }
+}
+
 // NHWC blur-pool on split planes: one thread per (output pixel, 8 channels)
 __global__ __launch_bounds__(256) void blurpool_split_kernel(const half_t* __restrict__ in_hi, const half_t* __restrict__ in_lo,
                                                              half_t* __restrict__ out_hi, half_t* __restrict__ out_lo, int H,
@@ -453,6 +562,7 @@ struct Plan {
     int H[4], W[4];       // conv input/output spatial size of layers 0..3
     int Cin[4], Cout[4];
     size_t act[4], pool[3];  // float offsets in the workspace (per batch)
+    size_t vsplit;           // NHWC4 hi / lo planes of the input frames (4 floats' worth of bytes per pixel)
     size_t total_floats;
 };
 
@@ -469,6 +579,7 @@ Plan make_plan(int video_h, int video_w, int C, int fb) {
             p.pool[l] = off; off += (size_t)fb * h * w * chans[l + 1];
         }
     }
+    p.vsplit = off; off += (size_t)fb * video_h * video_w * 4;
     p.total_floats = off;
     return p;
 }
@@ -489,7 +600,7 @@ extern "C" size_t dtk_delta_dino_packed_floats(int layer, int C) {
     const int chans[5] = {3, 64, 128, 256, C};
     if (layer < 0 || layer > 3 || C <= 0) return 0;
     const int cinp = pad_to(chans[layer], CK), coutp = pad_to(chans[layer + 1], TNC);
-    return f32_packed_floats(cinp, coutp) + (layer ? split_plane_halves(chans[layer], chans[layer + 1]) : 0);
+    return f32_packed_floats(cinp, coutp) + (layer ? split_plane_halves(chans[layer], chans[layer + 1]) : (size_t)64 * C1_K);
 }
 
 extern "C" int dtk_delta_dino_pack(int layer, int C, const float* w, const float* bias, const float* bn_w,
@@ -506,7 +617,11 @@ extern "C" int dtk_delta_dino_pack(int layer, int C, const float* w, const float
     const long long total = 25LL * cinp * coutp;
     DTK_LAUNCH("dd_pack", pack_conv_kernel, dim3(dtk_cdiv(total, 256)), dim3(256), 0, dtk_stream(stream), w, bias, bn_w,
                bn_b, bn_mean, bn_var, eps, cin, cout, cinp, coutp, Wk, scale, shift);
-    if (layer) {
+    if (layer == 0) {
+        half_t* Wh = reinterpret_cast<half_t*>(packed + f32_packed_floats(cinp, coutp));
+        DTK_LAUNCH("dd_pack", pack_conv1_split_kernel, dim3(dtk_cdiv(64 * C1_K, 256)), dim3(256), 0, dtk_stream(stream), w, Wh,
+                   Wh + 64 * C1_K);
+    } else {
         half_t* Wh = reinterpret_cast<half_t*>(packed + f32_packed_floats(cinp, coutp));
         const size_t nh = split_plane_halves(cin, cout);
         DTK_LAUNCH("dd_pack", pack_split_kernel, dim3(dtk_cdiv((long long)nh, 256)), dim3(256), 0, dtk_stream(stream), w, cin,
@@ -560,7 +675,17 @@ extern "C" int dtk_delta_dino_refine(const dtk_geom* g, const float* video, cons
             float* act = ws + p.act[l];
             // split activations: hi plane in the first half of the fp32-sized slot, lo plane in the second
             const size_t in_n = (size_t)nf * H * W * cin, out_n = (size_t)nf * H * W * cout;
-            if (l == 0 || !split) {
+            if (l == 0 && split) {
+                h4v* vh = reinterpret_cast<h4v*>(ws + p.vsplit);
+                h4v* vl = vh + (size_t)nf * H * W;
+                const long long npix = (long long)nf * H * W;
+                DTK_LAUNCH("dd_video_split", video_split4_kernel, dim3(dtk_cdiv(npix, 256)), dim3(256), 0, st, cur, vh, vl, H, W,
+                           npix);
+                const half_t* Wh = reinterpret_cast<const half_t*>(Wk + f32_packed_floats(cinp, coutp));
+                const int tiles_x = dtk_cdiv(W, C1_TX), tiles_y = dtk_cdiv(H, C1_TY);
+                DTK_LAUNCH("dd_conv1", conv1_split_kernel, dim3(tiles_x * tiles_y, 1, nf), dim3(256), 0, st, vh, vl, Wh,
+                           Wh + 64 * C1_K, scale, shift, act, H, W, tiles_x);
+            } else if (l == 0 || !split) {
                 const int tiles_x = dtk_cdiv(W, TP), tiles_y = dtk_cdiv(H, TP);
                 dim3 grid(tiles_x * tiles_y, coutp / TNC, nf);
                 if (l == 0) {
