@@ -70,6 +70,127 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// patch embedding on the split-fp16 MFMA (patch 14, stride 7): fp32-grade results from fp16 matrix instructions.
+// Every fp32 operand is carried as hi + lo fp16 halves and a product is xh.wh + xh.wl + xl.wh accumulated in fp32 (each
+// fp16 x fp16 product is exact in fp32; the dropped xl.wl term is 2^-22 relative).  The normalised frame is first
+// rewritten as two NHWC planes with 4 channels per pixel (channel 3 = 0), so that with k = (ky * 14 + kx) * 4 + c an
+// 8-wide A fragment is two neighbouring taps = two 8-byte LDS reads -- no im2col gather.  A workgroup owns 128
+// consecutive tokens of one patch row (a wave 32 of them) x 96 output features and walks K = 784 in seven chunks of two
+// kernel rows; per chunk the two pixel rows (903 px) and the 96 x 112 weight slab (both planes) are staged in LDS.
+// ---------------------------------------------------------------------------------------------------------------
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+constexpr int PE_P = 14, PE_S = 7, PE_TOK = 128, PE_NF = 96;
+constexpr int PE_ROWPX = (PE_TOK - 1) * PE_S + PE_P;  // 903 pixels of one kernel row for 128 tokens
+constexpr int PE_K = PE_P * PE_P * 4;                 // 784
+constexpr int PE_CK = 2 * PE_P * 4;                   // 112 k per chunk (two kernel rows)
+constexpr int PE_WP = PE_CK + 8;                      // weight row pitch in halves (240 B: conflict-free fragments)
+constexpr float PE_WSCALE = 256.f;                    // weights carry 2^8 so that their lo halves stay normal numbers
+
+__global__ __launch_bounds__(256) void frame_split4_kernel(const float* __restrict__ frames, const float* __restrict__ mean_std,
+                                                           h4v* __restrict__ hi_, h4v* __restrict__ lo_, int H, int W,
+                                                           long long npix) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // over frames * H * W
+    if (i >= npix) return;
+    const long long f = i / ((long long)H * W), p = i - f * (long long)H * W;
+    const float* fr = frames + f * 3 * (long long)H * W + p;
+    h4v h, l;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = (fr[(long long)c * H * W] - mean_std[c]) / mean_std[3 + c];
+        h[c] = (half_t)v;
+        l[c] = (half_t)(v - (float)h[c]);
+    }
+    h[3] = (half_t)0.f;
+    l[3] = (half_t)0.f;
+    hi_[i] = h;
+    lo_[i] = l;
+}
+
+// [D][3][14][14] fp32 -> split planes [D][784] of w * 2^8, k = (ky * 14 + kx) * 4 + c
+__global__ void pack_patch_split_kernel(const float* __restrict__ w, int D, half_t* __restrict__ Wh, half_t* __restrict__ Wl) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)D * PE_K) return;
+    const int n = (int)(idx / PE_K), k = (int)(idx - (long long)n * PE_K);
+    const int tap = k >> 2, c = k & 3;
+    const float v = c < 3 ? w[((size_t)n * 3 + c) * (PE_P * PE_P) + tap] * PE_WSCALE : 0.f;
+    const half_t h = (half_t)v;
+    Wh[idx] = h;
+    Wl[idx] = (half_t)(v - (float)h);
+}
+
+__global__ __launch_bounds__(256) void patch_embed_split_kernel(const h4v* __restrict__ in_hi, const h4v* __restrict__ in_lo,
+                                                                const half_t* __restrict__ Wh, const half_t* __restrict__ Wl,
+                                                                const float* __restrict__ bp, const float* __restrict__ pos,
+                                                                const float* __restrict__ cls_pos, float* __restrict__ x,
+                                                                int H, int W, int ph, int pw, int D, int S, int groups_x) {
+    __shared__ h4v Xh[2 * PE_ROWPX], Xl[2 * PE_ROWPX];
+    __shared__ __attribute__((aligned(16))) half_t Wsh[PE_NF * PE_WP], Wsl[PE_NF * PE_WP];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int pr = blockIdx.x / groups_x, pc0 = (blockIdx.x % groups_x) * PE_TOK;
+    const int n0 = blockIdx.y * PE_NF;
+    const size_t frame = blockIdx.z;
+    const int li = lane & 31, hh = lane >> 5;
+    const h4v* fh = in_hi + frame * (size_t)H * W;
+    const h4v* fl = in_lo + frame * (size_t)H * W;
+    const int tokl = w * 32 + li;  // this lane's token (row of the A operand) inside the group
+    f16v acc[3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    for (int c = 0; c < PE_P / 2; ++c) {
+        __syncthreads();
+        for (int idx = tid; idx < 2 * PE_ROWPX; idx += 256) {
+            const int r = idx / PE_ROWPX, px = idx - r * PE_ROWPX;
+            const size_t g = (size_t)(pr * PE_S + 2 * c + r) * W + min(pc0 * PE_S + px, W - 1);
+            Xh[idx] = fh[g];
+            Xl[idx] = fl[g];
+        }
+        for (int idx = tid; idx < PE_NF * (PE_CK / 8); idx += 256) {
+            const int f = idx / (PE_CK / 8), piece = idx - f * (PE_CK / 8);
+            const size_t src = (size_t)min(n0 + f, D - 1) * PE_K + c * PE_CK + piece * 8;
+            *reinterpret_cast<uint4*>(Wsh + f * PE_WP + piece * 8) = *reinterpret_cast<const uint4*>(Wh + src);
+            *reinterpret_cast<uint4*>(Wsl + f * PE_WP + piece * 8) = *reinterpret_cast<const uint4*>(Wl + src);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ls = 0; ls < PE_CK / 16; ++ls) {
+            const int t0 = 2 * (2 * ls + hh);  // first of this lane's two taps inside the chunk (kx even: same row)
+            const int p0 = (t0 / PE_P) * PE_ROWPX + tokl * PE_S + t0 % PE_P;
+            const h4v a0 = Xh[p0], a1 = Xh[p0 + 1], b0 = Xl[p0], b1 = Xl[p0 + 1];
+            const h8 xh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            const h8 xl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const int wo = (n * 32 + li) * PE_WP + ls * 16 + hh * 8;
+                const h8 wh = *reinterpret_cast<const h8*>(Wsh + wo), wl = *reinterpret_cast<const h8*>(Wsl + wo);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, acc[n], 0, 0, 0);
+            }
+        }
+    }
+    // D[i][j]: j = lane & 31 (feature), i = (r&3) + 8 (r>>2) + 4 hh (token of the wave's 32)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        const int co = n0 + n * 32 + li;
+        if (co >= D) continue;
+        const float b = bp[co];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pc = pc0 + w * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (pc < pw) {
+                const int pp = pr * pw + pc;
+                x[((size_t)frame * S + 1 + pp) * D + co] = acc[n][r] * (1.f / PE_WSCALE) + b + pos[(size_t)pp * D + co];
+            }
+        }
+        if (blockIdx.x == 0 && w == 0 && hh == 0) x[(size_t)frame * S * D + co] = cls_pos[co];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // LayerNorm: fp32 row -> bf16 row (A operand of the next GEMM); one wave per token
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, const float* __restrict__ delta,
@@ -760,9 +881,28 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
     for (int f0 = 0; f0 < nframes; f0 += p.FB) {
         const int nf = (nframes - f0) < p.FB ? (nframes - f0) : p.FB;
         const long long rows = (long long)nf * S;
-        DTK_LAUNCH("vit_patch_embed", patch_embed_kernel, dim3(dtk_cdiv(HW, 64), dtk_cdiv(D, 64), nf), dim3(256), 0, st,
-                   frames + (size_t)f0 * 3 * video_h * video_w, m->patch_w, m->patch_b, m->pos, m->cls_pos, m->mean_std, x,
-                   video_h, video_w, ph, pw, D, m->patch, m->stride, S);
+        const bool pe_fits = (size_t)nf * video_h * video_w * 16 <= p.delta - p.hid &&
+                             (size_t)D * PE_K * 4 <= p.total - p.delta;
+        if (m->patch == PE_P && m->stride == PE_S && pe_fits) {
+            // split planes of the normalised frames live in `hid`, the split weights in `delta` (both unused until the
+            // first block)
+            h4v* fh = reinterpret_cast<h4v*>(hid);
+            h4v* fl = fh + (size_t)nf * video_h * video_w;
+            half_t* wh = reinterpret_cast<half_t*>(delta);
+            half_t* wl = wh + (size_t)D * PE_K;
+            const long long npix = (long long)nf * video_h * video_w;
+            DTK_LAUNCH("vit_frame_split", frame_split4_kernel, dim3(dtk_cdiv(npix, 256)), dim3(256), 0, st,
+                       frames + (size_t)f0 * 3 * video_h * video_w, m->mean_std, fh, fl, video_h, video_w, npix);
+            DTK_LAUNCH("vit_frame_split", pack_patch_split_kernel, dim3(dtk_cdiv((long long)D * PE_K, 256)), dim3(256), 0, st,
+                       m->patch_w, D, wh, wl);
+            const int groups_x = dtk_cdiv(pw, PE_TOK);
+            DTK_LAUNCH("vit_patch_embed", patch_embed_split_kernel, dim3(groups_x * ph, dtk_cdiv(D, PE_NF), nf), dim3(256), 0,
+                       st, fh, fl, wh, wl, m->patch_b, m->pos, m->cls_pos, x, video_h, video_w, ph, pw, D, S, groups_x);
+        } else {
+            DTK_LAUNCH("vit_patch_embed", patch_embed_kernel, dim3(dtk_cdiv(HW, 64), dtk_cdiv(D, 64), nf), dim3(256), 0, st,
+                       frames + (size_t)f0 * 3 * video_h * video_w, m->patch_w, m->patch_b, m->pos, m->cls_pos, m->mean_std,
+                       x, video_h, video_w, ph, pw, D, m->patch, m->stride, S);
+        }
         // K = 384 GEMMs run weight-stationary; everything else (fc2, wider models) on the tiled kernel.  The residual
         // updates (LayerScale'd projection / MLP outputs) are written as `delta` and added by the next LayerNorm.
         const bool ws_ok = D == WS_K;
