@@ -650,6 +650,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const bf16_t* __restrict__
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int KP = 72;   // K tile row pitch in bf16 (144 B): ds_read_b128 of 16 rows hits 16 distinct 16-B slots
 constexpr int VP = 68;   // V^T tile row pitch in bf16 (136 B): ds_read_b64 of 32 rows hits 32 distinct 8-B slots
+constexpr int ATT_QT = 2;  // 32-query tiles per wave
 
 __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kg,
                                                         const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O, int S,
@@ -659,24 +660,40 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int fh = blockIdx.y;  // frame * heads + head
     const int frame = fh / heads, head = fh - frame * heads;
-    const int q0 = blockIdx.x * 128 + w * 32;
+    // a wave owns ATT_QT x 32 queries: every K / V^T fragment read from LDS feeds ATT_QT MFMAs (the kernel is bound by
+    // LDS bandwidth, not by the matrix cores, when each fragment is used once)
+    const int q0 = blockIdx.x * (128 * ATT_QT) + w * (32 * ATT_QT);
     const int lq = lane & 31, hi = lane >> 5;
     const bf16_t* Qb = Q + (size_t)fh * Sp * 64;
     const bf16_t* Kb = Kg + (size_t)fh * Sp * 64;
     const bf16_t* Vb = Vt + (size_t)fh * 64 * Sp;
     // Q^T fragments (B operand): lane (query lq, hi) holds d = 16*ks + 8*hi .. +7 for ks = 0..3
-    bf8 qf[4];
-    {
-        const int qrow = min(q0 + lq, Sp - 1);
+    bf8 qf[ATT_QT][4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf8*>(Qb + (size_t)qrow * 64 + ks * 16 + hi * 8);
+    for (int qt = 0; qt < ATT_QT; ++qt) {
+        const int qrow = min(q0 + qt * 32 + lq, Sp - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[qt][ks] = *reinterpret_cast<const bf8*>(Qb + (size_t)qrow * 64 + ks * 16 + hi * 8);
     }
-    f16v o[2];  // O^T accumulators: d-block db: rows d = 32*db + (r&3) + 8*(r>>2) + 4*hi, column = query lq
+    f16v o[ATT_QT][2];  // O^T accumulators: d-block db: rows d = 32*db + (r&3) + 8*(r>>2) + 4*hi, column = query lq
+    // m_run: softmax reference of this lane's query; negm = -m_run broadcast over an accumulator-shaped vector, used as
+    // the C operand of the first score MFMA, so that the scores arrive as s - m_run and the softmax needs no subtraction
+    // (a SIMD hides only ~4 VALU instructions under one 32x32x16 MFMA; everything beyond that is exposed)
+    float m_run[ATT_QT];
+    f2 l_run[ATT_QT];
+    f16v negm[ATT_QT];
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int qt = 0; qt < ATT_QT; ++qt) {
+        m_run[qt] = 0.f;
+        l_run[qt] = f2{0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+        for (int r = 0; r < 16; ++r) negm[qt][r] = 0.f;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qt][db][r] = 0.f;
+    }
     const int ntiles = (S + 63) / 64;
     // loader: thread -> (row, 16-byte piece) x 2 for each of K and V^T
     const int lr = tid >> 3, lp = tid & 7;  // rows lr, lr + 32; piece lp (8 bf16)
@@ -707,60 +724,71 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) ATT_LOAD_TILE(t + 1);
         // ---- S^T = K Q^T : two 32-key blocks x four 16-wide d steps ----
-        f16v sc[2];
+        f16v sc[ATT_QT][2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sc[b][r] = 0.f;
-#pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf8 kf = *reinterpret_cast<const bf8*>(&Ks[cur][(b * 32 + lq) * KP + ks * 16 + hi * 8]);
-                sc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[b], 0, 0, 0);
+#pragma unroll
+                for (int qt = 0; qt < ATT_QT; ++qt)
+                    sc[qt][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qt][ks], ks == 0 ? negm[qt] : sc[qt][b], 0, 0, 0);
             }
         }
         // keys beyond S (last tile only) are masked out
         if (t == ntiles - 1 && (S & 63) != 0) {
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int qt = 0; qt < ATT_QT; ++qt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = t * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= S) sc[b][r] = -1e30f;
-                }
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = t * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (key >= S) sc[qt][b][r] = -1e30f;
+                    }
         }
         // ---- online softmax (exp2 domain; Q carries log2(e)/sqrt(d)) : everything per query is lane-local ----
-        float tm = -1e30f;
+        bf8 pf[ATT_QT][2][2];  // P^T fragments: [query tile][key block][16-slot group]
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int qt = 0; qt < ATT_QT; ++qt) {
+            float tm = -3e38f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tm = fmaxf(tm, sc[b][r]);
-        tm = fmaxf(tm, __shfl_xor(tm, 32, WAVE));
-        // deferred maximum: the running reference only moves (and O, l are only rescaled) when some query of the wave
-        // sees a score more than 8 above it, so P stays <= 2^8 and the common path has no rescale
-        if (!__all(tm <= m_run + 8.f)) {
-            asm volatile("; rescale" ::: "memory");
-            const float m_new = fmaxf(m_run, tm);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // raw v_exp_f32 (exp2f() adds range handling)
-            m_run = m_new;
-            l_run *= alpha;
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
+                for (int r = 0; r < 16; ++r) tm = fmaxf(tm, sc[qt][b][r]);
+            tm = fmaxf(tm, __shfl_xor(tm, 32, WAVE));  // largest score of the tile relative to m_run
+            // deferred maximum: the reference only moves (and O, l are only rescaled) when some query of the wave sees a
+            // score more than 8 above it, so P stays <= 2^8 and the common path has no rescale.  The first tile always
+            // takes this path (m_run = 0 is not a reference yet).
+            if (t == 0 || !__all(tm <= 8.f)) {
+                asm volatile("; rescale" ::: "memory");
+                const float up = t == 0 ? tm : fmaxf(tm, 0.f);     // m_new - m_run
+                const float alpha = __builtin_amdgcn_exp2f(-up);   // raw v_exp_f32 (never used on the first tile: l = o = 0)
+                m_run[qt] += up;
+                l_run[qt] *= f2{alpha, alpha};
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[qt][db][r] *= alpha;
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[qt][b][r] -= up;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[qt][r] = -m_run[qt];
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const f2 p = {__builtin_amdgcn_exp2f(sc[qt][b][8 * j + e]), __builtin_amdgcn_exp2f(sc[qt][b][8 * j + e + 1])};
+                        l_run[qt] += p;
+                        pf[qt][b][j][e] = (bf16_t)p[0];
+                        pf[qt][b][j][e + 1] = (bf16_t)p[1];
+                    }
         }
-        float ls = 0.f;
-        bf8 pf[2][2];  // P^T fragments: [key block][16-slot group]
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float p = __builtin_amdgcn_exp2f(sc[b][8 * j + e] - m_run);
-                    ls += p;
-                    pf[b][j][e] = (bf16_t)p;
-                }
-        l_run += ls;
         // ---- O^T += V^T P^T : slot (hi, e) of group (b, j) is key 32b + 16j + 8(e>>2) + 4hi + (e&3) ----
 #pragma unroll
         for (int db = 0; db < 2; ++db)
@@ -771,26 +799,32 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
                     const bf16_t* vp = &Vs[cur][(db * 32 + lq) * VP + b * 32 + j * 16 + 4 * hi];
                     const bf4 v0 = *reinterpret_cast<const bf4*>(vp), v1 = *reinterpret_cast<const bf4*>(vp + 8);
                     const bf8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][j], o[db], 0, 0, 0);
+#pragma unroll
+                    for (int qt = 0; qt < ATT_QT; ++qt)
+                        o[qt][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qt][b][j], o[qt][db], 0, 0, 0);
                 }
         if (t + 1 < ntiles) ATT_STORE_TILE(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32, WAVE);
-    const float inv = 1.f / l_tot;
-    const int qi = q0 + lq;
-    if (qi < S) {
-        bf16_t* orow = O + ((size_t)frame * S + qi) * D + head * 64;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+    for (int qt = 0; qt < ATT_QT; ++qt) {
+        const float l_half = l_run[qt][0] + l_run[qt][1];
+        const float l_tot = l_half + __shfl_xor(l_half, 32, WAVE);
+        const float inv = 1.f / l_tot;
+        const int qi = q0 + qt * 32 + lq;
+        if (qi < S) {
+            bf16_t* orow = O + ((size_t)frame * S + qi) * D + head * 64;
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int d = db * 32 + 8 * rq + 4 * hi;
-                bf4 v = {(bf16_t)(o[db][4 * rq + 0] * inv), (bf16_t)(o[db][4 * rq + 1] * inv),
-                         (bf16_t)(o[db][4 * rq + 2] * inv), (bf16_t)(o[db][4 * rq + 3] * inv)};
-                *reinterpret_cast<bf4*>(orow + d) = v;
-            }
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int d = db * 32 + 8 * rq + 4 * hi;
+                    bf4 v = {(bf16_t)(o[qt][db][4 * rq + 0] * inv), (bf16_t)(o[qt][db][4 * rq + 1] * inv),
+                             (bf16_t)(o[qt][db][4 * rq + 2] * inv), (bf16_t)(o[qt][db][4 * rq + 3] * inv)};
+                    *reinterpret_cast<bf4*>(orow + d) = v;
+                }
+        }
     }
 }
 
@@ -930,7 +964,7 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
                 DTK_LAUNCH("vit_gemm_qkv", (gemm_bf16_kernel<EPI_QKV>), dim3(dtk_cdiv(3 * D, GN), dtk_cdiv(rows, GM)),
                            dim3(256), 0, st, xn, reinterpret_cast<const bf16_t*>(L.qkv_w), rows, 3 * D, D, e);
             }
-            DTK_LAUNCH("vit_attention", attention_kernel, dim3(dtk_cdiv(S, 128), nf * m->heads), dim3(256), 0, st, q, k, vt,
+            DTK_LAUNCH("vit_attention", attention_kernel, dim3(dtk_cdiv(S, 128 * ATT_QT), nf * m->heads), dim3(256), 0, st, q, k, vt,
                        ao, S, Sp, m->heads, D);
             e = GemmEpi{};
             e.bias = L.proj_b; e.delta = delta; e.gamma = L.ls1; e.no_store = dbg_ns;
