@@ -35,7 +35,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr float FSCALE = 32.f;            // fp16 operands carry 32 x unit vectors (keeps small components normal)
 constexpr float INV_SCALE2 = 1.f / 1024.f;
 constexpr float EPS_C = 3e-3f;            // candidate window: 2 x (fp16 operand + fp16 storage error bound)
-constexpr int KC = 8;                     // candidates kept per source
+constexpr int KC = 10;                    // candidates kept per source
 constexpr int CM = 64, CN = 128, CK = 32; // corr16 tile
 constexpr int NB_MAX = 1024;              // refine: largest window-union box (cells) correlated as one group
 constexpr int RD = 5;                     // disk radius in cells supported by refine32 (radius / stride <= 5)
@@ -414,7 +414,7 @@ constexpr int PK_CELLS = 32;              // cells per step
 constexpr int PK_IDX_BITS = 13;           // position tag: step << 4 | accumulator register
 constexpr int PK_VAL_BITS = 17;           // sources carry 2^12 x, cells 2^5 x unit vectors: the accumulator is 2^17 rho
 constexpr float PK_SRC_SCALE = 4096.f;
-constexpr int PK_TOP = 5;                 // list length per lane half
+constexpr int PK_TOP = 6;                 // list length per lane half
 // candidate band of the fused pass: two fp16 operand roundings bound |rho16 - rho| by 2^-10 (Cauchy-Schwarz over the
 // relative errors), so the exact arg-max cell is within 2 x 2^-10 of the fp16 maximum; + fp32 accumulation and the
 // truncation to PK_VAL_BITS
