@@ -274,8 +274,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     __shared__ uint4 As[2][GM * 4];
     __shared__ uint4 Bs[2][GN * 4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const long long m0 = (long long)blockIdx.y * GM;
-    const int n0 = blockIdx.x * GN;
+    // block -> tile: workgroup b runs on XCD b % 8 (round-robin dispatch); the column tiles of one row block are given
+    // to the same XCD back to back, so that A is fetched from HBM once and the other N/128 - 1 reads hit that XCD's L2
+    // (with column-major block order fc2 re-read its 0.75 GB operand three times: 5.2 TB/s, HBM-bound)
+    const int ncol = (N + GN - 1) / GN;
+    const long long nrow = (M + GM - 1) / GM;
+    const long long kb = blockIdx.x >> 3;
+    const long long row_blk = (kb / ncol) * 8 + (blockIdx.x & 7);
+    if (row_blk >= nrow) return;
+    const long long m0 = row_blk * GM;
+    const int n0 = (int)(kb % ncol) * GN;
     const int wr = w >> 1, wc = w & 1;  // wave tile 64 x 64
     const int fj = lane & 15, fg = lane >> 4;
     const int lrow = tid >> 2, lpiece = tid & 3;  // loader rows lrow, lrow + 64
@@ -849,6 +857,12 @@ __global__ __launch_bounds__(256) void drop_cls_kernel(const float* __restrict__
 // (their weights are loaded once per chunk); 30 frames of 67x121 tokens need ~2.6 GB of workspace
 constexpr int VIT_FRAME_BATCH = 30;
 
+// 1-D grid of gemm_bf16_kernel: 8 row blocks (one per XCD) x all column tiles per group
+inline unsigned gemm_grid(int N, long long rows) {
+    const long long ncol = dtk_cdiv(N, GN), nrow = dtk_cdiv(rows, GM);
+    return (unsigned)(dtk_cdiv(nrow, 8) * 8 * ncol);
+}
+
 struct VitPlan {
     int S, Sp, FB;
     size_t x, xn, q, k, vt, ao, hid, delta, total;
@@ -961,7 +975,7 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
                 DTK_LAUNCH("vit_gemm_qkv", (gemm_ws_kernel<EPI_QKV>), gr.first, dim3(256), 0, st, xn,
                            reinterpret_cast<const bf16_t*>(L.qkv_w), rows, 3 * D, e, gr.second);
             } else {
-                DTK_LAUNCH("vit_gemm_qkv", (gemm_bf16_kernel<EPI_QKV>), dim3(dtk_cdiv(3 * D, GN), dtk_cdiv(rows, GM)),
+                DTK_LAUNCH("vit_gemm_qkv", (gemm_bf16_kernel<EPI_QKV>), dim3(gemm_grid(3 * D, rows)),
                            dim3(256), 0, st, xn, reinterpret_cast<const bf16_t*>(L.qkv_w), rows, 3 * D, D, e);
             }
             DTK_LAUNCH("vit_attention", attention_kernel, dim3(dtk_cdiv(S, 128 * ATT_QT), nf * m->heads), dim3(256), 0, st, q, k, vt,
@@ -973,7 +987,7 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
                 DTK_LAUNCH("vit_gemm_proj", (gemm_ws_kernel<EPI_DELTA>), gr.first, dim3(256), 0, st, ao,
                            reinterpret_cast<const bf16_t*>(L.proj_w), rows, D, e, gr.second);
             } else {
-                DTK_LAUNCH("vit_gemm_proj", (gemm_bf16_kernel<EPI_DELTA>), dim3(dtk_cdiv(D, GN), dtk_cdiv(rows, GM)), dim3(256),
+                DTK_LAUNCH("vit_gemm_proj", (gemm_bf16_kernel<EPI_DELTA>), dim3(gemm_grid(D, rows)), dim3(256),
                            0, st, ao, reinterpret_cast<const bf16_t*>(L.proj_w), rows, D, D, e);
             }
             DTK_LAUNCH("vit_layernorm", layernorm_kernel, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x, (const float*)delta,
@@ -985,12 +999,12 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
                 DTK_LAUNCH("vit_gemm_fc1", (gemm_ws_kernel<EPI_GELU>), gr.first, dim3(256), 0, st, xn,
                            reinterpret_cast<const bf16_t*>(L.fc1_w), rows, 4 * D, e, gr.second);
             } else {
-                DTK_LAUNCH("vit_gemm_fc1", (gemm_bf16_kernel<EPI_GELU>), dim3(dtk_cdiv(4 * D, GN), dtk_cdiv(rows, GM)),
+                DTK_LAUNCH("vit_gemm_fc1", (gemm_bf16_kernel<EPI_GELU>), dim3(gemm_grid(4 * D, rows)),
                            dim3(256), 0, st, xn, reinterpret_cast<const bf16_t*>(L.fc1_w), rows, 4 * D, D, e);
             }
             e = GemmEpi{};
             e.bias = L.fc2_b; e.delta = delta; e.gamma = L.ls2;
-            DTK_LAUNCH("vit_gemm_fc2", (gemm_bf16_kernel<EPI_DELTA>), dim3(dtk_cdiv(D, GN), dtk_cdiv(rows, GM)), dim3(256), 0,
+            DTK_LAUNCH("vit_gemm_fc2", (gemm_bf16_kernel<EPI_DELTA>), dim3(gemm_grid(D, rows)), dim3(256), 0,
                        st, hid, reinterpret_cast<const bf16_t*>(L.fc2_w), rows, D, 4 * D, e);
         }
         if (m->depth > 0)  // the last MLP's residual update
