@@ -152,14 +152,12 @@ def main():
             "vit_gemm_proj": (2.0 * S * C * C * depth * T, MFMA_F16_PEAK_TF),
             "vit_gemm_fc1": (2.0 * S * C * 4 * C * depth * T, MFMA_F16_PEAK_TF),
             "vit_gemm_fc2": (2.0 * S * C * 4 * C * depth * T, MFMA_F16_PEAK_TF),
-            "vit_patch_embed": (2.0 * HW * 588 * C * T, F32_PEAK_TF),
-            "dd_conv1": (2.0 * 406504 * 4800 * T, F32_PEAK_TF),
-            "dd_conv23": (2.0 * (101626 * 204800 + 25466 * 819200) * T, F32_PEAK_TF),
-            "dd_conv4": (2.0 * 6420 * 6400 * C * T, F32_PEAK_TF),
-            "corr16": (2.0 * HW * C * maps, MFMA_F16_PEAK_TF),
-            "corr_exact": (2.0 * HW * C * maps, F32_PEAK_TF),
-            "head16": (576.0 * HW * maps, 2 * F32_PEAK_TF),       # v_dot2_f32_f16: 2 MACs per lane-op
-            "head_exact": (576.0 * HW * maps, F32_PEAK_TF),
+            # split-fp16 kernels: every fp32 MAC costs three fp16 MFMA MACs (hi*hi + hi*lo + lo*hi)
+            "vit_patch_embed": (2.0 * HW * 588 * C * T, MFMA_F16_PEAK_TF / 3),
+            "dd_conv1": (2.0 * 406504 * 4800 * T, MFMA_F16_PEAK_TF / 3),
+            "dd_conv23": (2.0 * (101626 * 204800 + 25466 * 819200) * T, MFMA_F16_PEAK_TF / 3),
+            "dd_conv4": (2.0 * 6420 * 6400 * C * T, MFMA_F16_PEAK_TF / 3),
+            "corr_peaks": (2.0 * HW * C * maps, MFMA_F16_PEAK_TF),
             "refine_corr": (2.0 * 225 * C * maps, F32_PEAK_TF),   # (2*RD+5)^2 window cells per map
             "refine_head": (2.0 * (169 + 121) * 144 * maps, F32_PEAK_TF),
         }
@@ -173,6 +171,15 @@ def main():
         else:
             roofline = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": None, "traffic": None}
+        # HBM-side bytes per launch of that kernel from the committed PMC passes (scripts/pmc_traffic.py)
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as fh:
+                tr = json.load(fh)["kernels"].get(dom)
+            if tr:
+                roofline["traffic"] = tr["bytes_per_launch"]
+                roofline["traffic_note"] = "bytes per launch, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/r01_pmc_traffic.json)"
+        except (OSError, ValueError, KeyError):
+            pass
         roofline["avg_launch_ms"] = round(ms / max(launches, 1), 4)
         roofline["launches"] = launches
         roofline["kernel_ms"] = {k: round(v[0], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("DTK_BENCH_KERNELS", "12"))]}

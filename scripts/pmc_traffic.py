@@ -1,0 +1,40 @@
+"""HBM-side traffic per launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, rocpd databases).
+
+Usage: python scripts/pmc_traffic.py <fetch.db> <write.db> > profiles/<round>_pmc_traffic.json
+Corrections as prescribed by MI355X_MICROARCH.md (HBM section): both counters are in KiB; on gfx950 FETCH_SIZE tallies
+the 128-byte requests of wide reads at 64 bytes, so it is doubled; WRITE_SIZE is uncalibrated and taken as is."""
+import json, re, sqlite3, sys
+
+NAMES = {  # kernel function -> launch name used by bench.py (only kernels with one launch name)
+    "attention_kernel": "vit_attention", "corr_peaks_kernel": "corr_peaks", "refine_corr_kernel": "refine_corr",
+    "refine_head_kernel": "refine_head", "layernorm_kernel": "vit_layernorm", "rescore_kernel": "rescore",
+    "patch_embed_split_kernel": "vit_patch_embed", "conv1_split_kernel": "dd_conv1",
+}
+
+def per_kernel(path, counter):
+    db = sqlite3.connect(path)
+    ks = [r[1] for r in db.execute("pragma table_info(rocpd_info_kernel_symbol)")]
+    name_col = "kernel_name" if "kernel_name" in ks else ks[-1]
+    rows = db.execute(f"""select s.{name_col}, count(*), sum(e.value) from rocpd_pmc_event e
+                          join rocpd_info_pmc p on e.pmc_id = p.id
+                          join rocpd_kernel_dispatch d on e.event_id = d.event_id
+                          join rocpd_info_kernel_symbol s on d.kernel_id = s.id where p.name = ? group by 1""", (counter,))
+    out = {}
+    for kn, n, v in rows:
+        m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", kn) or re.match(r"_Z(\d+)", kn)
+        short = kn[m.end():m.end() + int(m.group(1))] if m else kn[:40]
+        c = out.setdefault(short, [0, 0.0])
+        c[0] += n; c[1] += v
+    return out
+
+rd, wr = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+res = {}
+for fn, launch in NAMES.items():
+    if fn in rd and fn in wr:
+        fetch = 2.0 * rd[fn][1] * 1024.0 / rd[fn][0]
+        write = wr[fn][1] * 1024.0 / wr[fn][0]
+        res[launch] = {"kernel": fn, "launches_sampled": rd[fn][0], "fetch_bytes_per_launch": round(fetch),
+                       "write_bytes_per_launch": round(write), "bytes_per_launch": round(fetch + write)}
+print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of "
+                            "`python bench.py --steps 1 --warmup 0 --no-cpu-baseline`; FETCH_SIZE x 2 (gfx950), KiB -> bytes",
+                  "kernels": res}, indent=1))
