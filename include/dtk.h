@@ -106,10 +106,11 @@ int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int nframes, in
                     float* tokens_out, float* feat_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- P2: Delta-DINO refinement (models/tracker.py:113-135; models/networks/delta_dino.py:53-61;
- *      models/utils.py:7-45), fp32 on the f32-input MFMA ------------------------------------------------------------
+ *      models/utils.py:7-45), fp32-grade on the fp16 MFMA (operands split into hi + lo halves, 3 products) ----------
  * dtk_delta_dino_pack: layer l in 0..3 (state-dict keys layers.{4l}.{weight,bias} = conv [Cout][Cin][5][5] and
  *   layers.{4l+1}.{weight,bias,running_mean,running_var} = BatchNorm2d, eval mode) -> kernel layout
- *   packed = Wk[25][CinP][CoutP] | scale[CoutP] | shift[CoutP]  (dtk_delta_dino_packed_floats floats).
+ *   packed = Wk[25][CinP][CoutP] | scale[CoutP] | shift[CoutP] | split-fp16 weight planes (hi, lo; 2^8 w) in the
+ *   tile order of the convolution kernels  (dtk_delta_dino_packed_floats floats in total; opaque to the caller).
  * dtk_delta_dino_refine: for frames t0 .. t0+nframes-1: out[t] = dino[t] + align(CNN(video[t])), token-major, plus
  *   per-cell norms (may be NULL).  video is [T][3][video_h][video_w] fp32 in [0,1] (data/data_utils.py:79-104),
  *   packed = 4 device pointers (host array).  BlurPool = antialiased_cnns.BlurPool(stride 2): reflect-pad (1,2,1,2),
