@@ -131,7 +131,10 @@ struct SplitCfg {
     static constexpr int PY = STY + 4 * DIL, PX = STX + 4 * DIL;
     static constexpr int PXP = 24;  // row stride of 24 px * 48 B = 128 mod 256 B: two patch rows read conflict-free
     static constexpr int X_HALVES = PY * PXP * SPT;
-    static constexpr int W_HALVES = 5 * 64 * SPT;
+    // weight rows: 48-byte pitch (conflict-free) where LDS allows two workgroups per CU anyway; the dilated layer's
+    // larger patch needs the dense 32-byte pitch (2-way conflicts on the weight reads) to get there
+    static constexpr int WPT = DIL == 1 ? SPT : 16;
+    static constexpr int W_HALVES = 5 * 64 * WPT;
     static constexpr size_t LDS_BYTES = (size_t)(2 * X_HALVES + 2 * W_HALVES) * sizeof(half_t);
     static_assert(PX <= PXP, "patch wider than the padded LDS row");
 };
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(256) void conv5x5_split_kernel(const half_t* __rest
             for (int idx = tid; idx < 5 * 64 * 4; idx += 256) {
                 const int plane = idx & 1, piece = (idx >> 1) & 1, rowi = idx >> 2;  // rowi = tap*64 + cout
                 const half_t* src = (plane ? Wl : Wh) + wbase + (size_t)rowi * SK + piece * 8;
-                *reinterpret_cast<uint4*>((plane ? Wsl : Wsh) + rowi * SPT + piece * 8) = *reinterpret_cast<const uint4*>(src);
+                *reinterpret_cast<uint4*>((plane ? Wsl : Wsh) + rowi * Cfg::WPT + piece * 8) = *reinterpret_cast<const uint4*>(src);
             }
             __syncthreads();
 #pragma unroll
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void conv5x5_split_kernel(const half_t* __rest
                 }
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    const int wr = (kx * 64 + n * 32 + li) * SPT + hi * 8;
+                    const int wr = (kx * 64 + n * 32 + li) * Cfg::WPT + hi * 8;
                     const h8 wh = *reinterpret_cast<const h8*>(Wsh + wr);
                     const h8 wl = *reinterpret_cast<const h8*>(Wsl + wr);
 #pragma unroll
