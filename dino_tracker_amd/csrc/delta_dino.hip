@@ -129,11 +129,13 @@ constexpr float WSCALE = 256.f;
 template <int DIL>
 struct SplitCfg {
     static constexpr int PY = STY + 4 * DIL, PX = STX + 4 * DIL;
-    static constexpr int PXP = 24;  // row stride of 24 px * 48 B = 128 mod 256 B: two patch rows read conflict-free
-    static constexpr int X_HALVES = PY * PXP * SPT;
-    // weight rows: 48-byte pitch (conflict-free) where LDS allows two workgroups per CU anyway; the dilated layer's
-    // larger patch needs the dense 32-byte pitch (2-way conflicts on the weight reads) to get there
-    static constexpr int WPT = DIL == 1 ? SPT : 16;
+    // Occupancy beats conflict-free LDS here (measured: the dilated layer went 17.0 -> 9.9 ms when a second workgroup
+    // fitted a CU): dense 32-byte rows (2-way conflicts on the fragment reads) bring the stride-1 layers to three
+    // workgroups per CU and the dilated one to two.  XPT/WPT = 24 would be the conflict-free 48-byte pitch.
+    static constexpr int XPT = DIL == 1 ? 16 : SPT;
+    static constexpr int PXP = DIL == 1 ? PX : 24;  // padded row: 24 px * 48 B = 128 mod 256 B (conflict-free rows)
+    static constexpr int X_HALVES = PY * PXP * XPT;
+    static constexpr int WPT = 16;
     static constexpr int W_HALVES = 5 * 64 * WPT;
     static constexpr size_t LDS_BYTES = (size_t)(2 * X_HALVES + 2 * W_HALVES) * sizeof(half_t);
     static_assert(PX <= PXP, "patch wider than the padded LDS row");
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void conv5x5_split_kernel(const half_t* __rest
             const int py = p / PX, px = p - py * PX;
             const int gy = reflect(y0 - 2 * DIL + py, H), gx = reflect(x0 - 2 * DIL + px, W);
             const half_t* src = (plane ? fl : fh) + ((size_t)gy * W + gx) * Cin + ck * SK + piece * 8;
-            *reinterpret_cast<uint4*>((plane ? Xl : Xh) + (py * PXP + px) * SPT + piece * 8) =
+            *reinterpret_cast<uint4*>((plane ? Xl : Xh) + (py * PXP + px) * Cfg::XPT + piece * 8) =
                 *reinterpret_cast<const uint4*>(src);
         }
         for (int ky = 0; ky < 5; ++ky) {
@@ -197,8 +199,8 @@ __global__ __launch_bounds__(256) void conv5x5_split_kernel(const half_t* __rest
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     const int p = (ly + ky * DIL) * PXP + m * 8 + lx + kx * DIL;
-                    xh[m] = *reinterpret_cast<const h8*>(Xh + p * SPT + hi * 8);
-                    xl[m] = *reinterpret_cast<const h8*>(Xl + p * SPT + hi * 8);
+                    xh[m] = *reinterpret_cast<const h8*>(Xh + p * Cfg::XPT + hi * 8);
+                    xl[m] = *reinterpret_cast<const h8*>(Xl + p * Cfg::XPT + hi * 8);
                 }
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
