@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void patch_embed_split_kernel(const h4v* __res
 // ---------------------------------------------------------------------------------------------------------------
 // LayerNorm: fp32 row -> bf16 row (A operand of the next GEMM); one wave per token
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, const float* __restrict__ delta,
+__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
                                                         const float* __restrict__ gam, const float* __restrict__ bet,
                                                         bf16_t* __restrict__ y, long long rows, int D, float eps) {
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -210,8 +210,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
         if (c < D) {
             v[it] = *reinterpret_cast<const float4*>(p + c);
             if (delta) {
-                const float4 d = *reinterpret_cast<const float4*>(delta + row * D + c);
-                v[it].x += d.x; v[it].y += d.y; v[it].z += d.z; v[it].w += d.w;
+                const bf4 d = *reinterpret_cast<const bf4*>(delta + row * D + c);
+                v[it].x += (float)d[0]; v[it].y += (float)d[1]; v[it].z += (float)d[2]; v[it].w += (float)d[3];
                 *reinterpret_cast<float4*>(p + c) = v[it];
             }
             s += (v[it].x + v[it].y) + (v[it].z + v[it].w);
@@ -259,7 +259,7 @@ struct GemmEpi {
     bf16_t* out;         // [M][N]
     // EPI_DELTA
     int no_store;        // development: skip the stores of the weight-stationary kernel (DTK_DEBUG & 65536)
-    float* delta;        // [M][N] fp32: gamma * (A W^T + bias), added to the residual stream by the next LayerNorm
+    bf16_t* delta;       // [M][N] bf16: gamma * (A W^T + bias), added to the fp32 residual stream by the next LayerNorm
     const float* gamma;  // [N] LayerScale
 };
 
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const long long m = mb + r;
-                    if (m < M) e.delta[m * N + n] = gm * (acc[mi][ni][r] + bias);
+                    if (m < M) e.delta[m * N + n] = (bf16_t)(gm * (acc[mi][ni][r] + bias));
                 }
             }
         }
@@ -535,10 +535,9 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const bf16_t* __restrict__
             if (ok) *reinterpret_cast<bf8*>(e.out + m_ep * N + nb) = o;
         } else if (EPI == EPI_DELTA) {
             const float4 g0 = *reinterpret_cast<const float4*>(&s_gamma[w][fl]), g1 = *reinterpret_cast<const float4*>(&s_gamma[w][fl + 4]);
-            // fp32: row tile t fills unit t (32 features = 128 B per row)
-            float* dp = reinterpret_cast<float*>(&stage[w][t][0] + j * WS_PITCH + (16 * h + 8 * hv) * 4);
-            *reinterpret_cast<float4*>(dp) = make_float4(v[0] * g0.x, v[1] * g0.y, v[2] * g0.z, v[3] * g0.w);
-            *reinterpret_cast<float4*>(dp + 4) = make_float4(v[4] * g1.x, v[5] * g1.y, v[6] * g1.z, v[7] * g1.w);
+            bf8 o = {(bf16_t)(v[0] * g0.x), (bf16_t)(v[1] * g0.y), (bf16_t)(v[2] * g0.z), (bf16_t)(v[3] * g0.w),
+                     (bf16_t)(v[4] * g1.x), (bf16_t)(v[5] * g1.y), (bf16_t)(v[6] * g1.z), (bf16_t)(v[7] * g1.w)};
+            *reinterpret_cast<bf8*>(&stage[w][0][0] + j * WS_PITCH + fl * 2) = o;
         } else {
             const int dh = fl;  // 0..63 inside the head
             if (which == 2) {
@@ -564,14 +563,14 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const bf16_t* __restrict__
     auto flush = [&]() {
         if (EPI != EPI_GELU && n0 < N && !e.no_store && !(EPI == EPI_QKV && which == 2)) {
 #pragma unroll
-            for (int u = 0; u < (EPI == EPI_DELTA ? 2 : 1); ++u) {
+            for (int u = 0; u < 1; ++u) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const int row = 8 * p + (lane >> 3), piece = lane & 7;
                     const uint4 val = *reinterpret_cast<const uint4*>(&stage[w][u][0] + row * WS_PITCH + piece * 16);
                     if (mt_fl + row < M) {
                         if (EPI == EPI_DELTA) {
-                            *reinterpret_cast<uint4*>(e.delta + (mt_fl + row) * N + n0 + 32 * u + piece * 4) = val;
+                            *reinterpret_cast<uint4*>(e.delta + (mt_fl + row) * N + n0 + piece * 8) = val;
                         } else {
                             int f = f0_fl, sp = s0_fl + row;  // a tile crosses at most one frame end
                             if (sp >= e.S) { sp -= e.S; ++f; }
@@ -883,7 +882,7 @@ VitPlan vit_plan(const dtk_vit_model* m, int ph, int pw, int frames) {
     p.vt = off; off = al(off + (size_t)p.FB * m->heads * p.Sp * 64 * 2);
     p.ao = off; off = al(off + rows * m->D * 2);
     p.hid = off; off = al(off + rows * 4 * m->D * 2);
-    p.delta = off; off = al(off + rows * m->D * 4);
+    p.delta = off; off = al(off + rows * m->D * 2);
     p.total = off;
     return p;
 }
@@ -919,7 +918,7 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
     bf16_t* vt = reinterpret_cast<bf16_t*>(ws + p.vt);
     bf16_t* ao = reinterpret_cast<bf16_t*>(ws + p.ao);
     bf16_t* hid = reinterpret_cast<bf16_t*>(ws + p.hid);
-    float* delta = reinterpret_cast<float*>(ws + p.delta);
+    bf16_t* delta = reinterpret_cast<bf16_t*>(ws + p.delta);
     const int S = p.S, Sp = p.Sp;
     // Q/K/V^T padding rows (s >= S) must be finite zeros: they are read by the last KV tile
     {
@@ -966,7 +965,7 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
             const dtk_vit_layer& L = m->layers[l];
             GemmEpi e{};
             DTK_LAUNCH("vit_layernorm", layernorm_kernel, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x,
-                       l ? delta : (const float*)nullptr, L.ln1_w, L.ln1_b, xn, rows, D, m->ln_eps);
+                       l ? delta : (const bf16_t*)nullptr, L.ln1_w, L.ln1_b, xn, rows, D, m->ln_eps);
             e.bias = L.qkv_b; e.q = q; e.k = k; e.vt = vt; e.S = S; e.Sp = Sp; e.heads = m->heads; e.D = D;
             e.qscale = 0.125f * 1.4426950408889634f;
             e.no_store = dbg_ns;
@@ -990,7 +989,7 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
                 DTK_LAUNCH("vit_gemm_proj", (gemm_bf16_kernel<EPI_DELTA>), dim3(gemm_grid(D, rows)), dim3(256),
                            0, st, ao, reinterpret_cast<const bf16_t*>(L.proj_w), rows, D, D, e);
             }
-            DTK_LAUNCH("vit_layernorm", layernorm_kernel, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x, (const float*)delta,
+            DTK_LAUNCH("vit_layernorm", layernorm_kernel, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x, (const bf16_t*)delta,
                        L.ln2_w, L.ln2_b, xn, rows, D, m->ln_eps);
             e = GemmEpi{};
             e.bias = L.fc1_b; e.out = hid; e.no_store = dbg_ns;
@@ -1008,7 +1007,7 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
                        st, hid, reinterpret_cast<const bf16_t*>(L.fc2_w), rows, D, 4 * D, e);
         }
         if (m->depth > 0)  // the last MLP's residual update
-            DTK_LAUNCH("vit_layernorm", layernorm_kernel, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x, (const float*)delta,
+            DTK_LAUNCH("vit_layernorm", layernorm_kernel, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x, (const bf16_t*)delta,
                        (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, rows, D, m->ln_eps);
         if (tokens_out)
             DTK_HIP(hipMemcpyAsync(tokens_out + (size_t)f0 * S * D, x, (size_t)rows * D * sizeof(float),
