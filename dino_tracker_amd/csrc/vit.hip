@@ -726,6 +726,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     } while (0)
     ATT_LOAD_TILE(0);
     ATT_STORE_TILE(0);
+    // touch the Q fragments here: otherwise the compiler places their (first-iteration) vmcnt waits in front of the
+    // score MFMAs INSIDE the loop, where in steady state they wait for the next tile's K / V prefetch instead
+#pragma unroll
+    for (int qt = 0; qt < ATT_QT; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[qt][ks]));
     __syncthreads();
     int cur = 0;
     for (int t = 0; t < ntiles; ++t) {
