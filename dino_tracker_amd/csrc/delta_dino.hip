@@ -142,7 +142,7 @@ struct SplitCfg {
 };
 
 template <int DIL, bool OUT_SPLIT>
-__global__ __launch_bounds__(256) void conv5x5_split_kernel(const half_t* __restrict__ in_hi, const half_t* __restrict__ in_lo,
+__global__ __launch_bounds__(256, 3) void conv5x5_split_kernel(const half_t* __restrict__ in_hi, const half_t* __restrict__ in_lo,
                                                             const half_t* __restrict__ Wh, const half_t* __restrict__ Wl,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             half_t* __restrict__ out_hi, half_t* __restrict__ out_lo,
@@ -172,6 +172,30 @@ __global__ __launch_bounds__(256) void conv5x5_split_kernel(const half_t* __rest
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    // weights of one tap row (5 taps x 64 cout x 2 pieces, both planes = 5 x 16 bytes per thread) travel through
+    // registers one stage ahead, so that their L2 latency hides behind the MFMAs of the current row
+    // (macros with named registers: an array captured by a lambda ends up in scratch memory)
+    uint4 wr0, wr1, wr2, wr3, wr4;
+#define DD_WSRC(i) (((tid & 1) ? Wl : Wh) + wbase_ + (size_t)((tid + (i) * 256) >> 2) * SK + ((tid >> 1) & 1) * 8)
+#define DD_WDST(i) (((tid & 1) ? Wsl : Wsh) + ((tid + (i) * 256) >> 2) * Cfg::WPT + ((tid >> 1) & 1) * 8)
+#define wload(ck_, ky_)                                                                          \
+    do {                                                                                         \
+        const size_t wbase_ = ((((size_t)ct * nck + (ck_)) * 25) + (ky_) * 5) * 64 * SK;         \
+        wr0 = *reinterpret_cast<const uint4*>(DD_WSRC(0));                                       \
+        wr1 = *reinterpret_cast<const uint4*>(DD_WSRC(1));                                       \
+        wr2 = *reinterpret_cast<const uint4*>(DD_WSRC(2));                                       \
+        wr3 = *reinterpret_cast<const uint4*>(DD_WSRC(3));                                       \
+        wr4 = *reinterpret_cast<const uint4*>(DD_WSRC(4));                                       \
+    } while (0)
+#define wstore()                                                                                 \
+    do {                                                                                         \
+        *reinterpret_cast<uint4*>(DD_WDST(0)) = wr0;                                             \
+        *reinterpret_cast<uint4*>(DD_WDST(1)) = wr1;                                             \
+        *reinterpret_cast<uint4*>(DD_WDST(2)) = wr2;                                             \
+        *reinterpret_cast<uint4*>(DD_WDST(3)) = wr3;                                             \
+        *reinterpret_cast<uint4*>(DD_WDST(4)) = wr4;                                             \
+    } while (0)
+    wload(0, 0);
     for (int ck = 0; ck < nck; ++ck) {
         __syncthreads();
         // input patch, both planes: PY*PX pixels x 2 pieces of 8 cin
@@ -185,14 +209,10 @@ __global__ __launch_bounds__(256) void conv5x5_split_kernel(const half_t* __rest
         }
         for (int ky = 0; ky < 5; ++ky) {
             if (ky) __syncthreads();
-            // weights of this tap row: 5 taps x 64 cout x 2 pieces, both planes
-            const size_t wbase = ((((size_t)ct * nck + ck) * 25) + ky * 5) * 64 * SK;
-            for (int idx = tid; idx < 5 * 64 * 4; idx += 256) {
-                const int plane = idx & 1, piece = (idx >> 1) & 1, rowi = idx >> 2;  // rowi = tap*64 + cout
-                const half_t* src = (plane ? Wl : Wh) + wbase + (size_t)rowi * SK + piece * 8;
-                *reinterpret_cast<uint4*>((plane ? Wsl : Wsh) + rowi * Cfg::WPT + piece * 8) = *reinterpret_cast<const uint4*>(src);
-            }
+            wstore();  // weights of this tap row (requested while the previous row's MFMAs ran)
             __syncthreads();
+            if (ky < 4) wload(ck, ky + 1);
+            else if (ck + 1 < nck) wload(ck + 1, 0);
 #pragma unroll
             for (int kx = 0; kx < 5; ++kx) {
                 h8 xh[2], xl[2];
@@ -217,6 +237,10 @@ __global__ __launch_bounds__(256) void conv5x5_split_kernel(const half_t* __rest
             }
         }
     }
+#undef wload
+#undef wstore
+#undef DD_WSRC
+#undef DD_WDST
     // D[i][j]: j = lane&31 (cout), i = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel of the M-tile's 4 x 8 block)
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
