@@ -114,26 +114,29 @@ __global__ __launch_bounds__(256) void emit_sources_kernel(const float* __restri
     }
 }
 
-// |G[p][t] - traj[a]|.  Deliberately NOT inlined: the rank-selection below compares values of this function
-// computed at different program points, which must be bit-identical (an inlined copy may contract a*a+b*b into an
-// fma in one place and not in the other, so that an element compares "less than itself").
-__device__ __noinline__ float anchor_dist(const float* __restrict__ green, const float* __restrict__ tr, int p, int a,
-                                          int T, int t) {
+// |G[p][t] - traj[a]| without fma contraction (the reference evaluates sqrt(dx*dx + dy*dy) with separate roundings)
+__device__ __forceinline__ float anchor_dist(const float* __restrict__ green, const float* __restrict__ tr, int p, int a,
+                                             int T, int t) {
     const float dx = green[((size_t)p * T + t) * 2] - tr[2 * a];
     const float dy = green[((size_t)p * T + t) * 2 + 1] - tr[2 * a + 1];
     return sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
 }
 
-// one block per query
+// one block per query, one wave per frame t at a time: every anchor distance is computed ONCE into LDS (so the rank
+// selection compares stored values: an element can never compare "less than itself"), then lane k ranks d[k] against
+// all A values; the lane whose rank is the lower median's publishes it (torch.median semantics, ties by index).
 __global__ __launch_bounds__(256) void occlusion_kernel(const float* __restrict__ green,
                                                         const int32_t* __restrict__ pair_off,
                                                         const int32_t* __restrict__ pair_frame,
                                                         const float* __restrict__ traj, const float* __restrict__ cs,
                                                         float anchor_th, float cos_th, uint8_t* __restrict__ occ, int N,
                                                         int T) {
-    extern __shared__ float med[];  // [T]
+    extern __shared__ float smem_occ[];  // med[T] | d[4][T]
+    float* med = smem_occ;
     __shared__ float red[4];
     const int n = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float* d = smem_occ + T + w * T;
     const int p0 = pair_off[n], A = pair_off[n + 1] - p0;
     const float* tr = traj + (size_t)n * T * 2;
     if (A <= 0) {  // the reference raises here (torch.stack of an empty list); host reports it via counts[2]
@@ -141,25 +144,28 @@ __global__ __launch_bounds__(256) void occlusion_kernel(const float* __restrict_
         return;
     }
     const int want = (A - 1) / 2;  // torch.median: lower median
-    auto dist = [&](int k, int t) { return anchor_dist(green, tr, p0 + k, pair_frame[p0 + k], T, t); };
-    float tau = -INFINITY;
-    for (int t = threadIdx.x; t < T; t += 256) {
-        float m = 0.f;
-        for (int k = 0; k < A; ++k) {
-            const float dk = dist(k, t);
+    for (int t = w; t < T; t += 4) {
+        for (int k = lane; k < A; k += WAVE) d[k] = anchor_dist(green, tr, p0 + k, pair_frame[p0 + k], T, t);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < A; k += WAVE) {
+            const float dk = d[k];
             int rank = 0;
             for (int k2 = 0; k2 < A; ++k2) {
-                if (k2 == k) continue;
-                const float d2 = dist(k2, t);
+                const float d2 = d[k2];
                 rank += (d2 < dk || (d2 == dk && k2 < k)) ? 1 : 0;
             }
-            if (rank == want) m = dk;
+            if (rank == want) med[t] = dk;
         }
-        med[t] = m;
-        if (cs[(size_t)n * T + t] >= anchor_th) tau = fmaxf(tau, m);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // d is rewritten for the next frame
     }
+    __syncthreads();
+    float tau = -INFINITY;
+    for (int t = threadIdx.x; t < T; t += 256)
+        if (cs[(size_t)n * T + t] >= anchor_th) tau = fmaxf(tau, med[t]);
     tau = wave_max(tau);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tau;
+    if (lane == 0) red[w] = tau;
     __syncthreads();
     tau = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     for (int t = threadIdx.x; t < T; t += 256)
@@ -190,9 +196,9 @@ extern "C" int dtk_build_anchor_sources(const float* cs, float anchor_th, int N,
 extern "C" int dtk_occlusion(const float* green, const int32_t* pair_off, const int32_t* pair_frame, const float* traj,
                              const float* cs, float anchor_th, float cos_th, uint8_t* occ, int N, int T, void* stream) {
     DTK_REQUIRE(green && pair_off && pair_frame && traj && cs && occ && N >= 0 && T > 0, "dtk_occlusion: bad args");
-    DTK_REQUIRE((size_t)T * sizeof(float) <= 60 * 1024, "dtk_occlusion: T=%d too large", T);
+    DTK_REQUIRE((size_t)5 * T * sizeof(float) <= 60 * 1024, "dtk_occlusion: T=%d too large", T);
     if (N == 0) return DTK_OK;
-    DTK_LAUNCH("occlusion", occlusion_kernel, dim3(N), dim3(256), (size_t)T * sizeof(float), dtk_stream(stream), green,
+    DTK_LAUNCH("occlusion", occlusion_kernel, dim3(N), dim3(256), (size_t)5 * T * sizeof(float), dtk_stream(stream), green,
                        pair_off, pair_frame, traj, cs, anchor_th, cos_th, occ, N, T);
     return DTK_OK;
 }
