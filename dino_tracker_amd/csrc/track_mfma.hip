@@ -463,7 +463,8 @@ __device__ __forceinline__ int make_key(float x, int tag) {
 }
 
 // VAR: development variants (DTK_DEBUG bits 8192 / 16384 / 32768): 1 = no top-N updates, 2 = no tile requests after the
-// first two, 4 = no LDS reads.  0 in production.
+// first two, 4 = no LDS reads.  0 in production.  (Measured with them: MFMAs alone 1.63 PF; + LDS reads or + DMA alone
+// unchanged; both 1.22 PF; + list updates 0.90 PF.  Staging the tiles through registers instead of LDS-DMA: 0.39 PF.)
 template <int KS, int VAR>
 __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_t* __restrict__ f16,
                                                          const half_t* __restrict__ s16, const int32_t* __restrict__ tgt,
@@ -571,67 +572,31 @@ __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) accB[t][r] = 0.f;
-        if constexpr (VAR & 8) {
-            // register-staged variant: plain 16-byte loads one step ahead, written to the other buffer before the barrier
-            uint4 stg[LQ];
-            auto gload = [&](int n) {
-                const half_t* gp = (((n / tiles_per_row) & 1) ? gl_odd : gl) + (size_t)n * PK_CELLS * C;
-#pragma unroll
-                for (int q = 0; q < LQ; ++q) stg[q] = *reinterpret_cast<const uint4*>(gp + q * 16);
-            };
-            auto lwrite = [&](int buf) {
-#pragma unroll
-                for (int q = 0; q < LQ; ++q)
-                    *reinterpret_cast<uint4*>(&cells[buf][(w * LQ + q) * 1024 + lane * 16]) = stg[q];
-            };
-            gload(0);
-            lwrite(0);
-            gload(min(1, NT - 1));
-            __syncthreads();
-            int n = 0;
-            for (; n + 1 < NT; n += 2) {
-                step(0, accA, accB, max(n - 1, 0));
-                lwrite(1);
-                gload(min(n + 2, NT - 1));
-                __syncthreads();
-                step(1, accB, accA, n);
-                lwrite(0);
-                gload(min(n + 3, NT - 1));
-                __syncthreads();
-            }
-            if (n < NT) {
-                step(0, accA, accB, max(n - 1, 0));
-                epi(accA, n);
-            } else {
-                epi(accB, n - 1);
-            }
-        } else {
         // three LDS buffers, tiles requested two steps ahead (an L2 miss takes longer than one step): at the end of step
-            // n the tile of step n+1 must have landed while the LQ requests of step n+2 stay in flight -> vmcnt(LQ).  Tiles past
-            // the end are clamped to the last one (never read), which keeps that count uniform.
-            issue(0, 0);
-            issue(min(1, NT - 1), 1);
+        // n the tile of step n+1 must have landed while the LQ requests of step n+2 stay in flight -> vmcnt(LQ).  Tiles past
+        // the end are clamped to the last one (never read), which keeps that count uniform.
+        issue(0, 0);
+        issue(min(1, NT - 1), 1);
+        glds_wait<LQ>();
+        __syncthreads();
+        int n = 0, b0 = 0;  // b0 = n % 3
+        for (; n + 1 < NT; n += 2) {
+            const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+            issue(min(n + 2, NT - 1), b2);
+            step(b0, accA, accB, max(n - 1, 0));  // first step: accB = 0, pushes zeros
             glds_wait<LQ>();
             __syncthreads();
-            int n = 0, b0 = 0;  // b0 = n % 3
-            for (; n + 1 < NT; n += 2) {
-                const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
-                issue(min(n + 2, NT - 1), b2);
-                step(b0, accA, accB, max(n - 1, 0));  // first step: accB = 0, pushes zeros
-                glds_wait<LQ>();
-                __syncthreads();
-                issue(min(n + 3, NT - 1), b0);
-                step(b1, accB, accA, n);
-                glds_wait<LQ>();
-                __syncthreads();
-                b0 = b2;
-            }
-            if (n < NT) {  // NT odd: one more tile
-                step(b0, accA, accB, max(n - 1, 0));
-                epi(accA, n);
-            } else {
-                epi(accB, n - 1);
-            }
+            issue(min(n + 3, NT - 1), b0);
+            step(b1, accB, accA, n);
+            glds_wait<LQ>();
+            __syncthreads();
+            b0 = b2;
+        }
+        if (n < NT) {  // NT odd: one more tile
+            step(b0, accA, accB, max(n - 1, 0));
+            epi(accA, n);
+        } else {
+            epi(accB, n - 1);
         }
         glds_wait<0>();
         __syncthreads();  // every wave is done with the buffers before the next frame restages them
@@ -1501,13 +1466,11 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
             const dim3 pgrid(dtk_cdiv(scnt, PK_SRC));
 #define DTK_PEAKS(V)                                                                                                   \
     DTK_LAUNCH("corr_peaks", (corr_peaks_kernel<24, V>), pgrid, dim3(256), 0, st, *g, f16, s16, in.tgt, rec, (int)s0, scnt, L.HWp)
-            switch ((dbg >> 13) & 15) {
+            switch ((dbg >> 13) & 7) {
                 case 0: DTK_PEAKS(0); break;
                 case 1: DTK_PEAKS(1); break;
                 case 2: DTK_PEAKS(2); break;
                 case 4: DTK_PEAKS(4); break;
-                case 8: DTK_PEAKS(8); break;
-                case 9: DTK_PEAKS(9); break;
                 default: DTK_PEAKS(7); break;
             }
 #undef DTK_PEAKS
