@@ -109,7 +109,7 @@ class VitExtractor(nn.Module):
         frames = frames.to(self.device, torch.float32).contiguous()
         n, _, H, W = frames.shape
         layer = self.n_layers - 1 if layer is None else layer
-        if not 0 <= layer < self.n_layers:
+        if not -1 <= layer < self.n_layers:  # -1: patch embedding + position encoding only (no block)
             raise ValueError(f"layer {layer} out of range")
         patch = self.get_patch_size()
         ph, pw = 1 + (H - patch) // self.stride, 1 + (W - patch) // self.stride

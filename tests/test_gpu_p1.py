@@ -37,6 +37,24 @@ def test_small_frames_all_depths(vits, layer):
         _check(feat[t], ref)
 
 
+@pytest.mark.parametrize("shape", [(3, 140, 210), (1, 98, 126), (2, 476, 854)])
+def test_patch_embedding_is_fp32_grade(vits, shape):
+    """layer = -1: tokens = patch embedding + position encoding, no block.  The split-fp16 MFMA kernel (hi + lo halves,
+    three products; used when its scratch fits the workspace: the first and third shape) and the f32-input MFMA
+    fallback (second shape) must both agree with an fp32 convolution to fp32 rounding level, not to bf16 level."""
+    sd, ex = vits
+    n, h, w = shape
+    video = synth.synth_video(n, h, w, seed=77)
+    feat = ex.encode(video, layer=-1)
+    for t in range(n):
+        ref = A.vit_tokens(video[t:t + 1].double(), {k: v.double() for k, v in sd.items()}, "dinov2_vits14",
+                           layer=-1).permute(1, 2, 0).reshape(-1, 384)
+        got = feat[t].double().cpu()
+        rel = ((got - ref).norm() / ref.norm()).item()
+        assert rel <= 2e-6, rel
+        assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
 def test_full_resolution_first_blocks(vits):
     """476 x 854 -> 8107 patch tokens + CLS (not a multiple of the 64-key tile: exercises the masked tail)."""
     sd, ex = vits
