@@ -958,7 +958,9 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
         }
         // K = 384 GEMMs run weight-stationary; everything else (fc2, wider models) on the tiled kernel.  The residual
         // updates (LayerScale'd projection / MLP outputs) are written as `delta` and added by the next LayerNorm.
-        const bool ws_ok = D == WS_K;
+        // DTK_DEBUG bit 262144: run every GEMM on the tiled kernel (cross-check of the weight-stationary one)
+        static const bool ws_off = [] { const char* v = getenv("DTK_DEBUG"); return v && ((atoi(v) >> 18) & 1); }();
+        const bool ws_ok = D == WS_K && !ws_off;
         static const int dbg_ns = [] { const char* v = getenv("DTK_DEBUG"); return v ? (atoi(v) >> 16) & 3 : 0; }();
         auto ws_grid = [&](int N) {  // one resident round: one workgroup per CU
             const int colwg = dtk_cdiv(N, WS_COLS);

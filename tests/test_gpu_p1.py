@@ -55,6 +55,27 @@ def test_patch_embedding_is_fp32_grade(vits, shape):
         assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
+def test_weight_stationary_gemm_matches_tiled_gemm(tmp_path):
+    """The K = 384 GEMMs (QKV, projection, fc1) run on the weight-stationary kernel; DTK_DEBUG bit 262144 sends them to
+    the tiled kernel instead.  Both use bf16 operands, so after all 12 blocks the features must agree far more closely
+    than either agrees with the fp32 oracle (differences: accumulation order, erf polynomial vs erff)."""
+    import os, subprocess, sys
+    code = ("import sys, torch; sys.path.insert(0, '.')\n"
+            "from dino_tracker_amd import synth\n"
+            "from dino_tracker_amd.extractor import VitExtractor\n"
+            "sd = synth.make_vit_weights('dinov2_vits14', seed=2, layerscale=0.1)\n"
+            "ex = VitExtractor('dinov2_vits14', stride=7, device='cuda:0', state_dict=sd)\n"
+            "torch.save(ex.encode(synth.synth_video(2, 140, 210, seed=78)).cpu(), sys.argv[1])\n")
+    outs = []
+    for flag in ("0", "262144"):
+        out = str(tmp_path / f"feat_{flag}.pt")
+        env = dict(os.environ, DTK_DEBUG=flag)
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        outs.append(torch.load(out))
+    _check(outs[0], outs[1], cos_min=0.9999, rel_max=1e-2)
+
+
 def test_full_resolution_first_blocks(vits):
     """476 x 854 -> 8107 patch tokens + CLS (not a multiple of the 64-key tile: exercises the masked tail)."""
     sd, ex = vits
