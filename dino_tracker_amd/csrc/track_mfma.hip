@@ -40,7 +40,7 @@ constexpr int CM = 64, CN = 128, CK = 32; // corr16 tile
 constexpr int NB_MAX = 1024;              // refine: largest window-union box (cells) correlated as one group
 constexpr int RD = 5;                     // disk radius in cells supported by refine32 (radius / stride <= 5)
 constexpr int MFMA_CHUNK = 16384;
-constexpr int MFMA_SUPER = 262144;
+constexpr int MFMA_SUPER = 524288;
 
 struct Rec {  // per source, written by head16, read by refine32
     float amax;
