@@ -110,8 +110,8 @@ __global__ __launch_bounds__(256) void conv5x5_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// split-fp16 convolution (layers 2-4): every fp32 operand is carried as hi + lo fp16 halves (x = xh + xl exactly to
-// 2^-22 relative), and a product is three matrix-core products  xh.wh + xh.wl + xl.wh  accumulated in fp32 -- fp32-grade
+// split-fp16 convolution (layers 2-4): every fp32 operand is carried as hi + lo fp16 halves (x = xh + xl to 2^-22
+// relative, or to 2^-25 absolute where the lo half of |x| < 1/8 is an fp16 subnormal), and a product is three matrix-core products  xh.wh + xh.wl + xl.wh  accumulated in fp32 -- fp32-grade
 // results (each fp16 x fp16 product is exact in fp32; the dropped xl.wl term is 2^-22 relative) at a third of the fp16
 // MFMA rate instead of the 1/16 of the f32-input MFMA.  Activations live as two NHWC fp16 planes, weights as two planes in
 // [cout tile][cin chunk][tap][64 cout][16 cin] (pre-scaled by 2^8 so that the lo halves stay normal numbers).

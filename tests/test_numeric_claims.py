@@ -1,0 +1,95 @@
+"""CPU checks of the numeric claims the device kernels rely on; constants are parsed from the HIP
+sources so that the claims and the code cannot drift apart."""
+import os
+import re
+
+import numpy as np
+from scipy.special import erf
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dino_tracker_amd", "csrc")
+
+
+def _src(name):
+    with open(os.path.join(CSRC, name)) as fh:
+        return fh.read()
+
+
+def test_gelu_polynomial_error_bound():
+    """gelu2() in vit.hip: erf(s / sqrt 2) ~ s P(s^2) on |s| <= c, evaluated in fp32 exactly as the kernel does
+    (Horner with fused multiply-adds ~ float32 arithmetic here); claimed |GELU error| < 6e-5 everywhere."""
+    src = _src("vit.hip")
+    body = src[src.index("__device__ __forceinline__ f2 gelu2(f2 x)"):]
+    body = body[:body.index("return __builtin_elementwise_fma(hx, e, hx);")]
+    clamp = float(re.search(r"const f2 c = \{([0-9.eE+-]+)f", body).group(1))
+    lead = float(re.search(r"f2 p = \{([0-9.eE+-]+)f", body).group(1))
+    rest = [float(m) for m in re.findall(r"fma\(p, u, f2\{([0-9.eE+-]+)f", body)]
+    coefs = np.array([lead] + rest, dtype=np.float32)  # highest degree first
+    assert len(coefs) == 9 and clamp == 4.25
+    x = np.linspace(-12, 12, 2_000_001).astype(np.float32)
+    s = np.clip(x, -clamp, clamp).astype(np.float32)
+    u = (s * s).astype(np.float32)
+    p = np.full_like(u, coefs[0])
+    for c in coefs[1:]:
+        p = (p * u + c).astype(np.float32)
+    e = np.clip((s * p).astype(np.float32), -1, 1)
+    hx = (x * np.float32(0.5)).astype(np.float32)
+    got = (hx * e + hx).astype(np.float32)
+    ref = 0.5 * x.astype(np.float64) * (1 + erf(x.astype(np.float64) / np.sqrt(2)))
+    assert np.abs(got - ref).max() < 6e-5
+
+
+def test_split_fp16_products_are_fp32_grade():
+    """x = hi + lo with hi = fp16(x), lo = fp16(x - hi): representation error <= max(2^-22 |x|, 2^-25) (the second term
+    is half the fp16 subnormal spacing: lo halves of |x| < 1/8 are subnormal); the three products
+    xh.wh + xh.wl + xl.wh reproduce x.w to that accuracy (delta_dino.hip, vit.hip patch embedding; the weights carry
+    2^8 so that THEIR lo halves stay normal)."""
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(200_000) * rng.choice([1e-2, 1.0, 30.0], 200_000)).astype(np.float32)
+    w = (rng.standard_normal(200_000) * 0.05 * 256).astype(np.float32)  # weights carry 2^8
+    w = np.where(np.abs(w) < 0.125, np.float32(0.125), w)              # (a weight of |w| < 2^-11 before scaling)
+    xh = x.astype(np.float16)
+    xl = (x - xh.astype(np.float32)).astype(np.float16)
+    wh = w.astype(np.float16)
+    wl = (w - wh.astype(np.float32)).astype(np.float16)
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    rep_x = np.abs(xh.astype(np.float64) + xl.astype(np.float64) - x64)
+    rep_w = np.abs(wh.astype(np.float64) + wl.astype(np.float64) - w64)
+    assert (rep_x <= np.maximum(2.0 ** -22 * np.abs(x64), 2.0 ** -25)).all()
+    assert (rep_w <= 2.0 ** -22 * np.abs(w64)).all()
+    three = (xh.astype(np.float64) * wh.astype(np.float64) + xh.astype(np.float64) * wl.astype(np.float64)
+             + xl.astype(np.float64) * wh.astype(np.float64))
+    exact = x64 * w64
+    # representation errors of both factors + the dropped xl.wl term (<= 2^-22 relative)
+    tol = np.abs(w64) * np.maximum(2.0 ** -22 * np.abs(x64), 2.0 ** -25) + 2 * 2.0 ** -22 * np.abs(exact)
+    assert (np.abs(three - exact) <= tol).all()
+
+
+def test_candidate_band_covers_fp16_correlation_error():
+    """corr_peaks keeps the cells within EPS_PK of the fp16 maximum; the exact arg-max is guaranteed to be among them
+    iff EPS_PK >= 2 * sup|rho16 - rho| + accumulation + truncation.  The operand roundings give
+    |rho16 - rho| <= (2u + u^2) sum|a_i b_i| <= 2^-10 (u = 2^-11, Cauchy-Schwarz); checked here on random and on
+    adversarial (all components rounding the same way) unit vectors."""
+    src = _src("track_mfma.hip")
+    eps_pk = float(re.search(r"constexpr float EPS_PK = ([0-9.eE+-]+)f;", src).group(1))
+    val_bits = int(re.search(r"constexpr int PK_VAL_BITS = (\d+);", src).group(1))
+    src_scale = float(re.search(r"constexpr float PK_SRC_SCALE = ([0-9.eE+-]+)f;", src).group(1))
+    fscale = float(re.search(r"constexpr float FSCALE = ([0-9.eE+-]+)f;", src).group(1))
+    assert src_scale * fscale == 2.0 ** val_bits
+    bound = 2.0 ** -10 + 2.0 ** -22            # operand roundings
+    slack = 24 * 2.0 ** -24 + 2.0 ** -val_bits   # fp32 accumulation over 24 k-steps + truncation to fixed point
+    assert eps_pk >= 2 * (bound + slack)
+    rng = np.random.default_rng(1)
+    C = 384
+    worst = 0.0
+    for trial in range(200):
+        s = rng.standard_normal(C)
+        f = s + rng.standard_normal(C) * rng.choice([0.05, 0.5, 2.0])
+        if trial % 4 == 0:  # adversarial: mantissas just above a rounding boundary, same signs
+            s = np.abs(s) * (1 + 2.0 ** -12 * 0.999)
+            f = np.abs(f) * (1 + 2.0 ** -12 * 0.999)
+        a = src_scale * s / np.linalg.norm(s)
+        b = fscale * f / np.linalg.norm(f)
+        rho = float(a @ b) / 2.0 ** val_bits
+        rho16 = float(a.astype(np.float16).astype(np.float64) @ b.astype(np.float16).astype(np.float64)) / 2.0 ** val_bits
+        worst = max(worst, abs(rho16 - rho))
+    assert worst <= bound
