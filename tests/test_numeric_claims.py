@@ -93,3 +93,39 @@ def test_candidate_band_covers_fp16_correlation_error():
         rho16 = float(a.astype(np.float16).astype(np.float64) @ b.astype(np.float16).astype(np.float64)) / 2.0 ** val_bits
         worst = max(worst, abs(rho16 - rho))
     assert worst <= bound
+
+
+def test_refiner_upper_bound_of_the_certificate():
+    """Tier 1 of the tracker skips the whole-map softmax statistics when
+        z_ub(a) - z_w < 18.42 - 0.1 - ln(HW),   z_ub(a) = b2 + sum_ch [ W2+ relu(b1 + P1 a) + W2- relu(b1 + N1 a) ]
+    (P1 / N1 = positive / negative tap sums of the NORMALISED conv1 kernels, W2+ / W2- of conv2): z_ub(a) must bound the
+    refiner output over ANY map with values in [0, a] (refine_head_kernel / head16_pack_kernel in track_mfma.hip).
+    Checked against the oracle's refiner on random and on worst-case-shaped maps, benign and ill-conditioned weights."""
+    import torch
+
+    from dino_tracker_amd import synth
+    from oracle import ref_algo as A
+
+    torch.manual_seed(0)
+    for benign in (True, False):
+        for seed in (3, 4, 5):
+            head = synth.synth_head_weights(seed, benign=benign)
+            w1 = A.normalized_conv_weight(head["cnn_refiner.0.weight"])[:, 0].reshape(16, 9).double()
+            w2 = A.normalized_conv_weight(head["cnn_refiner.2.weight"])[0].reshape(16, 9).double()
+            b1 = head["cnn_refiner.0.bias"].double()
+            b2 = head["cnn_refiner.2.bias"].double()[0]
+            p1, n1 = w1.clamp(min=0).sum(1), w1.clamp(max=0).sum(1)
+            p2, n2 = w2.clamp(min=0).sum(1), w2.clamp(max=0).sum(1)
+            for a in (0.05, 0.4, 1.0):
+                zub = b2 + (p2 * torch.relu(b1 + p1 * a) + n2 * torch.relu(b1 + n1 * a)).sum()
+                maps = [torch.rand(8, 1, 20, 24) * a, (torch.rand(8, 1, 20, 24) > 0.5).float() * a,
+                        torch.full((1, 1, 20, 24), a), torch.zeros(1, 1, 20, 24)]
+                # maps shaped to excite each channel: a where the conv1 tap is positive (negative), 0 elsewhere
+                for ch in range(16):
+                    for sign in (1, -1):
+                        m = torch.zeros(1, 1, 9, 9)
+                        m[0, 0, 3:6, 3:6] = ((sign * w1[ch].reshape(3, 3)) > 0).float().flip(0, 1) * a
+                        maps.append(m)
+                for m in maps:
+                    z = A.head_refiner(m.float(), head).double()
+                    assert z.max() <= zub + 1e-4 * (1 + zub.abs()), (benign, seed, a, z.max().item(), zub.item())
