@@ -220,7 +220,9 @@ def main():
             "metric": "query-points*frames/s", "value": round(world * N * T * args.steps / dt, 1),
             "unit": "query-points*frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if method == ops.TRACK_EXACT else "f16-mfma+f32-refine",
+            "vs_baseline": None, "dtype": ("mixed: bf16 ViT, split-f16 convs (fp32-grade), " + ("f32 tracker" if method == ops.TRACK_EXACT
+                                                                       else "f16 candidates + f32 deciders in the tracker")
+                      + "; f32 accumulate"),
             "data": "synthetic",
             "config": {"workload": f"854x480x{T} synthetic video (model res 854x476, 67x121 tokens, C={C}), {N} grid "
                                    f"queries, one video per GPU",
