@@ -1284,30 +1284,34 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
     auto zfun = [&](int r, int c) { return zb[(r - (kr - RD)) * WZ + (c - (kc - RD))]; };
     if (fast) {
         // Certificate that the zero-mass fallback (tracker_head.py:86-94) cannot fire, without the map's softmax
-        // statistics: the masked mass is at least exp(zw)/(HW exp(z_ub)), zw = largest exact logit inside the disk (the
-        // arg-max cell is always inside), z_ub = bound of the refiner output over any map with values in [0, amax].
-        // If that exceeds the 1e-8 threshold the result is the plain ratio, in which the statistics cancel.
+        // statistics: the masked mass is at least exp(zw) / Z_ub, zw = largest exact logit inside the disk (the arg-max
+        // cell is always inside) and Z_ub >= sum over all cells of exp(z) for ANY map with values in [0, amax]:
+        //   interior cells (all nine conv2 taps inside the map):  z <= zi = b2 + sum_ch [W2+ hmax + W2- hmin]
+        //   border cells (conv2 sees zero-padded hidden cells):   z <= zb = b2 + sum_ch  W2+ hmax        (>= zi)
+        // with hmax = relu(b1 + P1 amax), hmin = relu(b1 + N1 amax) per channel (hmin must not be used where a hidden
+        // tap can be padding: 0 < hmin there).  If exp(zw) / Z_ub exceeds the 1e-8 threshold the result is the plain
+        // ratio, in which the statistics cancel.
         float zw = -INFINITY;
-        {
-            const float half = (float)(g.patch / 2);
-            for (int j = lane; j < WZ * WZ; j += WAVE) {
-                const int r = kr - RD + j / WZ, c = kc - RD + j % WZ;
-                if (r < 0 || r >= ph || c < 0 || c >= pw) continue;
-                const float dx = (float)((c - kc) * g.stride), dy = (float)((r - kr) * g.stride);
-                (void)half;
-                if (sqrtf(dx * dx + dy * dy) <= g.radius) zw = fmaxf(zw, zb[j]);
-            }
-            zw = wave_max(zw);
+        for (int j = lane; j < WZ * WZ; j += WAVE) {
+            const int r = kr - RD + j / WZ, c = kc - RD + j % WZ;
+            if (r < 0 || r >= ph || c < 0 || c >= pw) continue;
+            const float dx = (float)((c - kc) * g.stride), dy = (float)((r - kr) * g.stride);
+            if (sqrtf(dx * dx + dy * dy) <= g.radius) zw = fmaxf(zw, zb[j]);
         }
+        zw = wave_max(zw);
         const float* cf = zerr + 8;  // = wpk + 160: P1, N1, W2p, W2n per channel
         const float amx = fminf(rc.amax + 2e-3f, 1.f);
-        float zub = 0.f;
+        float zub_b = 0.f, zub_i = 0.f;
         if (lane < 16) {
             const float bb = head[144 + lane];
-            zub = cf[32 + lane] * fmaxf(bb + cf[lane] * amx, 0.f) + cf[48 + lane] * fmaxf(bb + cf[16 + lane] * amx, 0.f);
+            zub_b = cf[32 + lane] * fmaxf(bb + cf[lane] * amx, 0.f);
+            zub_i = zub_b + cf[48 + lane] * fmaxf(bb + cf[16 + lane] * amx, 0.f);
         }
-        zub = wave_sum(zub) + head[304];
-        const bool certified = (zub - zw) < (18.42f - 0.1f - logf((float)(ph * pw)));
+        zub_b = wave_sum(zub_b) + head[304];
+        zub_i = wave_sum(zub_i) + head[304];
+        const float n_int = (float)(max(ph - 2, 0) * max(pw - 2, 0)), n_brd = (float)(ph * pw) - n_int;
+        const float log_zsum = zub_b + logf(n_brd + n_int * expf(zub_i - zub_b));  // zub_i <= zub_b
+        const bool certified = (log_zsum - zw) < (18.42f - 0.1f);
         if (!certified) {
             if (lane == 0) {
                 const int slot = atomicAdd(uncert.count, 1);

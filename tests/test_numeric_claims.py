@@ -95,37 +95,66 @@ def test_candidate_band_covers_fp16_correlation_error():
     assert worst <= bound
 
 
+def _certificate_bounds(head, a):
+    """(zub_interior, zub_border) exactly as refine_head_kernel computes them (track_mfma.hip, `certified`)."""
+    import torch
+
+    from oracle import ref_algo as A
+
+    w1 = A.normalized_conv_weight(head["cnn_refiner.0.weight"])[:, 0].reshape(16, 9).double()
+    w2 = A.normalized_conv_weight(head["cnn_refiner.2.weight"])[0].reshape(16, 9).double()
+    b1 = head["cnn_refiner.0.bias"].double()
+    b2 = head["cnn_refiner.2.bias"].double()[0]
+    p1, n1 = w1.clamp(min=0).sum(1), w1.clamp(max=0).sum(1)
+    p2, n2 = w2.clamp(min=0).sum(1), w2.clamp(max=0).sum(1)
+    zb = b2 + (p2 * torch.relu(b1 + p1 * a)).sum()
+    zi = zb + (n2 * torch.relu(b1 + n1 * a)).sum()
+    return zi, zb, w1
+
+
 def test_refiner_upper_bound_of_the_certificate():
-    """Tier 1 of the tracker skips the whole-map softmax statistics when
-        z_ub(a) - z_w < 18.42 - 0.1 - ln(HW),   z_ub(a) = b2 + sum_ch [ W2+ relu(b1 + P1 a) + W2- relu(b1 + N1 a) ]
-    (P1 / N1 = positive / negative tap sums of the NORMALISED conv1 kernels, W2+ / W2- of conv2): z_ub(a) must bound the
-    refiner output over ANY map with values in [0, a] (refine_head_kernel / head16_pack_kernel in track_mfma.hip).
-    Checked against the oracle's refiner on random and on worst-case-shaped maps, benign and ill-conditioned weights."""
+    """Tier 1 of the tracker skips the whole-map softmax statistics when  ln Z_ub - z_w < 18.42 - 0.1  with
+        Z_ub = n_int exp(zi) + n_brd exp(zb),
+        zb = b2 + sum_ch W2+ relu(b1 + P1 a)                 bound of the refiner at cells whose conv2 window touches the
+                                                             zero padding (hidden = 0 there, so W2- earns nothing),
+        zi = zb + sum_ch W2- relu(b1 + N1 a)                 bound at interior cells,
+    (P1 / N1 = positive / negative tap sums of the NORMALISED conv1 kernels, W2+ / W2- of conv2).  Both must hold for
+    ANY map with values in [0, a]; round 1 used zi for every cell, which border cells violate.  Checked
+    against the oracle's refiner over many seeds, benign and ill-conditioned weights, a -> 0, random / saturated /
+    empty / per-channel worst-case maps, border cells included."""
     import torch
 
     from dino_tracker_amd import synth
     from oracle import ref_algo as A
 
     torch.manual_seed(0)
+    H, W = 12, 14
+    interior = torch.zeros(H, W, dtype=torch.bool)
+    interior[1:-1, 1:-1] = True
+    n_int, n_brd = int(interior.sum()), int((~interior).sum())
+    old_form_violations = 0
     for benign in (True, False):
-        for seed in (3, 4, 5):
+        for seed in range(40):
             head = synth.synth_head_weights(seed, benign=benign)
-            w1 = A.normalized_conv_weight(head["cnn_refiner.0.weight"])[:, 0].reshape(16, 9).double()
-            w2 = A.normalized_conv_weight(head["cnn_refiner.2.weight"])[0].reshape(16, 9).double()
-            b1 = head["cnn_refiner.0.bias"].double()
-            b2 = head["cnn_refiner.2.bias"].double()[0]
-            p1, n1 = w1.clamp(min=0).sum(1), w1.clamp(max=0).sum(1)
-            p2, n2 = w2.clamp(min=0).sum(1), w2.clamp(max=0).sum(1)
-            for a in (0.05, 0.4, 1.0):
-                zub = b2 + (p2 * torch.relu(b1 + p1 * a) + n2 * torch.relu(b1 + n1 * a)).sum()
-                maps = [torch.rand(8, 1, 20, 24) * a, (torch.rand(8, 1, 20, 24) > 0.5).float() * a,
-                        torch.full((1, 1, 20, 24), a), torch.zeros(1, 1, 20, 24)]
-                # maps shaped to excite each channel: a where the conv1 tap is positive (negative), 0 elsewhere
-                for ch in range(16):
+            for a in (0.002, 0.05, 0.4, 1.0):
+                zi, zb, w1 = _certificate_bounds(head, a)
+                assert zi <= zb + 1e-12
+                maps = [torch.rand(4, 1, H, W) * a, (torch.rand(4, 1, H, W) > 0.5).float() * a,
+                        torch.full((1, 1, H, W), a), torch.zeros(1, 1, H, W)]
+                # maps shaped to excite each channel: a where the conv1 tap is positive (negative), 0 elsewhere,
+                # tiled over the whole map so that border cells see them too
+                for ch in range(0, 16, 5):
                     for sign in (1, -1):
-                        m = torch.zeros(1, 1, 9, 9)
-                        m[0, 0, 3:6, 3:6] = ((sign * w1[ch].reshape(3, 3)) > 0).float().flip(0, 1) * a
-                        maps.append(m)
+                        pat = ((sign * w1[ch].reshape(3, 3)) > 0).float().flip(0, 1) * a
+                        maps.append(pat.repeat(H // 3 + 1, W // 3 + 1)[None, None, :H, :W])
                 for m in maps:
-                    z = A.head_refiner(m.float(), head).double()
-                    assert z.max() <= zub + 1e-4 * (1 + zub.abs()), (benign, seed, a, z.max().item(), zub.item())
+                    z = A.head_refiner(m.float(), head).double()[:, 0]
+                    tol_i, tol_b = 1e-4 * (1 + abs(zi)), 1e-4 * (1 + abs(zb))
+                    assert z[:, interior].max() <= zi + tol_i, (benign, seed, a)
+                    assert z.max() <= zb + tol_b, (benign, seed, a)
+                    old_form_violations += int(z.max() > zi + tol_i)
+                    # the quantity the certificate needs: ln sum exp(z) <= ln Z_ub
+                    lse = torch.logsumexp(z.reshape(z.shape[0], -1), dim=1).max()
+                    lzub = zb + torch.log(n_brd + n_int * torch.exp(zi - zb))
+                    assert lse <= lzub + tol_b
+    assert old_form_violations > 0  # the sweep does reach the border case the one-bound form missed
