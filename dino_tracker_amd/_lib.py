@@ -40,8 +40,27 @@ class VitLayer(ctypes.Structure):
 class VitModel(ctypes.Structure):
     """struct dtk_vit_model."""
     _fields_ = [("D", ctypes.c_int32), ("heads", ctypes.c_int32), ("depth", ctypes.c_int32), ("patch", ctypes.c_int32),
-                ("stride", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("patch_w", c_void_p), ("patch_b", c_void_p),
+                ("stride", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("flags", ctypes.c_int32),
+                ("patch_w", c_void_p), ("patch_b", c_void_p),
                 ("cls_pos", c_void_p), ("pos", c_void_p), ("mean_std", c_void_p), ("layers", ctypes.POINTER(VitLayer))]
+
+
+VIT_TILED_GEMMS = 1  # dtk_vit_model.flags
+
+
+class TrackOpts(ctypes.Structure):
+    """struct dtk_track_opts."""
+    _fields_ = [("method", ctypes.c_int32), ("normalized", ctypes.c_int32), ("round_sources", ctypes.c_int32),
+                ("tier", ctypes.c_int32)]
+
+
+class TrackStats(ctypes.Structure):
+    """struct dtk_track_stats (host side, filled by dtk_track)."""
+    _fields_ = [("sources", ctypes.c_int32), ("whole_map_tier", ctypes.c_int32), ("exact_tier", ctypes.c_int32),
+                ("syncs", ctypes.c_int32)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
 # name -> (restype, argtypes); must list every symbol include/dtk.h declares (tests/test_abi.py checks this)
@@ -58,7 +77,7 @@ SIGNATURES = {
     "dtk_feature_norms": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dtk_vit_workspace_bytes": (c_size_t, [ctypes.POINTER(VitModel), c_int, c_int, c_int]),
     "dtk_vit_forward": (c_int, [ctypes.POINTER(VitModel), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                c_size_t, c_void_p]),
+                                c_void_p, c_size_t, c_void_p]),
     "dtk_delta_dino_packed_floats": (c_size_t, [c_int, c_int]),
     "dtk_delta_dino_pack": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                     c_void_p, c_void_p]),
@@ -66,11 +85,17 @@ SIGNATURES = {
     "dtk_delta_dino_refine": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_void_p,
                                       c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "dtk_sample_points": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "dtk_sample_grid": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "dtk_normalized_conv2d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_void_p]),
+    "dtk_corr_maps": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_int, c_int, c_void_p]),
     "dtk_head_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dtk_head_forward": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "dtk_track_workspace_bytes": (c_size_t, [ctypes.POINTER(Geom), c_int, c_int]),
+    "dtk_track_workspace_bytes": (c_size_t, [ctypes.POINTER(Geom), c_int, ctypes.POINTER(TrackOpts)]),
     "dtk_track": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                          c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+                          c_void_p, c_void_p, c_int, c_void_p, ctypes.POINTER(TrackOpts), ctypes.POINTER(TrackStats),
+                          c_void_p, c_size_t, c_void_p]),
     "dtk_feat_f16_bytes": (c_size_t, [ctypes.POINTER(Geom)]),
     "dtk_make_feat_f16": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p]),
     "dtk_traj_cos_sims": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -36,6 +36,20 @@ void dtk_prof_end(const char* name, hipStream_t st);
         DTK_LAUNCHED();                                               \
     } while (0)
 
+// Development switches: a DTK_DEV build (make DEV=1) reads the DTK_DEBUG bit mask from the environment once; the
+// production library has none of it (dtk_dev_flags() == 0 and every DTK_DBG test folds to false at compile time).
+#ifdef DTK_DEV
+#include <stdlib.h>
+static inline int dtk_dev_flags() {
+    static const int v = [] { const char* e = getenv("DTK_DEBUG"); return e ? atoi(e) : 0; }();
+    return v;
+}
+#define DTK_DBG(flags, bit) ((flags) & (bit))
+#else
+static inline int dtk_dev_flags() { return 0; }
+#define DTK_DBG(flags, bit) 0
+#endif
+
 static inline hipStream_t dtk_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int dtk_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -202,6 +202,108 @@ extern "C" int dtk_sample_points(const dtk_geom* g, const float* feat, const flo
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Literal utils.bilinear_interpolate_video (utils.py:75-101): F.grid_sample of the 1 x C x T x h x w volume at
+// (x, y, t) in [-1, 1], trilinear, align_corners=True, padding_mode='border'.  One wave per point.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_grid_kernel(const float* __restrict__ feat, const float* __restrict__ pts,
+                                                          float* __restrict__ out, int T, int C, int ph, int pw, int B) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    // grid_sample: unnormalise ((x + 1) / 2 * (size - 1)), then clip to the border
+    auto axis = [](float xn, int size, int& i0, int& i1, float& f) {
+        float u = (xn + 1.f) * 0.5f * (float)(size - 1);
+        u = fminf(fmaxf(u, 0.f), (float)(size - 1));
+        const float u0 = floorf(u);
+        f = u - u0;
+        i0 = (int)u0;
+        i1 = min(i0 + 1, size - 1);
+    };
+    int u0, u1, v0, v1, t0, t1;
+    float fu, fv, ft;
+    axis(pts[3 * b], pw, u0, u1, fu);
+    axis(pts[3 * b + 1], ph, v0, v1, fv);
+    axis(pts[3 * b + 2], T, t0, t1, ft);
+    const float w00 = (1.f - fu) * (1.f - fv), w01 = fu * (1.f - fv), w10 = (1.f - fu) * fv, w11 = fu * fv;
+    float* o = out + (size_t)b * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float wt = k ? ft : 1.f - ft;
+            if (wt == 0.f) continue;  // integral t (the tracker's case): one frame is read
+            const size_t fb = (size_t)(k ? t1 : t0) * ph * pw;
+            const float4 a = *reinterpret_cast<const float4*>(feat + (fb + (size_t)v0 * pw + u0) * C + c);
+            const float4 bq = *reinterpret_cast<const float4*>(feat + (fb + (size_t)v0 * pw + u1) * C + c);
+            const float4 cq = *reinterpret_cast<const float4*>(feat + (fb + (size_t)v1 * pw + u0) * C + c);
+            const float4 d = *reinterpret_cast<const float4*>(feat + (fb + (size_t)v1 * pw + u1) * C + c);
+            r.x += wt * (a.x * w00 + bq.x * w01 + cq.x * w10 + d.x * w11);
+            r.y += wt * (a.y * w00 + bq.y * w01 + cq.y * w10 + d.y * w11);
+            r.z += wt * (a.z * w00 + bq.z * w01 + cq.z * w10 + d.z * w11);
+            r.w += wt * (a.w * w00 + bq.w * w01 + cq.w * w10 + d.w * w11);
+        }
+        *reinterpret_cast<float4*>(o + c) = r;
+    }
+}
+
+extern "C" int dtk_sample_grid(const float* feat, int T, int C, int ph, int pw, const float* pts, float* out, int B,
+                               void* stream) {
+    DTK_REQUIRE(feat && pts && out && B >= 0, "dtk_sample_grid: null pointer");
+    DTK_REQUIRE(T > 0 && C > 0 && C % 4 == 0 && ph > 0 && pw > 0, "dtk_sample_grid: bad sizes (C must be a multiple of 4)");
+    if (B == 0) return DTK_OK;
+    DTK_LAUNCH("sample_grid", sample_grid_kernel, dim3(dtk_cdiv(B, 4)), dim3(256), 0, dtk_stream(stream), feat, pts, out, T,
+               C, ph, pw, B);
+    return DTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// NormalizedConv2d.forward (models/networks/conv_norm.py:34-46) as a stand-alone layer: every (out, in) k x k kernel
+// divided by its own sum (|sum| < 1e-8 -> sign * 1e-8), stride 1, zero padding k/2.  The tracker path never calls this
+// (the two layers of TrackerHead.cnn_refiner live inside the fused head kernels); it exists so that the module's
+// forward() is the same arithmetic on the device.  One thread per output element.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void normalized_conv2d_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, float* __restrict__ y,
+                                                                int B, int Cin, int Cout, int H, int W, int k) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * Cout * H * W;
+    if (idx >= total) return;
+    const int col = (int)(idx % W), row = (int)((idx / W) % H), co = (int)((idx / ((long long)W * H)) % Cout);
+    const int b = (int)(idx / ((long long)W * H * Cout));
+    const int pad = k / 2;
+    float acc = bias ? bias[co] : 0.f;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float* wk = w + ((size_t)co * Cin + ci) * k * k;
+        float s = 0.f;
+        for (int t = 0; t < k * k; ++t) s += wk[t];
+        if (fabsf(s) < 1e-8f) s = (s > 0.f ? 1.f : (s < 0.f ? -1.f : 0.f)) * 1e-8f;
+        const float* xp = x + ((size_t)b * Cin + ci) * H * W;
+        float a = 0.f;
+        for (int dy = 0; dy < k; ++dy) {
+            const int rr = row + dy - pad;
+            if (rr < 0 || rr >= H) continue;
+            for (int dx = 0; dx < k; ++dx) {
+                const int cc = col + dx - pad;
+                if (cc >= 0 && cc < W) a = fmaf(wk[dy * k + dx] / s, xp[(size_t)rr * W + cc], a);
+            }
+        }
+        acc += a;
+    }
+    y[idx] = acc;
+}
+
+extern "C" int dtk_normalized_conv2d(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout,
+                                     int H, int W, int k, void* stream) {
+    DTK_REQUIRE(x && w && y, "dtk_normalized_conv2d: null pointer");
+    DTK_REQUIRE(B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && k > 0 && (k & 1), "dtk_normalized_conv2d: bad sizes");
+    const long long total = (long long)B * Cout * H * W;
+    if (total == 0) return DTK_OK;
+    DTK_LAUNCH("normalized_conv2d", normalized_conv2d_kernel, dim3(dtk_cdiv(total, 256)), dim3(256), 0, dtk_stream(stream), x,
+               w, bias, y, B, Cin, Cout, H, W, k);
+    return DTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // K14: cs[n][t] = <a,b> / (max(|a|,eps) max(|b|,eps)), a = S[n][tq[n]], b = S[n][t]; one wave per (n,t).
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cos_sims_kernel(const float* __restrict__ S, const int32_t* __restrict__ tq,

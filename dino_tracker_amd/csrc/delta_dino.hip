@@ -617,11 +617,8 @@ inline size_t f32_packed_floats(int cinp, int coutp) { return (size_t)25 * cinp 
 // halves in ONE split weight plane == floats taken by the two planes together
 inline size_t split_plane_halves(int cin, int cout) { return (size_t)((cout + 63) / 64) * (cin / SK) * 25 * 64 * SK; }
 
-// DTK_DEBUG bit 1024: run layers 2-4 on the fp32-input MFMA kernel instead of the split-fp16 one
-inline bool dd_force_f32() {
-    static const int v = [] { const char* e = getenv("DTK_DEBUG"); return e ? atoi(e) : 0; }();
-    return (v & 1024) != 0;
-}
+// DTK_DEV builds, DTK_DEBUG bit 1024: run layers 2-4 on the fp32-input MFMA kernel instead of the split-fp16 one
+inline bool dd_force_f32() { return DTK_DBG(dtk_dev_flags(), 1024) != 0; }
 
 }  // namespace
 

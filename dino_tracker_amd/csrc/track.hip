@@ -5,10 +5,11 @@ size_t dtk_track_exact_workspace_bytes(const dtk_geom* g, int M);
 int dtk_track_exact(const dtk_geom* g, const float* feat, const float* norms, const float* head, const float* emb,
                     const int32_t* src_row, const int32_t* tgt, const int32_t* out_idx, float* out_xy, int M,
                     const int32_t* dM, int normalized, void* workspace, size_t workspace_bytes, void* stream);
-size_t dtk_track_mfma_workspace_bytes(const dtk_geom* g, int M);
+size_t dtk_track_mfma_workspace_bytes(const dtk_geom* g, int M, int round_sources);
 int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, const void* feat_f16, const float* head,
                    const float* emb, const int32_t* src_row, const int32_t* tgt, const int32_t* out_idx, float* out_xy,
-                   int M, const int32_t* dM, int normalized, void* workspace, size_t workspace_bytes, void* stream);
+                   int M, const int32_t* dM, const dtk_track_opts* opts, dtk_track_stats* stats, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 static int check_track_geom(const dtk_geom* g) {
     DTK_REQUIRE(g != nullptr, "dtk_track: null geometry");
@@ -19,30 +20,35 @@ static int check_track_geom(const dtk_geom* g) {
     return DTK_OK;
 }
 
-extern "C" size_t dtk_track_workspace_bytes(const dtk_geom* g, int M, int method) {
-    if (!g || M <= 0) return 0;
+extern "C" size_t dtk_track_workspace_bytes(const dtk_geom* g, int M, const dtk_track_opts* opts) {
+    if (!g || M <= 0 || !opts) return 0;
     // (the MFMA figure already contains a region for the exact path, which re-does inconclusive sources)
-    if (method == DTK_TRACK_MFMA) return dtk_track_mfma_workspace_bytes(g, M);
+    if (opts->method == DTK_TRACK_MFMA) return dtk_track_mfma_workspace_bytes(g, M, opts->round_sources);
     return dtk_track_exact_workspace_bytes(g, M);
 }
 
 extern "C" int dtk_track(const dtk_geom* g, const float* feat, const float* norms, const void* feat_f16,
                          const float* head, const float* emb, const int32_t* src_row, const int32_t* tgt,
-                         const int32_t* out_idx, float* out_xy, int M, const int32_t* dM, int normalized, int method,
-                         void* workspace, size_t workspace_bytes, void* stream) {
+                         const int32_t* out_idx, float* out_xy, int M, const int32_t* dM, const dtk_track_opts* opts,
+                         dtk_track_stats* stats, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_track_geom(g);
     if (rc) return rc;
-    DTK_REQUIRE(feat && norms && head && emb && tgt && out_xy && workspace, "dtk_track: null pointer");
+    DTK_REQUIRE(feat && norms && head && emb && tgt && out_xy && workspace && opts, "dtk_track: null pointer");
     DTK_REQUIRE(M >= 0, "dtk_track: negative M");
+    DTK_REQUIRE(opts->round_sources >= 0 && (opts->tier == DTK_TIER_AUTO || opts->tier == DTK_TIER_WHOLE_MAP),
+                "dtk_track: bad options (round_sources %d, tier %d)", opts->round_sources, opts->tier);
+    if (stats) *stats = dtk_track_stats{0, 0, 0, 0};
     if (M == 0) return DTK_OK;
-    if (method == DTK_TRACK_EXACT)
-        return dtk_track_exact(g, feat, norms, head, emb, src_row, tgt, out_idx, out_xy, M, dM, normalized, workspace,
+    if (opts->method == DTK_TRACK_EXACT) {
+        if (stats) stats->sources = stats->exact_tier = M;  // (an upper bound when dM is given: the count stays on the device)
+        return dtk_track_exact(g, feat, norms, head, emb, src_row, tgt, out_idx, out_xy, M, dM, opts->normalized, workspace,
                                workspace_bytes, stream);
-    if (method == DTK_TRACK_MFMA) {
+    }
+    if (opts->method == DTK_TRACK_MFMA) {
         DTK_REQUIRE(feat_f16 != nullptr, "dtk_track(mfma): feat_f16 is null (call dtk_make_feat_f16)");
-        return dtk_track_mfma(g, feat, norms, feat_f16, head, emb, src_row, tgt, out_idx, out_xy, M, dM, normalized,
+        return dtk_track_mfma(g, feat, norms, feat_f16, head, emb, src_row, tgt, out_idx, out_xy, M, dM, opts, stats,
                               workspace, workspace_bytes, stream);
     }
-    dtk_set_error("dtk_track: unknown method %d", method);
+    dtk_set_error("dtk_track: unknown method %d", opts->method);
     return DTK_E_INVALID;
 }

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void corr_exact_kernel(dtk_geom g, const float
                                                          const int32_t* __restrict__ tgt,
                                                          const float* __restrict__ snorm, float* __restrict__ maps,
                                                          int m0, int count, int M, const int32_t* __restrict__ dM,
-                                                         int HWs) {
+                                                         int HWs, int relu) {
     __shared__ __attribute__((aligned(16))) float As[TK][TM + 4];
     __shared__ __attribute__((aligned(16))) float Bs[TK][TN + 4];
     __shared__ int s_tgt[TM];
@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void corr_exact_kernel(dtk_geom g, const float
                 const int cell = cell0 + tx * 4 + j;
                 if (cell < HW) {
                     const float den = fmaxf(sn * norms[(size_t)f * HW + cell], 1e-8f);
-                    maps[(size_t)ml * HWs + cell] = fmaxf(acc[i][j] / den, 0.f);
+                    const float rho = acc[i][j] / den;
+                    maps[(size_t)ml * HWs + cell] = relu ? fmaxf(rho, 0.f) : rho;
                 }
             }
         }
@@ -337,7 +338,7 @@ int dtk_track_exact(const dtk_geom* g, const float* feat, const float* norms, co
         DTK_LAUNCH("row_norms", row_norms_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, emb, src_row, snorm, (int)m0,
                            cnt, M, dM, g->C);
         DTK_LAUNCH("corr_exact", corr_exact_kernel, dim3(dtk_cdiv(HW, TN), dtk_cdiv(cnt, TM)), dim3(256), 0, st, *g, feat,
-                           norms, emb, src_row, tgt, snorm, maps, (int)m0, cnt, M, dM, HWs);
+                           norms, emb, src_row, tgt, snorm, maps, (int)m0, cnt, M, dM, HWs, 1);
         DTK_LAUNCH("head_exact", head_exact_kernel, dim3(cnt), dim3(256), lds, st, *g, head, maps, HWs, out_idx, out_xy,
                            (int)m0, cnt, M, dM, normalized);
     }
@@ -355,5 +356,27 @@ extern "C" int dtk_head_forward(const dtk_geom* g, const float* head, const floa
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     DTK_LAUNCH("head_exact", head_exact_kernel, dim3(B), dim3(256), lds, dtk_stream(stream), *g, head, maps, g->ph * g->pw,
                        (const int32_t*)nullptr, out_xy, 0, B, B, (const int32_t*)nullptr, normalized);
+    return DTK_OK;
+}
+
+// Tracker.get_corr_maps_for_frame_set (models/tracker.py:158-169) on its own: the cosine maps of M sources, fp32,
+// maps[m][cell] (cell = row * pw + col), WITHOUT the ReLU unless `relu` (the reference applies it afterwards, :173).
+extern "C" int dtk_corr_maps(const dtk_geom* g, const float* feat, const float* norms, const float* emb,
+                             const int32_t* src_row, const int32_t* tgt, float* maps, float* snorm_scratch, int M,
+                             int relu, void* stream) {
+    DTK_REQUIRE(g && feat && norms && emb && tgt && maps && snorm_scratch, "dtk_corr_maps: null pointer");
+    DTK_REQUIRE(g->T > 0 && g->ph > 0 && g->pw > 0 && g->C > 0 && g->C % TK == 0, "dtk_corr_maps: bad geometry (C %% %d)", TK);
+    DTK_REQUIRE(M >= 0, "dtk_corr_maps: negative M");
+    const int HW = g->ph * g->pw;
+    hipStream_t st = dtk_stream(stream);
+    const long long step = 65535LL * TM;
+    for (long long m0 = 0; m0 < M; m0 += step) {
+        const int cnt = (int)((M - m0) < step ? (M - m0) : step);
+        DTK_LAUNCH("row_norms", row_norms_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, emb, src_row, snorm_scratch + m0,
+                   (int)m0, cnt, M, (const int32_t*)nullptr, g->C);
+        DTK_LAUNCH("corr_exact", corr_exact_kernel, dim3(dtk_cdiv(HW, TN), dtk_cdiv(cnt, TM)), dim3(256), 0, st, *g, feat,
+                   norms, emb, src_row, tgt, snorm_scratch + m0, maps + (size_t)m0 * HW, (int)m0, cnt, M,
+                   (const int32_t*)nullptr, HW, relu);
+    }
     return DTK_OK;
 }

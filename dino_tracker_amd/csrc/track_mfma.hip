@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void corr16_tiled_kernel(dtk_geom g, const hal
 #pragma unroll
             for (int rr = 0; rr < CM; rr += 16) {
                 const int row = rr + r0;
-                if (s_tgt[row] == f && !(dbg & 256))
+                if (s_tgt[row] == f && !DTK_DBG(dbg, 256))
                     *reinterpret_cast<uint4*>(maps + (size_t)(tile_m0 - m0 + row) * MP + po + piece * 8) =
                         *reinterpret_cast<const uint4*>(Ts + row * TP16 + piece * 8);
             }
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __
     amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     const float thr = amax - EPS_C;
     const half_t thr_h = (half_t)fmaxf(thr - 1e-3f, -1.f);  // coarse fp16 pre-filter, exact test below
-    for (int c = tid; c < ((dbg & 64) ? 0 : n16); c += 256) {
+    for (int c = tid; c < (DTK_DBG(dbg, 64) ? 0 : n16); c += 256) {
         const uint4 v = xs16[c];
         const h2 m4 = __builtin_elementwise_max(__builtin_elementwise_max(as_h2(v.x), as_h2(v.y)),
                                                 __builtin_elementwise_max(as_h2(v.z), as_h2(v.w)));
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(256) void head16_kernel(dtk_geom g, const float* __
     const int wu = __builtin_amdgcn_readfirstlane(w);  // provably wave-uniform: the row loop below becomes scalar control flow
     // work item = (pair of 14-column segments, quarter of the rows); the two segments of a pair are advanced in lock-step
     const int npair = (nq + 1) >> 1;
-    for (int item = wu; item < ((dbg & 32) ? 0 : npair * 4); item += 4) {
+    for (int item = wu; item < (DTK_DBG(dbg, 32) ? 0 : npair * 4); item += 4) {
         const int qa = (item >> 2) * 2, qb = qa + 1, rq = item & 3;
         const bool has_b = qb < nq;  // wave-uniform
         const bool edge_a = qa == 0 || qa == nq - 1, edge_b = qb == nq - 1;
@@ -892,7 +892,7 @@ __device__ __forceinline__ int cell_key(int cell, int pw) {
     return (r >> 3) * (8 * pw) + c * 8 + (r & 7);
 }
 
-__device__ unsigned long long g_dbg[4];  // development counters (DTK_DEBUG & 16: refine_corr boxes; & 4096: redo reasons)
+__device__ unsigned long long g_dbg[4];  // counters of DTK_DEV builds (DTK_DEBUG & 16: refine_corr boxes; & 4096: redo reasons)
 
 // one wave per source: |s|, exact fp32 re-scoring of the candidates -> k*, histogram of (frame, cell key)
 __global__ __launch_bounds__(256) void rescore_kernel(dtk_geom g, const float* __restrict__ feat,
@@ -925,7 +925,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(dtk_geom g, const float* _
     float best = -1.f;
     int bi = INT_MAX;
     if (!redo_it) {
-        const int ncd = (dbg & 2) ? 1 : rc.ncand;
+        const int ncd = DTK_DBG(dbg, 2) ? 1 : rc.ncand;
         for (int k = 0; k < ncd; ++k) {
             const int cell = min(max(rc.cand[k], 0), HW - 1);
             const float* fp = feat + ((size_t)f * HW + cell) * C;
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(dtk_geom g, const float* _
         // a non-positive exact maximum means the relu'd map may be all-zero (argmax 0): let the exact path decide
         if (!(best > 0.f)) redo_it = true;
     }
-    if ((dbg & 4096) && lane == 0 && redo_it)
+    if (DTK_DBG(dbg, 4096) && lane == 0 && redo_it)
         atomicAdd(&g_dbg[rc.ncand > KC ? 0 : (rc.ncand < 1 ? 1 : 2)], 1ULL);
     if (lane == 0) {
         snorm[i] = sn;
@@ -1084,7 +1084,7 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const floa
     }
     __syncthreads();
     const int ng = s_ng;
-    if ((dbg & 16) && tid == 0) {
+    if (DTK_DBG(dbg, 16) && tid == 0) {
         atomicAdd(&g_dbg[0], 1ULL);
         atomicAdd(&g_dbg[1], (unsigned long long)ng);
         for (int gi = 0; gi < ng; ++gi) {
@@ -1105,7 +1105,7 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const floa
     const int lrow = tid >> 3, lk4 = (tid & 7) * 4;  // loader: row (cell or source), 4-float piece
     const float* arow = emb + (size_t)s_row[lrow & 15] * C + lk4;
     const int nkc = C / 32;
-    for (int gi = 0; gi < ((dbg & 1) ? 0 : ng); ++gi) {
+    for (int gi = 0; gi < (DTK_DBG(dbg, 1) ? 0 : ng); ++gi) {
         const int rmin = s_box[gi * 4], rmax = s_box[gi * 4 + 1], cmin = s_box[gi * 4 + 2], cmax = s_box[gi * 4 + 3];
         const int nc = cmax - cmin + 1, ncells = (rmax - rmin + 1) * nc;
         int gf = -1;
@@ -1153,14 +1153,14 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const floa
             f4 acc = {0.f, 0.f, 0.f, 0.f};
             int cur = 0;
             for (int kc = 0; kc < nkc; ++kc) {
-                if (kc + 1 < nkc && !(dbg & 8)) {
+                if (kc + 1 < nkc && !DTK_DBG(dbg, 8)) {
                     if (tid < 128) ra = *reinterpret_cast<const float4*>(arow + (kc + 1) * 32);
                     rb0 = *reinterpret_cast<const float4*>(b0 + (kc + 1) * 32);
                     rb1 = *reinterpret_cast<const float4*>(b1 + (kc + 1) * 32);
                 }
                 const float* ap = &As[cur][fj * RP + fg];
                 const float* bp = &Bs[cur][(w * 16 + fj) * RP + fg];
-                if (!(dbg & 4)) {
+                if (!DTK_DBG(dbg, 4)) {
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk)
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * 4], bp[kk * 4], acc, 0, 0, 0);
@@ -1360,10 +1360,14 @@ struct MfmaLayout {
     int HWp;
 };
 
-MfmaLayout mfma_layout(const dtk_geom* g, int M) {
+MfmaLayout mfma_layout(const dtk_geom* g, int M, int round_sources) {
     MfmaLayout L;
     L.chunk = M < MFMA_CHUNK ? ((M + CM - 1) / CM * CM) : MFMA_CHUNK;
-    L.super = M < MFMA_SUPER ? ((M + CM - 1) / CM * CM) : MFMA_SUPER;
+    // sources per round: MFMA_SUPER unless the caller asks for smaller rounds (dtk_track_opts.round_sources; tests use
+    // it to run several rounds on small inputs).  Multiples of 256 (corr_peaks owns 256 sources per workgroup).
+    const int round = round_sources > 0 ? (round_sources + 255) / 256 * 256 : MFMA_SUPER;
+    L.super = M < round ? ((M + CM - 1) / CM * CM) : round;
+    if (L.chunk > L.super) L.chunk = L.super;
     L.HWp = hw_pad(g->ph, g->pw);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t off = 0;
@@ -1399,22 +1403,19 @@ MfmaLayout mfma_layout(const dtk_geom* g, int M) {
 
 }  // namespace
 
-size_t dtk_track_mfma_workspace_bytes(const dtk_geom* g, int M) { return mfma_layout(g, M).total; }
+size_t dtk_track_mfma_workspace_bytes(const dtk_geom* g, int M, int round_sources) {
+    return mfma_layout(g, M, round_sources).total;
+}
 
-// development aid (not part of dtk.h): read and reset the refine_corr counters enabled by DTK_DEBUG & 16
+#ifdef DTK_DEV
+// development aid (DTK_DEV builds only, not part of dtk.h): read and reset the counters enabled by DTK_DEBUG & 16 / 4096
 extern "C" int dtk_debug_counters(unsigned long long* out4) {
     unsigned long long z[4] = {0, 0, 0, 0};
     DTK_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_dbg), sizeof(z)));
     DTK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)));
     return DTK_OK;
 }
-
-// development aid (not part of dtk.h): sources / uncertified / re-done counts of the last dtk_track(mfma) call
-static int g_last_track[3] = {0, 0, 0};
-extern "C" int dtk_debug_track_counts(int* out3) {
-    for (int i = 0; i < 3; ++i) out3[i] = g_last_track[i];
-    return DTK_OK;
-}
+#endif
 
 extern "C" size_t dtk_feat_f16_bytes(const dtk_geom* g) {
     if (!g || g->T <= 0 || g->C <= 0) return 0;
@@ -1463,13 +1464,14 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
     for (long long s0 = 0; s0 < M; s0 += L.super) {
         const int scnt = (int)((M - s0) < L.super ? (M - s0) : L.super);
         // source-stationary fused correlation + selection (C = 384, position tags of 13 bits)
-        const bool peaks = fast && g->C == 384 && L.HWp / PK_CELLS <= (1 << (PK_IDX_BITS - 4)) && !(dbg & 2048);
+        const bool peaks = fast && g->C == 384 && L.HWp / PK_CELLS <= (1 << (PK_IDX_BITS - 4)) && !DTK_DBG(dbg, 2048);
         if (peaks) {
             DTK_LAUNCH("src16", src16_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, emb, in.src_row, s16, (int)s0, scnt, M,
                        nodm, g->C, PK_SRC_SCALE);
             const dim3 pgrid(dtk_cdiv(scnt, PK_SRC));
 #define DTK_PEAKS(V)                                                                                                   \
     DTK_LAUNCH("corr_peaks", (corr_peaks_kernel<24, V>), pgrid, dim3(256), 0, st, *g, f16, s16, in.tgt, rec, (int)s0, scnt, L.HWp)
+#ifdef DTK_DEV
             switch ((dbg >> 13) & 7) {
                 case 0: DTK_PEAKS(0); break;
                 case 1: DTK_PEAKS(1); break;
@@ -1477,6 +1479,9 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
                 case 4: DTK_PEAKS(4); break;
                 default: DTK_PEAKS(7); break;
             }
+#else
+            DTK_PEAKS(0);
+#endif
 #undef DTK_PEAKS
         }
         for (long long m0 = s0; m0 < s0 + scnt && !peaks; m0 += L.chunk) {
@@ -1521,30 +1526,33 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
 
 }  // namespace
 
-// NOTE: unlike the rest of the library this entry synchronises `stream` (up to three times): the sizes of its second
-// and third phase (sources that need the whole-map refiner statistics; sources re-done on the exact path) are only
-// known on the device, and launching worst-case grids for them costs more than the round trips.
+// NOTE: unlike the rest of the library this entry synchronises `stream`: once after the first phase (the sizes of the
+// whole-map tier and of the exact tier are only known on the device, and launching worst-case grids for them costs
+// more than the round trip), once more if the whole-map tier ran, and once up front if `dM` is given.
 int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, const void* feat_f16, const float* head,
                    const float* emb, const int32_t* src_row, const int32_t* tgt, const int32_t* out_idx, float* out_xy,
-                   int M, const int32_t* dM, int normalized, void* workspace, size_t workspace_bytes, void* stream) {
+                   int M, const int32_t* dM, const dtk_track_opts* opts, dtk_track_stats* stats, void* workspace,
+                   size_t workspace_bytes, void* stream) {
     DTK_REQUIRE(g->C % CK == 0, "dtk_track(mfma): C=%d must be a multiple of %d", g->C, CK);
     DTK_REQUIRE((int)(g->radius / (float)g->stride) <= RD, "dtk_track(mfma): disk radius %g px > %d cells", g->radius, RD);
-    const MfmaLayout L = mfma_layout(g, M);
+    const int normalized = opts->normalized;
+    const MfmaLayout L = mfma_layout(g, M, opts->round_sources);
     if (workspace_bytes < L.total) {
         dtk_set_error("dtk_track(mfma): workspace %zu B < required %zu B", workspace_bytes, L.total);
         return DTK_E_WORKSPACE;
     }
     hipStream_t st = dtk_stream(stream);
-    const char* dbg_env = getenv("DTK_DEBUG");
-    const int dbg = dbg_env ? atoi(dbg_env) : 0;
+    const int dbg = dtk_dev_flags();
     unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
     int count = M;
-    if (dM) {  // data-dependent number of sources (anchor stage): read it instead of launching worst-case grids
+    if (dM) {  // data-dependent number of sources: read it instead of launching worst-case grids
         int32_t v = 0;
         DTK_HIP(hipMemcpyAsync(&v, dM, sizeof(v), hipMemcpyDeviceToHost, st));
         DTK_HIP(hipStreamSynchronize(st));
+        if (stats) stats->syncs++;
         count = v < M ? (v < 0 ? 0 : v) : M;
     }
+    if (stats) stats->sources = count;
     if (count == 0) return DTK_OK;
     int32_t* counters = reinterpret_cast<int32_t*>(ws + L.redo_cnt);
     Redo redo, uncert;
@@ -1565,22 +1573,23 @@ int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, con
     DTK_LAUNCH("head16_pack", head16_pack_kernel, dim3(1), dim3(256), 0, st, head, reinterpret_cast<uint32_t*>(ws + L.wpk));
     DTK_HIP(hipMemsetAsync(ws + L.maps, 0, (size_t)L.chunk * L.MP * 2, st));  // zero borders of the padded maps
     const half_t* f16 = reinterpret_cast<const half_t*>(feat_f16);
-    const bool fast_ok = !(dbg & 512);
+    const bool fast_ok = opts->tier != DTK_TIER_WHOLE_MAP && !DTK_DBG(dbg, 512);
     int rc = mfma_phase(g, L, ws, feat, norms, f16, head, emb, SrcLists{src_row, tgt, out_idx}, out_xy, count, normalized,
                         fast_ok, redo, uncert, lds_head, st, dbg);
     if (rc) return rc;
     int32_t hc[2] = {0, 0};
     DTK_HIP(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, st));
     DTK_HIP(hipStreamSynchronize(st));
-    g_last_track[0] = count; g_last_track[1] = hc[1]; g_last_track[2] = hc[0];
+    if (stats) { stats->syncs++; stats->whole_map_tier = fast_ok ? hc[1] : count; }
     if (hc[1] > 0) {  // sources without a no-fallback certificate: whole-map statistics
         rc = mfma_phase(g, L, ws, feat, norms, f16, head, emb, SrcLists{uncert.src_row, uncert.tgt, uncert.out_idx}, out_xy,
                         hc[1], normalized, false, redo, uncert, lds_head, st, dbg);
         if (rc) return rc;
         DTK_HIP(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, st));
         DTK_HIP(hipStreamSynchronize(st));
+        if (stats) stats->syncs++;
     }
-    g_last_track[2] = hc[0];
+    if (stats) stats->exact_tier = hc[0];
     if (hc[0] > 0) {  // sources the fp16 pass could not decide: the exact fp32 path
         rc = dtk_track_exact(g, feat, norms, head, emb, redo.src_row, redo.tgt, redo.out_idx, out_xy, hc[0], nullptr,
                              normalized, ws + L.exact, workspace_bytes - L.exact, stream);

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
 // bf16 GEMM  C[M][N] = A[M][K] . Wt[N][K]^T (+bias) with fused epilogues
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int GM = 128, GN = 128, GK = 32;
-enum { EPI_QKV = 0, EPI_GELU = 1, EPI_DELTA = 2 };
+enum { EPI_QKV = 0, EPI_GELU = 1, EPI_DELTA = 2, EPI_F32 = 3 };
 
 struct GemmEpi {
     const float* bias;   // [N]
@@ -261,6 +261,8 @@ struct GemmEpi {
     int no_store;        // development: skip the stores of the weight-stationary kernel (DTK_DEBUG & 65536)
     bf16_t* delta;       // [M][N] bf16: gamma * (A W^T + bias), added to the fp32 residual stream by the next LayerNorm
     const float* gamma;  // [N] LayerScale
+    // EPI_F32 (tiled kernel only)
+    float* out_f32;      // [M][N] fp32: A W^T + bias (the qkv facet output)
 };
 
 __device__ __forceinline__ int gswz(int row, int piece) {
@@ -384,6 +386,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
                         const float v = acc[mi][ni][r] + bias;
                         e.out[m * N + n] = (bf16_t)(0.5f * v * (1.f + erff(v * 0.70710678118654752f)));
                     }
+                }
+            } else if (EPI == EPI_F32) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long m = mb + r;
+                    if (m < M) e.out_f32[m * N + n] = acc[mi][ni][r] + bias;
                 }
             } else {
                 const float gm = e.gamma[n];
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const bf16_t* __restrict__
         for (int r = 0; r < 8; ++r) v[r] = acc[t][8 * hv + r];
         v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
         v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-        const bool ok = m_ep < M && nb < N && !e.no_store;
+        const bool ok = m_ep < M && nb < N && !DTK_DBG(e.no_store, 3);
         if (EPI == EPI_GELU) {
             bf8 o;
 #pragma unroll
@@ -561,7 +569,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const bf16_t* __restrict__
     int f0_fl = 0, s0_fl = 0;
     if (EPI == EPI_QKV) { f0_fl = (int)(mt_fl / e.S); s0_fl = (int)(mt_fl - (long long)f0_fl * e.S); }
     auto flush = [&]() {
-        if (EPI != EPI_GELU && n0 < N && !e.no_store && !(EPI == EPI_QKV && which == 2)) {
+        if (EPI != EPI_GELU && n0 < N && !DTK_DBG(e.no_store, 3) && !(EPI == EPI_QKV && which == 2)) {
 #pragma unroll
             for (int u = 0; u < 1; ++u) {
 #pragma unroll
@@ -902,8 +910,10 @@ extern "C" size_t dtk_vit_workspace_bytes(const dtk_vit_model* m, int video_h, i
 }
 
 extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int nframes, int video_h, int video_w,
-                               float* tokens_out, float* feat_out, void* workspace, size_t workspace_bytes, void* stream) {
-    DTK_REQUIRE(m && frames && workspace && (tokens_out || feat_out), "dtk_vit_forward: null pointer");
+                               float* tokens_out, float* feat_out, float* qkv_out, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    DTK_REQUIRE(m && frames && workspace && (tokens_out || feat_out || qkv_out), "dtk_vit_forward: null pointer");
+    DTK_REQUIRE(!qkv_out || m->depth > 0, "dtk_vit_forward: qkv_out needs at least one block");
     DTK_REQUIRE(m->D > 0 && m->heads > 0 && m->D == m->heads * 64, "dtk_vit_forward: d_head must be 64 (D=%d heads=%d)",
                 m->D, m->heads);
     DTK_REQUIRE(m->D % 32 == 0 && m->depth >= 0 && m->layers, "dtk_vit_forward: bad model");
@@ -958,10 +968,9 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
         }
         // K = 384 GEMMs run weight-stationary; everything else (fc2, wider models) on the tiled kernel.  The residual
         // updates (LayerScale'd projection / MLP outputs) are written as `delta` and added by the next LayerNorm.
-        // DTK_DEBUG bit 262144: run every GEMM on the tiled kernel (cross-check of the weight-stationary one)
-        static const bool ws_off = [] { const char* v = getenv("DTK_DEBUG"); return v && ((atoi(v) >> 18) & 1); }();
-        const bool ws_ok = D == WS_K && !ws_off;
-        static const int dbg_ns = [] { const char* v = getenv("DTK_DEBUG"); return v ? (atoi(v) >> 16) & 3 : 0; }();
+        // DTK_VIT_TILED_GEMMS: every GEMM on the tiled kernel (tests cross-check the weight-stationary one with it)
+        const bool ws_ok = D == WS_K && !(m->flags & DTK_VIT_TILED_GEMMS);
+        const int dbg_ns = DTK_DBG(dtk_dev_flags() >> 16, 3);  // DTK_DEV: skip the weight-stationary kernel's stores
         auto ws_grid = [&](int N) {  // one resident round: one workgroup per CU
             const int colwg = dtk_cdiv(N, WS_COLS);
             const int chunks = 256 / colwg > 0 ? 256 / colwg : 1;
@@ -974,6 +983,12 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
             GemmEpi e{};
             DTK_LAUNCH("vit_layernorm", layernorm_kernel, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x,
                        l ? delta : (const bf16_t*)nullptr, L.ln1_w, L.ln1_b, xn, rows, D, m->ln_eps);
+            if (qkv_out && l == m->depth - 1) {  // the qkv hook of the reference (models/extractor.py:107-118), fp32 out
+                e.bias = L.qkv_b; e.out_f32 = qkv_out + (size_t)f0 * S * 3 * D;
+                DTK_LAUNCH("vit_gemm_qkv_facet", (gemm_bf16_kernel<EPI_F32>), dim3(gemm_grid(3 * D, rows)), dim3(256), 0, st,
+                           xn, reinterpret_cast<const bf16_t*>(L.qkv_w), rows, 3 * D, D, e);
+                e = GemmEpi{};
+            }
             e.bias = L.qkv_b; e.q = q; e.k = k; e.vt = vt; e.S = S; e.Sp = Sp; e.heads = m->heads; e.D = D;
             e.qscale = 0.125f * 1.4426950408889634f;
             e.no_store = dbg_ns;

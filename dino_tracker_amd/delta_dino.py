@@ -10,12 +10,20 @@ from . import ops
 from ._lib import Geom, check, lib, make_geom
 
 
+def weights_key(delta_dino, device):
+    """Identity + version of every parameter / BN statistic of the CNN: changes whenever a weight is written."""
+    mods = delta_dino.layers
+    convs = [mods[0], mods[4], mods[8], mods[12]]
+    bns = [mods[1], mods[5], mods[9], mods[13]]
+    return tuple((t.data_ptr(), t._version) for m in convs + bns for t in list(m.parameters()) + list(m.buffers())) + (str(device),)
+
+
 def pack_weights(delta_dino, device):
     """[packed layer 0..3] device tensors; re-packed when any parameter / BN statistic changed."""
     mods = delta_dino.layers
     convs = [mods[0], mods[4], mods[8], mods[12]]
     bns = [mods[1], mods[5], mods[9], mods[13]]
-    key = tuple((t.data_ptr(), t._version) for m in convs + bns for t in list(m.parameters()) + list(m.buffers())) + (str(device),)
+    key = weights_key(delta_dino, device)
     cache = getattr(delta_dino, "_dtk_packed", None)
     if cache is not None and cache[0] == key:
         return cache[1]
@@ -59,3 +67,17 @@ def refine_frames(delta_dino, frames: torch.Tensor, dino_chw: torch.Tensor, g: G
     thwc, _ = ops.pack_features(dino_chw.to(torch.float32).contiguous())
     out, _ = _refine(delta_dino, frames.to(torch.float32), thwc, gg)
     return ops.unpack_features(out, g.ph, g.pw)
+
+
+def residual_frames(delta_dino, frames: torch.Tensor, vit_features: torch.Tensor) -> torch.Tensor:
+    """DeltaDINO.forward: the aligned CNN output alone (dtk_delta_dino_refine with a zero DINO volume)."""
+    n, _, H, W = frames.shape
+    _, C, h, w = vit_features.shape
+    patch = 14  # align_cnn_vit_features' default, which DeltaDINO.forward does not override (models/utils.py:8)
+    g = make_geom(n, C, H, W, patch, delta_dino.vit_stride)
+    if (g.ph, g.pw) != (h, w):
+        raise NotImplementedError(f"DeltaDINO on the device: ViT grid {h}x{w} must be the patch-14 stride-"
+                                  f"{delta_dino.vit_stride} grid of the {H}x{W} frames ({g.ph}x{g.pw})")
+    zero = torch.zeros((n, h * w, C), dtype=torch.float32, device=frames.device)
+    out, _ = _refine(delta_dino, frames.to(torch.float32), zero, g)
+    return ops.unpack_features(out, h, w)

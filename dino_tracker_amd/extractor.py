@@ -7,8 +7,10 @@ weights are a plain state dict in upstream facebookresearch/dinov2 naming (`patc
   2. the file named by $DTK_DINOV2_WEIGHTS (e.g. the official dinov2_vits14_pretrain.pth),
   3. a seeded random initialisation if `random_seed=` is given (synthetic benchmarks / parity tests).
 Anything else raises: there is no silent fallback.
-Only the `tokens` facet (block outputs, models/extractor.py:137-150) is implemented on the device; the q/k/v/attn
-facet getters keep their signatures and raise NotImplementedError.
+Facets: `tokens` (block outputs, models/extractor.py:137-150) is the hot path.  The qkv hook output of a block
+(models/extractor.py:107-118) comes from the same device program (`qkv_out` of dtk_vit_forward: fp32 output of the
+bf16-operand GEMM), so the key / query / value getters (:224-267) are reshapes of it like in the reference; the
+attention-map facet and the key self-similarity are small torch expressions over it (not on the hot path).
 """
 from __future__ import annotations
 
@@ -22,7 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from ._lib import VitLayer, VitModel, check, lib
+from ._lib import VIT_TILED_GEMMS, VitLayer, VitModel, check, lib
 from .synth import VIT_CONFIGS, make_vit_weights
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
@@ -48,6 +50,7 @@ class VitExtractor(nn.Module):
             raise RuntimeError("no DINOv2 weights: pass state_dict=, set $DTK_DINOV2_WEIGHTS to a checkpoint in "
                                "upstream naming, or ask for random_seed= explicitly (torch.hub needs the network)")
         self.n_layers = self.get_n_layers()
+        self.tiled_gemms = False  # run every GEMM on the tiled kernel (dtk_vit_model.flags; cross-check in the tests)
         self._sd = {k: v.detach().to(device=device, dtype=torch.float32).contiguous() for k, v in state_dict.items()
                     if k.startswith(("cls_token", "pos_embed", "patch_embed.", "blocks."))}
         self._keep = []      # device tensors referenced by the C structs
@@ -117,18 +120,22 @@ class VitExtractor(nn.Module):
         ms = torch.tensor((IMAGENET_MEAN + IMAGENET_STD) if normalize else (0.0, 0.0, 0.0, 1.0, 1.0, 1.0),
                           dtype=torch.float32, device=self.device)
         D = self.cfg["dim"]
-        m = VitModel(D, self.cfg["heads"], layer + 1, patch, self.stride, 1e-6, self._sd["patch_embed.proj.weight"].data_ptr(),
+        m = VitModel(D, self.cfg["heads"], layer + 1, patch, self.stride, 1e-6, VIT_TILED_GEMMS if self.tiled_gemms else 0,
+                     self._sd["patch_embed.proj.weight"].data_ptr(),
                      self._sd["patch_embed.proj.bias"].data_ptr(), cls_pos.data_ptr(), pos.data_ptr(), ms.data_ptr(),
                      ctypes.cast(self._layers, ctypes.POINTER(VitLayer)))
         ws_bytes = int(lib().dtk_vit_workspace_bytes(m, H, W, n))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
         S = ph * pw + 1
+        if want not in ("tokens", "feat", "qkv"):
+            raise ValueError(want)
         tokens = torch.empty((n, S, D), dtype=torch.float32, device=self.device) if want == "tokens" else None
         feat = torch.empty((n, ph * pw, D), dtype=torch.float32, device=self.device) if want == "feat" else None
-        check(lib().dtk_vit_forward(m, ops._p(frames), n, H, W, ops._p(tokens), ops._p(feat), ops._p(ws), ws_bytes,
-                                    ops._stream()))
+        qkv = torch.empty((n, S, 3 * D), dtype=torch.float32, device=self.device) if want == "qkv" else None
+        check(lib().dtk_vit_forward(m, ops._p(frames), n, H, W, ops._p(tokens), ops._p(feat), ops._p(qkv), ops._p(ws),
+                                    ws_bytes, ops._stream()))
         torch.cuda.current_stream().synchronize()  # `ms`, `ws` must outlive the launches
-        return tokens if want == "tokens" else feat
+        return {"tokens": tokens, "feat": feat, "qkv": qkv}[want]
 
     def get_feature_from_input(self, input_img, layers: List[int]):  # models/extractor.py:137-150
         """input_img [B,3,H,W] ALREADY ImageNet-normalised (as the reference's caller does) -> mean over `layers` of
@@ -136,12 +143,76 @@ class VitExtractor(nn.Module):
         outs = [self.encode(input_img, layer=l, normalize=False, want="tokens") for l in layers]
         return torch.stack(outs).mean(dim=0)
 
-    def _facet_unavailable(self, *a, **k):
-        raise NotImplementedError("only the `tokens` facet runs on the HIP encoder (SURVEY.md 8a row a4)")
+    # ---- the other facets (models/extractor.py:152-274) -----------------------------------------------------------
+    class _PerLayer:
+        """What the reference's hook lists are to their callers: indexable by layer, computed on demand (the reference
+        runs the whole network once and records every layer; here layer l costs one run of blocks 0..l)."""
 
-    get_qkv_feature_from_input = get_attn_feature_from_input = _facet_unavailable
-    get_keys_from_input = get_queries_from_input = get_values_from_input = _facet_unavailable
-    get_keys_self_sim_from_input = _facet_unavailable
+        def __init__(self, n, fn):
+            self._n, self._fn, self._cache = n, fn, {}
+
+        def __len__(self):
+            return self._n
+
+        def __getitem__(self, layer):
+            layer = range(self._n)[layer]
+            if layer not in self._cache:
+                self._cache[layer] = self._fn(layer)
+            return self._cache[layer]
+
+        def __iter__(self):
+            return (self[i] for i in range(self._n))
+
+    def get_qkv_feature_from_input(self, input_img):
+        """models/extractor.py:152-158: per layer, the output of blocks[l].attn.qkv, [B, 1+ph*pw, 3D]."""
+        return VitExtractor._PerLayer(self.n_layers, lambda l: self.encode(input_img, layer=l, normalize=False, want="qkv"))
+
+    def get_attn_feature_from_input(self, input_img):
+        """models/extractor.py:160-166: per layer, softmax(q k^T / sqrt(d_head)) [B, heads, S, S] (the input of attn_drop).
+        Not a hot path: S x S per head is materialised with torch on the device."""
+        heads = self.cfg["heads"]
+
+        def attn(l):
+            qkv = self.encode(input_img, layer=l, normalize=False, want="qkv")
+            b, s, _ = qkv.shape
+            q, k, _ = qkv.reshape(b, s, 3, heads, -1).permute(2, 0, 3, 1, 4)
+            return torch.softmax((q * q.shape[-1] ** -0.5) @ k.transpose(-2, -1), dim=-1)
+
+        return VitExtractor._PerLayer(self.n_layers, attn)
+
+    def _from_qkv(self, qkv, input_img_shape, which):
+        b = input_img_shape[0]
+        return qkv.reshape(b, self.get_patch_num(input_img_shape), 3, self.cfg["dim"])[:, :, which, :]
+
+    def get_queries_from_qkv(self, qkv, input_img_shape):
+        return self._from_qkv(qkv, input_img_shape, 0)
+
+    def get_keys_from_qkv(self, qkv, input_img_shape):
+        return self._from_qkv(qkv, input_img_shape, 1)
+
+    def get_values_from_qkv(self, qkv, input_img_shape):
+        return self._from_qkv(qkv, input_img_shape, 2)
+
+    def _facet_from_input(self, input_img, layers, which):
+        qkv = self.get_qkv_feature_from_input(input_img)
+        return torch.cat([self._from_qkv(qkv[l], input_img.shape, which) for l in layers], dim=2)
+
+    def get_queries_from_input(self, input_img, layers):
+        return self._facet_from_input(input_img, layers, 0)
+
+    def get_keys_from_input(self, input_img, layers):
+        return self._facet_from_input(input_img, layers, 1)
+
+    def get_values_from_input(self, input_img, layers):
+        return self._facet_from_input(input_img, layers, 2)
+
+    def get_keys_self_sim_from_input(self, input_img, layer_num):
+        """models/extractor.py:269-274 with attn_cosine_sim (:8-13)."""
+        keys = self.get_keys_from_input(input_img, layers=[layer_num])
+        h, t, d = keys.shape
+        x = keys.transpose(0, 1).reshape(t, h * d)[None]
+        norm = x.norm(dim=2, keepdim=True)
+        return (x @ x.permute(0, 2, 1)) / torch.clamp(norm @ norm.permute(0, 2, 1), min=1e-8)
 
     # ---- static model facts (models/extractor.py:168-222) ----------------------------------------------------------
     def get_patch_size(self):

@@ -8,7 +8,9 @@ pipeline:
                                                                              dtk_build_anchor_sources + dtk_track
   5. occ[n,t] = (lower-median_a |G[n][a,t]-traj[n,a]| > tau_n) or cs[n,t] < th2     dtk_occlusion
 
-No per-query Python loop and no host sync until the final zero-anchor check (the reference raises there).
+No per-query Python loop.  Host synchronisations per infer(): one read-back of the anchor counts (which also is the
+zero-anchor check: the reference raises there) plus the ones dtk_track(DTK_TRACK_MFMA) documents (one per call, for the
+sizes of its second / third tier); DTK_TRACK_EXACT adds none.
 `batch_size` is accepted for signature compatibility; it was a memory knob for the reference's per-call frame
 gathers (model_inference.py:45-49,138) and has no effect on results.
 """
@@ -66,7 +68,8 @@ class ModelInference(torch.nn.Module):
         super().__init__()
         self.model = model
         self.model.eval()
-        if self.model._refined is None:  # already cached => identical result, skip the recompute
+        # model_inference.py:88-89 always recomputes; a volume cached with the CURRENT Delta-DINO weights is identical
+        if self.model._refined is None or self.model.refined_is_stale():
             self.model.cache_refined_embeddings()
         self.range_normalizer = range_normalizer
         self.anchor_cosine_similarity_threshold = anchor_cosine_similarity_threshold
@@ -130,8 +133,13 @@ class ModelInference(torch.nn.Module):
             S = self._sample_along(trajectories)
         buf = ops.build_anchor_sources(cos_sims.contiguous(), self.anchor_cosine_similarity_threshold, self._anchor_buf)
         self._anchor_buf = buf
+        # one read-back of (pairs, sources, queries without anchors): sizes the anchor launches exactly and is the
+        # zero-anchor check of infer() as well
+        self.last_counts = buf.counts.cpu()
+        n_src = int(self.last_counts[1])
         green = torch.empty((N * T, T, 2), dtype=torch.float32, device=trajectories.device)
-        m.track_sources(m.features(), S, buf.src_row, buf.tgt, buf.out_idx, green, N * T * T, dM=buf.counts[1:2])
+        if n_src > 0:
+            m.track_sources(m.features(), S, buf.src_row, buf.tgt, buf.out_idx, green, n_src)
         return buf, green
 
     @torch.no_grad()
@@ -176,7 +184,6 @@ class ModelInference(torch.nn.Module):
         traj_xy = trajs[..., :2].contiguous()
         occ = ops.occlusion(green, buf.pair_off, buf.pair_frame, traj_xy, cos_sims,
                             self.anchor_cosine_similarity_threshold, self.cosine_similarity_threshold)
-        self.last_counts = buf.counts.cpu()  # the only host sync of the pipeline
         if int(self.last_counts[2]) > 0:
             raise RuntimeError("stack expects a non-empty TensorList")  # a query without anchors (model_inference.py:152)
         return traj_xy, occ

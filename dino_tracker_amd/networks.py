@@ -37,7 +37,12 @@ class NormalizedConv2d(nn.Module):
             nn.init.uniform_(self.bias, -bound, bound)
 
     def forward(self, x):
-        raise RuntimeError("NormalizedConv2d is evaluated inside the fused tracker-head kernel; call TrackerHead")
+        """conv_norm.py:42-46 on the device (dtk_normalized_conv2d).  The tracker path does not come through here: both
+        layers of TrackerHead.cnn_refiner are fused into the head kernels."""
+        if self.stride != 1 or self.padding != self.kernel_size // 2:
+            raise NotImplementedError("NormalizedConv2d on the device: stride 1, padding k // 2 (the reference's use)")
+        return ops.normalized_conv2d(x.detach().to(torch.float32).contiguous(), self.weight.detach().contiguous(),
+                                     None if self.bias is None else self.bias.detach().contiguous())
 
 
 class TrackerHead(nn.Module):
@@ -124,4 +129,7 @@ class DeltaDINO(nn.Module):
         return self.down_stride ** sum(self.downsample_layers)
 
     def forward(self, x, vit_features):
-        raise RuntimeError("DeltaDINO runs through Tracker.get_refined_embeddings (HIP path)")
+        """delta_dino.py:53-61: frames x [B,3,H,W] in [0,1], vit_features [B,C,h,w] (used for its grid size only, as in
+        the reference) -> the residual [B,C,h,w] = align_cnn_vit_features(CNN(x)) (models/utils.py:7-45, patch 14)."""
+        from .delta_dino import residual_frames
+        return residual_frames(self, x, vit_features)

@@ -7,9 +7,10 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import Geom, check, lib
+from ._lib import Geom, TrackOpts, TrackStats, check, lib
 
 TRACK_EXACT, TRACK_MFMA = 0, 1
+TIER_AUTO, TIER_WHOLE_MAP = 0, 1
 
 
 def _p(t: Optional[torch.Tensor], dtype: Optional[torch.dtype] = None):
@@ -61,6 +62,40 @@ def sample_points(g: Geom, feat: torch.Tensor, xy: torch.Tensor, t_idx: torch.Te
     return out
 
 
+def sample_grid(feat: torch.Tensor, ph: int, pw: int, pts: torch.Tensor) -> torch.Tensor:
+    """utils.bilinear_interpolate_video semantics: feat token-major [T, ph*pw, C], pts [B,3] = (x, y, t) in [-1,1]."""
+    T, HW, C = feat.shape
+    if HW != ph * pw:
+        raise RuntimeError(f"sample_grid: {HW} cells != {ph} x {pw}")
+    B = pts.shape[0]
+    out = torch.empty((B, C), dtype=torch.float32, device=feat.device)
+    check(lib().dtk_sample_grid(_p(feat, torch.float32), T, C, ph, pw, _p(pts, torch.float32), _p(out), B, _stream()))
+    return out
+
+
+def normalized_conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """NormalizedConv2d.forward (stride 1, padding k // 2) on the device."""
+    B, Cin, H, W = x.shape
+    Cout, Cin2, k, k2 = weight.shape
+    if Cin2 != Cin or k != k2:
+        raise RuntimeError(f"normalized_conv2d: weight {tuple(weight.shape)} does not match input {tuple(x.shape)}")
+    y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+    check(lib().dtk_normalized_conv2d(_p(x, torch.float32), _p(weight, torch.float32), _p(bias, torch.float32), _p(y), B,
+                                      Cin, Cout, H, W, k, _stream()))
+    return y
+
+
+def corr_maps(g: Geom, feat: torch.Tensor, norms: torch.Tensor, emb: torch.Tensor, tgt: torch.Tensor,
+              relu: bool = False) -> torch.Tensor:
+    """Cosine maps [M, ph, pw] of emb[m] against frame tgt[m] (models/tracker.py:158-169)."""
+    M = emb.shape[0]
+    maps = torch.empty((M, g.ph, g.pw), dtype=torch.float32, device=feat.device)
+    scratch = torch.empty(max(M, 1), dtype=torch.float32, device=feat.device)
+    check(lib().dtk_corr_maps(g, _p(feat, torch.float32), _p(norms, torch.float32), _p(emb, torch.float32), None,
+                              _p(tgt, torch.int32), _p(maps), _p(scratch), M, int(relu), _stream()))
+    return maps
+
+
 def head_prepare(sd: Dict[str, torch.Tensor], device) -> torch.Tensor:
     """TrackerHead.cnn_refiner state dict -> packed normalised parameters (dtk.h DTK_HEAD_PARAMS)."""
     w1 = sd["cnn_refiner.0.weight"].detach().to(device=device, dtype=torch.float32).contiguous()
@@ -82,8 +117,8 @@ def head_forward(g: Geom, head: torch.Tensor, maps: torch.Tensor, normalized: bo
     return out
 
 
-def track_workspace_bytes(g: Geom, M: int, method: int) -> int:
-    return int(lib().dtk_track_workspace_bytes(g, M, method))
+def track_workspace_bytes(g: Geom, M: int, method: int, round_sources: int = 0) -> int:
+    return int(lib().dtk_track_workspace_bytes(g, M, TrackOpts(method, 0, round_sources, TIER_AUTO)))
 
 
 def feat_f16_bytes(g: Geom) -> int:
@@ -99,11 +134,14 @@ def make_feat_f16(g: Geom, feat: torch.Tensor, norms: torch.Tensor) -> torch.Ten
 def track(g: Geom, feat: torch.Tensor, norms: torch.Tensor, feat_f16: Optional[torch.Tensor], head: torch.Tensor,
           emb: torch.Tensor, src_row: Optional[torch.Tensor], tgt: torch.Tensor, out_idx: Optional[torch.Tensor],
           out_xy: torch.Tensor, M: int, workspace: torch.Tensor, dM: Optional[torch.Tensor] = None,
-          normalized: bool = False, method: int = TRACK_EXACT) -> torch.Tensor:
+          normalized: bool = False, method: int = TRACK_EXACT, round_sources: int = 0, tier: int = TIER_AUTO,
+          stats: Optional[TrackStats] = None) -> torch.Tensor:
+    """dtk_track.  `stats` (a TrackStats) receives the tier sizes / sync count of this call."""
+    opts = TrackOpts(method, int(normalized), round_sources, tier)
     check(lib().dtk_track(g, _p(feat, torch.float32), _p(norms, torch.float32), _p(feat_f16), _p(head, torch.float32),
                           _p(emb, torch.float32), _p(src_row, torch.int32), _p(tgt, torch.int32),
-                          _p(out_idx, torch.int32), _p(out_xy, torch.float32), M, _p(dM, torch.int32), int(normalized),
-                          method, _p(workspace), workspace.numel() * workspace.element_size(), _stream()))
+                          _p(out_idx, torch.int32), _p(out_xy, torch.float32), M, _p(dM, torch.int32), opts, stats,
+                          _p(workspace), workspace.numel() * workspace.element_size(), _stream()))
     return out_xy
 
 

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import make_geom
+from ._lib import TrackStats, make_geom
 from .dataset import RangeNormalizer
 from .networks import DeltaDINO, TrackerHead
 
@@ -58,7 +58,11 @@ class Tracker(nn.Module):
         self._refined_f16 = None
         self._dino_f16 = None
         self._refined_chw = None   # lazily unpacked view for callers reading `.refined_features`
+        self._refined_key = None   # Delta-DINO parameter versions the cached refined volume was computed with
         self._workspace = None
+        self.track_round_sources = 0          # dtk_track_opts.round_sources (0 = library default)
+        self.track_tier = ops.TIER_AUTO       # dtk_track_opts.tier
+        self.last_track_stats = None          # dtk_track_stats of the most recent dtk_track call (dict)
 
         self._dino_chw = None
         self.load_dino_embed_video()
@@ -134,6 +138,7 @@ class Tracker(nn.Module):
 
     @refined_features.setter
     def refined_features(self, value):
+        self._refined_key = None  # an externally supplied volume is never invalidated by weight changes
         if value is None:
             self._refined = self._refined_norms = self._refined_f16 = self._refined_chw = None
         else:  # accept a T x C x h x w tensor (e.g. features refined elsewhere)
@@ -152,27 +157,22 @@ class Tracker(nn.Module):
                          device=points.device, dtype=points.dtype)
         return a * points + b
 
-    def _unnormalize_sampling_points(self, pts_norm):
-        t, c, h, w = self.video.shape
-        half = self.dino_patch_size / 2
-        last_h = ((h - self.dino_patch_size) // self.stride) * self.stride + half
-        last_w = ((w - self.dino_patch_size) // self.stride) * self.stride + half
-        x = (pts_norm[:, 0] + 1) / 2 * (last_w - half) + half
-        y = (pts_norm[:, 1] + 1) / 2 * (last_h - half) + half
-        return torch.stack([x, y], dim=1)
-
     def sample_embeddings(self, embeddings, source_points):
-        """tracker.py:96-111.  embeddings: T' x C x h x w, source_points: B x 3 (x,y in [-1,1] token-grid coords,
-        t = integral index into embeddings) -> B x C."""
-        if embeddings is self.refined_features and self._refined is not None:
+        """tracker.py:96-111 -> utils.bilinear_interpolate_video: embeddings T' x C x h x w, source_points B x 3 with
+        x, y in [-1, 1] (token-grid coordinates, see normalize_points_for_sampling) and t an index into `embeddings`
+        (normalised by T' - 1 like the reference, utils.py:97-100) -> B x C."""
+        t, c, h, w = embeddings.shape
+        if self._refined is not None and embeddings is self._refined_chw:
             feat = self._refined
+        elif self._dino is not None and embeddings is self._dino_chw:
+            feat = self._dino
         else:
-            feat, _ = ops.pack_features(embeddings.to(torch.float32).contiguous())
-        g = make_geom(feat.shape[0], feat.shape[2], self.geom.video_h, self.geom.video_w, self.dino_patch_size,
-                      self.stride, self.geom.radius)
-        xy = self._unnormalize_sampling_points(source_points.to(torch.float32)).contiguous()
-        t_idx = source_points[:, 2].round().to(torch.int32).contiguous()
-        return ops.sample_points(g, feat, xy, t_idx)
+            feat, _ = ops.pack_features(embeddings.to(self.device, torch.float32).contiguous())
+        pts = source_points.to(self.device, torch.float32).clone()
+        if t > 1:
+            pts[:, 2] = pts[:, 2] / (t - 1)
+        pts[:, 2] = pts[:, 2] * 2 - 1
+        return ops.sample_grid(feat, h, w, pts.contiguous())
 
     # ---- Delta-DINO --------------------------------------------------------------------------------------
     def get_refined_embeddings(self, frames_set_t, return_raw_embeddings=False):
@@ -195,8 +195,18 @@ class Tracker(nn.Module):
         self._refined_norms = ops.feature_norms(self._refined)
         self._refined_f16 = None
         self._refined_chw = None
+        self._refined_key = self._delta_key()
         # move_dino_to_cpu was a memory knob of the reference (two fp32 copies of the volume); the raw volume stays
         # on the device here because Tracker.forward(use_raw_features=True) reads it in place.
+
+    def _delta_key(self):
+        from .delta_dino import weights_key
+        return weights_key(self.delta_dino, self.device)
+
+    def refined_is_stale(self) -> bool:
+        """True when the cached refined volume was computed by cache_refined_embeddings() with Delta-DINO parameters
+        that have changed since (load_weights / load_state_dict / an optimiser step)."""
+        return self._refined is not None and self._refined_key is not None and self._refined_key != self._delta_key()
 
     def uncache_refined_embeddings(self, move_dino_to_gpu=False):
         self.refined_features = None
@@ -213,10 +223,14 @@ class Tracker(nn.Module):
             torch.load(os.path.join(self.ckpt_path, f"tracker_head_{iter}.pt"), map_location=self.device), self.tracker_head)
         self.delta_dino = load_pre_trained_model(
             torch.load(os.path.join(self.ckpt_path, f"delta_dino_{iter}.pt"), map_location=self.device), self.delta_dino)
+        if self._refined_key is not None:
+            self.refined_features = None  # refined with the previous Delta-DINO weights: never reuse it
 
     # ---- device state used by ModelInference -----------------------------------------------------------------
     def features(self, use_raw_features=False):
         """(feat [T][HW][C], norms [T][HW], fp16 copy or None) of the volume the tracker correlates against."""
+        if not use_raw_features and self.refined_is_stale():
+            self.cache_refined_embeddings()
         if use_raw_features or self._refined is None:
             if not use_raw_features and self._refined is None:
                 raise RuntimeError("refined features are not cached: call cache_refined_embeddings() first")
@@ -229,7 +243,7 @@ class Tracker(nn.Module):
         return self._refined, self._refined_norms, self._refined_f16
 
     def workspace(self, M: int) -> torch.Tensor:
-        need = ops.track_workspace_bytes(self.geom, M, self.track_method)
+        need = ops.track_workspace_bytes(self.geom, M, self.track_method, self.track_round_sources)
         if self._workspace is None or self._workspace.numel() < need:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._workspace
@@ -237,8 +251,42 @@ class Tracker(nn.Module):
     def track_sources(self, feats, emb, src_row, tgt, out_idx, out_xy, M, dM=None, normalized=False):
         feat, norms, f16 = feats
         head = self.tracker_head.packed_params(feat.device)
-        return ops.track(self.geom, feat, norms, f16, head, emb, src_row, tgt, out_idx, out_xy, M, self.workspace(M),
-                         dM=dM, normalized=normalized, method=self.track_method)
+        stats = TrackStats()
+        ops.track(self.geom, feat, norms, f16, head, emb, src_row, tgt, out_idx, out_xy, M, self.workspace(M), dM=dM,
+                  normalized=normalized, method=self.track_method, round_sources=self.track_round_sources,
+                  tier=self.track_tier, stats=stats)
+        self.last_track_stats = stats.as_dict()
+        return out_xy
+
+    # ---- the reference's per-call building blocks (tracker.py:158-180), on the device --------------------------
+    def cmap_relu(self, x):
+        return torch.relu(x)
+
+    def get_corr_maps_for_frame_set(self, source_embeddings, frame_embeddings_set, target_frame_indices):
+        """tracker.py:158-169: cosine maps of source b against frame_embeddings_set[target_frame_indices[b]] -> B x 1 x h x w.
+        (One map per source: the reference computes B x n maps and keeps the diagonal.)"""
+        n, c, h, w = frame_embeddings_set.shape
+        if self._refined is not None and frame_embeddings_set is self._refined_chw:
+            feat, norms = self._refined, self._refined_norms
+        else:
+            feat, norms = ops.pack_features(frame_embeddings_set.to(self.device, torch.float32).contiguous())
+        g = make_geom(n, c, self.geom.video_h, self.geom.video_w, self.dino_patch_size, self.stride, self.geom.radius)
+        if (g.ph, g.pw) != (h, w):
+            raise RuntimeError(f"frame embeddings {h}x{w} do not match the {g.ph}x{g.pw} token grid of the video")
+        emb = source_embeddings.to(self.device, torch.float32).contiguous()
+        tgt = target_frame_indices.to(self.device).to(torch.int32).contiguous()
+        return ops.corr_maps(g, feat, norms, emb, tgt)[:, None]
+
+    def get_point_predictions_from_embeddings(self, source_embeddings, frame_embeddings_set, target_frame_indices):
+        corr_maps = self.get_corr_maps_for_frame_set(source_embeddings, frame_embeddings_set, target_frame_indices)
+        return self.tracker_head(self.cmap_relu(corr_maps))
+
+    def get_point_predictions(self, inp, frame_embeddings):
+        source_points_unnormalized, source_frame_indices, target_frame_indices, _ = inp
+        source_points = self.normalize_points_for_sampling(source_points_unnormalized.to(self.device, torch.float32))
+        pts = torch.cat([source_points[:, :-1], source_frame_indices.to(self.device)[:, None].to(torch.float32)], dim=1)
+        source_embeddings = self.sample_embeddings(frame_embeddings, pts)
+        return self.get_point_predictions_from_embeddings(source_embeddings, frame_embeddings, target_frame_indices)
 
     # ---- forward (tracker.py:303-325) ----------------------------------------------------------------------------
     def forward(self, inp, use_raw_features=False):
@@ -246,7 +294,7 @@ class Tracker(nn.Module):
         frames_set_t n): embeddings are sampled at source_points in frame frames_set_t[source_frame_indices] and
         tracked into frame frames_set_t[target_frame_indices]; returns B x 2 in [-1,1]."""
         source_points, source_frame_indices, target_frame_indices, frames_set_t = inp
-        if not use_raw_features and self._refined is None:
+        if not use_raw_features and (self._refined is None or self.refined_is_stale()):
             self.cache_refined_embeddings()
         feats = self.features(use_raw_features)
         fs = frames_set_t.to(self.device).long()

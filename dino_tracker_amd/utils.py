@@ -30,38 +30,52 @@ def add_config_paths(data_path, config):
     return config
 
 
+_FACET_ROW = {"queries": 0, "keys": 1, "values": 2}
+
+
 @torch.no_grad()
 def get_dino_features_video_packed(video, model_name="dinov2_vitb14", facet="tokens", stride=7, layer=None,
                                    device: str = "cuda:0", extractor: VitExtractor = None, **extractor_kwargs):
     """Device-resident variant: T x (ph*pw) x C token-major fp32 (what Tracker consumes), no D2H per frame."""
-    if facet != "tokens":
-        raise NotImplementedError(f"facet {facet!r}: only 'tokens' runs on the HIP encoder")
     ex = extractor if extractor is not None else VitExtractor(model_name=model_name, stride=stride, device=device,
                                                               **extractor_kwargs)
-    return ex.encode(video, layer=layer, normalize=True, want="feat")
+    if facet == "tokens":
+        return ex.encode(video, layer=layer, normalize=True, want="feat")
+    if facet not in _FACET_ROW:
+        raise ValueError(f"facet {facet} not supported")  # utils.py:63
+    d = ex.cfg["dim"]
+    out = []
+    for i in range(video.shape[0]):  # one frame at a time: the qkv record is 3x the token volume
+        qkv = ex.encode(video[i:i + 1], layer=layer, normalize=True, want="qkv")
+        out.append(qkv[0, 1:, _FACET_ROW[facet] * d:(_FACET_ROW[facet] + 1) * d])
+    return torch.stack(out).contiguous()
 
 
 @torch.no_grad()
 def get_dino_features_video(video, model_name="dinov2_vitb14", facet="tokens", stride=7, layer=None,
                             device: str = "cuda:0", **extractor_kwargs):
     """utils.py:33-72: T x 3 x H x W frames in [0,1] -> T x C x ph x pw features on the CPU."""
-    feat = get_dino_features_video_packed(video, model_name, facet, stride, layer, device, **extractor_kwargs)
-    patch = 14
-    ph, pw = 1 + (video.shape[-2] - patch) // stride, 1 + (video.shape[-1] - patch) // stride
+    ex = extractor_kwargs.pop("extractor", None) or VitExtractor(model_name=model_name, stride=stride, device=device,
+                                                                 **extractor_kwargs)
+    feat = get_dino_features_video_packed(video, model_name, facet, stride, layer, device, extractor=ex)
+    ph, pw = ex.get_height_patch_num(video[[0]].shape), ex.get_width_patch_num(video[[0]].shape)
     return ops.unpack_features(feat, ph, pw).cpu()
 
 
 def bilinear_interpolate_video(video: torch.Tensor, points: torch.Tensor, h: int, w: int, t: int, normalize_h=False,
                                normalize_w=False, normalize_t=True):
-    """utils.py:75-101 signature; integral frame indices, runs dtk_sample_points.  video: 1 x C x T x H' x W',
-    points B x 3 (x, y in [-1,1] of the token grid, t) -> 1 x C x 1 x B x 1."""
-    if normalize_h or normalize_w:
-        raise NotImplementedError("pixel-normalised sampling is not used by the tracker path")
-    from ._lib import make_geom
-    emb = video[0].permute(1, 0, 2, 3).contiguous()  # T C H W
-    feat, _ = ops.pack_features(emb)
-    T, C, hh, ww = emb.shape
-    g = make_geom(T, C, 14 + 7 * (hh - 1), 14 + 7 * (ww - 1))
-    xy = torch.stack([(points[:, 0] + 1) / 2 * (ww - 1) * 7 + 7, (points[:, 1] + 1) / 2 * (hh - 1) * 7 + 7], 1).contiguous()
-    out = ops.sample_points(g, feat, xy.float(), points[:, 2].round().to(torch.int32).contiguous())
+    """utils.py:75-101 on the device (dtk_sample_grid): video 1 x C x T x H' x W', points B x 3 (x, y, t); the same
+    normalisation switches; trilinear, border, align_corners -> 1 x C x 1 x B x 1."""
+    samples = points.detach().clone().to(torch.float32)
+    if normalize_w:
+        samples[:, 0] = samples[:, 0] / (w - 1) * 2 - 1
+    if normalize_h:
+        samples[:, 1] = samples[:, 1] / (h - 1) * 2 - 1
+    if normalize_t:
+        if t > 1:
+            samples[:, 2] = samples[:, 2] / (t - 1)
+        samples[:, 2] = samples[:, 2] * 2 - 1
+    _, C, T, hh, ww = video.shape
+    feat, _ = ops.pack_features(video[0].permute(1, 0, 2, 3).to(torch.float32).contiguous())  # T C H' W' -> token-major
+    out = ops.sample_grid(feat, hh, ww, samples.to(feat.device).contiguous())
     return out.t()[None, :, None, :, None]

@@ -90,6 +90,7 @@ typedef struct dtk_vit_model {
     int32_t depth;                /* number of blocks to run = hooked layer + 1 (models/extractor.py:137-150) */
     int32_t patch, stride;        /* 14, 7 (models/extractor.py:41-55) */
     float ln_eps;                 /* 1e-6 */
+    int32_t flags;                /* 0, or DTK_VIT_TILED_GEMMS: run the K = 384 GEMMs on the tiled kernel too (cross-check) */
     const float* patch_w;         /* patch_embed.proj.weight fp32 [D][3][patch][patch] */
     const float* patch_b;         /* patch_embed.proj.bias */
     const float* cls_pos;         /* cls_token + pos_embed[0]  [D] */
@@ -98,12 +99,18 @@ typedef struct dtk_vit_model {
     const dtk_vit_layer* layers;  /* HOST array of `depth` entries */
 } dtk_vit_model;
 
+#define DTK_VIT_TILED_GEMMS 1
+
 /* frames [n][3][video_h][video_w] fp32 in [0,1] -> block output of layer depth-1 (before the final norm):
  * tokens_out [n][1 + ph*pw][D] (CLS first; what get_feature_from_input returns) and/or
- * feat_out   [n][ph*pw][D]     (CLS dropped: the token-major feature volume of this library).  Either may be NULL. */
+ * feat_out   [n][ph*pw][D]     (CLS dropped: the token-major feature volume of this library) and/or
+ * qkv_out    [n][1 + ph*pw][3D] the output of blocks[depth-1].attn.qkv (the tensor the reference's qkv hook records,
+ *            models/extractor.py:107-118; the key / query / value facets are reshapes of it, :245-267).
+ * Any of them may be NULL (not all). */
 size_t dtk_vit_workspace_bytes(const dtk_vit_model* m, int video_h, int video_w, int frames);
 int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int nframes, int video_h, int video_w,
-                    float* tokens_out, float* feat_out, void* workspace, size_t workspace_bytes, void* stream);
+                    float* tokens_out, float* feat_out, float* qkv_out, void* workspace, size_t workspace_bytes,
+                    void* stream);
 
 /* ---- P2: Delta-DINO refinement (models/tracker.py:113-135; models/networks/delta_dino.py:53-61;
  *      models/utils.py:7-45), fp32-grade on the fp16 MFMA (operands split into hi + lo halves, 3 products) ----------
@@ -130,6 +137,11 @@ int dtk_delta_dino_refine(const dtk_geom* g, const float* video, const float* di
 int dtk_sample_points(const dtk_geom* g, const float* feat, const float* xy, const int32_t* t_idx,
                       const int32_t* out_row, float* out, int B, void* stream);
 
+/* Literal utils.bilinear_interpolate_video (utils.py:75-101; what Tracker.sample_embeddings calls, models/tracker.py:96-111)
+ * on a token-major volume feat[T][ph*pw][C]: pts[B][3] = (x, y, t) ALREADY in [-1, 1] (grid_sample coordinates),
+ * trilinear, align_corners=True, border padding -> out[B][C].  No patch / stride enters. */
+int dtk_sample_grid(const float* feat, int T, int C, int ph, int pw, const float* pts, float* out, int B, void* stream);
+
 /* ---- TrackerHead parameters ---------------------------------------------------------------------------- */
 /* raw state-dict tensors (cnn_refiner.0.weight [16,1,3,3], .0.bias [16], .2.weight [1,16,3,3], .2.bias [1])
  * -> normalised packed parameters head[DTK_HEAD_PARAMS] (conv_norm.py:34-46). */
@@ -140,6 +152,17 @@ int dtk_head_prepare(const float* w1, const float* b1, const float* w2, const fl
 int dtk_head_forward(const dtk_geom* g, const float* head, const float* maps, float* out_xy, int B, int normalized,
                      void* stream);
 
+/* NormalizedConv2d.forward as a stand-alone layer (models/networks/conv_norm.py:34-46): x[B][Cin][H][W],
+ * w[Cout][Cin][k][k] (RAW weights: the per-kernel W / sum(W) is applied inside), bias[Cout] or NULL -> y[B][Cout][H][W];
+ * stride 1, zero padding k/2, k odd.  (The tracker path runs these layers fused inside dtk_track / dtk_head_forward.) */
+int dtk_normalized_conv2d(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int H,
+                          int W, int k, void* stream);
+
+/* Tracker.get_corr_maps_for_frame_set (models/tracker.py:158-169): cosine maps of M sources against their target
+ * frames, maps[m][ph*pw] fp32; relu != 0 applies cmap_relu (:173).  snorm_scratch: M floats. */
+int dtk_corr_maps(const dtk_geom* g, const float* feat, const float* norms, const float* emb, const int32_t* src_row,
+                  const int32_t* tgt, float* maps, float* snorm_scratch, int M, int relu, void* stream);
+
 /* ---- K9-K13: track sources into target frames ------------------------------------------------------------
  * For each source m < M:  s = emb[src_row[m]] (row of an [R][C] fp32 matrix), a = tgt[m]:
  *   rho = relu(cos(s, F[a](:, r, c)))                     models/tracker.py:158-173
@@ -147,20 +170,36 @@ int dtk_head_forward(const dtk_geom* g, const float* head, const float* maps, fl
  * and out_xy[out_idx[m]] = (x, y) in PIXELS (model_inference.py:52 already applied), or normalised to [-1,1]
  * if normalized != 0 (the value Tracker.forward returns, tracker.py:303-325).
  * src_row / out_idx may be NULL (identity).  Any order of tgt is correct; sources sorted by tgt run fastest.
- * `method`: DTK_TRACK_EXACT = fp32 everywhere (correlation volume staged through `workspace`), fully asynchronous;
- *           DTK_TRACK_MFMA  = fp16-MFMA correlation reduced on chip to peak records + fp32 window refinement;
- *                             sources that need the whole-map refiner statistics / the exact path are handled in a
- *                             second / third phase whose sizes are read back: this method SYNCHRONISES `stream`
- *                             up to three times per call.
- * `dM` (device int32*, may be NULL): if given, the number of sources is min(M, *dM) read on device -- lets the
- * anchor stage run without a host sync on the data-dependent anchor count. */
+ * opts->method: DTK_TRACK_EXACT = fp32 everywhere (correlation volume staged through `workspace`), fully asynchronous;
+ *               DTK_TRACK_MFMA  = fp16-MFMA correlation reduced on chip to peak records + fp32 window refinement.
+ *                 Three tiers decide a source: (1) the no-fallback certificate, (2) whole-map
+ *                 refiner statistics on the matrix cores for uncertified sources, (3) the exact path for sources the
+ *                 fp16 pass cannot decide.  The sizes of tiers 2 and 3 are read back: this method SYNCHRONISES
+ *                 `stream` once per call (twice if tier 2 ran; once more if `dM` is given).
+ * opts->normalized: 0 = pixels, 1 = [-1,1].
+ * opts->round_sources: sources per round of the MFMA pipeline (0 = default 524 288; rounded up to a multiple of 256).
+ *                 The workspace size follows it.  Results do not depend on it (tests run several rounds with it).
+ * opts->tier: DTK_TIER_AUTO, or DTK_TIER_WHOLE_MAP = skip the certificate, every source takes tier 2 (tests).
+ * `dM` (device int32*, may be NULL): if given, the number of sources is min(M, *dM).
+ * `stats` (HOST pointer, may be NULL): filled before returning; nothing is retained by the library between calls. */
 #define DTK_TRACK_EXACT 0
 #define DTK_TRACK_MFMA 1
-size_t dtk_track_workspace_bytes(const dtk_geom* g, int M, int method);
+#define DTK_TIER_AUTO 0
+#define DTK_TIER_WHOLE_MAP 1
+typedef struct dtk_track_opts {
+    int32_t method, normalized, round_sources, tier;
+} dtk_track_opts;
+typedef struct dtk_track_stats {
+    int32_t sources;         /* sources processed (min(M, *dM)) */
+    int32_t whole_map_tier;  /* of which decided with whole-map statistics (tier 2) */
+    int32_t exact_tier;      /* of which re-done on the exact fp32 path (tier 3) */
+    int32_t syncs;           /* host synchronisations of `stream` this call made */
+} dtk_track_stats;
+size_t dtk_track_workspace_bytes(const dtk_geom* g, int M, const dtk_track_opts* opts);
 int dtk_track(const dtk_geom* g, const float* feat, const float* norms, const void* feat_f16,
               const float* head, const float* emb, const int32_t* src_row, const int32_t* tgt,
-              const int32_t* out_idx, float* out_xy, int M, const int32_t* dM, int normalized, int method,
-              void* workspace, size_t workspace_bytes, void* stream);
+              const int32_t* out_idx, float* out_xy, int M, const int32_t* dM, const dtk_track_opts* opts,
+              dtk_track_stats* stats, void* workspace, size_t workspace_bytes, void* stream);
 
 /* fp16 unit-norm copy of the feature volume consumed by DTK_TRACK_MFMA: f16[t][row][col][c] = 32 F/|F| with every map
  * row padded with zero cells to a multiple of 128 columns (an N-tile of the GEMM is one map row); C % 32 == 0. */

@@ -30,9 +30,26 @@ def test_version_and_error_paths(handle):
     assert rc == -1 and b"multiple of 4" in handle.dtk_last_error()
     g = _lib.make_geom(4, 32, 140, 210)
     g.ph += 1
-    rc = handle.dtk_track(g, 1, 1, None, 1, 1, None, 1, None, 1, 1, None, 0, 0, 1, 1024, None)
+    exact = _lib.TrackOpts(0, 0, 0, 0)
+    rc = handle.dtk_track(g, 1, 1, None, 1, 1, None, 1, None, 1, 1, None, exact, None, 1, 1024, None)
     assert rc == -1 and b"inconsistent" in handle.dtk_last_error()
-    assert handle.dtk_track_workspace_bytes(_lib.make_geom(4, 32, 140, 210), 100, 0) == 100 * (576 + 1) * 4
+    g = _lib.make_geom(4, 32, 140, 210)
+    rc = handle.dtk_track(g, 1, 1, None, 1, 1, None, 1, None, 1, 1, None, _lib.TrackOpts(0, 0, 0, 7), None, 1, 1024, None)
+    assert rc == -1 and b"bad options" in handle.dtk_last_error()
+    assert handle.dtk_track_workspace_bytes(g, 100, exact) == 100 * (576 + 1) * 4
+    # the MFMA workspace follows the round size (smaller rounds -> smaller staging)
+    big = handle.dtk_track_workspace_bytes(g, 100000, _lib.TrackOpts(1, 0, 0, 0))
+    small = handle.dtk_track_workspace_bytes(g, 100000, _lib.TrackOpts(1, 0, 1024, 0))
+    assert 0 < small < big
+
+
+def test_production_library_has_no_development_switches(handle):
+    """The shipped libdtk.so is built without -DDTK_DEV: no getenv("DTK_DEBUG"), no debug exports."""
+    import subprocess
+    for name in ("dtk_debug_counters", "dtk_debug_track_counts"):
+        assert not hasattr(handle, name), name
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
 
 
 def test_hot_path_refuses_cpu_tensors():

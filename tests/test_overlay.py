@@ -1,8 +1,11 @@
 """CPU: the overlay makes the reference's module paths resolve to this implementation (namespace-package shadowing),
-while non-hot-path modules still come from the reference checkout when it is present."""
+while non-hot-path modules still come from the reference checkout when it is present -- and it does so for a REAL
+script file sitting in a reference-shaped directory, which is the case `python script.py` + PYTHONPATH gets wrong
+(the script's directory precedes PYTHONPATH): that is what `python -m dino_tracker_amd.run` is for."""
 import os
 import subprocess
 import sys
+import textwrap
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -34,3 +37,56 @@ def test_overlay_resolution():
     r = subprocess.run([sys.executable, "-c", f"REF = {ref!r}\n" + SCRIPT], capture_output=True, text=True, env=env,
                        cwd="/tmp", timeout=300)
     assert r.returncode == 0 and "overlay ok" in r.stdout, r.stdout + r.stderr
+
+
+def _fake_reference(tmp_path):
+    """A directory shaped like the reference checkout: a script in its root next to `models/`, `data/`, `utils.py`
+    whose hot-path modules are decoys (importing one of them is the failure)."""
+    root = tmp_path / "dino-tracker"
+    for d in ("models", "models/networks", "data"):
+        (root / d).mkdir(parents=True)
+    decoy = 'raise ImportError("decoy: the reference module was imported instead of the overlay")\n'
+    for f in ("models/tracker.py", "models/model_inference.py", "models/extractor.py", "models/networks/tracker_head.py",
+              "data/dataset.py", "utils.py"):
+        (root / f).write_text(decoy)
+    (root / "models" / "utils.py").write_text("WHO = 'reference models/utils.py'\n")  # not shadowed by the overlay
+    (root / "probe.py").write_text(textwrap.dedent('''
+        import sys
+        from models.tracker import Tracker
+        from models.model_inference import ModelInference
+        from data.dataset import RangeNormalizer
+        import utils, models.utils
+        assert __name__ == "__main__" and sys.argv[1:] == ["--flag", "7"], sys.argv
+        assert models.utils.WHO == "reference models/utils.py"
+        print("probe ok", Tracker.__module__, utils.__file__)
+    '''))
+    return root
+
+
+def test_launcher_runs_a_script_from_the_reference_root(tmp_path):
+    root = _fake_reference(tmp_path)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "dino_tracker_amd.run", str(root / "probe.py"), "--flag", "7"],
+                       capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "probe ok dino_tracker_amd.tracker" in r.stdout and os.path.join("overlay", "utils.py") in r.stdout
+
+
+def test_plain_python_with_pythonpath_hits_the_reference_modules(tmp_path):
+    """The failure mode the launcher exists for (ADVICE r1): documented, so INTEGRATION.md cannot regress to it."""
+    root = _fake_reference(tmp_path)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "overlay"), ROOT]))
+    r = subprocess.run([sys.executable, str(root / "probe.py"), "--flag", "7"], capture_output=True, text=True, env=env,
+                       cwd=str(tmp_path), timeout=300)
+    assert r.returncode != 0 and "decoy" in r.stderr
+
+
+def test_launcher_fails_loudly_when_a_hot_module_is_not_the_overlay(tmp_path):
+    root = _fake_reference(tmp_path)
+    (root / "models" / "tracker.py").write_text("Tracker = None\n")
+    (root / "sneaky.py").write_text("import sys, importlib.util\n"
+                                    f"spec = importlib.util.spec_from_file_location('models.tracker', r'{root}/models/tracker.py')\n"
+                                    "m = importlib.util.module_from_spec(spec); sys.modules['models.tracker'] = m\n")
+    r = subprocess.run([sys.executable, "-m", "dino_tracker_amd.run", str(root / "sneaky.py")], capture_output=True,
+                       text=True, env=dict(os.environ, PYTHONPATH=ROOT), cwd=str(tmp_path), timeout=300)
+    assert r.returncode != 0 and "did not resolve to the overlay" in r.stderr
