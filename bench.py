@@ -1,17 +1,23 @@
 #!/usr/bin/env python
-"""Benchmark of the per-video inference hot path on MI355X (contract: see the round prompt / DESIGN.md section 6).
+"""Benchmark of the per-video inference hot path on MI355X (contract: the round prompt / DESIGN.md section 6).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W         (N > 1 spawns its own ranks when WORLD_SIZE is unset)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the hot path over ONE synthetic video per rank (weak scaling: each rank tracks its own video,
-rank 0 gathers the trajectories over RCCL).  Metric: query-points*frames/s = world * N * T * K / wall.
-Prints ONE JSON line on rank 0.
+A "step" = one pass of the hot path (P1 ViT features -> P2 Delta-DINO refinement -> P3 ModelInference.infer) over
+  * default (weak scaling): ONE synthetic 854x480x90 video with 1024 grid queries per rank;
+  * --videos V (strong scaling): a batch of V videos sharded v = r (mod world) (north_star's 30-video batch:
+    4/4/4/4/4/4/3/3 on 8 GPUs), rank 0 receives every result through one RCCL gather per round;
+  * --mode query-parallel (strong scaling on ONE video, SURVEY 8e level 2): frames split over the ranks for P1 / P2,
+    one all-gather of the refined volume, queries split over the ranks for P3, one gather of the results.
+Metric: query-points*frames/s = videos * N * T * K / wall (max over ranks).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,6 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F16_PEAK_TF = 2500.0   # dense bf16/fp16 MFMA
 F32_PEAK_TF = 157.3         # f32 vector / f32-input MFMA
+H, W = 476, 854             # model resolution of an 854x480 source video (config/train.yaml:6-7)
 
 
 def parse():
@@ -35,6 +42,10 @@ def parse():
     ap.add_argument("--queries", type=int, default=1024)
     ap.add_argument("--width", type=int, default=384, help="feature width C (384 = ViT-S/14)")
     ap.add_argument("--method", default="auto", choices=["auto", "exact", "mfma"])
+    ap.add_argument("--videos", type=int, default=0,
+                    help="0: one video per rank and step (weak scaling); V > 0: a batch of V videos per step sharded over "
+                         "the ranks (strong scaling)")
+    ap.add_argument("--mode", default="video-parallel", choices=["video-parallel", "query-parallel"])
     ap.add_argument("--stages", default="extract,refine,track",
                     help="comma list of extract (ViT), refine (Delta-DINO), track (ModelInference.infer); stages that "
                          "are left out are computed once outside the timed region")
@@ -42,82 +53,111 @@ def parse():
                     help="vit: features come from the (random-weight) ViT on the synthetic video; synthetic: the "
                          "feature-level generator with dense anchors (worst case for the tracker stage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-queries", type=int, default=1, help="queries in the bounded CPU-baseline sample")
-    ap.add_argument("--cpu-frames", type=int, default=45,
-                    help="frames in the bounded CPU-baseline sample (the oracle's work grows with T^2: T + T*T maps per query)")
+    ap.add_argument("--cpu-queries", type=int, default=4, help="queries of the CPU sample (SURVEY 8d: K = 4, full T)")
+    ap.add_argument("--cpu-vit-frames", type=int, default=1, help="frames the oracle's ViT / Delta-DINO legs are timed on")
     return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: become `torch.distributed.run` for N ranks on this node."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
+    dist = None
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(dev))  # nccl == RCCL on ROCm
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == world == dist.get_world_size(), (rccl_ranks, world)
 
-    from dino_tracker_amd import ops, synth
+    from dino_tracker_amd import ops, sharding, synth
+    from dino_tracker_amd._lib import make_geom
     from dino_tracker_amd.dataset import RangeNormalizer
+    from dino_tracker_amd.extractor import VitExtractor
     from dino_tracker_amd.model_inference import ModelInference
-    import gpu_util
-    gpu_util.DEV = dev
+    from dino_tracker_amd.tracker import Tracker
 
-    H, W, T, N, C = 476, 854, args.frames, args.queries, args.width
+    T, N, C = args.frames, args.queries, args.width
     nx = int(round(N ** 0.5))
     ny = N // nx
     assert nx * ny == N, "--queries must be a square number (grid)"
     method = {"exact": ops.TRACK_EXACT, "mfma": ops.TRACK_MFMA}.get(args.method)
     if method is None:
-        method = ops.TRACK_MFMA if ops.feat_f16_bytes(__import__("dino_tracker_amd")._lib.make_geom(T, C, H, W)) > 0 else ops.TRACK_EXACT
-
+        method = ops.TRACK_MFMA if ops.feat_f16_bytes(make_geom(T, C, H, W)) > 0 else ops.TRACK_EXACT
     stages = [x for x in args.stages.split(",") if x]
-    from dino_tracker_amd.extractor import VitExtractor
-    from dino_tracker_amd.tracker import Tracker
-    import ctypes
-    from dino_tracker_amd._lib import lib, make_geom
+    qpar = args.mode == "query-parallel" and world > 1
     model_name = {384: "dinov2_vits14", 768: "dinov2_vitb14", 1024: "dinov2_vitl14"}[C]
-    # per-rank synthetic inputs: translating-texture video, seeded random weights
-    video = synth.synth_video(T, H, W, seed=2000 + rank).to(dev)
+
+    # ---- synthetic inputs (SURVEY.md 8d): translating-texture videos, seeded random weights -----------------------------
+    if qpar:
+        my_videos = [0]                       # every rank works on THE video
+    elif args.videos > 0:
+        my_videos = sharding.videos_of_rank(args.videos, rank, world)
+    else:
+        my_videos = [rank]
+    n_distinct = max(1, min(len(my_videos), 2))  # distinct clips held per rank; longer batches cycle through them
+    seeds = [2000 + (0 if qpar else (my_videos[i] if my_videos else rank)) for i in range(n_distinct)]
+    videos = [synth.synth_video(T, H, W, seed=s).to(dev) for s in seeds]
     head = synth.synth_head_weights(3)
     delta = synth.synth_delta_dino_weights(C, seed=4)
     queries = synth.grid_queries(nx, ny, H, W, 0).to(dev)
     # no DINOv2 checkpoint exists offline: seeded random weights of the named architecture; LayerScale mean 0.1 keeps
     # the untrained encoder from collapsing all tokens onto one vector (synth.make_vit_weights)
-    ex = VitExtractor(model_name, stride=7, device=dev,
-                      state_dict=synth.make_vit_weights(model_name, seed=2, layerscale=0.1))
+    vit_sd = synth.make_vit_weights(model_name, seed=2, layerscale=0.1)
+    ex = VitExtractor(model_name, stride=7, device=dev, state_dict=vit_sd)
     if args.features == "vit":
-        feats0 = ex.encode(video)
+        feats0 = ex.encode(videos[0])
     else:
         feats0 = synth.synth_features(T, C, 67, 121, seed=1000 + rank).to(dev).permute(0, 2, 3, 1).reshape(T, 67 * 121, C).contiguous()
         stages = [x for x in stages if x != "extract"]
-    trk = Tracker(video=video, dino_features=feats0, dino_patch_size=14, stride=7, device=dev, track_method=method)
+    trk = Tracker(video=videos[0], dino_features=feats0, dino_patch_size=14, stride=7, device=dev, track_method=method)
     trk.tracker_head.load_state_dict(head)
     trk.delta_dino.load_state_dict(delta)
     trk.to(dev).eval()
     mi = ModelInference(trk, RangeNormalizer((W, H, T), device=dev), 0.7, 0.6)  # caches refined features once
+    stats_acc = {"sources": 0, "whole_map_tier": 0, "exact_tier": 0, "syncs": 0}
 
-    gather_buf = None
-
-    def step():
-        nonlocal gather_buf
+    def one_video(video):
         if "extract" in stages:
             trk.set_video(video, ex.encode(video))        # P1: ViT-S/14 block-11 tokens, stride 7
         if "refine" in stages or "extract" in stages:
             trk.cache_refined_embeddings()                # P2: dino + Delta-DINO(video)
-        traj, occ = mi.infer(queries) if "track" in stages else (None, None)   # P3
+        return mi.infer(queries) if "track" in stages else (None, None)   # P3
+
+    def step():
+        if qpar:
+            return sharding.query_parallel_step(trk, ex, mi, videos[0], queries, dev, stages)
+        if args.videos > 0:
+            res = sharding.run_sharded(args.videos, N, T, dev, lambda v: one_video(videos[(v // world) % n_distinct]))
+            return res
+        traj, occ = one_video(videos[0])
         if world > 1 and traj is not None:
-            from dino_tracker_amd import sharding
-            gather_buf = sharding.gather_results(traj, occ, N, T, dev)  # RCCL gather of the results only
+            return sharding.gather_results(traj, occ, N, T, dev)  # RCCL gather of the results only
         return traj, occ
 
     def barrier():
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -130,24 +170,24 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        import torch.distributed as dist
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    videos_per_step = 1 if qpar else (args.videos if args.videos > 0 else world)
 
-    # ---- per-kernel profile pass (separate from the timed region) ------------------------------------------
+    # ---- per-kernel pass (separate from the timed region): hipEvents around every launch of the library ---------------
     pairs = int(mi.last_counts[0]) if hasattr(mi, "last_counts") else 0
     maps = N * T + pairs * T
+    tiers = dict(trk.last_track_stats) if trk.last_track_stats else None   # the anchor-stage dtk_track call
     ops.profile_enable(True)
-    step()
+    one_video(videos[0])
     prof = ops.profile_collect()
     ops.profile_enable(False)
     roofline = None
     if prof:
         HW, S = 67 * 121, 67 * 121 + 1
         depth = 12 if C in (384, 768) else 24
-        f_delta = 2.0 * (406504 * 4800 + 101626 * 204800 + 25466 * 819200 + 6420 * 6400 * C)
-        # ALGORITHMIC flops of one step per kernel, and the peak that bounds it (TFLOP/s, dense)
+        # ALGORITHMIC flops of one video per kernel, and the peak that bounds it (TFLOP/s, dense)
         algo = {
             "vit_attention": (4.0 * S * S * C * depth * T, MFMA_F16_PEAK_TF),
             "vit_gemm_qkv": (2.0 * S * C * 3 * C * depth * T, MFMA_F16_PEAK_TF),
@@ -174,67 +214,86 @@ def main():
             roofline = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": None, "traffic": None}
         # HBM-side bytes per launch of that kernel from the committed PMC passes (scripts/pmc_traffic.py)
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as fh:
-                tr = json.load(fh)["kernels"].get(dom)
-            if tr:
-                roofline["traffic"] = tr["bytes_per_launch"]
-                roofline["traffic_note"] = "bytes per launch, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/r01_pmc_traffic.json)"
-        except (OSError, ValueError, KeyError):
-            pass
+        for prof_file in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", prof_file)) as fh:
+                    tr = json.load(fh)["kernels"].get(dom)
+                if tr:
+                    roofline["traffic"] = tr["bytes_per_launch"]
+                    roofline["traffic_note"] = f"bytes per launch, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/{prof_file})"
+                    break
+            except (OSError, ValueError, KeyError):
+                pass
         roofline["avg_launch_ms"] = round(ms / max(launches, 1), 4)
         roofline["launches"] = launches
         roofline["kernel_ms"] = {k: round(v[0], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("DTK_BENCH_KERNELS", "12"))]}
         roofline["kernel_tflops"] = {k: round(algo[k][0] / (prof[k][0] * 1e-3) / 1e12, 1) for k in prof
                                      if k in algo and prof[k][0] > 0}
 
-    # ---- CPU baseline: the oracle (torch fp32 port of the reference algorithm) on a bounded sample --------------
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # ---- CPU baseline + parity sample: the oracle (torch fp32 port of the reference algorithm) on K queries at
+    # full T with all their anchors, one frame of its ViT and of its Delta-DINO, combined by
+    #     cpu_qpf = N T / (T t_vit + T t_delta + N t_query).
+    # The same K queries are then tracked by the HIP path on the same refined volume: `parity_sample`.
+    cpu = parity = None
+    if rank == 0 and not args.no_cpu_baseline and "track" in stages:
         from oracle import ref_algo as A
-        nq = max(1, args.cpu_queries)
-        tc = max(2, min(T, args.cpu_frames))
+        nq = max(1, min(N, args.cpu_queries))
         sel = torch.linspace(0, N - 1, nq).long()
         q_cpu = queries.cpu()[sel]
-        feats_cpu = trk.refined_features.cpu()[:tc].contiguous()
+        one_video(videos[0])                                 # the state the sample is compared against
+        refined_cpu = trk.refined_features.cpu()
         c0 = time.perf_counter()
-        _, _, cs_cpu, _ = A.infer(feats_cpu, q_cpu, head, H, W, return_aux=True)
-        cdt = time.perf_counter() - c0
-        cpu = {"value": round(nq * tc / cdt, 3), "unit": "query-points*frames/s", "cores": torch.get_num_threads(),
+        rt, ro, cs_cpu, _ = A.infer(refined_cpu, q_cpu, head, H, W, return_aux=True)
+        t_query = (time.perf_counter() - c0) / nq
+        a_bar = float((cs_cpu >= 0.7).sum()) / nq
+        nf = max(1, min(T, args.cpu_vit_frames))
+        vcpu = videos[0][:nf].cpu()
+        c0 = time.perf_counter()
+        dino_cpu = torch.stack([A.vit_tokens(vcpu[i:i + 1], vit_sd, model_name) for i in range(nf)]) if args.features == "vit" else None
+        t_vit = (time.perf_counter() - c0) / nf if dino_cpu is not None else 0.0
+        if dino_cpu is None:
+            dino_cpu = trk.dino_embed_video[:nf].cpu()
+        c0 = time.perf_counter()
+        A.refine_features(vcpu, dino_cpu, delta)
+        t_delta = (time.perf_counter() - c0) / nf
+        total = T * t_vit + T * t_delta + N * t_query
+        cpu = {"value": round(N * T / total, 3), "unit": "query-points*frames/s", "cores": torch.get_num_threads(),
                "kind": "port",
-               "sample": f"oracle.infer (ModelInference.infer restatement, fp32 torch CPU) on {nq} of the {N} queries and "
-                         f"the first {tc} of the {T} frames with all their anchors ({int((cs_cpu >= 0.7).sum())} anchor "
-                         f"pairs, {nq * tc + int((cs_cpu >= 0.7).sum()) * tc} correlation maps; the full workload has "
-                         f"{T + T * T} per query, i.e. costs more per query-frame), features resident; {cdt:.1f}s"}
+               "sample": f"oracle (fp32 torch restatement of the reference; the un-modified reference is not on this box): "
+                         f"infer on {nq} of the {N} queries at full T={T} with all their anchors ({a_bar:.1f} per query) "
+                         f"{t_query:.2f} s/query; ViT {t_vit:.2f} s/frame and Delta-DINO {t_delta:.2f} s/frame on {nf} frame(s); "
+                         f"N T / (T t_vit + T t_delta + N t_query), SURVEY 8d",
+               "t_query_s": round(t_query, 3), "t_vit_s": round(t_vit, 3), "t_delta_s": round(t_delta, 3),
+               "anchors_per_query": round(a_bar, 2)}
+        tg, og = mi.infer(queries[sel.to(dev)])
+        parity = {"queries": nq, "frames": T, "correlation_maps": int(nq * T + float((cs_cpu >= 0.7).sum()) * T),
+                  "max_dxy_px": round(float((tg.cpu() - rt).abs().max()), 6),
+                  "occ_mismatch": int((og.cpu() != ro).sum()), "occ_flags": int(ro.numel()),
+                  "tiers": dict(trk.last_track_stats),
+                  "note": "HIP infer vs oracle infer on the same refined volume (the one the timed step produced)"}
 
     if rank == 0:
-        if int(os.environ.get("DTK_DEBUG", "0")) & 4096:
-            dc = (ctypes.c_ulonglong * 4)()
-            lib().dtk_debug_counters(dc)
-            print("redo reasons [overflow, none, nonpositive, -]:", list(dc), file=sys.stderr)
-        tc = (ctypes.c_int * 3)()
-        track_counts = None
-        if hasattr(lib(), "dtk_debug_track_counts") and lib().dtk_debug_track_counts(tc) == 0:
-            track_counts = {"sources": tc[0], "whole_map_tier": tc[1], "exact_tier": tc[2]}  # last dtk_track call
         out = {
-            "metric": "query-points*frames/s", "value": round(world * N * T * args.steps / dt, 1),
+            "metric": "query-points*frames/s", "value": round(videos_per_step * N * T * args.steps / dt, 1),
             "unit": "query-points*frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong" if (qpar or args.videos > 0) else "weak",
             "vs_baseline": None, "dtype": ("mixed: bf16 ViT, split-f16 convs (fp32-grade), " + ("f32 tracker" if method == ops.TRACK_EXACT
                                                                        else "f16 candidates + f32 deciders in the tracker")
                       + "; f32 accumulate"),
             "data": "synthetic",
             "config": {"workload": f"854x480x{T} synthetic video (model res 854x476, 67x121 tokens, C={C}), {N} grid "
-                                   f"queries, one video per GPU",
-                       "stages": stages, "features": args.features,
+                                   f"queries; {videos_per_step} video(s) per step over {world} GPU(s)",
+                       "stages": stages, "features": args.features, "mode": args.mode if world > 1 else "single",
                        "track_method": "exact" if method == ops.TRACK_EXACT else "mfma",
-                       "anchor_pairs": pairs, "correlation_maps_per_step": maps, "anchor_track_tiers": track_counts,
-                       "parallelism": f"video-parallel x{world}"},
-            "roofline": roofline, "cpu_baseline": cpu,
+                       "anchor_pairs": pairs, "correlation_maps_per_video": maps, "anchor_track_tiers": tiers,
+                       "rccl_ranks": rccl_ranks,
+                       "parallelism": (f"query-parallel x{world} (frames split for P1/P2, queries for P3)" if qpar
+                                       else f"video-parallel x{world}")},
+            "roofline": roofline, "cpu_baseline": cpu, "parity_sample": parity,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
-        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -103,6 +103,8 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dtk_occlusion": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_int,
                               c_int, c_void_p]),
+    "dtk_tapvid_counts": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
+                                  c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 
 _LIB = None

@@ -202,3 +202,66 @@ extern "C" int dtk_occlusion(const float* green, const int32_t* pair_off, const 
                        pair_off, pair_frame, traj, cs, anchor_th, cos_th, occ, N, T);
     return DTK_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------
+// TAP-Vid metric counts on the device (eval/metrics.py:7-147, compute_tapvid_metrics for ONE video), so that the
+// trajectories of inference_benchmark.py never have to leave the GPU as .npy files to be scored.
+// One thread per (query, frame); counts[18] (uint64):
+//   [0] evaluated points  [1] occlusion prediction == ground truth  [2] visible in the ground truth
+//   [3+3i] within threshold 2^i px & visible  [4+3i] ... & predicted visible (true positives)  [5+3i] false positives
+// all restricted to the evaluated frames of the query (strided: every frame but the query frame; first: later frames).
+// The distance test replicates the float32 arithmetic of the numpy code: (px*sp - gx*sg)^2 summed, < thresh^2.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tapvid_counts_kernel(const float* __restrict__ pred, const uint8_t* __restrict__ pred_occ,
+                                                            const float* __restrict__ gt, const uint8_t* __restrict__ gt_occ,
+                                                            const int32_t* __restrict__ qframe, float spx, float spy,
+                                                            float sgx, float sgy, int first_mode, int N, int T,
+                                                            unsigned long long* __restrict__ counts) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    int c[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) c[k] = 0;
+    if (i < (long long)N * T) {
+        const int n = (int)(i / T), t = (int)(i - (long long)n * T);
+        const int qf = qframe[n];
+        const bool ev = first_mode ? (t > qf) : (t != qf);
+        if (ev) {
+            const bool vis = gt_occ[i] == 0, pvis = pred_occ[i] == 0;
+            const float dx = __fsub_rn(__fmul_rn(pred[2 * i], spx), __fmul_rn(gt[2 * i], sgx));
+            const float dy = __fsub_rn(__fmul_rn(pred[2 * i + 1], spy), __fmul_rn(gt[2 * i + 1], sgy));
+            const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+            c[0] = 1;
+            c[1] = (pvis == vis);
+            c[2] = vis;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const float th = (float)(1 << k);
+                const bool within = d2 < th * th;
+                c[3 + 3 * k] = within && vis;
+                c[4 + 3 * k] = within && vis && pvis;
+                c[5 + 3 * k] = ((!vis) && pvis) || ((!within) && pvis);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+        const int s = wave_sum_i(c[k]);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&counts[k], (unsigned long long)s);
+    }
+}
+
+extern "C" int dtk_tapvid_counts(const float* pred_tracks, const uint8_t* pred_occluded, const float* gt_tracks,
+                                 const uint8_t* gt_occluded, const int32_t* query_frame, float pred_scale_x,
+                                 float pred_scale_y, float gt_scale_x, float gt_scale_y, int first_mode, int N, int T,
+                                 unsigned long long* counts18, void* stream) {
+    DTK_REQUIRE(pred_tracks && pred_occluded && gt_tracks && gt_occluded && query_frame && counts18, "dtk_tapvid_counts: null pointer");
+    DTK_REQUIRE(N >= 0 && T > 0, "dtk_tapvid_counts: bad sizes");
+    hipStream_t st = dtk_stream(stream);
+    DTK_HIP(hipMemsetAsync(counts18, 0, 18 * sizeof(unsigned long long), st));
+    if (N == 0) return DTK_OK;
+    DTK_LAUNCH("tapvid_counts", tapvid_counts_kernel, dim3(dtk_cdiv((long long)N * T, 256)), dim3(256), 0, st, pred_tracks,
+               pred_occluded, gt_tracks, gt_occluded, query_frame, pred_scale_x, pred_scale_y, gt_scale_x, gt_scale_y,
+               first_mode, N, T, counts18);
+    return DTK_OK;
+}

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <utility>
 #include "common.h"
+#include "vit_attention2.h"
 
 namespace {
 

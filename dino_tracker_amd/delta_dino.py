@@ -60,6 +60,12 @@ def refine_video_packed(delta_dino, video: torch.Tensor, dino_thwc: torch.Tensor
     return _refine(delta_dino, video, dino_thwc, g)[0]
 
 
+def refine_packed_subset(delta_dino, frames: torch.Tensor, dino_thwc: torch.Tensor, g: Geom) -> torch.Tensor:
+    """A frame subset, token-major in and out: frames [n,3,H,W], dino [n, HW, C] -> refined [n, HW, C]."""
+    gg = make_geom(frames.shape[0], g.C, g.video_h, g.video_w, g.patch, g.stride, g.radius)
+    return _refine(delta_dino, frames.to(torch.float32), dino_thwc.contiguous(), gg)[0]
+
+
 def refine_frames(delta_dino, frames: torch.Tensor, dino_chw: torch.Tensor, g: Geom) -> torch.Tensor:
     """Arbitrary frame subset in the reference layout: frames [n,3,H,W], dino [n,C,h,w] -> refined [n,C,h,w]."""
     n = frames.shape[0]

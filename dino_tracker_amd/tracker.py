@@ -199,6 +199,17 @@ class Tracker(nn.Module):
         # move_dino_to_cpu was a memory knob of the reference (two fp32 copies of the volume); the raw volume stays
         # on the device here because Tracker.forward(use_raw_features=True) reads it in place.
 
+    @torch.no_grad()
+    def set_refined_packed(self, refined_thwc: torch.Tensor):
+        """Install a refined volume that is already token-major [T, ph*pw, C] on the device (e.g. all-gathered from the
+        ranks that refined a slice of the frames each, sharding.query_parallel)."""
+        if tuple(refined_thwc.shape) != (self.geom.T, self.geom.ph * self.geom.pw, self.geom.C):
+            raise RuntimeError(f"set_refined_packed: {tuple(refined_thwc.shape)} != (T, tokens, C)")
+        self._refined = refined_thwc.to(self.device, torch.float32).contiguous()
+        self._refined_norms = ops.feature_norms(self._refined)
+        self._refined_f16 = self._refined_chw = None
+        self._refined_key = self._delta_key()
+
     def _delta_key(self):
         from .delta_dino import weights_key
         return weights_key(self.delta_dino, self.device)

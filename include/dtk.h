@@ -228,6 +228,18 @@ int dtk_build_anchor_sources(const float* cs, float anchor_th, int N, int T, int
 int dtk_occlusion(const float* green, const int32_t* pair_off, const int32_t* pair_frame, const float* traj,
                   const float* cs, float anchor_th, float cos_th, uint8_t* occ, int N, int T, void* stream);
 
+/* ---- TAP-Vid metric counts (eval/metrics.py:7-147 for one video) ----------------------------------
+ * pred_tracks / gt_tracks [N][T][2] f32 (x, y), *_occluded [N][T] (uint8 0/1), query_frame [N]; coordinates are scaled
+ * to the 256 x 256 evaluation raster by the four factors first (eval/metrics.py:204-211).  first_mode = 0: 'strided'
+ * queries (every frame but the query frame is evaluated), 1: 'first'.  counts18 (device, uint64):
+ * [0] evaluated, [1] occlusion agreements, [2] visible, then for thresholds 1, 2, 4, 8, 16 px:
+ * [3+3i] within & visible, [4+3i] true positives, [5+3i] false positives.  The host turns them into
+ * occlusion_accuracy, pts_within_*, jaccard_* and their averages (dino_tracker_amd/tapvid.py). */
+int dtk_tapvid_counts(const float* pred_tracks, const uint8_t* pred_occluded, const float* gt_tracks,
+                      const uint8_t* gt_occluded, const int32_t* query_frame, float pred_scale_x, float pred_scale_y,
+                      float gt_scale_x, float gt_scale_y, int first_mode, int N, int T, unsigned long long* counts18,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,9 +9,13 @@ Pinning status (see tests/test_oracle_vs_reference.py and tests/golden/):
     fixtures written by tests/golden/make_golden.py from that reference.
   * DeltaDINO / align_cnn_vit_features: PINNED against the reference modules, with `antialiased_cnns.BlurPool`
     being a restatement itself (oracle/shims/antialiased_cnns) -- BlurPool is "parity unpinned".
-  * DINOv2 encoder: upstream facebookresearch/dinov2 is un-vendored (torch.hub, network) => the block
-    arithmetic is restated from its published definition and cross-checked against the independent
-    `transformers.Dinov2Model` port (blocks only).  "parity unpinned" for the encoder.
+  * DINOv2 encoder: upstream facebookresearch/dinov2 is un-vendored (torch.hub, network).  Everything the
+    REFERENCE does around the network (models/extractor.py:23-150: stride surgery, `_fix_pos_enc`, hooks, layer
+    mean, qkv facets; utils.py:33-72: normalisation, CLS removal, layout) is PINNED: tests/golden/p1_small.npz is
+    written by the un-modified VitExtractor / get_dino_features_video running on a DINOv2-API module
+    (oracle/shims/dinov2_stub) and `vit_tokens` / `vit_all_tokens` / `vit_qkv` reproduce it.  The block arithmetic
+    INSIDE that module is restated from upstream's published definition and cross-checked against the independent
+    `transformers.Dinov2Model` port: "parity unpinned" for the blocks themselves.
 
 All citations are file:line in /root/reference.
 """
@@ -140,14 +144,28 @@ def tracker_head(x: torch.Tensor, head: Dict[str, torch.Tensor], video_h: int, v
 def track(src: torch.Tensor, feats: torch.Tensor, tgt: torch.Tensor, head: Dict[str, torch.Tensor], video_h: int,
           video_w: int, patch: int = 14, stride: int = 7, chunk: int = 64) -> torch.Tensor:
     """Track source embeddings src [M,C] into frames tgt [M] of feats [T,C,h,w]; returns pixel (x,y) [M,2]
-    (models/tracker.py:171-180 + model_inference.py:52 un-normalisation)."""
-    outs = []
-    for i in range(0, src.shape[0], chunk):
-        s = src[i:i + chunk]
-        x = F.relu(cosine_maps(s, feats[tgt[i:i + chunk].long()]))
-        o = tracker_head(x, head, video_h, video_w, patch, stride)
-        outs.append(torch.stack([(o[:, 0] + 1) / 2 * (video_w - 1), (o[:, 1] + 1) / 2 * (video_h - 1)], dim=1))
-    return torch.cat(outs) if outs else src.new_zeros((0, 2))
+    (models/tracker.py:171-180 + model_inference.py:52 un-normalisation).  Sources are grouped by target frame so
+    that each frame's maps are one matrix product (the same sums as `cosine_maps`, which gathers a frame per source)."""
+    m = src.shape[0]
+    out = src.new_zeros((m, 2))
+    if m == 0:
+        return out
+    _, c, h, w = feats.shape
+    order = torch.argsort(tgt, stable=True)
+    frames, counts = torch.unique_consecutive(tgt[order], return_counts=True)
+    snorm = src.norm(dim=1)
+    pos = 0
+    for f, n in zip(frames.tolist(), counts.tolist()):
+        idx = order[pos:pos + n]
+        pos += n
+        fr = feats[f].reshape(c, h * w)
+        fnorm = fr.norm(dim=0)
+        for i in range(0, n, chunk):
+            ii = idx[i:i + chunk]
+            x = (src[ii] @ fr) / (snorm[ii, None] * fnorm[None]).clamp(min=EPS)
+            o = tracker_head(F.relu(x).reshape(-1, h, w), head, video_h, video_w, patch, stride)
+            out[ii] = torch.stack([(o[:, 0] + 1) / 2 * (video_w - 1), (o[:, 1] + 1) / 2 * (video_h - 1)], dim=1)
+    return out
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -286,12 +304,14 @@ def vit_pos_embed(sd: Dict[str, torch.Tensor], h0: int, w0: int) -> torch.Tensor
     return torch.cat([pe[:, :1], grid], dim=1)
 
 
-def vit_block(x: torch.Tensor, sd: Dict[str, torch.Tensor], i: int, heads: int) -> torch.Tensor:
-    """DINOv2 NestedTensorBlock at eval: x += g1*proj(MHSA(LN1 x)); x += g2*fc2(GELU(fc1(LN2 x))); LN eps 1e-6."""
+def vit_block(x: torch.Tensor, sd: Dict[str, torch.Tensor], i: int, heads: int, return_qkv: bool = False):
+    """DINOv2 NestedTensorBlock at eval: x += g1*proj(MHSA(LN1 x)); x += g2*fc2(GELU(fc1(LN2 x))); LN eps 1e-6.
+    return_qkv: also the output of attn.qkv [B,S,3D] (what the reference's qkv hook records, extractor.py:107-118)."""
     p = f"blocks.{i}."
     b, s, d = x.shape
     y = F.layer_norm(x, (d,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps=1e-6)
-    qkv = F.linear(y, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]).reshape(b, s, 3, heads, d // heads)
+    qkv_flat = F.linear(y, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"])
+    qkv = qkv_flat.reshape(b, s, 3, heads, d // heads)
     q, k, v = qkv.permute(2, 0, 3, 1, 4)
     a = F.scaled_dot_product_attention(q, k, v)
     a = a.transpose(1, 2).reshape(b, s, d)
@@ -299,28 +319,85 @@ def vit_block(x: torch.Tensor, sd: Dict[str, torch.Tensor], i: int, heads: int) 
     y = F.layer_norm(x, (d,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps=1e-6)
     y = F.linear(F.gelu(F.linear(y, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])), sd[p + "mlp.fc2.weight"],
                  sd[p + "mlp.fc2.bias"])
-    return x + sd[p + "ls2.gamma"] * y
+    out = x + sd[p + "ls2.gamma"] * y
+    return (out, qkv_flat) if return_qkv else out
 
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)  # utils.py:46
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
-def vit_tokens(frame: torch.Tensor, sd: Dict[str, torch.Tensor], model_name: str, layer: Optional[int] = None,
-               stride: int = 7, patch: int = 14, normalize: bool = True) -> torch.Tensor:
-    """get_dino_features_video for one frame, facet 'tokens' (utils.py:54-67, models/extractor.py:137-150):
-    frame [1,3,H,W] in [0,1] -> block-`layer` output without CLS, laid out [C, ph, pw]."""
+def vit_all_tokens(frame: torch.Tensor, sd: Dict[str, torch.Tensor], model_name: str, layer: Optional[int] = None,
+                   stride: int = 7, patch: int = 14, normalize: bool = True, return_qkv: bool = False):
+    """VitExtractor.get_feature_from_input(img, [layer]) (models/extractor.py:137-150) for frames [B,3,H,W] in [0,1]
+    (normalize=True applies utils.py:46 first): block-`layer` output [B, 1+ph*pw, D], CLS first; with return_qkv also
+    the qkv record of that block [B, 1+ph*pw, 3D]."""
     cfg = VIT_CONFIGS[model_name]
     layer = cfg["depth"] - 1 if layer is None else layer
     x = frame
     if normalize:
-        m = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
-        s = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+        m = torch.tensor(IMAGENET_MEAN, dtype=frame.dtype).view(1, 3, 1, 1)
+        s = torch.tensor(IMAGENET_STD, dtype=frame.dtype).view(1, 3, 1, 1)
         x = (x - m) / s
     ph, pw = feature_grid(frame.shape[-2], frame.shape[-1], patch, stride)
     tok = F.conv2d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=stride)
     tok = tok.flatten(2).transpose(1, 2)
     tok = torch.cat([sd["cls_token"].expand(tok.shape[0], -1, -1), tok], dim=1) + vit_pos_embed(sd, ph, pw)
+    qkv = None
     for i in range(layer + 1):
-        tok = vit_block(tok, sd, i, cfg["heads"])
+        if return_qkv and i == layer:
+            tok, qkv = vit_block(tok, sd, i, cfg["heads"], return_qkv=True)
+        else:
+            tok = vit_block(tok, sd, i, cfg["heads"])
+    return (tok, qkv) if return_qkv else tok
+
+
+def vit_qkv(frame: torch.Tensor, sd: Dict[str, torch.Tensor], model_name: str, layer: int, normalize: bool = True):
+    """get_qkv_feature_from_input(img)[layer] (models/extractor.py:152-158): [B, 1+ph*pw, 3D]."""
+    return vit_all_tokens(frame, sd, model_name, layer, normalize=normalize, return_qkv=True)[1]
+
+
+def vit_tokens(frame: torch.Tensor, sd: Dict[str, torch.Tensor], model_name: str, layer: Optional[int] = None,
+               stride: int = 7, patch: int = 14, normalize: bool = True) -> torch.Tensor:
+    """get_dino_features_video for one frame, facet 'tokens' (utils.py:54-67, models/extractor.py:137-150):
+    frame [1,3,H,W] in [0,1] -> block-`layer` output without CLS, laid out [C, ph, pw]."""
+    ph, pw = feature_grid(frame.shape[-2], frame.shape[-1], patch, stride)
+    tok = vit_all_tokens(frame, sd, model_name, layer, stride, patch, normalize)
     return tok[0, 1:].reshape(ph, pw, -1).permute(2, 0, 1)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# TAP-Vid metrics (eval/metrics.py) -- numpy restatement, pinned against the reference in tests/test_oracle_vs_reference.py
+# --------------------------------------------------------------------------------------------------------------
+def tapvid_metrics(query_frames, gt_occluded, gt_tracks, pred_occluded, pred_tracks, pred_size, gt_size,
+                   query_mode: str = "strided") -> Dict[str, float]:
+    """compute_tapvid_metrics_for_video + compute_tapvid_metrics for one video (eval/metrics.py:7-147,204-223):
+    tracks [N,T,2] (x,y), flags [N,T], query_frames [N]; both track sets are scaled to the 256 x 256 raster in float32."""
+    import numpy as np
+    gt = np.array(gt_tracks, dtype=np.float32)
+    pr = np.array(pred_tracks, dtype=np.float32)
+    gt[..., 0] *= 256 / gt_size[0]
+    gt[..., 1] *= 256 / gt_size[1]
+    pr[..., 0] *= 256 / pred_size[0]
+    pr[..., 1] *= 256 / pred_size[1]
+    gocc = np.asarray(gt_occluded).astype(bool)
+    pocc = np.asarray(pred_occluded).astype(bool)
+    n, t = gocc.shape
+    ts = np.arange(t)[None, :]
+    qf = np.round(np.asarray(query_frames)).astype(np.int64)[:, None]
+    ev = (ts != qf) if query_mode == "strided" else (ts > qf)
+    vis, pvis = ~gocc, ~pocc
+    out = {"occlusion_accuracy": float(((pocc == gocc) & ev).sum() / ev.sum())}
+    d2 = np.square(pr - gt).sum(axis=-1)
+    jac, frac = [], []
+    for th in (1, 2, 4, 8, 16):
+        within = d2 < np.square(th)
+        correct = within & vis
+        frac.append(float((correct & ev).sum() / (vis & ev).sum()))
+        fp = ((~vis) & pvis) | ((~within) & pvis)
+        jac.append(float((correct & pvis & ev).sum() / ((vis & ev).sum() + (fp & ev).sum())))
+        out[f"pts_within_{th}"] = frac[-1]
+        out[f"jaccard_{th}"] = jac[-1]
+    out["average_jaccard"] = float(np.mean(jac))
+    out["average_pts_within_thresh"] = float(np.mean(frac))
+    return out

@@ -1,0 +1,74 @@
+"""End-to-end error of the bf16 ViT: video -> HIP ViT -> HIP Delta-DINO -> HIP infer, against the fp32 oracle run on the
+same VIDEO (oracle ViT -> oracle refine -> oracle infer).  north_star's 1e-3 px is stated on identical inputs; the
+P3 / P2 tests hold it on identical FEATURES, this script measures what the bf16 operands of P1 add on top.
+Writes gpurun_out/e2e_error.json (copied to profiles/ by hand).  Usage: python scripts/e2e_error.py [H W T nq]"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from dino_tracker_amd import ops, synth  # noqa: E402
+from dino_tracker_amd.dataset import RangeNormalizer  # noqa: E402
+from dino_tracker_amd.extractor import VitExtractor  # noqa: E402
+from dino_tracker_amd.model_inference import ModelInference  # noqa: E402
+from dino_tracker_amd.tracker import Tracker  # noqa: E402
+from oracle import ref_algo as A  # noqa: E402
+
+
+def run(H, W, T, nq, layerscale=0.1, seed=2000):
+    dev = "cuda:0"
+    name = "dinov2_vits14"
+    sd = synth.make_vit_weights(name, seed=2, layerscale=layerscale)
+    video = synth.synth_video(T, H, W, seed=seed)
+    head = synth.synth_head_weights(3)
+    delta = synth.synth_delta_dino_weights(384, seed=4)
+    queries = synth.grid_queries(nq, nq, H, W, 0, margin=min(60.0, H / 6))
+    ex = VitExtractor(name, stride=7, device=dev, state_dict=sd)
+    feat = ex.encode(video)
+    trk = Tracker(video=video.to(dev), dino_features=feat, dino_patch_size=14, stride=7, device=dev)
+    trk.tracker_head.load_state_dict(head)
+    trk.delta_dino.load_state_dict(delta)
+    trk.to(dev).eval()
+    mi = ModelInference(trk, RangeNormalizer((W, H, T), device=dev), 0.7, 0.6)
+    traj, occ = mi.infer(queries.to(dev))
+    t0 = time.time()
+    ph, pw = A.feature_grid(H, W)
+    dino = torch.stack([A.vit_tokens(video[t:t + 1], sd, name) for t in range(T)])
+    refined = A.refine_features(video, dino, delta)
+    rt, ro, rcs, _ = A.infer(refined, queries, head, H, W, return_aux=True)
+    dt = time.time() - t0
+    # feature-level error too
+    dfe = feat.cpu().reshape(T, ph, pw, -1).permute(0, 3, 1, 2)
+    rel = ((dfe - dino).norm() / dino.norm()).item()
+    # P3 on IDENTICAL features (the device's own refined volume through the oracle): isolates P1's contribution
+    rt_same, ro_same = A.infer(trk.refined_features.cpu(), queries, head, H, W)
+    err = (traj.cpu() - rt).norm(dim=-1).reshape(-1)
+    err_same = (traj.cpu() - rt_same).norm(dim=-1).reshape(-1)
+    q = torch.tensor([0.5, 0.9, 0.99, 1.0])
+    return {
+        "config": f"{W}x{H}x{T}, {nq * nq} queries, ViT-S/14 random weights (LayerScale {layerscale}), seed {seed}",
+        "feature_rel_err_P1": rel,
+        "px_err_vs_oracle_on_same_video": {"p50": err.quantile(q[0]).item(), "p90": err.quantile(q[1]).item(),
+                                           "p99": err.quantile(q[2]).item(), "max": err.max().item(),
+                                           "frac_le_1e-3": (err <= 1e-3).float().mean().item(),
+                                           "frac_le_1e-1": (err <= 1e-1).float().mean().item(),
+                                           "frac_le_1px": (err <= 1.0).float().mean().item()},
+        "px_err_vs_oracle_on_same_features": {"max": err_same.max().item()},
+        "occ_mismatch_same_video": int((occ.cpu() != ro).sum()), "occ_mismatch_same_features": int((occ.cpu() != ro_same).sum()),
+        "occ_total": int(ro.numel()), "anchors_oracle": int((rcs >= 0.7).sum()), "oracle_seconds": dt,
+    }
+
+
+if __name__ == "__main__":
+    a = [int(x) for x in sys.argv[1:5]] if len(sys.argv) >= 5 else [238, 322, 6, 4]
+    out = [run(*a)]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"e2e_error_{a[0]}x{a[1]}x{a[2]}.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out, indent=1))

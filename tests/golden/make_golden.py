@@ -78,8 +78,113 @@ def run_reference(cfg):
     return out
 
 
+# ---- P1: the reference's own VitExtractor / get_dino_features_video around a DINOv2-API stub --------------------------
+P1_CASE = dict(H=98, W=126, T=2, seed=74, model="dinov2_vits14")
+
+
+def p1_video():
+    return synth.synth_video(P1_CASE["T"], P1_CASE["H"], P1_CASE["W"], seed=P1_CASE["seed"])
+
+
+def p1_weights(layerscale):
+    return synth.make_vit_weights(P1_CASE["model"], seed=2, layerscale=layerscale)
+
+
+def run_reference_p1():
+    """models/extractor.py:23-150 + utils.py:33-72 un-modified; torch.hub.load is answered by oracle/shims/dinov2_stub
+    (upstream is un-vendored and needs the network) loaded with the seeded weights."""
+    R = ref_harness.load()
+    import dinov2_stub
+    video = p1_video()
+    name = P1_CASE["model"]
+    out = {}
+    orig = torch.hub.load
+    try:
+        for tag, ls in (("ls1", 1.0), ("ls01", 0.1)):
+            sd = p1_weights(ls)
+            torch.hub.load = lambda repo, model_name, *a, **k: dinov2_stub.build(model_name, sd)
+            with torch.no_grad():
+                out[f"tokens_{tag}_l11"] = R.utils.get_dino_features_video(
+                    video if tag == "ls1" else video[:1], model_name=name, facet="tokens", stride=7, layer=None,
+                    device="cpu").numpy()  # layer=None: the last block (utils.py:51)
+                if tag == "ls1":
+                    out["tokens_ls1_l3"] = R.utils.get_dino_features_video(
+                        video[:1], model_name=name, facet="tokens", stride=7, layer=3, device="cpu").numpy()
+                    out["keys_l3"] = R.utils.get_dino_features_video(
+                        video[:1], model_name=name, facet="keys", stride=7, layer=3, device="cpu").numpy()
+                    ex = R.extractor.VitExtractor(model_name=name, stride=7, device="cpu").eval()
+                    m = torch.tensor((0.485, 0.456, 0.406)).view(1, 3, 1, 1)
+                    sdev = torch.tensor((0.229, 0.224, 0.225)).view(1, 3, 1, 1)
+                    x = (video[:1] - m) / sdev
+                    out["feature_with_cls_l2_l5"] = ex.get_feature_from_input(x, layers=[2, 5]).numpy()  # mean over layers
+                    out["qkv_l1"] = ex.get_qkv_feature_from_input(x)[1].numpy()
+                    out["keys_self_sim_l1"] = ex.get_keys_self_sim_from_input(x, layer_num=1).numpy()
+    finally:
+        torch.hub.load = orig
+    return out
+
+
+# ---- configs 1 and 3: the reference's SCRIPTS, un-modified, on CPU ------------------------------------------------------
+def run_reference_scripts(only_cfg3=False):
+    """inference_grid.py (config 1) and inference_benchmark.py + eval/metrics.py (configs 3-4) of the reference, run as
+    __main__ through runpy with the CPU shims; their .npy outputs and the TAP-Vid metrics are the golden values the
+    `-m gpu` test compares the launcher-run HIP outputs with (tests/test_gpu_reference_scripts.py)."""
+    import runpy
+    import ref_scripts_data as D
+    R = ref_harness.load()
+    ref = ref_harness.REFERENCE_ROOT
+    out = {}
+    tmp = tempfile.mkdtemp()
+    argv0 = sys.argv
+    cwd = os.getcwd()
+    try:
+        os.chdir(ref)
+        if only_cfg3:  # keep the (slow) config-1 outputs of the existing fixture
+            old = np.load(os.path.join(OUT, "ref_scripts.npz"))
+            out["cfg1_traj"], out["cfg1_occ"] = old["cfg1_traj"], old["cfg1_occ"]
+        else:
+            d1 = D.build_data_dir(os.path.join(tmp, "cfg1"), ref, D.CFG1)
+            sys.argv = ["inference_grid.py", "--config", os.path.join(ref, "config", "train.yaml"), "--data-path", d1,
+                        "--interval", str(D.CFG1["interval"])]
+            runpy.run_path(os.path.join(ref, "inference_grid.py"), run_name="__main__")
+            out["cfg1_traj"] = np.load(os.path.join(d1, "grid_trajectories", "grid_trajectories.npy"))
+            out["cfg1_occ"] = np.load(os.path.join(d1, "grid_occlusions", "grid_occlusions.npy"))
+        d3 = D.build_data_dir(os.path.join(tmp, "cfg3"), ref, D.CFG3)
+        pkl = os.path.join(tmp, "tapvid_synth.pkl")
+        bench = D.build_tapvid_pickle(pkl, D.CFG3)
+        sys.argv = ["inference_benchmark.py", "--config", os.path.join(ref, "config", "train.yaml"), "--data-path", d3,
+                    "--benchmark-pickle-path", pkl, "--video-id", str(D.CFG3["video_idx"])]
+        runpy.run_path(os.path.join(ref, "inference_benchmark.py"), run_name="__main__")
+        for f in D.CFG3["query_frames"]:
+            out[f"cfg3_traj_{f}"] = np.load(os.path.join(d3, "trajectories", f"trajectories_{f}.npy"))
+            out[f"cfg3_occ_{f}"] = np.load(os.path.join(d3, "occlusions", f"occlusion_preds_{f}.npy"))
+        import eval.metrics as EM
+        m = EM.compute_tapvid_metrics_for_video(os.path.join(d3, "trajectories"), os.path.join(d3, "occlusions"), bench,
+                                                D.CFG3["video_idx"], pred_video_sizes=[854, 476])
+        out["cfg3_metric_names"] = np.array(sorted(m))
+        out["cfg3_metric_values"] = np.array([m[k] for k in sorted(m)], dtype=np.float64)
+    finally:
+        sys.argv = argv0
+        os.chdir(cwd)
+    return out
+
+
 if __name__ == "__main__":
-    names = sys.argv[1:] or list(CASES)
+    names = sys.argv[1:] or list(CASES) + ["p1_small"]
+    if "ref_scripts" in names or "ref_scripts_cfg3" in names:
+        only3 = "ref_scripts_cfg3" in names
+        names = [n for n in names if not n.startswith("ref_scripts")]
+        res = run_reference_scripts(only_cfg3=only3)
+        path = os.path.join(OUT, "ref_scripts.npz")
+        np.savez_compressed(path, **res)
+        print("ref_scripts", {k: v.shape for k, v in res.items()}, dict(zip(res["cfg3_metric_names"], res["cfg3_metric_values"])),
+              os.path.getsize(path) // 1024, "KiB")
+    if "p1_small" in names:
+        names.remove("p1_small")
+        res = run_reference_p1()
+        path = os.path.join(OUT, "p1_small.npz")
+        np.savez_compressed(path, **res)
+        print("p1_small", {k: v.shape for k, v in res.items()}, os.path.getsize(path) // 1024, "KiB")
     for name in names:
         res = run_reference(CASES[name])
         path = os.path.join(OUT, f"{name}.npz")

@@ -1,0 +1,321 @@
+"""-m gpu: parity evidence for the code paths bench.py times and for the public wrappers the round-1 tests skipped
+(VERDICT r1 "What's weak" 2): several rounds of the MFMA pipeline, the whole-map tier and the exact-redo tier
+at 67 x 121 / C = 384, the in-memory feature hand-off (dino_features= / set_video), C = 1024, the per-call API of the
+reference's Tracker, checkpoint round trips and cache invalidation.  Everything goes through the C-ABI; the oracle is
+oracle/ref_algo.py.  Tolerances (north_star): <= 1e-3 px, identical occlusion flags."""
+import os
+
+import pytest
+import torch
+
+from dino_tracker_amd import ops, synth
+from dino_tracker_amd._lib import make_geom
+from oracle import ref_algo as A
+
+pytestmark = pytest.mark.gpu
+H, W = 476, 854
+PX_TOL = 1e-3
+
+
+def _sources(feats, M, seed, T):
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.rand(M, 2, generator=g) * torch.tensor([W - 1.0, H - 1.0])
+    ts = torch.randint(0, T, (M,), generator=g)
+    tgt = torch.randint(0, T, (M,), generator=g)
+    return A.sample_bilinear(feats, pts, ts, H, W), tgt
+
+
+@pytest.fixture(scope="module")
+def full384():
+    T, C = 4, 384
+    feats = synth.synth_features(T, C, 67, 121, seed=61)
+    head = synth.synth_head_weights(3)
+    return T, C, feats, head
+
+
+def _tracker(feats, head, method=ops.TRACK_MFMA, T=None):
+    from gpu_util import make_tracker
+    T = feats.shape[0] if T is None else T
+    return make_tracker(torch.zeros(T, 3, H, W), feats, head, method=method)
+
+
+def test_several_rounds_of_the_mfma_pipeline(full384):
+    """bench.py's anchor stage runs 16 rounds of 524 288 sources; here the round is shrunk to 512 sources through
+    dtk_track_opts.round_sources so that 1 900 sources take 4 rounds (the last one ragged), unsorted target order."""
+    T, C, feats, head = full384
+    M = 1900
+    src, tgt = _sources(feats, M, 7, T)
+    ref = A.track(src, feats, tgt, head, H, W)
+    trk = _tracker(feats, head)
+    outs = {}
+    for rounds in (0, 512):
+        trk.track_round_sources = rounds
+        trk._workspace = None
+        out = torch.full((M, 2), float("nan"), device="cuda")
+        trk.track_sources(trk.features(), src.cuda().contiguous(), None, tgt.int().cuda(), None, out, M)
+        st = trk.last_track_stats
+        assert st["sources"] == M and st["syncs"] >= 1
+        outs[rounds] = out.cpu()
+        err = (outs[rounds] - ref).abs().max(dim=1).values
+        assert torch.isfinite(outs[rounds]).all() and err.max() < PX_TOL, (rounds, err.argmax(), err.max())
+    assert torch.equal(outs[0], outs[512])  # the round size is not visible in the results
+
+
+def test_whole_map_tier_at_full_resolution(full384):
+    """Tier 2 (fp16 maps + head16 whole-map refiner statistics): never reached by the benign benchmark weights, so it is
+    forced through dtk_track_opts.tier; 67 x 121, C = 384, two rounds."""
+    T, C, feats, head = full384
+    M = 700
+    src, tgt = _sources(feats, M, 8, T)
+    ref = A.track(src, feats, tgt, head, H, W)
+    trk = _tracker(feats, head)
+    trk.track_tier = ops.TIER_WHOLE_MAP
+    trk.track_round_sources = 512
+    out = torch.full((M, 2), float("nan"), device="cuda")
+    trk.track_sources(trk.features(), src.cuda().contiguous(), None, tgt.int().cuda(), None, out, M)
+    st = trk.last_track_stats
+    assert st["whole_map_tier"] == M
+    err = (out.cpu() - ref).abs().max(dim=1).values
+    assert err.max() < PX_TOL, (err.argmax(), err.max(), st)
+
+
+def test_whole_map_tier_with_fallback_weights():
+    """Ill-conditioned refiner (|logits| ~ 100): the zero-mass fallback of tracker_head.py:86-94 does fire, which the
+    certificate must refuse and tiers 2 / 3 must reproduce."""
+    T, C = 3, 384
+    feats = synth.synth_features(T, C, 67, 121, seed=62)
+    head = synth.synth_head_weights(5, benign=False)
+    M = 300
+    src, tgt = _sources(feats, M, 9, T)
+    x = torch.relu(A.cosine_maps(src, feats[tgt]))
+    _, _, _, fb = A.tracker_head(x, head, H, W, return_aux=True)
+    ref = A.track(src, feats, tgt, head, H, W)
+    trk = _tracker(feats, head)
+    out = torch.full((M, 2), float("nan"), device="cuda")
+    trk.track_sources(trk.features(), src.cuda().contiguous(), None, tgt.int().cuda(), None, out, M)
+    st = trk.last_track_stats
+    err = (out.cpu() - ref).abs().max(dim=1).values
+    print("fallback sources in the oracle:", int(fb.sum()), "tiers:", st, "max err", err.max().item())
+    assert st["whole_map_tier"] + st["exact_tier"] >= int(fb.sum())  # no fallback source may have been certified
+    assert err.max() < 2e-3, (err.argmax(), err.max())  # (fp32 oracle itself is 4e-6 normalised units from fp64 here)
+
+
+def test_exact_redo_tier_at_full_resolution(full384):
+    """Tier 3: sources the fp16 pass cannot decide.  Crafted: (a) a 4 x 5 block of IDENTICAL cells equal to the source
+    (20 exact ties > the 10 candidates a record holds; torch.argmax = lowest index), (b) negated sources (non-positive
+    maximum), (c) a zero source."""
+    T, C, feats, head = full384
+    feats = feats.clone()
+    M = 600
+    src, tgt = _sources(feats, M, 10, T)
+    v = feats[2, :, 30, 40].clone()
+    feats[1, :, 10:14, 50:55] = v[:, None, None]
+    src[:40] = v
+    tgt[:40] = 1
+    src[40:80] = -src[40:80]
+    src[80] = 0.0
+    ref = A.track(src, feats, tgt, head, H, W)
+    trk = _tracker(feats, head)
+    trk.track_round_sources = 256
+    out = torch.full((M, 2), float("nan"), device="cuda")
+    trk.track_sources(trk.features(), src.cuda().contiguous(), None, tgt.int().cuda(), None, out, M)
+    st = trk.last_track_stats
+    assert st["exact_tier"] >= 40, st
+    err = (out.cpu() - ref).abs().max(dim=1).values
+    assert err.max() < PX_TOL, (err.argmax(), err.max(), st)
+
+
+def test_feature_handoff_and_set_video(full384):
+    """What bench.py does: Tracker(dino_features=<token-major volume from the extractor>) and set_video() for the next
+    video, instead of the dino_embed_video.pt round trip.  Same results as the file path, bit for bit."""
+    from gpu_util import make_inference
+    from dino_tracker_amd.tracker import Tracker
+    T, C, feats, head = full384
+    delta = synth.synth_delta_dino_weights(C, seed=4)
+    video = synth.synth_video(T, H, W, seed=90)
+    queries = synth.grid_queries(3, 2, H, W, 1)
+    from gpu_util import make_tracker
+    a = make_tracker(video, feats, head, delta=delta, method=ops.TRACK_MFMA)
+    ta, oa = make_inference(a, H, W, T).infer(queries.cuda())
+    thwc = feats.permute(0, 2, 3, 1).reshape(T, 67 * 121, C).contiguous().cuda()
+    b = Tracker(video=video.cuda(), dino_features=thwc, dino_patch_size=14, stride=7, device="cuda:0",
+                track_method=ops.TRACK_MFMA)
+    b.tracker_head.load_state_dict(head)
+    b.delta_dino.load_state_dict(delta)
+    b.to("cuda:0").eval()
+    mb = make_inference(b, H, W, T)
+    tb, ob = mb.infer(queries.cuda())
+    assert torch.equal(ta, tb) and torch.equal(oa, ob)
+    # against the oracle, end to end over P2 + P3
+    refined = A.refine_features(video, feats, delta)
+    rt, ro = A.infer(refined, queries, head, H, W)
+    assert (tb.cpu() - rt).abs().max() < PX_TOL and torch.equal(ob.cpu(), ro)
+    # next video through set_video(): everything derived from the old one must be dropped
+    feats2 = synth.synth_features(T, C, 67, 121, seed=63)
+    video2 = synth.synth_video(T, H, W, seed=91)
+    b.set_video(video2.cuda(), feats2.permute(0, 2, 3, 1).reshape(T, 67 * 121, C).contiguous().cuda())
+    b.cache_refined_embeddings()
+    t2, o2 = mb.infer(queries.cuda())
+    r2 = A.refine_features(video2, feats2, delta)
+    rt2, ro2 = A.infer(r2, queries, head, H, W)
+    assert (t2.cpu() - rt2).abs().max() < PX_TOL and torch.equal(o2.cpu(), ro2)
+
+
+def test_infer_at_c1024():
+    """The reference's own configuration is ViT-L (C = 1024, config/preprocessing.yaml:10-13): the tracker takes the tiled
+    correlation kernels there.  Both methods vs the oracle at 67 x 121."""
+    from gpu_util import make_inference
+    T, C = 4, 1024
+    feats = synth.synth_features(T, C, 67, 121, seed=64)
+    head = synth.synth_head_weights(3)
+    queries = torch.cat([synth.grid_queries(3, 2, H, W, 0), synth.grid_queries(2, 1, H, W, 2)])
+    rt, ro, rcs, _ = A.infer(feats, queries, head, H, W, return_aux=True)
+    for method in (ops.TRACK_EXACT, ops.TRACK_MFMA):
+        trk = _tracker(feats, head, method=method)
+        mi = make_inference(trk, H, W, T)
+        traj, occ = mi.infer(queries.cuda())
+        assert (traj.cpu() - rt).abs().max() < PX_TOL, method
+        assert torch.equal(occ.cpu(), ro), method
+
+
+# ---- the reference's per-call API ------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def small():
+    Hs, Ws, T, C = 140, 210, 5, 32
+    feats = synth.synth_features(T, C, 19, 29, seed=65)
+    head = synth.synth_head_weights(3)
+    delta = synth.synth_delta_dino_weights(C, seed=6)
+    video = synth.synth_video(T, Hs, Ws, seed=92)
+    from gpu_util import make_tracker
+    trk = make_tracker(video, feats, head, delta=delta, method=ops.TRACK_EXACT, cache=False)
+    return Hs, Ws, T, C, feats, head, delta, video, trk
+
+
+def test_sampling_wrappers(small):
+    """normalize_points_for_sampling (tracker.py:77-94), sample_embeddings (:96-111), utils.bilinear_interpolate_video
+    (utils.py:75-101) vs their literal restatements, incl. out-of-frame points and a fractional t."""
+    from dino_tracker_amd.utils import bilinear_interpolate_video
+    Hs, Ws, T, C, feats, head, delta, video, trk = small
+    g = torch.Generator().manual_seed(3)
+    pts = torch.cat([torch.rand(64, 2, generator=g) * torch.tensor([Ws + 20.0, Hs + 20.0]) - 10.0,
+                     torch.randint(0, T, (64, 1), generator=g).float()], dim=1)
+    pn = trk.normalize_points_for_sampling(pts.cuda())
+    assert torch.equal(pn.cpu(), A.points_to_grid_coords(pts, Hs, Ws))
+    ref = A.sample_embeddings_literal(feats, A.points_to_grid_coords(pts, Hs, Ws))
+    got = trk.sample_embeddings(feats.cuda(), pn)
+    assert (got.cpu() - ref).abs().max() < 2e-5
+    # cached refined volume is sampled in place
+    trk.cache_refined_embeddings()
+    refined = A.refine_features(video, feats, delta)
+    got = trk.sample_embeddings(trk.refined_features, pn)
+    assert (got.cpu() - A.sample_embeddings_literal(refined, A.points_to_grid_coords(pts, Hs, Ws))).abs().max() < 1e-4
+    # the utils function with its normalisation switches and a fractional time coordinate
+    vol = feats.permute(1, 0, 2, 3)[None]
+    p2 = torch.cat([torch.rand(32, 1, generator=g) * 28, torch.rand(32, 1, generator=g) * 18,
+                    torch.rand(32, 1, generator=g) * (T - 1)], dim=1)
+    import torch.nn.functional as F
+    samples = p2[None, None, :, None].clone()
+    samples[..., 0] = samples[..., 0] / 28 * 2 - 1
+    samples[..., 1] = samples[..., 1] / 18 * 2 - 1
+    samples[..., 2] = samples[..., 2] / (T - 1) * 2 - 1
+    ref2 = F.grid_sample(vol, samples, align_corners=True, padding_mode="border")
+    got2 = bilinear_interpolate_video(vol.cuda(), p2.cuda(), h=19, w=29, t=T, normalize_h=True, normalize_w=True)
+    assert got2.shape == ref2.shape and (got2.cpu() - ref2).abs().max() < 2e-5
+
+
+def test_corr_maps_and_point_predictions(small):
+    """get_corr_maps_for_frame_set / get_point_predictions_from_embeddings / get_point_predictions (tracker.py:158-180)."""
+    Hs, Ws, T, C, feats, head, delta, video, trk = small
+    g = torch.Generator().manual_seed(4)
+    B = 9
+    src = torch.randn(B, C, generator=g)
+    tgt = torch.randint(0, T, (B,), generator=g)
+    maps = trk.get_corr_maps_for_frame_set(src.cuda(), feats.cuda(), tgt.cuda())
+    ref = A.cosine_maps(src, feats[tgt])
+    assert maps.shape == (B, 1, 19, 29) and (maps[:, 0].cpu() - ref).abs().max() < 2e-6
+    assert (maps < 0).any()  # no ReLU here: the reference applies cmap_relu afterwards (tracker.py:173)
+    coords = trk.get_point_predictions_from_embeddings(src.cuda(), feats.cuda(), tgt.cuda())
+    assert (coords.cpu() - A.tracker_head(torch.relu(ref), head, Hs, Ws)).abs().max() < 3e-6
+    pts = torch.cat([torch.rand(B, 2, generator=g) * torch.tensor([Ws - 1.0, Hs - 1.0]), torch.zeros(B, 1)], dim=1)
+    sfi = torch.randint(0, T, (B,), generator=g)
+    inp = (pts.cuda(), sfi.cuda(), tgt.cuda(), torch.arange(T).cuda())
+    got = trk.get_point_predictions(inp, feats.cuda())
+    emb = A.sample_bilinear(feats, pts[:, :2], sfi, Hs, Ws)
+    want = A.tracker_head(torch.relu(A.cosine_maps(emb, feats[tgt])), head, Hs, Ws)
+    assert (got.cpu() - want).abs().max() < 3e-6
+
+
+def test_module_forwards_run_on_the_device(small):
+    """DeltaDINO.forward (delta_dino.py:53-61) and NormalizedConv2d.forward (conv_norm.py:42-46) are the kernels too."""
+    import torch.nn.functional as F
+    Hs, Ws, T, C, feats, head, delta, video, trk = small
+    res = trk.delta_dino(video[:2].cuda(), feats[:2].cuda())
+    ref = A.align_to_vit_grid(A.delta_dino_cnn(video[:2], delta), 19, 29)
+    assert res.shape == ref.shape and (res.cpu() - ref).abs().max() < 3e-5
+    conv = trk.tracker_head.cnn_refiner[0]
+    x = torch.rand(3, 1, 19, 29)
+    y = conv(x.cuda())
+    want = F.conv2d(x, A.normalized_conv_weight(head["cnn_refiner.0.weight"]), head["cnn_refiner.0.bias"], padding=1)
+    assert (y.cpu() - want).abs().max() < 1e-5
+    conv2 = trk.tracker_head.cnn_refiner[2]
+    h = torch.rand(2, 16, 19, 29)
+    want2 = F.conv2d(h, A.normalized_conv_weight(head["cnn_refiner.2.weight"]), head["cnn_refiner.2.bias"], padding=1)
+    assert (conv2(h.cuda()).cpu() - want2).abs().max() < 1e-5
+
+
+def test_per_query_helpers_and_raw_features(small):
+    """generate_trajectory_input / generate_trajectory / generate_trajectories (model_inference.py:8-74) and
+    Tracker.forward(use_raw_features=True)."""
+    from dino_tracker_amd.dataset import RangeNormalizer
+    from dino_tracker_amd.model_inference import ModelInference, generate_trajectories, generate_trajectory
+    Hs, Ws, T, C, feats, head, delta, video, trk = small
+    rn = RangeNormalizer(shapes=(Ws, Hs, T), device="cuda:0")
+    mi = ModelInference(trk, rn, 0.7, 0.6)
+    queries = synth.grid_queries(2, 2, Hs, Ws, 1, margin=20.0).cuda()
+    batched = mi.compute_trajectories(queries)
+    one = generate_trajectory(queries[0], trk.video, trk, rn, batch_size=2)  # chunked like model_inference.py:45-49
+    assert one.shape == (T, 3) and (one - batched[0]).abs().max() < 1e-4
+    allq = generate_trajectories(queries, trk.video, trk, rn)
+    assert (allq - batched).abs().max() < 1e-4
+    raw = generate_trajectory(queries[0], trk.video, trk, rn, use_raw_features=True)
+    q = queries[0].cpu()
+    emb = A.sample_bilinear(feats, q[None, :2], q[2:3].long(), Hs, Ws)
+    want = A.track(emb.expand(T, -1).contiguous(), feats, torch.arange(T), head, Hs, Ws)
+    assert (raw[:, :2].cpu() - want).abs().max() < PX_TOL
+
+
+def test_checkpoint_round_trip_invalidates_refined_cache(small, tmp_path):
+    """save_weights / load_weights (tracker.py:144-156) with the reference's file names and keys; a cached refined
+    volume must not survive a Delta-DINO weight change (forward() -> load_weights() -> ModelInference())."""
+    from gpu_util import make_inference
+    Hs, Ws, T, C, feats, head, delta, video, trk = small
+    trk.ckpt_path = str(tmp_path)
+    trk.save_weights(7)
+    assert sorted(os.listdir(tmp_path)) == ["delta_dino_7.pt", "tracker_head_7.pt"]
+    sd = torch.load(tmp_path / "delta_dino_7.pt")
+    assert set(sd) == set(delta) and "layers.3.filt" in sd
+    queries = synth.grid_queries(2, 2, Hs, Ws, 0, margin=20.0)
+    mi = make_inference(trk, Hs, Ws, T)
+    t_old, _ = mi.infer(queries.cuda())
+    # other weights on disk under the same names
+    delta2 = synth.synth_delta_dino_weights(C, seed=16)
+    head2 = synth.synth_head_weights(4)
+    torch.save(delta2, tmp_path / "delta_dino_9.pt")
+    torch.save(head2, tmp_path / "tracker_head_9.pt")
+    trk.load_weights(9)
+    assert trk.refined_features is None  # dropped, not reused
+    mi2 = make_inference(trk, Hs, Ws, T)
+    t_new, o_new = mi2.infer(queries.cuda())
+    rt, ro = A.infer(A.refine_features(video, feats, delta2), queries, head2, Hs, Ws)
+    assert (t_new.cpu() - rt).abs().max() < PX_TOL and torch.equal(o_new.cpu(), ro)
+    assert (t_new - t_old).abs().max() > 1e-2
+    # in-place weight edit (an optimiser step) is noticed through the parameter versions
+    with torch.no_grad():
+        trk.delta_dino.layers[12].weight.mul_(0.5)
+    assert trk.refined_is_stale()
+    t3, _ = make_inference(trk, Hs, Ws, T).infer(queries.cuda())
+    d3 = {k: v.clone() for k, v in delta2.items()}
+    d3["layers.12.weight"] = d3["layers.12.weight"] * 0.5
+    rt3, _ = A.infer(A.refine_features(video, feats, d3), queries, head2, Hs, Ws)
+    assert (t3.cpu() - rt3).abs().max() < PX_TOL
+    trk.load_weights(7)  # restore for the other tests of this module

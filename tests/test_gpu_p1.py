@@ -55,25 +55,19 @@ def test_patch_embedding_is_fp32_grade(vits, shape):
         assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
-def test_weight_stationary_gemm_matches_tiled_gemm(tmp_path):
-    """The K = 384 GEMMs (QKV, projection, fc1) run on the weight-stationary kernel; DTK_DEBUG bit 262144 sends them to
-    the tiled kernel instead.  Both use bf16 operands, so after all 12 blocks the features must agree far more closely
-    than either agrees with the fp32 oracle (differences: accumulation order, erf polynomial vs erff)."""
-    import os, subprocess, sys
-    code = ("import sys, torch; sys.path.insert(0, '.')\n"
-            "from dino_tracker_amd import synth\n"
-            "from dino_tracker_amd.extractor import VitExtractor\n"
-            "sd = synth.make_vit_weights('dinov2_vits14', seed=2, layerscale=0.1)\n"
-            "ex = VitExtractor('dinov2_vits14', stride=7, device='cuda:0', state_dict=sd)\n"
-            "torch.save(ex.encode(synth.synth_video(2, 140, 210, seed=78)).cpu(), sys.argv[1])\n")
-    outs = []
-    for flag in ("0", "262144"):
-        out = str(tmp_path / f"feat_{flag}.pt")
-        env = dict(os.environ, DTK_DEBUG=flag)
-        subprocess.run([sys.executable, "-c", code, out], check=True, env=env,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        outs.append(torch.load(out))
-    _check(outs[0], outs[1], cos_min=0.9999, rel_max=1e-2)
+def test_weight_stationary_gemm_matches_tiled_gemm():
+    """The K = 384 GEMMs (QKV, projection, fc1) run on the weight-stationary kernel; dtk_vit_model.flags =
+    DTK_VIT_TILED_GEMMS sends them to the tiled kernel instead.  Both use bf16 operands, so after all 12 blocks the
+    features must agree far more closely than either agrees with the fp32 oracle (differences: accumulation order, erf
+    polynomial vs erff).  Run with the benchmark's LayerScale (0.1)."""
+    sd = synth.make_vit_weights("dinov2_vits14", seed=2, layerscale=0.1)
+    ex = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd)
+    video = synth.synth_video(2, 140, 210, seed=78)
+    a = ex.encode(video).cpu()
+    ex.tiled_gemms = True
+    b = ex.encode(video).cpu()
+    assert not torch.equal(a, b)  # two different kernels did run
+    _check(a, b, cos_min=0.9999, rel_max=1e-2)
 
 
 def test_full_resolution_first_blocks(vits):
@@ -130,3 +124,86 @@ def test_attention_large_logits_force_rescale():
     feat = ex.encode(video, layer=0)
     ref = A.vit_tokens(video, sd, "dinov2_vits14", layer=0).permute(1, 2, 0).reshape(-1, d)
     _check(feat[0], ref, cos_min=0.998, rel_max=3e-2)
+
+
+# ---- against the un-modified reference extractor (tests/golden/p1_small.npz, written by make_golden.py) -----------------
+def _gold():
+    import os
+    import numpy as np
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "p1_small.npz"))
+
+
+@pytest.mark.parametrize("tag,ls", [("ls1", 1.0), ("ls01", 0.1)])
+def test_tokens_match_reference_extractor_golden(tag, ls):
+    """utils.get_dino_features_video (reference signature) on the device vs the reference's own extractor code run on
+    the DINOv2-API stub; layer=None = last block.  bf16 operand tolerance, stated per token."""
+    import make_golden as MG
+    from dino_tracker_amd.utils import get_dino_features_video
+    gold = torch.from_numpy(_gold()[f"tokens_{tag}_l11"])
+    video = MG.p1_video()[:gold.shape[0]]
+    out = get_dino_features_video(video.cuda(), model_name=MG.P1_CASE["model"], facet="tokens", stride=7, layer=None,
+                                  device="cuda:0", state_dict=MG.p1_weights(ls))
+    assert out.shape == gold.shape and out.device.type == "cpu"
+    for t in range(gold.shape[0]):
+        cos, rel = _check(out[t].permute(1, 2, 0).reshape(-1, 384), gold[t].permute(1, 2, 0).reshape(-1, 384))
+        print(f"tokens {tag} frame {t}: min cos {cos:.6f} rel {rel:.2e}")
+
+
+def test_cls_row_and_layer_mean_match_reference_golden():
+    """get_feature_from_input(img, [2, 5]): mean over two hooked layers, CLS row included (models/extractor.py:137-150)."""
+    import make_golden as MG
+    gold = torch.from_numpy(_gold()["feature_with_cls_l2_l5"])
+    ex = VitExtractor(MG.P1_CASE["model"], stride=7, device="cuda:0", state_dict=MG.p1_weights(1.0))
+    m = torch.tensor(A.IMAGENET_MEAN).view(1, 3, 1, 1)
+    s = torch.tensor(A.IMAGENET_STD).view(1, 3, 1, 1)
+    x = ((MG.p1_video()[:1] - m) / s).cuda()
+    tok = ex.get_feature_from_input(x, layers=[2, 5]).cpu()
+    assert tok.shape == gold.shape
+    _check(tok[0], gold[0])
+    cls_err = (tok[0, 0] - gold[0, 0]).norm() / gold[0, 0].norm()
+    assert cls_err < 2e-2, cls_err  # the CLS token itself, not just "finite"
+
+
+def test_qkv_facets_match_reference_golden():
+    """a4: qkv record, key facet through utils.get_dino_features_video(facet='keys'), key self-similarity."""
+    import make_golden as MG
+    from dino_tracker_amd.utils import get_dino_features_video
+    g = _gold()
+    sd = MG.p1_weights(1.0)
+    ex = VitExtractor(MG.P1_CASE["model"], stride=7, device="cuda:0", state_dict=sd)
+    m = torch.tensor(A.IMAGENET_MEAN).view(1, 3, 1, 1)
+    s = torch.tensor(A.IMAGENET_STD).view(1, 3, 1, 1)
+    video = MG.p1_video()[:1]
+    x = ((video - m) / s).cuda()
+    qkv = ex.get_qkv_feature_from_input(x)
+    assert len(qkv) == 12
+    _check(qkv[1][0].cpu(), torch.from_numpy(g["qkv_l1"])[0], cos_min=0.9995, rel_max=2e-2)
+    keys = get_dino_features_video(video.cuda(), model_name=MG.P1_CASE["model"], facet="keys", stride=7, layer=3,
+                                   device="cuda:0", state_dict=sd)
+    gk = torch.from_numpy(g["keys_l3"])
+    assert keys.shape == gk.shape
+    _check(keys[0].permute(1, 2, 0).reshape(-1, 384), gk[0].permute(1, 2, 0).reshape(-1, 384), cos_min=0.9995)
+    q = ex.get_queries_from_input(x, layers=[1])
+    v = ex.get_values_from_input(x, layers=[1])
+    gq = torch.from_numpy(g["qkv_l1"]).reshape(1, 222, 3, 384)
+    _check(q[0].cpu(), gq[0, :, 0], cos_min=0.9995)
+    _check(v[0].cpu(), gq[0, :, 2], cos_min=0.9995)
+    ssim = ex.get_keys_self_sim_from_input(x, layer_num=1).cpu()
+    assert (ssim - torch.from_numpy(g["keys_self_sim_l1"])).abs().max() < 2e-2
+    attn = ex.get_attn_feature_from_input(x)[1]
+    assert attn.shape == (1, 6, 222, 222) and (attn.sum(-1) - 1).abs().max() < 1e-4
+    ref_attn = torch.softmax((gq[:, :, 0].reshape(1, 222, 6, 64).permute(0, 2, 1, 3) * 0.125)
+                             @ gq[:, :, 1].reshape(1, 222, 6, 64).permute(0, 2, 3, 1), dim=-1)
+    assert (attn.cpu() - ref_attn).abs().max() < 5e-3
+
+
+def test_full_resolution_all_blocks_bench_weights():
+    """476 x 854, all 12 blocks, the benchmark's weights (LayerScale 0.1) vs the fp32 oracle: the feature-level error
+    of the bf16 path on exactly what bench.py runs (one frame; the oracle's ViT costs ~1.6 TFLOP on the host)."""
+    sd = synth.make_vit_weights("dinov2_vits14", seed=2, layerscale=0.1)
+    ex = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd)
+    video = synth.synth_video(1, 476, 854, seed=2000)
+    feat = ex.encode(video)
+    ref = A.vit_tokens(video, sd, "dinov2_vits14").permute(1, 2, 0).reshape(-1, 384)
+    cos, rel = _check(feat[0], ref)
+    print(f"full-res 12 blocks, bench weights: min token cos {cos:.6f}, rel Frobenius {rel:.3e}")

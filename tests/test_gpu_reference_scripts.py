@@ -1,0 +1,163 @@
+"""-m gpu: the reference's SCRIPTS run un-modified on the HIP implementation (BASELINE.json configs 1, 3, 4).
+
+`python -m dino_tracker_amd.run <reference>/inference_grid.py ...` and `.../inference_benchmark.py ...` read the on-disk
+layout of utils.py:10-29, go through dino_tracker.DINOTracker -> models.tracker.Tracker -> models.model_inference
+(which the launcher resolves to overlay/ = this implementation) and write their .npy files; those are compared with
+tests/golden/ref_scripts.npz = the same scripts run on the REFERENCE'S OWN PyTorch code on CPU (make_golden.py
+ref_scripts).  TAP-Vid metrics come from the reference's eval/metrics.py on the files, and from the device-side
+dtk_tapvid_counts on the tensors (N2); both must equal the golden metrics.
+
+The reference checkout is not part of this repository and not on the GPU box: the tests run only when
+$DTK_REFERENCE_ROOT points at one (scripts/stage_reference.sh puts a scratch copy next to a gpurun call), and skip
+otherwise.  The parts that need no reference (N2 batching + device metrics vs the oracle) always run.
+"""
+import json
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("DTK_REFERENCE_ROOT", "")
+HAVE_REF = bool(REF) and os.path.isfile(os.path.join(REF, "inference_grid.py"))
+needs_ref = pytest.mark.skipif(not HAVE_REF, reason="$DTK_REFERENCE_ROOT does not point at a reference checkout")
+pytestmark = pytest.mark.gpu
+LOGDIR = os.path.join(ROOT, "gpurun_out", "ref_scripts")
+
+
+def _launch(script, args, log):
+    os.makedirs(LOGDIR, exist_ok=True)
+    cmd = [sys.executable, "-m", "dino_tracker_amd.run", "--path", os.path.join(ROOT, "oracle", "shims"),
+           os.path.join(REF, script)] + args
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=REF, timeout=1800)
+    with open(os.path.join(LOGDIR, log), "w") as fh:
+        fh.write("$ " + " ".join(cmd) + "\n" + r.stdout + "\n--- stderr ---\n" + r.stderr)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return r
+
+
+def _gold():
+    return np.load(os.path.join(ROOT, "tests", "golden", "ref_scripts.npz"))
+
+
+@needs_ref
+def test_config1_inference_grid_unmodified(tmp_path):
+    import ref_scripts_data as D
+    d = D.build_data_dir(str(tmp_path / "cfg1"), REF, D.CFG1)
+    _launch("inference_grid.py", ["--config", os.path.join(REF, "config", "train.yaml"), "--data-path", d,
+                                  "--interval", str(D.CFG1["interval"])], "cfg1_inference_grid.log")
+    traj = np.load(os.path.join(d, "grid_trajectories", "grid_trajectories.npy"))
+    occ = np.load(os.path.join(d, "grid_occlusions", "grid_occlusions.npy"))
+    g = _gold()
+    assert traj.shape == g["cfg1_traj"].shape and traj.shape[1:] == (D.CFG1["T"], 2) and traj.shape[0] >= 64
+    err = np.abs(traj - g["cfg1_traj"]).max()
+    mism = int((occ != g["cfg1_occ"]).sum())
+    with open(os.path.join(LOGDIR, "cfg1_result.json"), "w") as fh:
+        json.dump({"queries": int(traj.shape[0]), "frames": int(traj.shape[1]), "max_dxy_px_vs_reference_cpu": float(err),
+                   "occlusion_mismatches": mism, "occluded_fraction": float(g["cfg1_occ"].mean())}, fh)
+    assert err < 1e-3, err
+    assert mism == 0, mism
+
+
+@needs_ref
+def test_config3_inference_benchmark_and_metrics_unmodified(tmp_path):
+    import ref_scripts_data as D
+    d = D.build_data_dir(str(tmp_path / "cfg3"), REF, D.CFG3)
+    pkl = str(tmp_path / "tapvid_synth.pkl")
+    bench = D.build_tapvid_pickle(pkl, D.CFG3)
+    _launch("inference_benchmark.py", ["--config", os.path.join(REF, "config", "train.yaml"), "--data-path", d,
+                                       "--benchmark-pickle-path", pkl, "--video-id", str(D.CFG3["video_idx"])],
+            "cfg3_inference_benchmark.log")
+    g = _gold()
+    worst = 0.0
+    for f in D.CFG3["query_frames"]:
+        traj = np.load(os.path.join(d, "trajectories", f"trajectories_{f}.npy"))
+        occ = np.load(os.path.join(d, "occlusions", f"occlusion_preds_{f}.npy"))
+        worst = max(worst, float(np.abs(traj - g[f"cfg3_traj_{f}"]).max()))
+        assert np.array_equal(occ, g[f"cfg3_occ_{f}"]), f
+    assert worst < 1e-3, worst
+    # the reference's own scorer on the files this implementation wrote
+    code = ("import json, pickle, sys\nimport eval.metrics as EM\n"
+            "b = pickle.load(open(sys.argv[1], 'rb'))\n"
+            "m = EM.compute_tapvid_metrics_for_video(sys.argv[2] + '/trajectories', sys.argv[2] + '/occlusions', b, "
+            f"{D.CFG3['video_idx']}, pred_video_sizes=[854, 476])\nprint('METRICS ' + json.dumps(m))\n")
+    probe = tmp_path / "score.py"
+    probe.write_text(code)
+    r = subprocess.run([sys.executable, "-m", "dino_tracker_amd.run", "--path", os.path.join(ROOT, "oracle", "shims"),
+                        "--path", REF, str(probe), pkl, d], capture_output=True, text=True,
+                       env=dict(os.environ, PYTHONPATH=ROOT), cwd=REF, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("METRICS ")][0][8:])
+    want = dict(zip(g["cfg3_metric_names"].tolist(), g["cfg3_metric_values"].tolist()))
+    with open(os.path.join(LOGDIR, "cfg3_result.json"), "w") as fh:
+        json.dump({"max_dxy_px_vs_reference_cpu": worst, "metrics_hip": m, "metrics_reference_cpu": want}, fh, indent=1)
+    for k, v in want.items():
+        assert abs(m[k] - v) < 1e-9, (k, m[k], v)  # AJ / OA / delta_avg reproduced (north_star asks +-0.2 pts)
+
+
+def test_batched_start_frames_and_device_metrics():
+    """N2 without the reference: every start frame of a video in ONE infer (inference_benchmark.py:36-42 loops), and
+    the TAP-Vid numbers from device tensors (dtk_tapvid_counts) == the oracle's restatement of eval/metrics.py."""
+    import ref_scripts_data as D
+    from gpu_util import make_inference, make_tracker
+    from dino_tracker_amd import ops, synth, tapvid
+    from oracle import ref_algo as A
+    H, W = 476, 854
+    cfg = dict(D.CFG3, C=384)
+    T, C = cfg["T"], cfg["C"]
+    feats = synth.synth_features(T, C, 67, 121, seed=cfg["feat_seed"])
+    head = synth.synth_head_weights(cfg["head_seed"])
+    trk = make_tracker(torch.zeros(T, 3, H, W), feats, head, method=ops.TRACK_MFMA)
+    mi = make_inference(trk, H, W, T)
+    import tempfile
+    bench = D.build_tapvid_pickle(os.path.join(tempfile.mkdtemp(), "b.pkl"), cfg)
+    vc = bench["videos"][0]
+    qp = {f: [[x * W / vc["w"], y * H / vc["h"], f] for x, y in pts] for f, pts in vc["query_points"].items()}
+    batched = tapvid.infer_benchmark(mi, qp)
+    for f in qp:  # == the per-frame loop of the reference's script
+        t1, o1 = mi.infer(torch.tensor(qp[f], dtype=torch.float32, device="cuda"))
+        assert torch.equal(batched[f][0], t1) and torch.equal(batched[f][1], o1)
+    got = tapvid.tapvid_metrics(batched, vc, pred_size=(W, H))
+    frames = list(vc["query_points"])
+    want = A.tapvid_metrics(np.concatenate([[f] * len(vc["query_points"][f]) for f in frames]),
+                            np.concatenate([vc["occluded"][f] for f in frames]),
+                            np.concatenate([vc["target_points"][f] for f in frames]),
+                            torch.cat([batched[f][1] for f in frames]).cpu().numpy(),
+                            torch.cat([batched[f][0] for f in frames]).cpu().numpy(), (W, H), (vc["w"], vc["h"]))
+    assert set(got) == set(want)
+    for k in want:
+        assert got[k] == pytest.approx(want[k], abs=1e-12), k
+    # and the oracle's own trajectories give the same metrics (position parity => metric parity)
+    allq = torch.tensor(sum((qp[f] for f in frames), []), dtype=torch.float32)
+    rt, ro = A.infer(feats, allq, head, H, W)
+    want2 = A.tapvid_metrics(allq[:, 2].numpy(), np.concatenate([vc["occluded"][f] for f in frames]),
+                             np.concatenate([vc["target_points"][f] for f in frames]), ro.numpy(), rt.numpy(), (W, H),
+                             (vc["w"], vc["h"]))
+    for k in want2:
+        assert got[k] == pytest.approx(want2[k], abs=1e-9), k
+
+
+def test_device_metrics_random_tracks_first_and_strided():
+    from dino_tracker_amd import tapvid
+    from oracle import ref_algo as A
+    g = np.random.default_rng(1)
+    N, T = 257, 33
+    gt = g.uniform(0, 255, (N, T, 2)).astype(np.float32)
+    pred = ((gt + g.normal(size=(N, T, 2)) * g.choice([0.4, 1.0, 3.0, 7.0, 20.0], size=(N, T, 1)))
+            * np.array([854 / 256, 476 / 256])).astype(np.float32)
+    gocc = g.uniform(size=(N, T)) < 0.3
+    pocc = gocc ^ (g.uniform(size=(N, T)) < 0.25)
+    qf = g.integers(0, T, N)
+    for mode in ("strided", "first"):
+        counts = tapvid.tapvid_counts(torch.from_numpy(pred).cuda(), torch.from_numpy(pocc).cuda(),
+                                      torch.from_numpy(gt).cuda(), torch.from_numpy(gocc).cuda(),
+                                      torch.from_numpy(qf).cuda(), (854, 476), (256, 256), mode)
+        got = tapvid.metrics_from_counts(counts.cpu().tolist())
+        want = A.tapvid_metrics(qf, gocc, gt, pocc, pred, (854, 476), (256, 256), mode)
+        for k in want:
+            assert got[k] == pytest.approx(want[k], abs=1e-12), (mode, k)

@@ -63,3 +63,26 @@ def test_sampling_literal_vs_algorithmic():
     lit = A.sample_embeddings_literal(emb, A.points_to_grid_coords(pts, 140, 210))
     alg = A.sample_bilinear(emb, pts[:, :2], pts[:, 2], 140, 210)
     assert (lit - alg).abs().max() < 2e-5
+
+
+def test_vit_oracle_matches_reference_extractor_golden():
+    """p1_small.npz: the UN-MODIFIED reference VitExtractor / get_dino_features_video (models/extractor.py:23-150,
+    utils.py:33-72) around the DINOv2-API stub.  Pins rows a1-a4 of the oracle: position-encoding interpolation, patch
+    embedding at stride 7, hooked block outputs, layer mean incl. CLS, qkv record, key facet, key self-similarity."""
+    g = load("p1_small")
+    video = MG.p1_video()
+    name = MG.P1_CASE["model"]
+    for tag, ls in (("ls1", 1.0), ("ls01", 0.1)):
+        sd = MG.p1_weights(ls)
+        gold = g[f"tokens_{tag}_l11"]
+        for t in range(gold.shape[0]):
+            got = A.vit_tokens(video[t:t + 1], sd, name, layer=None)
+            assert np.abs(got.numpy() - gold[t]).max() < 2e-5 * max(1.0, np.abs(gold[t]).max())
+    sd = MG.p1_weights(1.0)
+    assert np.abs(A.vit_tokens(video[:1], sd, name, layer=3).numpy() - g["tokens_ls1_l3"][0]).max() < 2e-5
+    cls = torch.stack([A.vit_all_tokens(video[:1], sd, name, layer=l) for l in (2, 5)]).mean(0)
+    assert np.abs(cls.numpy() - g["feature_with_cls_l2_l5"]).max() < 2e-5
+    qkv = A.vit_qkv(video[:1], sd, name, layer=1)
+    assert np.abs(qkv.numpy() - g["qkv_l1"]).max() < 2e-5
+    k3 = A.vit_qkv(video[:1], sd, name, layer=3)[0, 1:, 384:768].reshape(13, 17, 384).permute(2, 0, 1)
+    assert np.abs(k3.numpy() - g["keys_l3"][0]).max() < 2e-5

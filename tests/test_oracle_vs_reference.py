@@ -60,3 +60,37 @@ def test_vit_blocks_match_hf_port():
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hf_crosscheck.py")
     r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_tapvid_metrics_match_reference(tmp_path):
+    """oracle.tapvid_metrics vs the reference's compute_tapvid_metrics_for_video (eval/metrics.py:150-223) fed through
+    its own .npy / pickle-dict interface, on random tracks with realistic error scales."""
+    import numpy as np
+    ref_harness.load()
+    import eval.metrics as EM
+    g = np.random.default_rng(0)
+    T = 9
+    cfg = {"video_idx": 3, "h": 256, "w": 256, "query_points": {}, "target_points": {}, "occluded": {}}
+    preds = {}
+    for f, n in ((0, 5), (4, 7), (8, 3)):
+        gt = g.uniform(0, 255, (n, T, 2)).astype(np.float32)
+        occ = g.uniform(size=(n, T)) < 0.3
+        noise = g.normal(size=(n, T, 2)) * g.choice([0.3, 1.5, 6.0, 30.0], size=(n, T, 1))
+        pred = ((gt + noise) * np.array([854 / 256, 476 / 256])).astype(np.float32)  # predictions live at 854 x 476
+        pocc = occ ^ (g.uniform(size=(n, T)) < 0.2)
+        cfg["query_points"][f] = gt[:, f].tolist()
+        cfg["target_points"][f], cfg["occluded"][f] = gt, occ
+        preds[f] = (pred, pocc)
+        np.save(tmp_path / f"trajectories_{f}.npy", pred)
+        np.save(tmp_path / f"occlusion_preds_{f}.npy", pocc)
+    want = EM.compute_tapvid_metrics_for_video(str(tmp_path), str(tmp_path), {"videos": [cfg]}, 3, pred_video_sizes=[854, 476])
+    frames = list(cfg["query_points"])
+    got = A.tapvid_metrics(np.concatenate([[f] * len(cfg["query_points"][f]) for f in frames]),
+                           np.concatenate([cfg["occluded"][f] for f in frames]),
+                           np.concatenate([cfg["target_points"][f] for f in frames]),
+                           np.concatenate([preds[f][1] for f in frames]), np.concatenate([preds[f][0] for f in frames]),
+                           (854, 476), (256, 256))
+    assert set(got) == set(want)
+    for k in want:
+        assert got[k] == pytest.approx(want[k], abs=1e-12), k
+    assert 0.05 < want["average_jaccard"] < 0.95  # a non-degenerate case

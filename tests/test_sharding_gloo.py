@@ -51,3 +51,55 @@ def test_assignment_matches_davis_layout():
     sizes = [len(sharding.videos_of_rank(30, r, 8)) for r in range(8)]
     assert sizes == [4, 4, 4, 4, 4, 4, 3, 3] and sum(sizes) == 30
     assert sorted(v for r in range(8) for v in sharding.videos_of_rank(30, r, 8)) == list(range(30))
+
+
+def _qp_worker(rank, world, port, t, hw, c, n, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        state = {}
+
+        def refine(t0, t1):  # "features" of frame f are the constant f + 1
+            state["frames"] = (t0, t1)
+            return (torch.arange(t0, t1, dtype=torch.float32) + 1)[:, None, None].expand(t1 - t0, hw, c).clone()
+
+        def set_refined(vol):
+            state["vol"] = vol.clone()
+
+        def infer(q):  # a stand-in that needs EVERY frame of the gathered volume
+            s = state["vol"].sum(dim=(1, 2))
+            traj = q[:, None, :2] + s[None, :, None]
+            return traj.contiguous(), (q[:, None, 0] + s[None]) % 2 > 1
+
+        queries = torch.stack([torch.arange(n, dtype=torch.float32) * 3, torch.arange(n, dtype=torch.float32) * 5,
+                               torch.zeros(n)], dim=1)
+        out = sharding.query_parallel(refine, set_refined, infer, t, hw, c, queries, "cpu")
+        assert state["frames"] == sharding.split_range(t, rank, world)[:2]
+        assert torch.equal(state["vol"].sum(dim=(1, 2)), (torch.arange(t, dtype=torch.float32) + 1) * hw * c)
+        if rank == 0:
+            traj, occ = out
+            s = (torch.arange(t, dtype=torch.float32) + 1) * hw * c
+            assert traj.shape == (n, t, 2) and occ.shape == (n, t)
+            assert torch.equal(traj, queries[:, None, :2] + s[None, :, None])
+            assert torch.equal(occ, (queries[:, None, 0] + s[None]) % 2 > 1)
+        else:
+            assert out is None
+        ret[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_query_parallel_world2():
+    """SURVEY 8e level 2: frames split for P1 / P2, all-gather, queries split for P3, gather; ragged sizes."""
+    world, t, hw, c, n = 2, 5, 3, 4, 7
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 30500 + (os.getpid() % 1000)
+    mp.spawn(_qp_worker, args=(world, port, t, hw, c, n, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_split_range():
+    assert [sharding.split_range(90, r, 8)[:2] for r in range(8)] == [(0, 12), (12, 24), (24, 36), (36, 48), (48, 60),
+                                                                        (60, 72), (72, 84), (84, 90)]
+    assert sharding.split_range(3, 3, 4) == (3, 3, 1) and sharding.split_range(5, 1, 2) == (3, 5, 3)
