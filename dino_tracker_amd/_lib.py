@@ -78,6 +78,7 @@ SIGNATURES = {
     "dtk_vit_workspace_bytes": (c_size_t, [ctypes.POINTER(VitModel), c_int, c_int, c_int]),
     "dtk_vit_forward": (c_int, [ctypes.POINTER(VitModel), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_size_t, c_void_p]),
+    "dtk_vit_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dtk_delta_dino_packed_floats": (c_size_t, [c_int, c_int]),
     "dtk_delta_dino_pack": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                     c_void_p, c_void_p]),

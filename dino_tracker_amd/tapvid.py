@@ -61,11 +61,16 @@ def tapvid_counts(pred_tracks: torch.Tensor, pred_occluded: torch.Tensor, gt_tra
     dev = pred_tracks.device
     counts = torch.zeros(18, dtype=torch.int64, device=dev)
     f32 = lambda x: float(torch.tensor(x, dtype=torch.float32))  # noqa: E731  (numpy multiplies by the float32 value)
-    check(lib().dtk_tapvid_counts(
-        ops._p(pred_tracks.to(torch.float32).contiguous()), ops._p(pred_occluded.to(torch.uint8).contiguous()),
-        ops._p(gt_tracks.to(dev, torch.float32).contiguous()), ops._p(gt_occluded.to(dev).to(torch.uint8).contiguous()),
-        ops._p(query_frames.to(dev).to(torch.int32).contiguous()), f32(256 / pred_size[0]), f32(256 / pred_size[1]),
-        f32(256 / gt_size[0]), f32(256 / gt_size[1]), int(query_mode == "first"), n, t, ops._p(counts), ops._stream()))
+    # locals keep the converted tensors alive until the launch is enqueued (a temporary released right after its
+    # data_ptr() was taken can be handed out again by the caching allocator for the NEXT temporary)
+    pt = pred_tracks.to(torch.float32).contiguous()
+    po = pred_occluded.to(torch.uint8).contiguous()
+    gt = gt_tracks.to(dev, torch.float32).contiguous()
+    go = gt_occluded.to(dev).to(torch.uint8).contiguous()
+    qf = query_frames.to(dev).to(torch.int32).contiguous()
+    check(lib().dtk_tapvid_counts(ops._p(pt), ops._p(po), ops._p(gt), ops._p(go), ops._p(qf), f32(256 / pred_size[0]),
+                                  f32(256 / pred_size[1]), f32(256 / gt_size[0]), f32(256 / gt_size[1]),
+                                  int(query_mode == "first"), n, t, ops._p(counts), ops._stream()))
     return counts
 
 

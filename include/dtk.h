@@ -112,6 +112,16 @@ int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int nframes, in
                     float* tokens_out, float* feat_out, float* qkv_out, void* workspace, size_t workspace_bytes,
                     void* stream);
 
+/* The multi-head self-attention stage of a block on its own, d_head = 64 (what runs between the QKV and the projection
+ * GEMMs inside dtk_vit_forward; upstream Attention.forward, hooked by models/extractor.py:101-104).  bf16 operands:
+ *   q  [frames][heads][Sp][64]   queries, ALREADY multiplied by log2(e) / sqrt(64) (the softmax runs in the exp2 domain)
+ *   k  [frames][heads][Sp][64]   keys; rows S .. Sp-1 must be finite (zero)
+ *   vt [frames][heads][64][Sp]   values, transposed; columns S .. Sp-1 must be finite (zero)
+ *   out[frames][S][heads*64]     softmax(q k^T) v, heads concatenated (the input of attn.proj)
+ * Sp = S rounded up to a multiple of 64 (dtk_vit_forward uses 128). */
+int dtk_vit_attention(const void* q, const void* k, const void* vt, void* out, int frames, int heads, int S, int Sp,
+                      void* stream);
+
 /* ---- P2: Delta-DINO refinement (models/tracker.py:113-135; models/networks/delta_dino.py:53-61;
  *      models/utils.py:7-45), fp32-grade on the fp16 MFMA (operands split into hi + lo halves, 3 products) ----------
  * dtk_delta_dino_pack: layer l in 0..3 (state-dict keys layers.{4l}.{weight,bias} = conv [Cout][Cin][5][5] and

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <vector>
 #include "../../dino_tracker_amd/csrc/vit.hip"
+#include "attention_v1.h"
 
 void dtk_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 void dtk_prof_begin(const char*, hipStream_t) {}
@@ -39,6 +40,15 @@ int main(int argc, char** argv) {
                 hk[((size_t)fh * Sp + s) * 64 + d] = f2bf(gauss(seed));
                 hv[((size_t)fh * 64 + d) * Sp + s] = f2bf(gauss(seed));
             }
+    // stress rows for the guard / safe-pass logic of the optimistic softmax (frame 0, head 0): every key gets +50 in
+    // dimension 0; query 5 is scaled so that its scores reach ~+-60 (row sums beyond 2^40: power-of-two rescale), query 6 so
+    // that they reach ~+-300 (inf: poisoned, safe pass), query 7 sits at about -300 for EVERY key (all-zero row: safe pass)
+    for (int s2 = 0; s2 < S; ++s2) hk[((size_t)0 * Sp + s2) * 64 + 0] = f2bf(bf2f(hk[((size_t)0 * Sp + s2) * 64 + 0]) + 50.f);
+    for (int d = 0; d < 64; ++d) {
+        hq[((size_t)0 * Sp + 5) * 64 + d] = f2bf(bf2f(hq[((size_t)0 * Sp + 5) * 64 + d]) * 25.f);
+        hq[((size_t)0 * Sp + 6) * 64 + d] = f2bf(bf2f(hq[((size_t)0 * Sp + 6) * 64 + d]) * 120.f);
+        hq[((size_t)0 * Sp + 7) * 64 + d] = f2bf(d == 0 ? -6.f : 0.01f * bf2f(hq[((size_t)0 * Sp + 7) * 64 + d]));
+    }
     bf16_t *q, *k, *vt, *o1, *o2;
     CK(hipMalloc(&q, nqk * 2)); CK(hipMalloc(&k, nqk * 2)); CK(hipMalloc(&vt, nqk * 2));
     const size_t no = (size_t)F * S * D;
@@ -55,6 +65,7 @@ int main(int argc, char** argv) {
     std::vector<Row> rows;
     for (int i = 0; i < 48; ++i) {
         Row r; r.fh = (i * 37) % FH; r.qi = i == 0 ? 0 : (i == 1 ? S - 1 : (int)((uint64_t)(i * 2654435761u) % S));
+        if (i >= 2 && i <= 6) { r.fh = 0; r.qi = i + 2; }  // the stress rows 5, 6, 7 and their neighbours 4, 8
         std::vector<double> p(S);
         double mx = -1e300;
         for (int s = 0; s < S; ++s) {
@@ -76,10 +87,13 @@ int main(int argc, char** argv) {
         double worst = 0, scale = 0;
         for (auto& r : rows) {
             const int frame = r.fh / heads, head = r.fh % heads;
+            double rw = 0, rs = 0;
             for (int d = 0; d < 64; ++d) {
                 const double got = bf2f(ho[((size_t)frame * S + r.qi) * D + head * 64 + d]);
-                worst = fmax(worst, fabs(got - r.o[d])); scale = fmax(scale, fabs(r.o[d]));
+                rw = fmax(rw, fabs(got - r.o[d])); rs = fmax(rs, fabs(r.o[d]));
             }
+            if (rw > 2e-3) printf("    row fh=%d q=%d: err %.3e (|ref| %.3e)\n", r.fh, r.qi, rw, rs);
+            worst = fmax(worst, rw); scale = fmax(scale, rs);
         }
         printf("  %-22s max |err| vs fp64 on %zu rows: %.3e (max |ref| %.3e)\n", name, rows.size(), worst, scale);
     };
@@ -97,13 +111,26 @@ int main(int argc, char** argv) {
     };
     printf("attention d=64: %d frames x %d heads, S = %d (Sp %d), %.2f TFLOP per launch\n", F, heads, S, Sp, flop * 1e-12);
     timeit("v1 (round 1)", [&] { hipLaunchKernelGGL(attention_kernel, dim3(dtk_cdiv(S, 128 * ATT_QT), FH), dim3(256), 0, 0, q, k, vt, o1, S, Sp, heads, D); }, o1);
-    {
+#define V2_RUN(QT_, MODE_, PIN_, NAME) do { int QB; const unsigned g = att2::attention2_grid(FH, S, QT_, &QB); \
+        timeit(NAME, [&] { hipLaunchKernelGGL((att2::attention2_kernel<QT_, 0, MODE_, PIN_>), dim3(g), dim3(512), 0, 0, q, k, vt, o2, S, Sp, heads, D, FH, QB); }, o2); } while (0)
+    V2_RUN(1, 0, true, "v2 QT1 max pin");
+    V2_RUN(1, 1, true, "v2 QT1 opt pin");
+    V2_RUN(1, 1, false, "v2 QT1 opt nopin");
+    V2_RUN(2, 1, true, "v2 QT2 opt pin");
+    { int QB; const unsigned g = att2::attention2_grid(FH, S, 1, &QB);
+      timeit("v2 QT1 opt pin prio", [&] { hipLaunchKernelGGL((att2::attention2_kernel<1, 0, 1, true, true>), dim3(g), dim3(512), 0, 0, q, k, vt, o2, S, Sp, heads, D, FH, QB); }, o2);
+      timeit("v2 QT1 opt nopin prio", [&] { hipLaunchKernelGGL((att2::attention2_kernel<1, 0, 1, false, true>), dim3(g), dim3(512), 0, 0, q, k, vt, o2, S, Sp, heads, D, FH, QB); }, o2); }
+    if (argc > 3) {  // ablations of v2 QT=1 (results are wrong by construction; timing only)
         int QB; const unsigned g = att2::attention2_grid(FH, S, 1, &QB);
-        timeit("v2 QT=1 (16 waves/CU)", [&] { hipLaunchKernelGGL(att2::attention2_kernel<1>, dim3(g), dim3(512), 0, 0, q, k, vt, o2, S, Sp, heads, D, FH, QB); }, o2);
-    }
-    {
-        int QB; const unsigned g = att2::attention2_grid(FH, S, 2, &QB);
-        timeit("v2 QT=2 (8 waves/CU)", [&] { hipLaunchKernelGGL(att2::attention2_kernel<2>, dim3(g), dim3(512), 0, 0, q, k, vt, o2, S, Sp, heads, D, FH, QB); }, o2);
+#define ABL_RUN(A, NAME) timeit(NAME, [&] { hipLaunchKernelGGL((att2::attention2_kernel<1, A, 1, true>), dim3(g), dim3(512), 0, 0, q, k, vt, o2, S, Sp, heads, D, FH, QB); }, o2)
+        ABL_RUN(1, "abl: no exp");
+        ABL_RUN(2, "abl: no DMA");
+        ABL_RUN(4, "abl: one LDS address");
+        ABL_RUN(8, "abl: no max logic");
+        ABL_RUN(16, "abl: no barrier");
+        ABL_RUN(1 | 8, "abl: no exp, no max");
+        ABL_RUN(2 | 4, "abl: no DMA, one LDS");
+        ABL_RUN(1 | 2 | 4 | 8 | 16, "abl: MFMA + cvt only");
     }
     return 0;
 }

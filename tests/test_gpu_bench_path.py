@@ -187,7 +187,7 @@ def small():
     delta = synth.synth_delta_dino_weights(C, seed=6)
     video = synth.synth_video(T, Hs, Ws, seed=92)
     from gpu_util import make_tracker
-    trk = make_tracker(video, feats, head, delta=delta, method=ops.TRACK_EXACT, cache=False)
+    trk = make_tracker(video, feats, head, delta=delta, method=ops.TRACK_EXACT, cache=False).eval()
     return Hs, Ws, T, C, feats, head, delta, video, trk
 
 

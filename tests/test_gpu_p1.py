@@ -207,3 +207,48 @@ def test_full_resolution_all_blocks_bench_weights():
     ref = A.vit_tokens(video, sd, "dinov2_vits14").permute(1, 2, 0).reshape(-1, 384)
     cos, rel = _check(feat[0], ref)
     print(f"full-res 12 blocks, bench weights: min token cos {cos:.6f}, rel Frobenius {rel:.3e}")
+
+
+def test_attention_guards_and_safe_pass():
+    """dtk_vit_attention alone on crafted bf16 operands vs an fp64 softmax on the SAME operands.  The kernel exponentiates
+    scores optimistically against a reference that starts at 0 (vit_attention2.h, MODE 1); the rows below force every
+    branch of that logic: (5) scores up to +-60 -> row sums beyond 2^40 -> power-of-two rescale of O / l; (6) scores of
+    +-300 -> inf -> poisoned sum -> safe pass; (7) about -300 for EVERY key -> all-zero row -> safe pass; and ordinary
+    rows that share their wave with them.  S is not a multiple of the 64-key tile (masked tail)."""
+    from dino_tracker_amd import ops
+    from dino_tracker_amd._lib import check, lib
+    g = torch.Generator().manual_seed(11)
+    F, Hh, S = 1, 2, 1000
+    Sp = 1024
+    qs = 0.125 * 1.4426950408889634
+    q = torch.zeros(F, Hh, Sp, 64)
+    k = torch.zeros(F, Hh, Sp, 64)
+    v = torch.zeros(F, Hh, Sp, 64)
+    q[:, :, :S] = torch.randn(F, Hh, S, 64, generator=g) * qs * 1.5
+    k[:, :, :S] = torch.randn(F, Hh, S, 64, generator=g)
+    v[:, :, :S] = torch.randn(F, Hh, S, 64, generator=g)
+    k[0, 0, :S, 0] += 50.0
+    q[0, 0, 5] *= 25.0
+    q[0, 0, 6] *= 120.0
+    q[0, 0, 7] *= 0.01
+    q[0, 0, 7, 0] = -6.0
+    q[0, 1, 700] *= 120.0   # a poisoned row in another wave / head, late in the sweep
+    qb, kb, vb = q.bfloat16(), k.bfloat16(), v.bfloat16()
+    vt = vb.transpose(2, 3).contiguous()  # [F][H][64][Sp]
+    out = torch.empty(F, S, Hh * 64, dtype=torch.bfloat16, device="cuda")
+    qd, kd, vd = qb.cuda().contiguous(), kb.cuda().contiguous(), vt.cuda().contiguous()
+    check(lib().dtk_vit_attention(ops._p(qd), ops._p(kd), ops._p(vd), ops._p(out), F, Hh, S, Sp, ops._stream()))
+    s = qb.double()[:, :, :S] @ kb.double()[:, :, :S].transpose(2, 3)            # exp2-domain scores
+    p = torch.softmax(s * 0.6931471805599453, dim=-1)
+    ref = (p @ vb.double()[:, :, :S]).permute(0, 2, 1, 3).reshape(F, S, Hh * 64)
+    got = out.double().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().amax(dim=-1)[0]
+    scale = ref.abs().amax(dim=-1)[0].clamp(min=0.05)
+    rel = err / scale
+    # bf16 P and bf16 output: 2^-8 of the row's largest output, every row, incl. the crafted ones
+    assert rel.max() < 6e-3, (int(rel.argmax()), rel.max().item())
+    for row in (5, 6, 7, 700):
+        assert p[0, row // 1000 if row == 700 else 0].max() > 0  # (rows exist)
+    # the crafted rows really are extreme: near one-hot / far from the reference 0
+    assert s[0, 0, 6].abs().max() > 200 and s[0, 0, 7].max() < -150 and s[0, 0, 5].abs().max() > 45
