@@ -6,7 +6,7 @@ the 128-byte requests of wide reads at 64 bytes, so it is doubled; WRITE_SIZE is
 import json, re, sqlite3, sys
 
 NAMES = {  # kernel function -> launch name used by bench.py (only kernels with one launch name)
-    "attention_kernel": "vit_attention", "corr_peaks_kernel": "corr_peaks", "refine_corr_kernel": "refine_corr",
+    "attention_kernel": "vit_attention", "attention2_kernel": "vit_attention", "corr_peaks_kernel": "corr_peaks", "refine_corr_kernel": "refine_corr",
     "refine_head_kernel": "refine_head", "layernorm_kernel": "vit_layernorm", "rescore_kernel": "rescore",
     "patch_embed_split_kernel": "vit_patch_embed", "conv1_split_kernel": "dd_conv1",
 }
@@ -21,7 +21,7 @@ def per_kernel(path, counter):
                           join rocpd_info_kernel_symbol s on d.kernel_id = s.id where p.name = ? group by 1""", (counter,))
     out = {}
     for kn, n, v in rows:
-        m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", kn) or re.match(r"_Z(\d+)", kn)
+        m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", kn) or re.match(r"_ZN4att2(\d+)", kn) or re.match(r"_Z(\d+)", kn)
         short = kn[m.end():m.end() + int(m.group(1))] if m else kn[:40]
         c = out.setdefault(short, [0, 0.0])
         c[0] += n; c[1] += v

@@ -15,7 +15,7 @@ total = sum(r[2] for r in rows)
 print("| kernel | calls | total ms | avg us | min us | max us | % |")
 print("|---|---:|---:|---:|---:|---:|---:|")
 for name, n, tot, mn, mx in rows:
-    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name) or re.match(r"_Z(\d+)", name)
+    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name) or re.match(r"_ZN4att2(\d+)", name) or re.match(r"_Z(\d+)", name)
     if m:  # Itanium mangling: <len><identifier>; template arguments are kept as a suffix
         start = m.end()
         short = name[start:start + int(m.group(1))]
