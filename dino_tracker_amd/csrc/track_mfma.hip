@@ -1032,6 +1032,21 @@ __global__ __launch_bounds__(256) void scatter_kernel(dtk_geom g, const int32_t*
     perm[off[key] + atomicAdd(&cursor[key], 1)] = i;
 }
 
+// Window correlations, fp32-grade on the fp16 matrix cores.
+//   * A workgroup takes RC_SRC = 64 key-consecutive sources (after the counting sort they sit on the same or neighbouring
+//     arg-max cells of one frame) and correlates them with the cells of their windows' union box: one pass over the box's
+//     feature rows (1.5 KB per cell at C = 384) serves up to 64 windows.  Round 1 took 16 sources per workgroup, moved 9 KB
+//     of features per source through the fabric and sat at 3.9 TB/s (PMC) -- memory-bound.
+//   * Workgroup b runs on XCD b % 8; every XCD gets a contiguous range of the key-sorted tiles, so that the overlapping
+//     boxes of neighbouring tiles are re-read from that XCD's L2.
+//   * The arithmetic: each fp32 operand is split while it is staged into LDS, x = hi + lo (both fp16, 2^5 x so that the
+//     lo halves stay normal), and a product is hi.hi + hi.lo + lo.hi on MFMA 16x16x32 f16 with fp32 accumulation -- the
+//     scheme of delta_dino.hip: error <= 2^-22 relative per operand (tests/test_numeric_claims.py), three instructions at
+//     16x the f32-input MFMA rate instead of one (64 sources x 256 cells x 384 channels on the f32 MFMA alone cost
+//     more than the whole round-1 kernel).
+constexpr int RC_SRC = 64;
+constexpr float RC_SCALE = 32.f;
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const float* __restrict__ feat,
                                                           const float* __restrict__ norms,
                                                           const float* __restrict__ emb,
@@ -1041,15 +1056,18 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const floa
                                                           const float* __restrict__ snorm,
                                                           const int32_t* __restrict__ perm,
                                                           const int32_t* __restrict__ nvalid,
-                                                          float* __restrict__ xwin, int m0, int dbg) {
-    __shared__ float s_sn[16];
-    __shared__ int s_row[16], s_f[16], s_k[16], s_m[16], s_grp[16], s_box[64], s_ng;
+                                                          float* __restrict__ xwin, int m0, int ntiles, int dbg) {
+    __shared__ float s_sn[RC_SRC];
+    __shared__ int s_row[RC_SRC], s_f[RC_SRC], s_k[RC_SRC], s_m[RC_SRC], s_grp[RC_SRC], s_box[RC_SRC * 4], s_first[RC_SRC],
+        s_last[RC_SRC], s_ng;
     const int ph = g.ph, pw = g.pw, HW = ph * pw, C = g.C;
     const int nv = *nvalid;
-    const int t0 = blockIdx.x * 16;
-    if (t0 >= nv) return;
+    const int per = (ntiles + 7) / 8;
+    const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int t0 = tile * RC_SRC;
+    if ((int)(blockIdx.x >> 3) >= per || tile >= ntiles || t0 >= nv) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid < 16) {
+    if (tid < RC_SRC) {
         const bool ok = t0 + tid < nv;
         const int i = perm[ok ? t0 + tid : t0];  // index inside the round
         const int m = m0 + i;
@@ -1064,7 +1082,7 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const floa
     // greedy grouping: consecutive (key-sorted) sources with the same frame whose window union stays small
     if (tid == 0) {
         int ng = 0, cf = -2, r0 = 0, r1 = 0, c0 = 0, c1 = 0;
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < RC_SRC; ++s) {
             s_grp[s] = -1;
             if (s_f[s] < 0) continue;
             const int kr = s_k[s] / pw, kc = s_k[s] % pw;
@@ -1075,8 +1093,9 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const floa
                 const int n0 = min(r0, a0), n1 = max(r1, a1), e0 = min(c0, b0), e1 = max(c1, b1);
                 if ((n1 - n0 + 1) * (e1 - e0 + 1) <= NB_MAX) { r0 = n0; r1 = n1; c0 = e0; c1 = e1; fits = true; }
             }
-            if (!fits) { ++ng; cf = s_f[s]; r0 = a0; r1 = a1; c0 = b0; c1 = b1; }
+            if (!fits) { ++ng; cf = s_f[s]; r0 = a0; r1 = a1; c0 = b0; c1 = b1; s_first[ng - 1] = s; }
             s_grp[s] = ng - 1;
+            s_last[ng - 1] = s;
             s_box[(ng - 1) * 4 + 0] = r0; s_box[(ng - 1) * 4 + 1] = r1;
             s_box[(ng - 1) * 4 + 2] = c0; s_box[(ng - 1) * 4 + 3] = c1;
         }
@@ -1094,76 +1113,78 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const floa
         }
     }
 
-    // ---- fp32 correlation of all 16 sources with the cells of each group's union box ------------------------------
-    // f32-input MFMA 16x16x4; A (16 sources) and B (64 cells per block, one 16-cell N-tile per wave) are staged through
-    // LDS in 32-float K chunks with coalesced 128-byte row segments, double-buffered.  Row pitch 34 floats makes the
-    // fragment reads (lane (fg, fj) reads [row fj][4*kk + fg]) conflict-free.
-    constexpr int RP = 34;
-    __shared__ __attribute__((aligned(16))) float As[2][16 * RP];
-    __shared__ __attribute__((aligned(16))) float Bs[2][64 * RP];
+    // ---- correlation of the group's sources with the cells of its union box ------------------------------------------
+    // LDS: hi and lo planes of A (64 sources = four 16-row M tiles) and B (64 cells per block, one 16-cell N tile per wave),
+    // 32-channel K chunks, double-buffered.  Row pitch 40 halves (80 B): a fragment read (lane (fg, fj): 8 halves at
+    // [row fj][8 fg]) is a conflict-free ds_read_b128.  A B fragment pair feeds up to 12 MFMAs (4 M tiles x 3 products).
+    constexpr int RP = 40;
+    __shared__ __attribute__((aligned(16))) half_t Ah[2][RC_SRC * RP], Al[2][RC_SRC * RP], Bh[2][64 * RP], Bl[2][64 * RP];
     const int fj = lane & 15, fg = lane >> 4;
-    const int lrow = tid >> 3, lk4 = (tid & 7) * 4;  // loader: row (cell or source), 4-float piece
-    const float* arow = emb + (size_t)s_row[lrow & 15] * C + lk4;
+    const int lrow = tid >> 3, lk4 = (tid & 7) * 4;  // loader: rows lrow, lrow + 32 (cells or sources), 4-float piece
+    const float* arow0 = emb + (size_t)s_row[lrow] * C + lk4;
+    const float* arow1 = emb + (size_t)s_row[lrow + 32] * C + lk4;
     const int nkc = C / 32;
     for (int gi = 0; gi < (DTK_DBG(dbg, 1) ? 0 : ng); ++gi) {
         const int rmin = s_box[gi * 4], rmax = s_box[gi * 4 + 1], cmin = s_box[gi * 4 + 2], cmax = s_box[gi * 4 + 3];
         const int nc = cmax - cmin + 1, ncells = (rmax - rmin + 1) * nc;
-        int gf = -1;
-        for (int s = 0; s < 16; ++s)
-            if (s_grp[s] == gi) gf = s_f[s];
-        // my four sources' window origins (rows 4*fg + r of the D fragment)
-        int wr0[4], wc0[4];
-        float sn4[4];
-        bool in_g[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int s = fg * 4 + r;
-            in_g[r] = s_grp[s] == gi;
-            wr0[r] = s_k[s] / pw - (RD + 2);
-            wc0[r] = s_k[s] % pw - (RD + 2);
-            sn4[r] = s_sn[s];
-        }
+        const int mt0 = s_first[gi] >> 4, mt1 = s_last[gi] >> 4;  // M tiles that hold members (members are consecutive)
+        const int gf = s_f[s_first[gi]];
         const float* fbase = feat + (size_t)gf * HW * C;
         for (int blk = 0; blk < ncells; blk += 64) {
             // loader cells of this thread (clamped: results of padded cells are never stored)
             const int l0 = min(blk + lrow, ncells - 1), l1 = min(blk + lrow + 32, ncells - 1);
             const float* b0 = fbase + (size_t)((rmin + l0 / nc) * pw + cmin + l0 % nc) * C + lk4;
             const float* b1 = fbase + (size_t)((rmin + l1 / nc) * pw + cmin + l1 % nc) * C + lk4;
-            float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb0, rb1;
-            if (tid < 128) ra = *reinterpret_cast<const float4*>(arow);
+            float4 ra0, ra1, rb0, rb1;
+            ra0 = *reinterpret_cast<const float4*>(arow0);
+            ra1 = *reinterpret_cast<const float4*>(arow1);
             rb0 = *reinterpret_cast<const float4*>(b0);
             rb1 = *reinterpret_cast<const float4*>(b1);
             __syncthreads();  // previous block / group finished reading LDS
-#define RC_STORE(buf)                                                                                  \
-    do {                                                                                               \
-        if (tid < 128) {                                                                               \
-            float2* pa = reinterpret_cast<float2*>(&As[buf][lrow * RP + lk4]);                         \
-            pa[0] = make_float2(ra.x, ra.y);                                                           \
-            pa[1] = make_float2(ra.z, ra.w);                                                           \
-        }                                                                                              \
-        float2* pb0 = reinterpret_cast<float2*>(&Bs[buf][lrow * RP + lk4]);                            \
-        pb0[0] = make_float2(rb0.x, rb0.y);                                                            \
-        pb0[1] = make_float2(rb0.z, rb0.w);                                                            \
-        float2* pb1 = reinterpret_cast<float2*>(&Bs[buf][(lrow + 32) * RP + lk4]);                     \
-        pb1[0] = make_float2(rb1.x, rb1.y);                                                            \
-        pb1[1] = make_float2(rb1.z, rb1.w);                                                            \
+            // split x (scaled) into fp16 hi + lo and store 8 bytes into each plane
+            auto split_store = [&](half_t* hp, half_t* lp, int row, const float4& v) {
+                const float x[4] = {v.x * RC_SCALE, v.y * RC_SCALE, v.z * RC_SCALE, v.w * RC_SCALE};
+                h4v hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hi[e] = (half_t)x[e];
+                    lo[e] = (half_t)(x[e] - (float)hi[e]);
+                }
+                *reinterpret_cast<h4v*>(hp + row * RP + lk4) = hi;
+                *reinterpret_cast<h4v*>(lp + row * RP + lk4) = lo;
+            };
+#define RC_STORE(buf)                                        \
+    do {                                                     \
+        split_store(Ah[buf], Al[buf], lrow, ra0);            \
+        split_store(Ah[buf], Al[buf], lrow + 32, ra1);       \
+        split_store(Bh[buf], Bl[buf], lrow, rb0);            \
+        split_store(Bh[buf], Bl[buf], lrow + 32, rb1);       \
     } while (0)
             RC_STORE(0);
             __syncthreads();
-            f4 acc = {0.f, 0.f, 0.f, 0.f};
+            f4 acc[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = f4{0.f, 0.f, 0.f, 0.f};
             int cur = 0;
             for (int kc = 0; kc < nkc; ++kc) {
                 if (kc + 1 < nkc && !DTK_DBG(dbg, 8)) {
-                    if (tid < 128) ra = *reinterpret_cast<const float4*>(arow + (kc + 1) * 32);
+                    ra0 = *reinterpret_cast<const float4*>(arow0 + (kc + 1) * 32);
+                    ra1 = *reinterpret_cast<const float4*>(arow1 + (kc + 1) * 32);
                     rb0 = *reinterpret_cast<const float4*>(b0 + (kc + 1) * 32);
                     rb1 = *reinterpret_cast<const float4*>(b1 + (kc + 1) * 32);
                 }
-                const float* ap = &As[cur][fj * RP + fg];
-                const float* bp = &Bs[cur][(w * 16 + fj) * RP + fg];
                 if (!DTK_DBG(dbg, 4)) {
+                    const h8 bh = *reinterpret_cast<const h8*>(&Bh[cur][(w * 16 + fj) * RP + fg * 8]);
+                    const h8 bl = *reinterpret_cast<const h8*>(&Bl[cur][(w * 16 + fj) * RP + fg * 8]);
 #pragma unroll
-                    for (int kk = 0; kk < 8; ++kk)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * 4], bp[kk * 4], acc, 0, 0, 0);
+                    for (int mt = 0; mt < 4; ++mt) {
+                        if (mt < mt0 || mt > mt1) continue;  // workgroup-uniform
+                        const h8 ah = *reinterpret_cast<const h8*>(&Ah[cur][(mt * 16 + fj) * RP + fg * 8]);
+                        const h8 al = *reinterpret_cast<const h8*>(&Al[cur][(mt * 16 + fj) * RP + fg * 8]);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[mt], 0, 0, 0);
+                    }
                 }
                 if (kc + 1 < nkc) RC_STORE(cur ^ 1);
                 __syncthreads();
@@ -1175,11 +1196,17 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const floa
                 const int cr = rmin + ci / nc, ccol = cmin + ci % nc;
                 const float fn = norms[(size_t)gf * HW + cr * pw + ccol];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int dr = cr - wr0[r], dc = ccol - wc0[r];
-                    if (in_g[r] && dr >= 0 && dr < WX && dc >= 0 && dc < WX)
-                        xwin[((size_t)(s_m[fg * 4 + r] - m0) * WX + dr) * WX + dc] =
-                            fmaxf(acc[r] / fmaxf(sn4[r] * fn, 1e-8f), 0.f);
+                for (int mt = 0; mt < 4; ++mt) {
+                    if (mt < mt0 || mt > mt1) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int sidx = mt * 16 + fg * 4 + r;  // rows 4*fg + r of the D fragment of M tile mt
+                        if (s_grp[sidx] != gi) continue;
+                        const int dr = cr - (s_k[sidx] / pw - (RD + 2)), dc = ccol - (s_k[sidx] % pw - (RD + 2));
+                        if (dr >= 0 && dr < WX && dc >= 0 && dc < WX)
+                            xwin[((size_t)(s_m[sidx] - m0) * WX + dr) * WX + dc] =
+                                fmaxf(acc[mt][r] * (1.f / (RC_SCALE * RC_SCALE)) / fmaxf(s_sn[sidx] * fn, 1e-8f), 0.f);
+                    }
                 }
             }
         }
@@ -1515,8 +1542,11 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
         DTK_LAUNCH("key_scan", scan_final_kernel, dim3(L.nblocks), dim3(256), 0, st, hist, bsum, koff, L.nkeys);
         DTK_LAUNCH("key_scatter", scatter_kernel, dim3(dtk_cdiv(scnt, 256)), dim3(256), 0, st, *g, in.tgt, kstar, koff, cursor,
                    perm, L.HWk, (int)s0, scnt);
-        DTK_LAUNCH("refine_corr", refine_corr_kernel, dim3(dtk_cdiv(scnt, 16)), dim3(256), 0, st, *g, feat, norms, emb,
-                   in.src_row, in.tgt, kstar, snorm, perm, nvalid, xwin, (int)s0, dbg);
+        {
+            const int rtiles = dtk_cdiv(scnt, RC_SRC);
+            DTK_LAUNCH("refine_corr", refine_corr_kernel, dim3(8 * dtk_cdiv(rtiles, 8)), dim3(256), 0, st, *g, feat, norms, emb,
+                       in.src_row, in.tgt, kstar, snorm, perm, nvalid, xwin, (int)s0, rtiles, dbg);
+        }
         DTK_LAUNCH("refine_head", refine_head_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, *g, head, in.src_row, in.tgt,
                    in.out_idx, out_xy, rec, kstar, xwin, reinterpret_cast<const float*>(wpk) + 152, redo, uncert,
                    fast ? 1 : 0, (int)s0, scnt, M, nodm, normalized);
