@@ -97,6 +97,8 @@ SIGNATURES = {
     "dtk_track": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_int, c_void_p, ctypes.POINTER(TrackOpts), ctypes.POINTER(TrackStats),
                           c_void_p, c_size_t, c_void_p]),
+    "dtk_argmax_cells": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "dtk_feat_f16_bytes": (c_size_t, [ctypes.POINTER(Geom)]),
     "dtk_make_feat_f16": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p]),
     "dtk_traj_cos_sims": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -52,3 +52,30 @@ extern "C" int dtk_track(const dtk_geom* g, const float* feat, const float* norm
     dtk_set_error("dtk_track: unknown method %d", opts->method);
     return DTK_E_INVALID;
 }
+
+int dtk_argmax_exact(const dtk_geom* g, const float* feat, const float* norms, const float* emb, const int32_t* src_row,
+                     const int32_t* tgt, const int32_t* out_idx, int32_t* arg_cell, float* arg_cos, int M, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int dtk_argmax_mfma(const dtk_geom* g, const float* feat, const float* norms, const void* feat_f16, const float* emb,
+                    const int32_t* src_row, const int32_t* tgt, int32_t* arg_cell, float* arg_cos, int M, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+extern "C" int dtk_argmax_cells(const dtk_geom* g, const float* feat, const float* norms, const void* feat_f16,
+                                const float* emb, const int32_t* src_row, const int32_t* tgt, int32_t* arg_cell,
+                                float* arg_cos, int M, int method, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_track_geom(g);
+    if (rc) return rc;
+    DTK_REQUIRE(feat && norms && emb && tgt && arg_cell && arg_cos && workspace, "dtk_argmax_cells: null pointer");
+    DTK_REQUIRE(M >= 0, "dtk_argmax_cells: negative M");
+    if (M == 0) return DTK_OK;
+    if (method == DTK_TRACK_MFMA) {
+        DTK_REQUIRE(feat_f16 != nullptr, "dtk_argmax_cells(mfma): feat_f16 is null (call dtk_make_feat_f16)");
+        return dtk_argmax_mfma(g, feat, norms, feat_f16, emb, src_row, tgt, arg_cell, arg_cos, M, workspace, workspace_bytes,
+                               stream);
+    }
+    if (method == DTK_TRACK_EXACT)
+        return dtk_argmax_exact(g, feat, norms, emb, src_row, tgt, nullptr, arg_cell, arg_cos, M, workspace, workspace_bytes,
+                                stream);
+    dtk_set_error("dtk_argmax_cells: unknown method %d", method);
+    return DTK_E_INVALID;
+}

@@ -289,6 +289,40 @@ __global__ __launch_bounds__(256) void head_exact_kernel(dtk_geom g, const float
 
 }  // namespace
 
+// first maximum of a raw cosine map (torch.argmax semantics: ties -> lowest flat index) and its value; one workgroup per map
+__global__ __launch_bounds__(256) void argmax_exact_kernel(const float* __restrict__ maps, int HW, int HWs,
+                                                           const int32_t* __restrict__ out_idx, int32_t* __restrict__ arg_cell,
+                                                           float* __restrict__ arg_cos, int m0, int count) {
+    __shared__ float red[4];
+    __shared__ int redi[4];
+    const int i = blockIdx.x;
+    if (i >= count) return;
+    const int tid = threadIdx.x;
+    const float* map = maps + (size_t)i * HWs;
+    float best = -INFINITY;
+    int bi = INT_MAX;
+    for (int c = tid; c < HW; c += 256) {
+        const float v = map[c];
+        if (v > best) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, WAVE);
+        const int oi = __shfl_xor(bi, o, WAVE);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { red[tid >> 6] = best; redi[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        best = red[0]; bi = redi[0];
+        for (int w = 1; w < 4; ++w)
+            if (red[w] > best || (red[w] == best && redi[w] < bi)) { best = red[w]; bi = redi[w]; }
+        const int oi = out_idx ? out_idx[m0 + i] : m0 + i;
+        arg_cell[oi] = bi;
+        arg_cos[oi] = best;
+    }
+}
+
 extern "C" int dtk_head_prepare(const float* w1, const float* b1, const float* w2, const float* b2, float* head,
                                 void* stream) {
     DTK_REQUIRE(w1 && b1 && w2 && b2 && head, "dtk_head_prepare: null pointer");
@@ -377,6 +411,34 @@ extern "C" int dtk_corr_maps(const dtk_geom* g, const float* feat, const float* 
         DTK_LAUNCH("corr_exact", corr_exact_kernel, dim3(dtk_cdiv(HW, TN), dtk_cdiv(cnt, TM)), dim3(256), 0, st, *g, feat,
                    norms, emb, src_row, tgt, snorm_scratch + m0, maps + (size_t)m0 * HW, (int)m0, cnt, M,
                    (const int32_t*)nullptr, HW, relu);
+    }
+    return DTK_OK;
+}
+
+// exact fp32 arg-max of the RAW cosine maps (no ReLU: torch.argmax of the affinity row, extract_dino_best_buddies.py:38-39)
+int dtk_argmax_exact(const dtk_geom* g, const float* feat, const float* norms, const float* emb, const int32_t* src_row,
+                     const int32_t* tgt, const int32_t* out_idx, int32_t* arg_cell, float* arg_cos, int M, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    DTK_REQUIRE(g->C % TK == 0, "dtk_argmax_cells(exact): C=%d must be a multiple of %d", g->C, TK);
+    const int HWs = exact_hws(g), HW = g->ph * g->pw;
+    long long chunk = (long long)(workspace_bytes / ((size_t)(HWs + 1) * sizeof(float)));
+    if (chunk > M) chunk = M;
+    if (chunk > 65535LL * TM) chunk = 65535LL * TM;
+    if (chunk < 1) {
+        dtk_set_error("dtk_argmax_cells(exact): workspace of %zu B holds no map", workspace_bytes);
+        return DTK_E_WORKSPACE;
+    }
+    hipStream_t st = dtk_stream(stream);
+    float* maps = reinterpret_cast<float*>(workspace);
+    float* snorm = maps + (size_t)chunk * HWs;
+    for (long long m0 = 0; m0 < M; m0 += chunk) {
+        const int cnt = (int)((M - m0) < chunk ? (M - m0) : chunk);
+        DTK_LAUNCH("row_norms", row_norms_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, emb, src_row, snorm, (int)m0, cnt, M,
+                   (const int32_t*)nullptr, g->C);
+        DTK_LAUNCH("corr_exact", corr_exact_kernel, dim3(dtk_cdiv(HW, TN), dtk_cdiv(cnt, TM)), dim3(256), 0, st, *g, feat, norms,
+                   emb, src_row, tgt, snorm, maps, (int)m0, cnt, M, (const int32_t*)nullptr, HWs, 0);
+        DTK_LAUNCH("argmax_exact", argmax_exact_kernel, dim3(cnt), dim3(256), 0, st, maps, HW, HWs, out_idx, arg_cell, arg_cos,
+                   (int)m0, cnt);
     }
     return DTK_OK;
 }

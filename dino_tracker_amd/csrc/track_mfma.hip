@@ -901,7 +901,8 @@ __global__ __launch_bounds__(256) void rescore_kernel(dtk_geom g, const float* _
                                                       const int32_t* __restrict__ out_idx, const Rec* __restrict__ rec,
                                                       int32_t* __restrict__ kstar, float* __restrict__ snorm,
                                                       int32_t* __restrict__ hist, int HWk, Redo redo, int m0, int count,
-                                                      int M, const int32_t* __restrict__ dM, int dbg) {
+                                                      int M, const int32_t* __restrict__ dM, int dbg,
+                                                      int32_t* __restrict__ arg_cell, float* __restrict__ arg_cos) {
     const int HW = g.ph * g.pw, C = g.C;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -951,6 +952,10 @@ __global__ __launch_bounds__(256) void rescore_kernel(dtk_geom g, const float* _
             redo.tgt[slot] = f;
             redo.out_idx[slot] = out_idx ? out_idx[m] : m;
             kstar[i] = -1;
+        } else if (arg_cell) {  // dtk_argmax_cells: the exact arg-max cell and its cosine are the result
+            const int oi = out_idx ? out_idx[m] : m;
+            arg_cell[oi] = bi;
+            arg_cos[oi] = best;
         } else {
             kstar[i] = bi;
             atomicAdd(&hist[(size_t)f * HWk + cell_key(bi, g.pw)], 1);
@@ -1472,7 +1477,8 @@ struct SrcLists {
 //                 statistics; undecidable sources go to `redo`
 int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const float* feat, const float* norms,
                const half_t* f16, const float* head, const float* emb, SrcLists in, float* out_xy, int count,
-               int normalized, bool fast, Redo redo, Redo uncert, size_t lds_head, hipStream_t st, int dbg) {
+               int normalized, bool fast, Redo redo, Redo uncert, size_t lds_head, hipStream_t st, int dbg,
+               int32_t* arg_cell = nullptr, float* arg_cos = nullptr) {
     half_t* s16 = reinterpret_cast<half_t*>(ws + L.s16);
     half_t* maps = reinterpret_cast<half_t*>(ws + L.maps);
     Rec* rec = reinterpret_cast<Rec*>(ws + L.rec);
@@ -1536,7 +1542,8 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
         }
         DTK_HIP(hipMemsetAsync(ws + L.hist, 0, L.cursor + (size_t)L.nkeys * 4 - L.hist, st));
         DTK_LAUNCH("rescore", rescore_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, *g, feat, norms, emb, in.src_row,
-                   in.tgt, in.out_idx, rec, kstar, snorm, hist, L.HWk, redo, (int)s0, scnt, M, nodm, dbg);
+                   in.tgt, in.out_idx, rec, kstar, snorm, hist, L.HWk, redo, (int)s0, scnt, M, nodm, dbg, arg_cell, arg_cos);
+        if (arg_cell) continue;  // arg-max only: no window refinement
         DTK_LAUNCH("key_scan", scan_blocksum_kernel, dim3(L.nblocks), dim3(256), 0, st, hist, bsum, L.nkeys);
         DTK_LAUNCH("key_scan", scan_top_kernel, dim3(1), dim3(256), 0, st, bsum, L.nblocks, nvalid);
         DTK_LAUNCH("key_scan", scan_final_kernel, dim3(L.nblocks), dim3(256), 0, st, hist, bsum, koff, L.nkeys);
@@ -1625,5 +1632,43 @@ int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, con
                              normalized, ws + L.exact, workspace_bytes - L.exact, stream);
         if (rc) return rc;
     }
+    return DTK_OK;
+}
+
+int dtk_argmax_exact(const dtk_geom* g, const float* feat, const float* norms, const float* emb, const int32_t* src_row,
+                     const int32_t* tgt, const int32_t* out_idx, int32_t* arg_cell, float* arg_cos, int M, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+// dtk_argmax_cells on the MFMA path: fp16 candidate search + fp32 re-scoring (the first two stages of dtk_track); sources
+// the fp16 pass cannot decide (more than 10 cells in the band, non-positive maximum) take the exact fp32 path.
+int dtk_argmax_mfma(const dtk_geom* g, const float* feat, const float* norms, const void* feat_f16, const float* emb,
+                    const int32_t* src_row, const int32_t* tgt, int32_t* arg_cell, float* arg_cos, int M, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+    DTK_REQUIRE(g->C % CK == 0, "dtk_argmax_cells(mfma): C=%d must be a multiple of %d", g->C, CK);
+    const MfmaLayout L = mfma_layout(g, M, 0);
+    if (workspace_bytes < L.total) {
+        dtk_set_error("dtk_argmax_cells(mfma): workspace %zu B < required %zu B", workspace_bytes, L.total);
+        return DTK_E_WORKSPACE;
+    }
+    hipStream_t st = dtk_stream(stream);
+    unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
+    int32_t* counters = reinterpret_cast<int32_t*>(ws + L.redo_cnt);
+    Redo redo, uncert;
+    redo.count = counters;
+    redo.src_row = reinterpret_cast<int32_t*>(ws + L.redo_lists);
+    redo.tgt = redo.src_row + L.cap;
+    redo.out_idx = redo.tgt + L.cap;
+    uncert = redo;
+    DTK_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(int32_t), st));
+    int rc = mfma_phase(g, L, ws, feat, norms, reinterpret_cast<const half_t*>(feat_f16), nullptr, emb,
+                        SrcLists{src_row, tgt, nullptr}, nullptr, M, 0, true, redo, uncert, 0, st, dtk_dev_flags(), arg_cell,
+                        arg_cos);
+    if (rc) return rc;
+    int32_t hc = 0;
+    DTK_HIP(hipMemcpyAsync(&hc, counters, sizeof(hc), hipMemcpyDeviceToHost, st));
+    DTK_HIP(hipStreamSynchronize(st));
+    if (hc > 0)
+        return dtk_argmax_exact(g, feat, norms, emb, redo.src_row, redo.tgt, redo.out_idx, arg_cell, arg_cos, hc, ws + L.exact,
+                                workspace_bytes - L.exact, stream);
     return DTK_OK;
 }

@@ -145,6 +145,21 @@ def track(g: Geom, feat: torch.Tensor, norms: torch.Tensor, feat_f16: Optional[t
     return out_xy
 
 
+def argmax_cells(g: Geom, feat: torch.Tensor, norms: torch.Tensor, feat_f16: Optional[torch.Tensor], emb: torch.Tensor,
+                 src_row: Optional[torch.Tensor], tgt: torch.Tensor, method: int = TRACK_MFMA,
+                 workspace: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """dtk_argmax_cells: (cell [M] int32, cosine [M] f32) of the first maximum of each source's raw cosine map."""
+    M = tgt.shape[0]
+    cell = torch.empty(M, dtype=torch.int32, device=feat.device)
+    cos = torch.empty(M, dtype=torch.float32, device=feat.device)
+    if workspace is None:
+        workspace = torch.empty(track_workspace_bytes(g, M, method), dtype=torch.uint8, device=feat.device)
+    check(lib().dtk_argmax_cells(g, _p(feat, torch.float32), _p(norms, torch.float32), _p(feat_f16), _p(emb, torch.float32),
+                                 _p(src_row, torch.int32), _p(tgt, torch.int32), _p(cell), _p(cos), M, method,
+                                 _p(workspace), workspace.numel(), _stream()))
+    return cell, cos
+
+
 def traj_cos_sims(S: torch.Tensor, tq: torch.Tensor, N: int, T: int) -> torch.Tensor:
     C = S.shape[-1]
     cs = torch.empty((N, T), dtype=torch.float32, device=S.device)

@@ -211,6 +211,15 @@ int dtk_track(const dtk_geom* g, const float* feat, const float* norms, const vo
               const int32_t* out_idx, float* out_xy, int M, const int32_t* dM, const dtk_track_opts* opts,
               dtk_track_stats* stats, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Arg-max cell of the RAW cosine map of each source against its target frame, and the cosine there: row arg-max of
+ * the affinity matrix of the best-buddies preprocessing (preprocessing_dino_bb/extract_dino_best_buddies.py:36-39;
+ * torch.argmax semantics: first maximum).  Sources are rows of `emb` like in dtk_track (src_row may be NULL); results go to
+ * arg_cell[m], arg_cos[m].  DTK_TRACK_MFMA = fp16 candidate search + fp32 re-scoring, undecidable sources on the exact path
+ * (one stream synchronisation); DTK_TRACK_EXACT = fp32 everywhere.  Workspace: dtk_track_workspace_bytes of the method. */
+int dtk_argmax_cells(const dtk_geom* g, const float* feat, const float* norms, const void* feat_f16, const float* emb,
+                     const int32_t* src_row, const int32_t* tgt, int32_t* arg_cell, float* arg_cos, int M, int method,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* fp16 unit-norm copy of the feature volume consumed by DTK_TRACK_MFMA: f16[t][row][col][c] = 32 F/|F| with every map
  * row padded with zero cells to a multiple of 128 columns (an N-tile of the GEMM is one map row); C % 32 == 0. */
 size_t dtk_feat_f16_bytes(const dtk_geom* g);

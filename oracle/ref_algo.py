@@ -401,3 +401,18 @@ def tapvid_metrics(query_frames, gt_occluded, gt_tracks, pred_occluded, pred_tra
     out["average_jaccard"] = float(np.mean(jac))
     out["average_pts_within_thresh"] = float(np.mean(frac))
     return out
+
+
+# --------------------------------------------------------------------------------------------------------------
+# DINO best buddies (preprocessing_dino_bb/extract_dino_best_buddies.py:26-48) for one ordered frame pair
+# --------------------------------------------------------------------------------------------------------------
+def best_buddies_pair(fs: torch.Tensor, ft: torch.Tensor):
+    """fs, ft [HW, C] features of the source / target frame -> (source cell indices, target cell indices, cosines) of the
+    mutual nearest neighbours, in source order."""
+    aff = fs @ ft.t()
+    aff = aff / torch.clamp(fs.norm(dim=1)[:, None] * ft.norm(dim=1)[None], min=1e-8)
+    smax = torch.argmax(aff, dim=1)
+    tmax = torch.argmax(aff, dim=0)
+    rng = torch.arange(fs.shape[0])
+    keep = rng == tmax[smax]
+    return rng[keep], smax[keep], aff[rng[keep], smax[keep]]

@@ -319,3 +319,31 @@ def test_checkpoint_round_trip_invalidates_refined_cache(small, tmp_path):
     rt3, _ = A.infer(A.refine_features(video, feats, d3), queries, head2, Hs, Ws)
     assert (t3.cpu() - rt3).abs().max() < PX_TOL
     trk.load_weights(7)  # restore for the other tests of this module
+
+
+@pytest.mark.parametrize("method", [ops.TRACK_EXACT, ops.TRACK_MFMA], ids=["exact", "mfma"])
+def test_best_buddies(method):
+    """N4: extract_dino_best_buddies on the device (row arg-max of every frame pair through dtk_argmax_cells, mutual test
+    by index arithmetic) vs the oracle's restatement of the reference script, incl. exact ties (duplicated cells) and an
+    all-negative affinity row."""
+    from dino_tracker_amd.best_buddies import create_meshgrid, extract_best_buddies
+    Hs, Ws, T, C = 238, 322, 3, 64
+    feats = synth.synth_features(T, C, 33, 45, seed=66)
+    feats[1, :, 5, 6] = feats[1, :, 5, 7]          # two identical cells in frame 1: first-index tie break
+    feats[2, :, 20, 30] = -feats[0].mean(dim=(1, 2)) * 50.0  # a cell that correlates negatively with (almost) everything
+    bb = extract_best_buddies(feats, Hs, Ws, stride=7, device="cuda:0", method=method)
+    coords = create_meshgrid(Hs, Ws)
+    tm = feats.permute(0, 2, 3, 1).reshape(T, -1, C)
+    assert len(bb) == T * (T - 1)
+    total = 0
+    for s in range(T):
+        for t in range(T):
+            if s == t:
+                continue
+            si, ti, cs = A.best_buddies_pair(tm[s], tm[t])
+            e = bb[f"{s}_{t}"]
+            assert torch.equal(e["source_coords"].cpu(), coords[si]), (s, t)
+            assert torch.equal(e["target_coords"].cpu(), coords[ti]), (s, t)
+            assert (e["cos_sims"].cpu() - cs).abs().max() < 2e-6
+            total += si.numel()
+    assert total > 100

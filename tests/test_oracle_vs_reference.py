@@ -94,3 +94,29 @@ def test_tapvid_metrics_match_reference(tmp_path):
     for k in want:
         assert got[k] == pytest.approx(want[k], abs=1e-12), k
     assert 0.05 < want["average_jaccard"] < 0.95  # a non-degenerate case
+
+
+def test_best_buddies_match_reference(tmp_path):
+    """oracle.best_buddies_pair vs the reference script preprocessing_dino_bb/extract_dino_best_buddies.py run as is (CPU)."""
+    import types
+    from dino_tracker_amd import synth
+    ref_harness.load()
+    import preprocessing_dino_bb.extract_dino_best_buddies as BB
+    T, C, Hh, Ww = 3, 16, 98, 126
+    feats = synth.synth_features(T, C, 13, 17, seed=33)
+    torch.save(feats, tmp_path / "emb.pt")
+    out = tmp_path / "bb" / "bb.pt"
+    BB.run(types.SimpleNamespace(dino_emb_path=str(tmp_path / "emb.pt"), h=Hh, w=Ww, stride=7, out_path=str(out)))
+    bb = torch.load(out)
+    from dino_tracker_amd.best_buddies import create_meshgrid
+    coords = create_meshgrid(Hh, Ww)
+    tm = feats.permute(0, 2, 3, 1).reshape(T, -1, C)
+    assert len(bb) == T * (T - 1)
+    for s in range(T):
+        for t in range(T):
+            if s == t:
+                continue
+            si, ti, cs = A.best_buddies_pair(tm[s], tm[t])
+            e = bb[f"{s}_{t}"]
+            assert torch.equal(e["source_coords"].cpu(), coords[si]) and torch.equal(e["target_coords"].cpu(), coords[ti])
+            assert (e["cos_sims"].cpu() - cs).abs().max() < 1e-6
