@@ -235,7 +235,7 @@ def main():
     #     cpu_qpf = N T / (T t_vit + T t_delta + N t_query).
     # The same K queries are then tracked by the HIP path on the same refined volume: `parity_sample`.
     cpu = parity = None
-    if rank == 0 and not args.no_cpu_baseline and "track" in stages:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and "track" in stages:
         from oracle import ref_algo as A
         nq = max(1, min(N, args.cpu_queries))
         sel = torch.linspace(0, N - 1, nq).long()

@@ -79,3 +79,13 @@ def bilinear_interpolate_video(video: torch.Tensor, points: torch.Tensor, h: int
     feat, _ = ops.pack_features(video[0].permute(1, 0, 2, 3).to(torch.float32).contiguous())  # T C H' W' -> token-major
     out = ops.sample_grid(feat, hh, ww, samples.to(feat.device).contiguous())
     return out.t()[None, :, None, :, None]
+
+
+def save_dino_embed_video(path: str, features: torch.Tensor, dtype: torch.dtype = torch.float32) -> None:
+    """Write `dino_embeddings/dino_embed_video.pt` (utils.py:18; preprocessing/save_dino_embed_video.py:26): T x C x h x w.
+    The reference stores fp32 (1.1 GB at T = 90, C = 384; 3 GB at C = 1024); `dtype=torch.bfloat16` halves the file -- the
+    ViT produced the values from bf16 operands anyway -- and `Tracker.load_dino_embed_video` widens whatever it finds to the
+    fp32 token-major volume.  `features` may also be the token-major [T, h*w, C] device volume with (h, w) given as a tuple
+    in place of a tensor layout: pass `ops.unpack_features(feat, h, w)` for that."""
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    torch.save(features.detach().to("cpu", dtype).contiguous(), path)
