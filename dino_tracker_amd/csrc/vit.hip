@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
 // ---------------------------------------------------------------------------------------------------------------
 // bf16 GEMM  C[M][N] = A[M][K] . Wt[N][K]^T (+bias) with fused epilogues
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int GM = 128, GN = 128;
+constexpr int GM = 128, GN = 128, GK = 32;
 enum { EPI_QKV = 0, EPI_GELU = 1, EPI_DELTA = 2, EPI_F32 = 3 };
 
 struct GemmEpi {
@@ -259,25 +259,27 @@ struct GemmEpi {
     // EPI_GELU
     bf16_t* out;         // [M][N]
     // EPI_DELTA
-    int no_store;        // development: skip the stores of the weight-stationary kernel (DTK_DEBUG & 65536)
+    int no_store;        // DTK_DEV builds: skip the stores of the weight-stationary kernel (DTK_DEBUG & 65536)
     bf16_t* delta;       // [M][N] bf16: gamma * (A W^T + bias), added to the fp32 residual stream by the next LayerNorm
     const float* gamma;  // [N] LayerScale
     // EPI_F32 (tiled kernel only)
     float* out_f32;      // [M][N] fp32: A W^T + bias (the qkv facet output)
 };
 
-// Round 2: the operand tiles arrive by LDS-DMA (att2::glds16) in 64-wide K stages, two stages in flight; an LDS row is
-// the 128 bytes of one operand row with its 16-byte pieces XOR-swizzled through the per-lane source address
-// (piece ^ ((row >> 1) & 7)): a 16-row fragment read is a conflict-free ds_read_b128.  Round 1 staged 32-wide K steps
-// through registers (two barriers per 32 k, 0.6 PF on fc2).  Requires K % 64 == 0 (384, 768, 1024 and their 4x).
-constexpr int GK2 = 64;
-constexpr int G_STAGE_BYTES = (GM + GN) * GK2 * 2;  // 32 KB
+__device__ __forceinline__ int gswz(int row, int piece) {
+    const int f = (0x1230 >> (((row >> 2) & 3) * 4)) & 3;  // {0,3,2,1}: conflict-free ds_read_b128 fragments
+    return row * 4 + (piece ^ f);
+}
+
+// (Round 2 measured two LDS-DMA forms of this main loop on fc2, K = 1536: 64-wide stages, two in flight, two barriers per
+// stage: 17.9 ms; 32-wide stages in a ring of four, three in flight, one barrier per stage: 20.0 ms; this register-staged
+// form: 17.1-17.5 ms.  Kept.)
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
                                                         long long M, int N, int K, GemmEpi e) {
-    __shared__ __attribute__((aligned(1024))) unsigned char stage[2][G_STAGE_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __shared__ uint4 As[2][GM * 4];
+    __shared__ uint4 Bs[2][GN * 4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // block -> tile: workgroup b runs on XCD b % 8 (round-robin dispatch); the column tiles of one row block are given
     // to the same XCD back to back, so that A is fetched from HBM once and the other N/128 - 1 reads hit that XCD's L2
     // (with column-major block order fc2 re-read its 0.75 GB operand three times: 5.2 TB/s, HBM-bound)
@@ -290,69 +292,59 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     const int n0 = (int)(kb % ncol) * GN;
     const int wr = w >> 1, wc = w & 1;  // wave tile 64 x 64
     const int fj = lane & 15, fg = lane >> 4;
-    // DMA: one request = 8 rows x 128 B; wave w fills rows 32 w .. 32 w + 31 of the A tile and of the B tile (4 + 4 requests).
-    // Rows past the end of M / N are clamped (their results are never stored).
-    const int lr = lane >> 3, lpc = lane & 7;
-    const bf16_t* asrc[4];
-    const bf16_t* bsrc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = w * 32 + q * 8 + lr;
-        const int pc = lpc ^ ((r >> 1) & 7);
-        asrc[q] = A + (size_t)min(m0 + r, M - 1) * K + pc * 8;
-        bsrc[q] = Wt + (size_t)min(n0 + r, N - 1) * K + pc * 8;
-    }
-    const unsigned lds_base = (unsigned)(size_t)&stage[0][0];
-    auto issue = [&](int ks, int buf) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            att2::glds16(asrc[q] + ks * GK2, lds_base + buf * G_STAGE_BYTES + (w * 4 + q) * 1024);
-            att2::glds16(bsrc[q] + ks * GK2, lds_base + buf * G_STAGE_BYTES + GM * 128 + (w * 4 + q) * 1024);
-        }
-    };
+    const int lrow = tid >> 2, lpiece = tid & 3;  // loader rows lrow, lrow + 64
+    // clamp loader rows so that ragged M / N never read out of bounds (results of clamped rows are not stored)
+    const long long ar0 = min(m0 + lrow, M - 1), ar1 = min(m0 + lrow + 64, M - 1);
+    const int br0 = min(n0 + lrow, N - 1), br1 = min(n0 + lrow + 64, N - 1);
+    const bf16_t* a0 = A + ar0 * K + lpiece * 8;
+    const bf16_t* a1 = A + ar1 * K + lpiece * 8;
+    const bf16_t* b0 = Wt + (size_t)br0 * K + lpiece * 8;
+    const bf16_t* b1 = Wt + (size_t)br1 * K + lpiece * 8;
     f4 acc[4][4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f4{0.f, 0.f, 0.f, 0.f};
-    // fragment byte offsets inside a stage (kk = 0; the second 32-wide k step XORs piece bit 2)
-    int aoff[4], boff[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int ra = wr * 64 + t * 16 + fj, rb = wc * 64 + t * 16 + fj;
-        aoff[t] = ra * 128 + ((fg ^ ((ra >> 1) & 7)) << 4);
-        boff[t] = GM * 128 + rb * 128 + ((fg ^ ((rb >> 1) & 7)) << 4);
-    }
-    const int nk = K / GK2;
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    if (nk > 1) att2::vm_wait<8>(); else att2::vm_wait<0>();
+    uint4 ra0 = *reinterpret_cast<const uint4*>(a0), ra1 = *reinterpret_cast<const uint4*>(a1);
+    uint4 rb0 = *reinterpret_cast<const uint4*>(b0), rb1 = *reinterpret_cast<const uint4*>(b1);
+    As[0][gswz(lrow, lpiece)] = ra0;
+    As[0][gswz(lrow + 64, lpiece)] = ra1;
+    Bs[0][gswz(lrow, lpiece)] = rb0;
+    Bs[0][gswz(lrow + 64, lpiece)] = rb1;
     __syncthreads();
+    const int nk = K / GK;
+    int cur = 0;
     for (int ks = 0; ks < nk; ++ks) {
-        const unsigned char* sb = &stage[ks & 1][0];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf8 af[4], bfr[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                af[t] = *reinterpret_cast<const bf8*>(sb + (aoff[t] ^ (kk << 6)));
-                bfr[t] = *reinterpret_cast<const bf8*>(sb + (boff[t] ^ (kk << 6)));
-            }
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+        if (ks + 1 < nk) {
+            ra0 = *reinterpret_cast<const uint4*>(a0 + (ks + 1) * GK);
+            ra1 = *reinterpret_cast<const uint4*>(a1 + (ks + 1) * GK);
+            rb0 = *reinterpret_cast<const uint4*>(b0 + (ks + 1) * GK);
+            rb1 = *reinterpret_cast<const uint4*>(b1 + (ks + 1) * GK);
         }
-        // stage ks is consumed by every wave before it is refilled with stage ks + 2; stage ks + 1 must have landed
-        __syncthreads();
-        if (ks + 2 < nk) {
-            issue(ks + 2, ks & 1);
-            att2::vm_wait<8>();   // the 8 requests of stage ks + 1 have landed, those of ks + 2 stay in flight
-        } else {
-            att2::vm_wait<0>();
+        bf8 af[4], bfr[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const uint4 v = As[cur][gswz(wr * 64 + mi * 16 + fj, fg)];
+            af[mi] = *reinterpret_cast<const bf8*>(&v);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const uint4 v = Bs[cur][gswz(wc * 64 + ni * 16 + fj, fg)];
+            bfr[ni] = *reinterpret_cast<const bf8*>(&v);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+        if (ks + 1 < nk) {
+            As[cur ^ 1][gswz(lrow, lpiece)] = ra0;
+            As[cur ^ 1][gswz(lrow + 64, lpiece)] = ra1;
+            Bs[cur ^ 1][gswz(lrow, lpiece)] = rb0;
+            Bs[cur ^ 1][gswz(lrow + 64, lpiece)] = rb1;
         }
         __syncthreads();
+        cur ^= 1;
     }
     // D fragment: lane (fg, fj) holds rows 4*fg + r (r = 0..3), column fj of each 16x16 tile
 #pragma unroll
