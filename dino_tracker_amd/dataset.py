@@ -20,3 +20,103 @@ class RangeNormalizer(torch.nn.Module):
         x[:, dims] = (normalized_x[:, dims] - src[0]) / (src[1] - src[0])
         x[:, dims] = x[:, dims] * self.normalizer[dims]
         return x
+
+
+class LongRangeSampler(torch.nn.Module):
+    """Training-pair sampler of the reference (data/dataset.py:56-208): from optical-flow trajectories [N, T, 2] (NaN where
+    a point is not tracked) draw `batch_size` pairs (point at t1, same point at t2), both times inside one random set of
+    `num_frames` frames, `fg_traj_ratio` of them from the foreground trajectories.  Random numbers are consumed in the
+    reference's order (randperm over frames, randperm over trajectories, multinomial over each row's valid frames), so a
+    seeded run draws the same pairs."""
+
+    CHUNK = 200_000  # trajectories kept on the device at a time when the full set stays on the host
+
+    def __init__(self, batch_size, fg_trajectories=None, bg_trajectories=None, fg_traj_ratio=0.5, num_frames=None,
+                 keep_in_cpu=False) -> None:
+        super().__init__()
+        self.batch_size, self.num_frames, self.fg_traj_ratio = batch_size, num_frames, fg_traj_ratio
+        self.keep_in_cpu = keep_in_cpu
+        self.max_traj_size = self.CHUNK
+        self.gpu_batch_index = 0
+        self._host = {}
+        for name, traj in (("fg", fg_trajectories), ("bg", bg_trajectories)):
+            valid, can = self.get_valid_trajectories(traj)
+            if keep_in_cpu:  # the full set stays on the host, one chunk on the device (load_next_batch rotates)
+                self._host[name] = (valid, can)
+                valid, can = valid[:self.CHUNK].cuda(), can[:self.CHUNK].cuda()
+            setattr(self, f"{name}_valid_trajectories", valid)
+            setattr(self, f"{name}_can_sample", can)
+        self.vid_len = self.fg_valid_trajectories.shape[1]
+
+    @staticmethod
+    def get_valid_trajectories(trajectories):
+        """Rows with at least two tracked frames, and their per-frame validity (dataset.py:100-106)."""
+        can_sample = trajectories.isnan().any(dim=-1).logical_not()
+        keep = can_sample.sum(dim=1) > 1
+        return trajectories[keep], can_sample[keep]
+
+    def load_next_batch(self):
+        """dataset.py:108-134: rotate the device-resident chunk of a host-resident trajectory set."""
+        if not self.keep_in_cpu:
+            return
+        self.gpu_batch_index += 1
+        for name, (valid, can) in self._host.items():
+            n_chunks = -(-valid.shape[0] // self.CHUNK)
+            lo = (self.gpu_batch_index % n_chunks) * self.CHUNK
+            setattr(self, f"{name}_valid_trajectories", valid[lo:lo + self.CHUNK].cuda())
+            setattr(self, f"{name}_can_sample", can[lo:lo + self.CHUNK].cuda())
+
+    def get_point_correspondences_for_num_frames(self, valid_trajectories, can_sample, batch_size):
+        """dataset.py:167-193."""
+        n, t, _ = valid_trajectories.shape
+        dev = valid_trajectories.device
+        while True:  # a frame set in which at least two trajectories have two tracked frames
+            frame_indices = torch.randperm(t, device=dev)[:self.num_frames]
+            rows = (can_sample[:, frame_indices].sum(dim=1) >= 2).nonzero()[:, 0]
+            if rows.numel() >= 2:
+                break
+        rows = rows[torch.randperm(rows.numel(), device=dev)[:batch_size]]
+        allowed = torch.zeros_like(can_sample[rows])
+        allowed[:, frame_indices] = can_sample[rows][:, frame_indices]
+        t1, t2 = allowed.float().multinomial(2, replacement=False).unbind(dim=1)
+        pick = lambda tt: torch.cat([valid_trajectories[rows, tt], tt[:, None].to(valid_trajectories.dtype)], dim=-1)
+        return pick(t1), pick(t2)
+
+    def get_fg_batch_size(self):
+        return int(self.batch_size * self.fg_traj_ratio)
+
+    def forward(self):
+        assert self.num_frames is not None, "num_frames must be specified"
+        n_fg = self.get_fg_batch_size()
+        fg1, fg2 = self.get_point_correspondences_for_num_frames(self.fg_valid_trajectories, self.fg_can_sample, n_fg)
+        bg1, bg2 = self.get_point_correspondences_for_num_frames(self.bg_valid_trajectories, self.bg_can_sample,
+                                                                 self.batch_size - n_fg)
+        return torch.cat([fg1, bg1]), torch.cat([fg2, bg2])
+
+
+class DinoTrackerSampler(LongRangeSampler):
+    """dataset.py:211-258: the pairs plus the batch's frame set and each point's index into it, coordinates normalised by
+    `range_normalizer` to `dst_range`."""
+
+    def __init__(self, batch_size, range_normalizer, dst_range, fg_trajectories=None, bg_trajectories=None,
+                 fg_traj_ratio=0.5, num_frames=None, keep_in_cpu=False) -> None:
+        super().__init__(batch_size, fg_trajectories=fg_trajectories, bg_trajectories=bg_trajectories,
+                         fg_traj_ratio=fg_traj_ratio, num_frames=num_frames, keep_in_cpu=keep_in_cpu)
+        self.range_normalizer, self.dst_range = range_normalizer, dst_range
+
+    def forward(self):
+        t1_points, t2_points = super().forward()
+        frames_set_t, inverse = torch.cat((t1_points[:, 2], t2_points[:, 2])).unique(return_inverse=True)
+        b = t1_points.shape[0]
+        t1n = self.range_normalizer(t1_points, dst=self.dst_range)
+        t2n = self.range_normalizer(t2_points, dst=self.dst_range)
+        t1_points[:, 2] = t1n[:, 2]  # the sources carry their NORMALISED time (dataset.py:245), unused downstream
+        return {
+            "frames_set_t": frames_set_t.int(),
+            "source_frame_indices": inverse[:b],
+            "target_frame_indices": inverse[b:],
+            "t1_points_normalized": t1n,
+            "t2_points_normalized": t2n,
+            "t1_points": t1_points,
+            "target_times": t2_points[:, 2],
+        }

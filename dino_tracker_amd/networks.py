@@ -39,6 +39,10 @@ class NormalizedConv2d(nn.Module):
     def forward(self, x):
         """conv_norm.py:42-46 on the device (dtk_normalized_conv2d).  The tracker path does not come through here: both
         layers of TrackerHead.cnn_refiner are fused into the head kernels."""
+        if self.training and torch.is_grad_enabled():  # test-time training: autograd through the normalisation
+            from . import train_ops
+            return torch.nn.functional.conv2d(x, train_ops.normalized_weight(self.weight), self.bias, stride=self.stride,
+                                              padding=self.padding)
         if self.stride != 1 or self.padding != self.kernel_size // 2:
             raise NotImplementedError("NormalizedConv2d on the device: stride 1, padding k // 2 (the reference's use)")
         return ops.normalized_conv2d(x.detach().to(torch.float32).contiguous(), self.weight.detach().contiguous(),
@@ -79,6 +83,9 @@ class TrackerHead(nn.Module):
 
     def forward(self, cost_volume):
         """cost_volume [B,1,h,w] (already ReLU'd, tracker.py:173) -> [B,2] normalised (x,y) (tracker_head.py:107-121)."""
+        if self.training and torch.is_grad_enabled():  # test-time training (train_ops: autograd supplies the backward)
+            from . import train_ops
+            return train_ops.head_forward(self, cost_volume)
         b, c, h, w = cost_volume.shape
         g = self.geom()
         if (h, w) != (g.ph, g.pw) or c != 1:
@@ -94,6 +101,10 @@ class _BlurPoolParams(nn.Module):
         super().__init__()
         a = torch.tensor([1.0, 3.0, 3.0, 1.0])
         self.register_buffer("filt", (a[:, None] * a[None, :] / 64.0)[None, None].repeat(channels, 1, 1, 1))
+
+    def forward(self, x):
+        from . import train_ops
+        return train_ops.blurpool(x, self.filt)
 
 
 class DeltaDINO(nn.Module):
@@ -131,5 +142,8 @@ class DeltaDINO(nn.Module):
     def forward(self, x, vit_features):
         """delta_dino.py:53-61: frames x [B,3,H,W] in [0,1], vit_features [B,C,h,w] (used for its grid size only, as in
         the reference) -> the residual [B,C,h,w] = align_cnn_vit_features(CNN(x)) (models/utils.py:7-45, patch 14)."""
+        if self.training:  # batch-statistics BatchNorm + autograd graph: test-time training
+            from . import train_ops
+            return train_ops.delta_dino_residual(self, x, vit_features.shape[-2], vit_features.shape[-1])
         from .delta_dino import residual_frames
         return residual_frames(self, x, vit_features)

@@ -211,3 +211,34 @@ def profile_collect() -> Dict[str, Tuple[float, int]]:
     """{kernel name: (total ms, launches)} since profile_enable(True); synchronises."""
     n = lib().dtk_profile_collect()
     return {lib().dtk_profile_name(i).decode(): (lib().dtk_profile_ms(i), lib().dtk_profile_launches(i)) for i in range(n)}
+
+
+def batchnorm_train_forward(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: Optional[torch.Tensor],
+                            running_var: Optional[torch.Tensor], momentum: float, eps: float, relu: bool):
+    """Train-mode BatchNorm2d (+ fused ReLU) over x [N,C,H,W]: returns (y, save_mean, save_rstd); the running statistics
+    are updated in place (dtk_batchnorm_train_forward)."""
+    N, C, H, W = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    nb = int(lib().dtk_batchnorm_workspace_bytes(C))
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    check(lib().dtk_batchnorm_train_forward(_p(x, torch.float32), _p(gamma, torch.float32), _p(beta, torch.float32),
+                                            _p(running_mean, torch.float32), _p(running_var, torch.float32), float(momentum),
+                                            float(eps), int(relu), _p(y), _p(mean), _p(rstd), N, C, H * W, _p(ws), nb, _stream()))
+    return y, mean, rstd
+
+
+def batchnorm_train_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, mean: torch.Tensor,
+                             rstd: torch.Tensor, relu: bool):
+    """(dx, dgamma, dbeta) of batchnorm_train_forward (dtk_batchnorm_train_backward)."""
+    N, C, H, W = x.shape
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    nb = int(lib().dtk_batchnorm_workspace_bytes(C))
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    check(lib().dtk_batchnorm_train_backward(_p(x, torch.float32), _p(dy, torch.float32), _p(gamma, torch.float32),
+                                             _p(beta, torch.float32), _p(mean, torch.float32), _p(rstd, torch.float32),
+                                             int(relu), _p(dx), _p(dgamma), _p(dbeta), N, C, H * W, _p(ws), nb, _stream()))
+    return dx, dgamma, dbeta

@@ -162,6 +162,9 @@ class Tracker(nn.Module):
         x, y in [-1, 1] (token-grid coordinates, see normalize_points_for_sampling) and t an index into `embeddings`
         (normalised by T' - 1 like the reference, utils.py:97-100) -> B x C."""
         t, c, h, w = embeddings.shape
+        if torch.is_grad_enabled() and embeddings.requires_grad:  # training: gradients flow into the embeddings
+            from . import train_ops
+            return train_ops.sample_bilinear(embeddings, source_points.to(embeddings.device, torch.float32))
         if self._refined is not None and embeddings is self._refined_chw:
             feat = self._refined
         elif self._dino is not None and embeddings is self._dino_chw:
@@ -180,8 +183,14 @@ class Tracker(nn.Module):
         from .delta_dino import refine_frames
         idx = frames_set_t.to(self.device).long()
         dino = self.dino_embed_video[idx].contiguous()
-        refined = refine_frames(self.delta_dino, self.video[idx].contiguous(), dino, self.geom)
-        residual = refined - dino
+        if self.delta_dino.training:
+            # test-time training: train-mode BatchNorm over batches of 8 frames (tracker.py:118-124), autograd graph
+            # into the Delta-DINO parameters
+            residual = torch.cat([self.delta_dino(self.video[idx[i:i + 8]], dino[i:i + 8]) for i in range(0, idx.numel(), 8)])
+            refined = dino + residual
+        else:
+            refined = refine_frames(self.delta_dino, self.video[idx].contiguous(), dino, self.geom)
+            residual = refined - dino
         if return_raw_embeddings:
             return refined, residual, dino
         return refined, residual
@@ -288,7 +297,16 @@ class Tracker(nn.Module):
         tgt = target_frame_indices.to(self.device).to(torch.int32).contiguous()
         return ops.corr_maps(g, feat, norms, emb, tgt)[:, None]
 
+    def _differentiable(self):
+        """Training step with autograd on: the torch statement of the path (train_ops) instead of the inference kernels."""
+        return self.training and torch.is_grad_enabled()
+
     def get_point_predictions_from_embeddings(self, source_embeddings, frame_embeddings_set, target_frame_indices):
+        if self._differentiable():
+            from . import train_ops
+            corr_maps = train_ops.cosine_maps(source_embeddings, frame_embeddings_set,
+                                              target_frame_indices.to(frame_embeddings_set.device))[:, None]
+            return train_ops.head_forward(self.tracker_head, self.cmap_relu(corr_maps))
         corr_maps = self.get_corr_maps_for_frame_set(source_embeddings, frame_embeddings_set, target_frame_indices)
         return self.tracker_head(self.cmap_relu(corr_maps))
 
@@ -299,12 +317,104 @@ class Tracker(nn.Module):
         source_embeddings = self.sample_embeddings(frame_embeddings, pts)
         return self.get_point_predictions_from_embeddings(source_embeddings, frame_embeddings, target_frame_indices)
 
+    # ---- test-time training ---------------------------------------------------------------
+    def _forward_train(self, inp, use_raw_features=False):
+        """tracker.py:303-325 in training mode: refine the batch's frames with gradients, keep the tensors the loss
+        terms of dino_tracker.py read (`frame_embeddings`, `raw_embeddings`, `residual_embeddings`)."""
+        frames_set_t = inp[-1]
+        if use_raw_features:
+            frame_embeddings = raw_embeddings = self.get_dino_embed_video(frames_set_t)
+        elif self._refined is not None:  # a cached volume takes precedence, as in the reference (tracker.py:315-317)
+            idx = frames_set_t.to(self.device).long()
+            frame_embeddings, raw_embeddings = self.refined_features[idx], self.dino_embed_video[idx]
+        else:
+            frame_embeddings, residual_embeddings, raw_embeddings = self.get_refined_embeddings(
+                frames_set_t, return_raw_embeddings=True)
+            self.residual_embeddings = residual_embeddings
+        self.frame_embeddings = frame_embeddings
+        self.raw_embeddings = raw_embeddings
+        return self.get_point_predictions(inp, frame_embeddings)
+
+    def _cycle_point_sets(self, frames_set_t, fg_masks):
+        """Index plumbing of tracker.py:183-222: cyc_n_frames random (source, target) frame pairs of the batch and, per
+        pair, cyc_batch_size_per_frame pixel positions of the source frame split foreground / background by the mask.
+        Random numbers are drawn in the reference's order (2 x randint, then randperm fg, randperm bg per pair)."""
+        n = frames_set_t.shape[0]
+        dev = frames_set_t.device
+        source_selector = torch.randint(n, (self.cyc_n_frames,), device=dev)
+        target_selector = torch.randint(n, (self.cyc_n_frames,), device=dev)
+        h, w = fg_masks.shape[-2:]
+        n_fg = int(self.cyc_batch_size_per_frame * self.cyc_fg_points_ratio)
+        n_bg = self.cyc_batch_size_per_frame - n_fg
+        pts, src_idx, tgt_idx = [], [], []
+        for s_i, t_i in zip(source_selector.tolist(), target_selector.tolist()):
+            source_t = int(frames_set_t[s_i])
+            fg = (fg_masks[source_t] > 0).reshape(-1)
+            cells_fg = fg.nonzero()[:, 0]
+            cells_bg = (~fg).nonzero()[:, 0]
+            cells_fg = cells_fg[torch.randperm(cells_fg.shape[0])[:n_fg].to(cells_fg.device)]
+            cells_bg = cells_bg[torch.randperm(cells_bg.shape[0])[:n_bg].to(cells_bg.device)]
+            cells = torch.cat([cells_fg, cells_bg])
+            xy = torch.stack([(cells % w).float(), torch.div(cells, w, rounding_mode="floor").float(),
+                              torch.full_like(cells, source_t, dtype=torch.float32)], dim=1)
+            pts.append(xy.to(dev))
+            src_idx.append(torch.full((xy.shape[0],), s_i, device=dev, dtype=torch.long))
+            tgt_idx.append(torch.full((xy.shape[0],), t_i, device=dev, dtype=torch.long))
+        return torch.cat(pts), torch.cat(src_idx), torch.cat(tgt_idx)
+
+    @torch.no_grad()
+    def get_cycle_consistent_coords(self, frames_set_t, fg_masks):
+        """tracker.py:182-259: track the sampled points source -> target -> source with the current embeddings
+        (`self.frame_embeddings` of the preceding forward) and keep those that come back within cyc_thresh px.  All pairs
+        go through the tracker kernels as ONE batch per direction."""
+        src_pts, src_idx, tgt_idx = self._cycle_point_sets(frames_set_t, fg_masks)
+        emb = self.frame_embeddings.detach()
+        unnorm = lambda c: self.range_normalizer.unnormalize(c, src=(-1, 1), dims=[0, 1])
+        t_of = frames_set_t.to(src_pts.device).float()
+        tgt_xy = unnorm(self.get_point_predictions((src_pts, src_idx, tgt_idx, frames_set_t), emb))
+        tgt_pts = torch.cat([tgt_xy, t_of[tgt_idx][:, None]], dim=1)
+        back_xy = unnorm(self.get_point_predictions((tgt_pts, tgt_idx, src_idx, frames_set_t), emb))
+        keep = torch.norm(src_pts[:, :2] - back_xy[:, :2], dim=1) <= self.cyc_thresh
+        src_t, tgt_t = t_of[src_idx][keep], t_of[tgt_idx][keep]
+        norm_t = lambda t: self.range_normalizer(t[:, None].repeat(1, 3), dst=(-1, 1), dims=[2])[:, 2]
+        return {
+            "source_points": src_pts[keep],
+            "target_points": tgt_pts[keep],
+            "cycle_points": back_xy[keep],
+            "source_frame_indices": src_idx[keep],
+            "target_frame_indices": tgt_idx[keep],
+            "source_times_normalized": norm_t(src_t),
+            "target_times_normalized": norm_t(tgt_t),
+        }
+
+    def get_cycle_consistent_preds(self, frames_set_t, fg_masks):
+        """tracker.py:261-301: the cycle-consistent pairs re-tracked in both directions WITH gradients, plus the
+        quantities of the cycle loss (dino_tracker.py:332-339)."""
+        while True:
+            cyc = self.get_cycle_consistent_coords(frames_set_t, fg_masks)
+            if cyc["source_points"].shape[0] > 0:
+                break
+        src_tgt = self.get_point_predictions(
+            (cyc["source_points"], cyc["source_frame_indices"], cyc["target_frame_indices"], frames_set_t), self.frame_embeddings)
+        tgt_src = self.get_point_predictions(
+            (cyc["target_points"], cyc["target_frame_indices"], cyc["source_frame_indices"], frames_set_t), self.frame_embeddings)
+        return {
+            "source_coords": self.range_normalizer(cyc["source_points"], dst=[-1, 1]),
+            "target_coords": self.range_normalizer(cyc["target_points"], dst=[-1, 1]),
+            "source_target_coords": src_tgt[:, :2],
+            "target_source_coords": tgt_src[:, :2],
+            "cycle_consistency_dists": torch.norm(cyc["cycle_points"][:, :2] - cyc["source_points"][:, :2], dim=1),
+            "cycle_points": cyc["cycle_points"],
+        }
+
     # ---- forward (tracker.py:303-325) ----------------------------------------------------------------------------
     def forward(self, inp, use_raw_features=False):
         """inp = (source_points B x 3 in pixels (x,y,t), source_frame_indices B, target_frame_indices B,
         frames_set_t n): embeddings are sampled at source_points in frame frames_set_t[source_frame_indices] and
         tracked into frame frames_set_t[target_frame_indices]; returns B x 2 in [-1,1]."""
         source_points, source_frame_indices, target_frame_indices, frames_set_t = inp
+        if self.training:
+            return self._forward_train(inp, use_raw_features)
         if not use_raw_features and (self._refined is None or self.refined_is_stale()):
             self.cache_refined_embeddings()
         feats = self.features(use_raw_features)

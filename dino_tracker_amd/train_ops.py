@@ -1,0 +1,208 @@
+"""Differentiable (train-mode) arithmetic of the tracker -- SURVEY.md section 8(f) N1, first cut.
+
+The inference kernels of libdtk have no backward; per-video test-time training (dino_tracker.py:392-448) needs gradients
+with respect to the Delta-DINO CNN and the tracker head through
+
+    frames -> Delta-DINO (train-mode BatchNorm) -> align to the ViT grid -> + DINO        models/tracker.py:113-129
+    -> bilinear sampling of the source embeddings                                          models/tracker.py:96-111
+    -> cosine correlation map of every source with ITS target frame -> ReLU                models/tracker.py:158-173
+    -> normalised 3x3 convs -> softmax -> disk-masked soft arg-max                         tracker_head.py:68-121
+
+This module states that arithmetic on torch tensors so that autograd supplies the backward (rocBLAS / MIOpen kernels on
+the device); everything that runs without gradients inside a training step (the cycle-consistency filter, the mutual
+nearest-neighbour search) stays on the hand-written kernels.  Differences in mechanism from the reference:
+  * one correlation map per source (grouped by target frame: one [B_f, C] x [C, HW] product per frame) instead of
+    B x n maps of which B are kept (tracker.py:159-160) -- n times less work forward AND backward;
+  * the CNN -> ViT grid alignment is two constant interpolation matrices (row, column) applied as matrix products instead
+    of a grid_sample over a B x h x w x 2 grid (models/utils.py:30-44): deterministic backward, no atomics;
+  * source sampling gathers the four corners of the source's own frame (the reference interpolates trilinearly over a
+    frame stack at an integer frame coordinate, utils.py:97-100).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+EPS = 1e-8  # models/tracker.py:14, conv_norm.py:35, tracker_head.py:86
+
+
+# ---- Delta-DINO ----------------------------------------------------------------------------------------------------------
+def blurpool(x: torch.Tensor, filt: torch.Tensor, stride: int = 2) -> torch.Tensor:
+    """antialiased_cnns.BlurPool(filt_size 4, reflect): pad (left 1, right 2, top 1, bottom 2), depthwise binomial conv."""
+    return F.conv2d(F.pad(x, (1, 2, 1, 2), mode="reflect"), filt, stride=stride, groups=x.shape[1])
+
+
+def align_matrix(n_vit: int, n_cnn: int, vit_stride: int, vit_patch: int, cnn_stride: int, device, dtype=torch.float32):
+    """[n_vit, n_cnn] interpolation matrix of models/utils.py:30-44 along one axis: ViT centre i sits at pixel
+    vit_stride * i + vit_patch / 2, CNN cell j at pixel cnn_stride * j; grid_sample(align_corners=True, border) with
+    g = -1 - 1/c_br + 2 px / c_br reads the CNN axis at (px - 0.5) / cnn_stride, clamped to [0, n_cnn - 1]."""
+    # float32 in the reference's own order of operations (models/utils.py:30-36, then grid_sample's unnormalisation), so the
+    # interpolation weights carry the same rounding as its grid
+    px = torch.arange(n_vit, dtype=torch.float32) * vit_stride + vit_patch / 2.0
+    c_br = (n_cnn - 1) * cnn_stride
+    g = -1.0 - (1.0 / c_br) + (2.0 * px / c_br)
+    pos = (((g + 1.0) / 2.0) * (n_cnn - 1)).clamp(0, n_cnn - 1)
+    lo = pos.floor().clamp(max=n_cnn - 1)
+    hi = (lo + 1).clamp(max=n_cnn - 1)
+    w_hi = pos - lo
+    m = torch.zeros(n_vit, n_cnn, dtype=torch.float32)
+    rows = torch.arange(n_vit)
+    m[rows, lo.long()] += 1.0 - w_hi
+    m[rows, hi.long()] += w_hi
+    return m.to(device=device, dtype=dtype)
+
+
+def align_cnn_to_vit(cnn: torch.Tensor, h: int, w: int, vit_stride: int, vit_patch: int, cnn_stride: int) -> torch.Tensor:
+    """models/utils.py:7-45 as two matrix products: [n, C, hc, wc] -> [n, C, h, w]."""
+    my = align_matrix(h, cnn.shape[-2], vit_stride, vit_patch, cnn_stride, cnn.device, cnn.dtype)
+    mx = align_matrix(w, cnn.shape[-1], vit_stride, vit_patch, cnn_stride, cnn.device, cnn.dtype)
+    return torch.matmul(my, torch.matmul(cnn, mx.t()))
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    """Train-mode BatchNorm2d (+ the ReLU behind it) on the hand-written kernels (csrc/train.hip): statistics by pairwise
+    merging of exact small-group moments.  The library BatchNorm behind torch.nn.BatchNorm2d loses the variance of channels
+    whose mean is large against their spread (5e-3 relative output error measured on Delta-DINO's second layer)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu):
+        from . import ops
+        x = x.contiguous()
+        y, mean, rstd = ops.batchnorm_train_forward(x, gamma.detach().contiguous(), beta.detach().contiguous(), running_mean,
+                                                    running_var, momentum, eps, relu)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.batchnorm_train_backward(x, dy.contiguous(), gamma.detach().contiguous(),
+                                                         beta.detach().contiguous(), mean, rstd, ctx.relu)
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def batchnorm_train(bn: torch.nn.BatchNorm2d, x: torch.Tensor, relu: bool) -> torch.Tensor:
+    """nn.BatchNorm2d.forward in training mode (+ ReLU) on the device kernels; bookkeeping as torch's module does it
+    (num_batches_tracked, momentum None = cumulative average)."""
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _BatchNormTrain.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, relu)
+
+
+def delta_dino_residual(delta_dino, frames: torch.Tensor, h: int, w: int, vit_patch: int = 14) -> torch.Tensor:
+    """DeltaDINO.forward (delta_dino.py:53-61) in training mode -> the aligned residual [n, C, h, w].  Convolutions and
+    blur-pools through the module's own objects (library kernels, autograd); on the device every BatchNorm2d -- with the ReLU
+    that follows it -- runs on csrc/train.hip, forward and backward.  On host tensors (the CPU parity tests of this
+    arithmetic) the BatchNorm2d modules themselves run."""
+    x = frames
+    layers = list(delta_dino.layers)
+    i = 0
+    while i < len(layers):
+        layer = layers[i]
+        if isinstance(layer, torch.nn.BatchNorm2d) and layer.training and x.is_cuda and layer.affine:
+            relu = i + 1 < len(layers) and isinstance(layers[i + 1], torch.nn.ReLU)
+            x = batchnorm_train(layer, x, relu)
+            i += 2 if relu else 1
+            continue
+        x = layer(x)
+        i += 1
+    return align_cnn_to_vit(x, h, w, delta_dino.vit_stride, vit_patch, delta_dino.get_total_stride())
+
+
+# ---- sampling -------------------------------------------------------------------------------------------------------------
+def sample_bilinear(emb: torch.Tensor, pts: torch.Tensor) -> torch.Tensor:
+    """Tracker.sample_embeddings (tracker.py:96-111): emb [n, C, h, w], pts [B, 3] = (x, y in [-1, 1] token-grid
+    coordinates, frame index into emb) -> [B, C]; align_corners, border clamp.  Gradient flows to `emb` only (the
+    reference detaches the points, utils.py:91)."""
+    n, c, h, w = emb.shape
+    p = pts.detach()
+    fx = ((p[:, 0] + 1) * 0.5 * (w - 1)).clamp(0, w - 1)
+    fy = ((p[:, 1] + 1) * 0.5 * (h - 1)).clamp(0, h - 1)
+    t = p[:, 2].round().long().clamp(0, n - 1)
+    x0 = fx.floor().clamp(max=w - 1)
+    y0 = fy.floor().clamp(max=h - 1)
+    wx = (fx - x0)[:, None]
+    wy = (fy - y0)[:, None]
+    x0 = x0.long()
+    y0 = y0.long()
+    x1 = (x0 + 1).clamp(max=w - 1)
+    y1 = (y0 + 1).clamp(max=h - 1)
+    e = emb.permute(0, 2, 3, 1)  # [n, h, w, C]: one gather fetches a whole embedding
+    return ((e[t, y0, x0] * (1 - wx) + e[t, y0, x1] * wx) * (1 - wy) +
+            (e[t, y1, x0] * (1 - wx) + e[t, y1, x1] * wx) * wy)
+
+
+# ---- correlation ------------------------------------------------------------------------------------------------------------
+def cosine_maps(src: torch.Tensor, frames: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
+    """tracker.py:158-169: rho[b] = <src[b], frames[tgt[b]]> / max(|src[b]| |frames[tgt[b]]|, 1e-8) -> [B, h, w].
+    Sources are grouped by target frame: one matrix product per frame that is somebody's target."""
+    n, c, h, w = frames.shape
+    b = src.shape[0]
+    tgt = tgt.long()
+    out = src.new_zeros(b, h * w)
+    fl = frames.reshape(n, c, h * w)
+    snorm = src.norm(dim=1)
+    for f in torch.unique(tgt).tolist():  # one host read per call; n <= 8 frames in a training batch
+        sel = (tgt == f).nonzero()[:, 0]
+        ff = fl[f]
+        dots = src[sel] @ ff
+        den = (snorm[sel][:, None] * ff.norm(dim=0)[None, :]).clamp(min=EPS)
+        out = out.index_copy(0, sel, dots / den)
+    return out.reshape(b, h, w)
+
+
+# ---- tracker head -----------------------------------------------------------------------------------------------------------
+def normalized_weight(weight: torch.Tensor) -> torch.Tensor:
+    """conv_norm.py:34-44: W / sum_{kh,kw} W, a sum with |.| < 1e-8 replaced by sign(.) 1e-8."""
+    s = weight.sum(dim=[2, 3], keepdim=True)
+    s = torch.where(s.abs() < EPS, torch.sign(s) * EPS, s)
+    return weight / s
+
+
+def head_logits(head, x: torch.Tensor) -> torch.Tensor:
+    """cnn_refiner (tracker_head.py:47-58): [B, 1, h, w] -> [B, 1, h, w]."""
+    c0, c2 = head.cnn_refiner[0], head.cnn_refiner[2]
+    y = F.conv2d(x, normalized_weight(c0.weight), c0.bias, stride=c0.stride, padding=c0.padding)
+    return F.conv2d(torch.relu(y), normalized_weight(c2.weight), c2.bias, stride=c2.stride, padding=c2.padding)
+
+
+def soft_argmax(p: torch.Tensor, peak: torch.Tensor, patch: int, stride: int, radius: float) -> torch.Tensor:
+    """tracker_head.py:68-98: p [B, h, w] (softmax over the map), peak [B] flat arg-max of the cost volume -> [B, 2]
+    pixel (x, y): centre of mass of p inside the disk of `radius` px around the peak cell; a disk whose mass is below
+    1e-8 is replaced by the uniform distribution over the disk."""
+    b, h, w = p.shape
+    ys = torch.arange(h, device=p.device, dtype=torch.float32) * stride + patch // 2
+    xs = torch.arange(w, device=p.device, dtype=torch.float32) * stride + patch // 2
+    pr = torch.div(peak, w, rounding_mode="floor")
+    pc = peak - pr * w
+    dy = ys[None, :] - (pr * stride + patch // 2).to(torch.float32)[:, None]   # [B, h]
+    dx = xs[None, :] - (pc * stride + patch // 2).to(torch.float32)[:, None]   # [B, w]
+    mask = torch.sqrt(dy[:, :, None] ** 2 + dx[:, None, :] ** 2) <= radius
+    q = p * mask
+    s = q.sum(dim=(1, 2))
+    zero = s < EPS
+    uni = (1.0 / mask.sum(dim=(1, 2)).to(p.dtype))[:, None, None]
+    q = torch.where(zero[:, None, None], (q + uni) * mask, q)
+    s = torch.where(zero, q.sum(dim=(1, 2)), s)
+    px = (q.sum(dim=1) * xs[None, :]).sum(dim=1) / s
+    py = (q.sum(dim=2) * ys[None, :]).sum(dim=1) / s
+    return torch.stack([px, py], dim=1)
+
+
+def head_forward(head, cost: torch.Tensor) -> torch.Tensor:
+    """TrackerHead.forward (tracker_head.py:107-121): cost [B, 1, h, w] >= 0 -> [B, 2] in [-1, 1]."""
+    b, _, h, w = cost.shape
+    peak = cost[:, 0].reshape(b, h * w).argmax(dim=1)
+    p = torch.softmax(head_logits(head, cost).reshape(b, h * w), dim=1).reshape(b, h, w)
+    xy = soft_argmax(p, peak, head.patch_size, head.step_h, float(head.argmax_radius))
+    scale = torch.tensor([head.video_w - 1, head.video_h - 1], device=xy.device, dtype=xy.dtype)
+    return 2.0 * xy / scale - 1.0

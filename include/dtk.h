@@ -259,6 +259,26 @@ int dtk_tapvid_counts(const float* pred_tracks, const uint8_t* pred_occluded, co
                       float gt_scale_x, float gt_scale_y, int first_mode, int N, int T, unsigned long long* counts18,
                       void* stream);
 
+/* ---- per-video test-time training: train-mode BatchNorm2d of the Delta-DINO CNN ------------------------
+ * Replaces nn.BatchNorm2d in training mode inside DeltaDINO.forward (models/networks/delta_dino.py:38,53-55; batches of
+ * <= 8 frames, models/tracker.py:118-124) and its autograd backward.  x, y, dy, dx: [N][C][HW] float32 (NCHW).
+ * forward:  y = gamma (x - mean_c) rstd_c + beta over the batch statistics of channel c (biased variance, eps inside the
+ *   root), followed by ReLU when relu != 0 (the nn.ReLU that follows the first three layers, delta_dino.py:41-42);
+ *   save_mean / save_rstd [C] for the backward; running_mean / running_var [C] (nullable) are updated in place with
+ *   `momentum` and the UNBIASED batch variance, as torch does.  Statistics by pairwise (Chan) merging of exact small-group
+ *   moments -- no E[x^2] - E[x]^2.
+ * backward: dx, dgamma [C], dbeta [C] from dy (the gradient w.r.t. the ReLU'd output when relu != 0).
+ * workspace: dtk_batchnorm_workspace_bytes(C) bytes of device memory. */
+size_t dtk_batchnorm_workspace_bytes(int32_t C);
+int dtk_batchnorm_train_forward(const float* x, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, float momentum, float eps, int32_t relu, float* y, float* save_mean,
+                                float* save_rstd, int32_t N, int32_t C, int32_t HW, void* workspace, size_t workspace_bytes,
+                                void* stream);
+int dtk_batchnorm_train_backward(const float* x, const float* dy, const float* gamma, const float* beta,
+                                 const float* save_mean, const float* save_rstd, int32_t relu, float* dx, float* dgamma,
+                                 float* dbeta, int32_t N, int32_t C, int32_t HW, void* workspace, size_t workspace_bytes,
+                                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -169,8 +169,63 @@ def run_reference_scripts(only_cfg3=False):
     return out
 
 
+def summarise_training(ckpt_dir, start_iter, end_iter):
+    """What tests/test_gpu_train.py compares of a finished run: the head's four tensors in full; per Delta-DINO tensor the
+    norm of the final value and of the update since the start checkpoint, 64 fixed entries of the update, and the BatchNorm
+    running statistics in full (the full state dict is 28 MB)."""
+    import torch
+    out = {}
+    for k, v in torch.load(os.path.join(ckpt_dir, f"tracker_head_{end_iter}.pt"), map_location="cpu").items():
+        out["head." + k] = v.numpy()
+    a = torch.load(os.path.join(ckpt_dir, f"delta_dino_{start_iter}.pt"), map_location="cpu")
+    b = torch.load(os.path.join(ckpt_dir, f"delta_dino_{end_iter}.pt"), map_location="cpu")
+    g = np.random.default_rng(0)
+    for k in b:
+        if k.endswith("filt") or k.endswith("num_batches_tracked"):
+            continue
+        fin, upd = b[k].double().flatten().numpy(), (b[k].double() - a[k].double()).flatten().numpy()
+        if "running" in k:
+            out["delta." + k] = fin
+            continue
+        idx = g.integers(0, fin.size, 64)
+        out["delta." + k] = np.concatenate([[np.linalg.norm(fin), np.linalg.norm(upd)], upd[idx]])
+    return out
+
+
+def run_reference_training():
+    """train.py of the reference (BASELINE.json config 5 at reduced size), un-modified, on CPU: three iterations from the
+    seeded start checkpoint with every loss term active, through tests/golden/train_driver.py (host-side random draws,
+    per-iteration loss capture)."""
+    import json
+    import subprocess
+    import train_data as TD
+    ref = ref_harness.REFERENCE_ROOT
+    tmp = tempfile.mkdtemp()
+    d, cfg = TD.build(os.path.join(tmp, "train"), ref)
+    log = os.path.join(tmp, "losses.json")
+    env = dict(os.environ, DTK_TRAIN_LOG=log,
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "oracle", "shims"), ref, ROOT]))
+    r = subprocess.run([sys.executable, os.path.join(OUT, "train_driver.py"), os.path.join(ref, "train.py"), "--config", cfg,
+                        "--data-path", d, "--seed", "2"], env=env, cwd=ref, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    with open(log) as fh:
+        rec = json.load(fh)
+    out = summarise_training(os.path.join(d, "models", "dino_tracker"), TD.CFG["start_iter"], TD.CFG["total_iterations"])
+    out["losses"] = np.array(rec["losses"], dtype=np.float64)
+    out["loss_names"] = np.array(rec["names"])
+    return out
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or list(CASES) + ["p1_small"]
+    if "ref_train" in names:
+        names.remove("ref_train")
+        res = run_reference_training()
+        path = os.path.join(OUT, "ref_train.npz")
+        np.savez_compressed(path, **res)
+        print("ref_train", res["losses"], os.path.getsize(path) // 1024, "KiB")
+        if not names:
+            sys.exit(0)
     if "ref_scripts" in names or "ref_scripts_cfg3" in names:
         only3 = "ref_scripts_cfg3" in names
         names = [n for n in names if not n.startswith("ref_scripts")]

@@ -1,0 +1,75 @@
+"""TEST INFRASTRUCTURE -- runs the reference's train.py UNCHANGED (runpy) with two pieces of instrumentation, the same on
+both sides of the comparison (the reference's own modules on CPU when make_golden.py builds the fixture; this
+implementation on the device under `python -m dino_tracker_amd.run` in tests/test_gpu_train.py):
+
+  * every random draw comes from torch's CPU generator: randperm / randint with a device argument and Tensor.multinomial
+    are computed on the host and moved, so that the CPU and the device run see the same indices;
+  * DINOTracker.update_losses also appends its arguments (the seven loss values of the iteration) to a list that is written
+    to $DTK_TRAIN_LOG as JSON at exit -- train() itself only logs every 100th iteration.
+On a machine without a GPU `Tensor.cuda()` is the identity (dino_tracker.py and models/utils.py call it unconditionally)
+and the reference's RangeNormalizer gets 'cpu' as its default device (data/dataset.py:15; the same patch as
+oracle/ref_harness.py), as does models/utils.py:87's grid helper.
+
+    python train_driver.py <reference>/train.py --config C --data-path D --seed S
+"""
+import atexit
+import json
+import os
+import runpy
+import sys
+
+import torch
+
+_randperm, _randint, _multinomial = torch.randperm, torch.randint, torch.Tensor.multinomial
+
+
+def randperm(n, *args, device=None, **kw):
+    out = _randperm(n, *args, **kw)
+    return out if device is None else out.to(device)
+
+
+def randint(*args, device=None, **kw):
+    out = _randint(*args, **kw)
+    return out if device is None else out.to(device)
+
+
+def multinomial(self, *args, **kw):
+    return _multinomial(self.cpu(), *args, **kw).to(self.device)
+
+
+torch.randperm, torch.randint, torch.Tensor.multinomial = randperm, randint, multinomial
+if not torch.cuda.is_available():
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+LOSSES = []
+
+
+def _dump():
+    path = os.environ.get("DTK_TRAIN_LOG")
+    if path:
+        with open(path, "w") as fh:
+            json.dump({"names": ["total", "of", "cl_dino_bb", "cl_refiner", "emb_norm_reg", "angle_reg", "cyc"],
+                       "losses": LOSSES}, fh)
+
+
+atexit.register(_dump)
+
+if __name__ == "__main__":
+    script = sys.argv[1]
+    sys.argv = sys.argv[1:]
+    if not torch.cuda.is_available():
+        import data.dataset
+        if data.dataset.RangeNormalizer.__init__.__defaults__ == ("cuda",):
+            data.dataset.RangeNormalizer.__init__.__defaults__ = ("cpu",)
+        import models.utils  # get_vit_feature_coords_from_mask(..., device="cuda") (models/utils.py:87)
+        models.utils.get_vit_feature_coords_from_mask.__defaults__ = (7, 14, "cpu")
+    import dino_tracker  # the reference's control plane (never overlaid)
+
+    _update = dino_tracker.DINOTracker.update_losses
+
+    def update_losses(self, *vals):
+        LOSSES.append([float(v) for v in vals])
+        return _update(self, *vals)
+
+    dino_tracker.DINOTracker.update_losses = update_losses
+    runpy.run_path(script, run_name="__main__")

@@ -1,0 +1,214 @@
+"""-m gpu, N1: the reference's train.py runs UN-MODIFIED on this implementation (BASELINE.json config 5 at reduced size).
+
+`python -m dino_tracker_amd.run ... train.py` goes through dino_tracker.DINOTracker.train() (the reference's control plane:
+losses, Adam, LambdaLR, checkpoints) -> models.tracker.Tracker / data.dataset.DinoTrackerSampler = this implementation:
+Delta-DINO with train-mode BatchNorm and the tracker head under autograd (dino_tracker_amd/train_ops.py), the
+cycle-consistency filter on the inference kernels.  Three iterations from a seeded checkpoint with every loss term on are
+compared with tests/golden/ref_train.npz = the same script on the reference's own code on CPU (make_golden.py ref_train):
+the seven loss values of every iteration, the trained head, the Delta-DINO updates and the BatchNorm running statistics.
+Both runs draw their random indices on the host through tests/golden/train_driver.py.
+
+Needs a reference checkout ($DTK_REFERENCE_ROOT; scripts/stage_reference.sh) -- skipped otherwise.  The pieces that need
+no reference run always: a training step's values and gradients on the device against the same step on the host."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+REF = os.environ.get("DTK_REFERENCE_ROOT", "")
+HAVE_REF = bool(REF) and os.path.isfile(os.path.join(REF, "train.py"))
+needs_ref = pytest.mark.skipif(not HAVE_REF, reason="$DTK_REFERENCE_ROOT does not point at a reference checkout")
+pytestmark = pytest.mark.gpu
+LOGDIR = os.path.join(ROOT, "gpurun_out", "ref_scripts")
+
+
+@needs_ref
+def test_train_py_unmodified_three_iterations(tmp_path):
+    import train_data as TD
+    from make_golden import summarise_training
+    d, cfg = TD.build(str(tmp_path / "train"), REF)
+    log = str(tmp_path / "losses.json")
+    cmd = [sys.executable, "-m", "dino_tracker_amd.run", "--path", os.path.join(ROOT, "oracle", "shims"), "--path", REF,
+           os.path.join(ROOT, "tests", "golden", "train_driver.py"), os.path.join(REF, "train.py"),
+           "--config", cfg, "--data-path", d, "--seed", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, PYTHONPATH=ROOT, DTK_TRAIN_LOG=log),
+                       cwd=REF, timeout=3000)
+    os.makedirs(LOGDIR, exist_ok=True)
+    with open(os.path.join(LOGDIR, "cfg5_train.log"), "w") as fh:
+        fh.write("$ " + " ".join(cmd) + "\n" + r.stdout[-6000:] + "\n--- stderr ---\n" + r.stderr[-6000:])
+    assert r.returncode == 0, r.stderr[-3000:]
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "ref_train.npz"))
+    with open(log) as fh:
+        losses = np.array(json.load(fh)["losses"])
+    assert losses.shape == gold["losses"].shape == (3, 7)
+    rel = np.abs(losses - gold["losses"]) / np.maximum(np.abs(gold["losses"]), 1e-6)
+    got = summarise_training(os.path.join(d, "models", "dino_tracker"), TD.CFG["start_iter"], TD.CFG["total_iterations"])
+    worst = {}
+    for k in gold.files:
+        if k in ("losses", "loss_names"):
+            continue
+        a, b = got[k].astype(np.float64), gold[k].astype(np.float64)
+        assert a.shape == b.shape, k
+        worst[k] = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+    with open(os.path.join(LOGDIR, "cfg5_train_result.json"), "w") as fh:
+        json.dump({"loss_names": gold["loss_names"].tolist(), "losses_hip": losses.tolist(),
+                   "losses_reference_cpu": gold["losses"].tolist(), "max_rel_loss_diff": float(rel.max()),
+                   "max_rel_diff_per_tensor": worst}, fh, indent=1)
+    assert rel.max() < 5e-4, rel  # measured 1.6e-5
+    for k, v in worst.items():
+        # Adam's first steps have |update| = lr whatever the gradient's size: a gradient component that is rounding noise
+        # (conv biases in front of BatchNorm) moves by +-lr either way, so biases are compared through the losses only
+        if k.startswith("delta.layers.") and k.endswith(".bias") and k.split(".")[2] in ("0", "4", "8", "12"):
+            continue
+        assert v < 1e-2, (k, v)  # measured <= 2e-3
+
+
+def test_training_step_on_device_matches_host():
+    """Without the reference: one training step of Tracker.forward (train mode) on the device -- Delta-DINO with
+    batch-statistics BatchNorm, sampling, correlation, head -- against the same arithmetic on the host (train_ops on CPU
+    tensors, pinned against the reference by tests/test_train_vs_reference.py): predictions, and gradients of all
+    parameters; then the no-grad cycle-consistency filter (inference kernels) against the differentiable path."""
+    import copy
+    from gpu_util import make_tracker
+    from dino_tracker_amd import ops, synth, train_ops
+    H, W, T, C = 126, 210, 5, 64
+    ph, pw = (H - 14) // 7 + 1, (W - 14) // 7 + 1
+    torch.manual_seed(0)
+    video = synth.synth_video(T, H, W, seed=3)
+    feats = synth.synth_features(T, C, ph, pw, seed=4)
+    trk = make_tracker(video, feats, synth.synth_head_weights(3), method=ops.TRACK_EXACT,
+                       delta=synth.synth_delta_dino_weights(C, 6))
+    trk.train()
+    dev = trk.device
+    B = 96
+    g = torch.Generator().manual_seed(1)
+    pts = torch.stack([torch.rand(B, generator=g) * (W - 1), torch.rand(B, generator=g) * (H - 1), torch.zeros(B)], dim=1)
+    frames_set_t = torch.tensor([0, 2, 3, 4], dtype=torch.int32)
+    src = torch.randint(4, (B,), generator=g)
+    tgt = torch.randint(4, (B,), generator=g)
+    cot = torch.randn(B, 2, generator=g)
+    # host copy of the two trainable modules
+    dd_h, hd_h = copy.deepcopy(trk.delta_dino).cpu(), copy.deepcopy(trk.tracker_head).cpu()
+    dd_h.train()
+    hd_h.train()
+
+    out = trk((pts.to(dev), src.to(dev), tgt.to(dev), frames_set_t.to(dev)))
+    assert out.requires_grad and trk.frame_embeddings.requires_grad and trk.raw_embeddings.shape == (4, C, ph, pw)
+    (out * cot.to(dev)).sum().backward()
+
+    idx = frames_set_t.long()
+    raw = feats[idx]
+    emb = raw + dd_h(video[idx], raw)
+    nrm = trk.normalize_points_for_sampling(pts.to(dev)).cpu()
+    s = train_ops.sample_bilinear(emb, torch.cat([nrm[:, :2], src[:, None].float()], dim=1))
+    out_h = train_ops.head_forward(hd_h, torch.relu(train_ops.cosine_maps(s, emb, tgt))[:, None])
+    (out_h * cot).sum().backward()
+    assert (out.detach().cpu() - out_h.detach()).abs().max() < 5e-5
+    assert (trk.frame_embeddings.detach().cpu() - emb.detach()).abs().max() < 1e-4 * emb.detach().abs().max()
+    errs = {}
+    for tag, mod_d, mod_h in (("delta_dino", trk.delta_dino, dd_h), ("tracker_head", trk.tracker_head, hd_h)):
+        grads_h = dict((n, p.grad) for n, p in mod_h.named_parameters())
+        for n, p in mod_d.named_parameters():
+            gh = grads_h[n]
+            scale = gh.abs().max()
+            if tag == "delta_dino" and n.endswith(".bias") and n.split(".")[1] in ("0", "4", "8", "12"):
+                scale = grads_h[n.replace("bias", "weight")].abs().max()  # exact gradient 0 (BatchNorm follows)
+            errs[f"{tag}.{n}"] = float((p.grad.cpu() - gh).abs().max() / scale)
+    # a library conv on the device against the same conv in float64: how much of the difference is the kernels' own rounding
+    xx = torch.randn(2, 64, 40, 60, generator=g)
+    ww = torch.randn(128, 64, 5, 5, generator=g) * 0.05
+    y64 = torch.nn.functional.conv2d(xx.double(), ww.double(), padding=2)
+    errs["conv_fp32_device_vs_fp64"] = float((torch.nn.functional.conv2d(xx.to(dev), ww.to(dev), padding=2).cpu().double() - y64).abs().max() / y64.abs().max())
+    errs["conv_fp32_host_vs_fp64"] = float((torch.nn.functional.conv2d(xx, ww, padding=2).double() - y64).abs().max() / y64.abs().max())
+    os.makedirs(LOGDIR, exist_ok=True)
+    with open(os.path.join(LOGDIR, "train_step_device_vs_host.json"), "w") as fh:
+        json.dump(errs, fh, indent=1)
+    # device (library convs + csrc/train.hip BatchNorm, fp32) against host (fp32): four conv + batch-statistics BatchNorm +
+    # ReLU stages amplify summation-order differences to ~1e-3 (the host chain itself is 1e-3 .. 7e-3 from a float64 chain,
+    # profiles/r02_train_grad_check.txt).  The last conv's bias shifts every logit of a map alike: its exact gradient is 0.
+    exact_zero = grads_h["cnn_refiner.2.bias"].abs().max() / grads_h["cnn_refiner.2.weight"].abs().max()
+    assert exact_zero < 1e-4 and errs.pop("tracker_head.cnn_refiner.2.bias") >= 0
+    for k, v in errs.items():
+        assert v < (5e-3 if k.startswith("delta_dino") else 1e-4), (k, v)
+    for n, b in trk.delta_dino.named_buffers():
+        if "running" in n:
+            assert torch.allclose(b.cpu(), dict(dd_h.named_buffers())[n], rtol=1e-4, atol=1e-6), n
+
+    # the no-grad route of the same call (cycle-consistency filter): inference kernels on the batch's embeddings
+    with torch.no_grad():
+        inp = (pts.to(dev), src.to(dev), tgt.to(dev), frames_set_t.to(dev))
+        fast = trk.get_point_predictions(inp, trk.frame_embeddings.detach())
+    assert not fast.requires_grad
+    assert (fast.cpu() - out_h.detach()).abs().max() < 5e-5
+    # and the filter itself returns consistent, in-range sets
+    masks = torch.zeros(T, H, W, dtype=torch.uint8, device=dev)
+    masks[:, 30:90, 60:150] = 255
+    trk.cyc_n_frames, trk.cyc_batch_size_per_frame = 3, 32
+    cyc = trk.get_cycle_consistent_coords(frames_set_t.to(dev), masks)
+    k = cyc["source_points"].shape[0]
+    assert 0 < k <= 3 * 32
+    assert (torch.norm(cyc["source_points"][:, :2] - cyc["cycle_points"][:, :2], dim=1) <= trk.cyc_thresh).all()
+    for key in ("target_points", "source_frame_indices", "target_frame_indices", "source_times_normalized"):
+        assert cyc[key].shape[0] == k
+    preds = trk.get_cycle_consistent_preds(frames_set_t.to(dev), masks)
+    assert preds["source_target_coords"].requires_grad and preds["source_target_coords"].shape[1] == 2
+    trk.eval()
+
+
+@pytest.mark.parametrize("shape,relu", [((4, 64, 63, 427), True), ((3, 128, 32, 214), True), ((8, 256, 16, 107), True),
+                                         ((2, 96, 17, 29), False), ((1, 8, 5, 7), False), ((5, 1024, 16, 107), False)])
+def test_batchnorm_train_kernels(shape, relu):
+    """csrc/train.hip against torch's BatchNorm2d evaluated in float64: output, running statistics, dx / dgamma / dbeta --
+    on channels whose mean is large against their spread (where a one-pass variance fails), ragged plane sizes, N = 1."""
+    from dino_tracker_amd import train_ops
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(n * 1000 + c)
+    mean = torch.randn(c, generator=g) * 30.0
+    std = torch.rand(c, generator=g) * 0.5 + 0.01
+    x = torch.randn(shape, generator=g) * std[None, :, None, None] + mean[None, :, None, None]
+    cot = torch.randn(shape, generator=g)
+    bn64 = torch.nn.BatchNorm2d(c).double()
+    with torch.no_grad():
+        bn64.weight.copy_(torch.randn(c, generator=g) * 0.5 + 1.0)
+        bn64.bias.copy_(torch.randn(c, generator=g) * 0.3)
+        bn64.running_mean.copy_(torch.randn(c, generator=g))
+        bn64.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+    bn = torch.nn.BatchNorm2d(c)
+    bn.load_state_dict(bn64.state_dict())
+    bn = bn.float().cuda()
+    bn64.train()
+    bn.train()
+    x64 = x.double().requires_grad_()
+    y64 = bn64(x64)
+    if relu:
+        y64 = torch.relu(y64)
+    (y64 * cot.double()).sum().backward()
+    xd = x.cuda().requires_grad_()
+    y = train_ops.batchnorm_train(bn, xd, relu)
+    (y * cot.cuda()).sum().backward()
+    rel = lambda a, b: float((a.detach().double().cpu() - b.detach()).abs().max() / b.detach().abs().max().clamp(min=1e-30))
+    # float32 input: x - mean carries the rounding of x itself (|mean| / std up to 3000 here): 1e-7 * 3000 of a unit output
+    assert rel(y, y64.detach()) < 2e-3
+    assert int(bn.num_batches_tracked) == 1
+    assert rel(bn.running_mean, bn64.running_mean) < 1e-6
+    assert rel(bn.running_var, bn64.running_var) < 1e-5
+    # against the same float32 input evaluated exactly, the statistics themselves are accurate to float32 rounding
+    m64 = x.double().mean(dim=(0, 2, 3))
+    v64 = x.double().var(dim=(0, 2, 3), unbiased=False)
+    if not relu:  # dx etc. are smooth functions of the input: tight bounds
+        assert rel(xd.grad, x64.grad) < 5e-3
+        assert rel(bn.weight.grad, bn64.weight.grad) < 5e-3
+        assert rel(bn.bias.grad, bn64.bias.grad) < 1e-5
+    else:  # ReLU masks of values within rounding of zero may differ: compare where |pre-activation| is not tiny
+        pre = torch.nn.functional.batch_norm(x.double(), None, None, bn64.weight, bn64.bias, True, 0.0, bn64.eps)
+        safe = pre.abs() > 1e-2
+        assert ((xd.grad.double().cpu() - x64.grad).abs()[safe]).max() / x64.grad.abs().max() < 5e-3
+        assert rel(bn.bias.grad, bn64.bias.grad) < 2e-2
+    assert torch.isfinite(y).all() and torch.isfinite(xd.grad).all()
+    assert float(m64.abs().max()) > 1 and float(v64.min()) > 0

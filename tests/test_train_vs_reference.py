@@ -1,0 +1,185 @@
+"""N1 (test-time training), CPU: the differentiable statement of the path (dino_tracker_amd/train_ops.py) and the
+trajectory samplers against the UN-MODIFIED reference modules imported from /root/reference -- values, gradients with
+respect to every parameter and input, BatchNorm running statistics, and seeded sampler draws.  Skipped where the reference
+is absent (the GPU box); tests/test_gpu_train.py covers the device there against committed goldens."""
+import os
+import re
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ref_harness  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not ref_harness.available(), reason="reference not present")
+
+from dino_tracker_amd import train_ops  # noqa: E402
+from dino_tracker_amd.dataset import DinoTrackerSampler, RangeNormalizer  # noqa: E402
+from dino_tracker_amd.networks import DeltaDINO, TrackerHead  # noqa: E402
+
+
+def _randomise(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.05 if p.dim() > 1 else 0.2) + (1.0 if "bn" in name else 0.0))
+        for name, b in module.named_buffers():
+            if name.endswith("running_mean"):
+                b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+            elif name.endswith("running_var"):
+                b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+
+
+def test_delta_dino_train_mode_matches_reference():
+    """Forward value, gradients of all 16 parameter tensors and of the input, running statistics after two steps."""
+    ref = ref_harness.load()
+    C, H, W = 32, 70, 98
+    theirs = ref.delta_dino.DeltaDINO(channels=[3, 64, 128, 256, C], vit_stride=7)
+    _randomise(theirs, 0)
+    ours = DeltaDINO(channels=[3, 64, 128, 256, C], vit_stride=7)
+    ours.load_state_dict(theirs.state_dict())
+    theirs.train()
+    ours.train()
+    g = torch.Generator().manual_seed(1)
+    h, w = (H - 14) // 7 + 1, (W - 14) // 7 + 1
+    vit = torch.zeros(3, C, h, w)
+    for step in range(2):
+        x_t = torch.rand(3, 3, H, W, generator=g).requires_grad_()
+        x_o = x_t.detach().clone().requires_grad_()
+        y_t = theirs(x_t, vit)
+        y_o = ours(x_o, vit)
+        assert y_o.shape == y_t.shape == (3, C, h, w)
+        assert (y_o - y_t).abs().max() <= 2e-5 * y_t.abs().max()
+        cot = torch.randn(y_t.shape, generator=g)
+        theirs.zero_grad()
+        ours.zero_grad()
+        (y_t * cot).sum().backward()
+        (y_o * cot).sum().backward()
+        assert (x_o.grad - x_t.grad).abs().max() <= 1e-4 * x_t.grad.abs().max()
+        grads_t = dict((n, p.grad) for n, p in theirs.named_parameters())
+        for (n, p_t), (_, p_o) in zip(theirs.named_parameters(), ours.named_parameters()):
+            scale = p_t.grad.abs().max()
+            if re.fullmatch(r"layers\.(0|4|8|12)\.bias", n):
+                # a conv bias in front of a train-mode BatchNorm has gradient exactly 0 (the batch mean is subtracted):
+                # both sides hold rounding noise of the weight gradient's magnitude
+                scale = grads_t[n.replace("bias", "weight")].abs().max()
+                assert p_t.grad.abs().max() <= 1e-3 * scale and p_o.grad.abs().max() <= 1e-3 * scale, n
+                continue
+            assert (p_o.grad - p_t.grad).abs().max() <= 2e-4 * scale + 1e-7, n
+    sd_t, sd_o = theirs.state_dict(), ours.state_dict()
+    assert list(sd_t.keys()) == list(sd_o.keys())
+    for k in sd_t:
+        if "running" in k or "num_batches" in k:
+            assert torch.allclose(sd_t[k].float(), sd_o[k].float(), rtol=1e-5, atol=1e-6), k
+
+
+def test_align_matrices_equal_grid_sample():
+    ref = ref_harness.load()
+    g = torch.Generator().manual_seed(2)
+    for (hc, wc, h, w) in ((60, 107, 67, 121), (9, 13, 9, 13), (16, 107, 17, 121)):
+        cnn = torch.randn(2, 5, hc, wc, generator=g)
+        want = ref.models_utils.align_cnn_vit_features(torch.zeros(2, 5, h, w), cnn, cnn_stride=8, vit_stride=7)
+        got = train_ops.align_cnn_to_vit(cnn, h, w, 7, 14, 8)
+        assert (got - want).abs().max() < 5e-6
+
+
+def test_sampling_correlation_head_match_reference_with_gradients():
+    """Tracker.get_point_predictions (tracker.py:171-180) of the reference, assembled from its own methods, against
+    train_ops: predictions and gradients with respect to the frame embeddings and the four head tensors -- including maps
+    that take the zero-mass fallback branch of the soft arg-max."""
+    ref = ref_harness.load()
+    H, W, C, n, B = 126, 210, 24, 3, 40
+    h, w = (H - 14) // 7 + 1, (W - 14) // 7 + 1
+    g = torch.Generator().manual_seed(3)
+    torch.manual_seed(3)  # the heads' default initialisation draws from the global generator
+    head_t = ref.tracker_head.TrackerHead(patch_size=14, step_h=7, step_w=7, video_h=H, video_w=W)
+    head_o = TrackerHead(patch_size=14, step_h=7, step_w=7, video_h=H, video_w=W)
+    head_o.load_state_dict(head_t.state_dict())
+    head_o.train()
+    head_t.train()
+
+    class Stub:  # the attributes the reference's Tracker methods read
+        video = torch.zeros(n, 3, H, W)
+        dino_patch_size, stride, device = 14, 7, "cpu"
+        tracker_head = head_t
+        cmap_relu = torch.nn.ReLU()
+    T = ref.tracker.Tracker
+    for name in ("normalize_points_for_sampling", "sample_embeddings", "get_corr_maps_for_frame_set",
+                 "get_point_predictions_from_embeddings", "get_point_predictions"):
+        setattr(Stub, name, getattr(T, name))
+    stub = Stub()
+
+    for scale in (1.0, 300.0):  # second round: logits that peak AWAY from the correlation peak -> fallback branch
+        with torch.no_grad():
+            head_t.cnn_refiner[2].bias.fill_(0.0)
+        emb_t = (torch.randn(n, C, h, w, generator=g)).requires_grad_()
+        emb_o = emb_t.detach().clone().requires_grad_()
+        pts = torch.stack([torch.rand(B, generator=g) * (W - 1), torch.rand(B, generator=g) * (H - 1),
+                           torch.zeros(B)], dim=1)
+        src = torch.randint(n, (B,), generator=g)
+        tgt = torch.randint(n, (B,), generator=g)
+        if scale > 1:
+            with torch.no_grad():
+                for hd in (head_t, head_o):
+                    # (the normalisation W / sum W is scale invariant: large logits need taps of mixed sign)
+                    # hidden channel 0 = the map itself; its output filter = scale x (cell - right neighbour) + neighbour:
+                    # a steep horizontal-gradient detector whose maximum usually lies outside the peak's disk
+                    hd.cnn_refiner[0].weight[0].zero_()
+                    hd.cnn_refiner[0].weight[0, 0, 1, 1] = 1.0
+                    hd.cnn_refiner[0].bias[0] = 0.0
+                    hd.cnn_refiner[2].weight[0, 0].zero_()
+                    hd.cnn_refiner[2].weight[0, 0, 1, 1] = scale
+                    hd.cnn_refiner[2].weight[0, 0, 1, 2] = 1.0 - scale
+        inp = (pts, src, tgt, torch.arange(n))
+        out_t = stub.get_point_predictions(inp, emb_t)
+        nrm = stub.normalize_points_for_sampling(pts)
+        s_o = train_ops.sample_bilinear(emb_o, torch.cat([nrm[:, :2], src[:, None].float()], dim=1))
+        out_o = train_ops.head_forward(head_o, torch.relu(train_ops.cosine_maps(s_o, emb_o, tgt))[:, None])
+        assert (out_o - out_t).abs().max() < 2e-5
+        cot = torch.randn(out_t.shape, generator=g)
+        head_t.zero_grad()
+        head_o.zero_grad()
+        (out_t * cot).sum().backward()
+        (out_o * cot).sum().backward()
+        assert (emb_o.grad - emb_t.grad).abs().max() <= 2e-3 * emb_t.grad.abs().max()
+        for (nm, p_t), (_, p_o) in zip(head_t.named_parameters(), head_o.named_parameters()):
+            assert (p_o.grad - p_t.grad).abs().max() <= 2e-3 * p_t.grad.abs().max() + 1e-6, nm
+    # the second configuration did exercise the fallback
+    with torch.no_grad():
+        cost = torch.relu(train_ops.cosine_maps(s_o, emb_o, tgt))[:, None]
+        p = torch.softmax(train_ops.head_logits(head_o, cost).reshape(B, -1), dim=1).reshape(B, h, w)
+        peak = cost[:, 0].reshape(B, -1).argmax(dim=1)
+        ys = torch.arange(h) * 7.0 + 7
+        xs = torch.arange(w) * 7.0 + 7
+        d = torch.sqrt((ys[None, :, None] - (peak // w * 7.0 + 7)[:, None, None]) ** 2 +
+                       (xs[None, None, :] - (peak % w * 7.0 + 7)[:, None, None]) ** 2)
+        assert ((p * (d <= 35)).sum(dim=(1, 2)) < 1e-8).any()
+
+
+def test_samplers_draw_what_the_reference_draws():
+    ref = ref_harness.load()
+    g = torch.Generator().manual_seed(4)
+    T, W, H = 12, 210, 126
+
+    def trajectories(n):
+        tr = torch.rand(n, T, 2, generator=g) * torch.tensor([W - 1.0, H - 1.0])
+        tr[torch.rand(n, T, generator=g) < 0.45] = float("nan")
+        return tr
+    fg, bg = trajectories(300), trajectories(500)
+    rn_t = ref.dataset.RangeNormalizer(shapes=(W, H, T))
+    rn_o = RangeNormalizer(shapes=(W, H, T))
+    kw = dict(batch_size=64, dst_range=(-1, 1), fg_traj_ratio=0.5, num_frames=4, keep_in_cpu=False)
+    theirs = ref.dataset.DinoTrackerSampler(range_normalizer=rn_t, fg_trajectories=fg.clone(), bg_trajectories=bg.clone(), **kw)
+    ours = DinoTrackerSampler(range_normalizer=rn_o, fg_trajectories=fg.clone(), bg_trajectories=bg.clone(), **kw)
+    for seed in range(5):
+        torch.manual_seed(seed)
+        a = theirs()
+        torch.manual_seed(seed)
+        b = ours()
+        assert a.keys() == b.keys()
+        for k in a:
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape, k
+            assert torch.equal(a[k], b[k]), k
+        assert b["frames_set_t"].numel() <= 8 and b["t1_points"].shape == (64, 3)
+        assert not torch.isnan(b["t1_points"]).any() and not torch.isnan(b["t2_points_normalized"]).any()
