@@ -30,8 +30,35 @@ EPS = 1e-8  # models/tracker.py:14, conv_norm.py:35, tracker_head.py:86
 
 # ---- Delta-DINO ----------------------------------------------------------------------------------------------------------
 def blurpool(x: torch.Tensor, filt: torch.Tensor, stride: int = 2) -> torch.Tensor:
-    """antialiased_cnns.BlurPool(filt_size 4, reflect): pad (left 1, right 2, top 1, bottom 2), depthwise binomial conv."""
-    return F.conv2d(F.pad(x, (1, 2, 1, 2), mode="reflect"), filt, stride=stride, groups=x.shape[1])
+    """antialiased_cnns.BlurPool(filt_size 4, reflect): pad (left 1, right 2, top 1, bottom 2), depthwise 4 x 4 binomial
+    filter at `stride`.  The filter is separable and the same for every channel (outer([1,3,3,1]) / 64, the module's `filt`
+    buffer): two passes of four strided views each -- plain elementwise kernels, no convolution library."""
+    a = filt[0, 0].sum(dim=1)
+    a = (a / a.sum()).tolist()  # the 1-D factor, [1, 3, 3, 1] / 8
+    xp = F.pad(x, (1, 2, 1, 2), mode="reflect")
+    hp, wp = xp.shape[-2:]
+    ho, wo = (hp - 4) // stride + 1, (wp - 4) // stride + 1
+    rows = sum(a[k] * xp[:, :, k:k + stride * (ho - 1) + 1:stride, :] for k in range(4))
+    return sum(a[k] * rows[:, :, :, k:k + stride * (wo - 1) + 1:stride] for k in range(4))
+
+
+def conv2d_gemm(x: torch.Tensor, weight: torch.Tensor, bias, padding: int, dilation: int = 1, padding_mode: str = "zeros"):
+    """Stride-1 convolution as ONE matrix product over the unfolded input ([Cout, Cin k k] x [Cin k k, H W] per frame):
+    forward and both backward products run on the BLAS GEMM kernels, im2col / col2im on plain copy kernels.  (The
+    convolution library's per-call solver selection costs the host ~0.3 s per forward call and seconds per backward call on
+    this stack -- 40 s per training iteration, against 0.05 s of kernels.)"""
+    n, cin, h, w = x.shape
+    cout, _, kh, kw = weight.shape
+    if padding and padding_mode != "zeros":
+        x = F.pad(x, (padding,) * 4, mode=padding_mode)
+        padding = 0
+    cols = F.unfold(x, (kh, kw), dilation=dilation, padding=padding)      # [n, Cin kh kw, L]
+    ho = x.shape[-2] + 2 * padding - dilation * (kh - 1)
+    wo = x.shape[-1] + 2 * padding - dilation * (kw - 1)
+    y = torch.matmul(weight.reshape(cout, cin * kh * kw), cols)            # [n, Cout, L]
+    if bias is not None:
+        y = y + bias[None, :, None]
+    return y.reshape(n, cout, ho, wo)
 
 
 def align_matrix(n_vit: int, n_cnn: int, vit_stride: int, vit_patch: int, cnn_stride: int, device, dtype=torch.float32):
@@ -99,10 +126,10 @@ def batchnorm_train(bn: torch.nn.BatchNorm2d, x: torch.Tensor, relu: bool) -> to
 
 
 def delta_dino_residual(delta_dino, frames: torch.Tensor, h: int, w: int, vit_patch: int = 14) -> torch.Tensor:
-    """DeltaDINO.forward (delta_dino.py:53-61) in training mode -> the aligned residual [n, C, h, w].  Convolutions and
-    blur-pools through the module's own objects (library kernels, autograd); on the device every BatchNorm2d -- with the ReLU
-    that follows it -- runs on csrc/train.hip, forward and backward.  On host tensors (the CPU parity tests of this
-    arithmetic) the BatchNorm2d modules themselves run."""
+    """DeltaDINO.forward (delta_dino.py:53-61) in training mode -> the aligned residual [n, C, h, w].  Convolutions as
+    unfold + GEMM (conv2d_gemm), blur-pools as strided views; on the device every BatchNorm2d -- with the ReLU that follows
+    it -- runs on csrc/train.hip, forward and backward.  On host tensors (the CPU parity tests of this arithmetic) the
+    BatchNorm2d modules themselves run."""
     x = frames
     layers = list(delta_dino.layers)
     i = 0
@@ -113,7 +140,10 @@ def delta_dino_residual(delta_dino, frames: torch.Tensor, h: int, w: int, vit_pa
             x = batchnorm_train(layer, x, relu)
             i += 2 if relu else 1
             continue
-        x = layer(x)
+        if isinstance(layer, torch.nn.Conv2d):
+            x = conv2d_gemm(x, layer.weight, layer.bias, layer.padding[0], layer.dilation[0], layer.padding_mode)
+        else:
+            x = layer(x)
         i += 1
     return align_cnn_to_vit(x, h, w, delta_dino.vit_stride, vit_patch, delta_dino.get_total_stride())
 
@@ -169,10 +199,11 @@ def normalized_weight(weight: torch.Tensor) -> torch.Tensor:
 
 
 def head_logits(head, x: torch.Tensor) -> torch.Tensor:
-    """cnn_refiner (tracker_head.py:47-58): [B, 1, h, w] -> [B, 1, h, w]."""
+    """cnn_refiner (tracker_head.py:47-58): [B, 1, h, w] -> [B, 1, h, w]; both 3 x 3 convolutions as matrix products
+    (conv2d_gemm): 1 -> 16 over the unfolded map, 16 -> 1 over the unfolded hidden planes."""
     c0, c2 = head.cnn_refiner[0], head.cnn_refiner[2]
-    y = F.conv2d(x, normalized_weight(c0.weight), c0.bias, stride=c0.stride, padding=c0.padding)
-    return F.conv2d(torch.relu(y), normalized_weight(c2.weight), c2.bias, stride=c2.stride, padding=c2.padding)
+    y = conv2d_gemm(x, normalized_weight(c0.weight), c0.bias, c0.padding)
+    return conv2d_gemm(torch.relu(y), normalized_weight(c2.weight), c2.bias, c2.padding)
 
 
 def soft_argmax(p: torch.Tensor, peak: torch.Tensor, patch: int, stride: int, radius: float) -> torch.Tensor:

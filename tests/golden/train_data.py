@@ -37,13 +37,32 @@ def _tracks(g, n, T, W, H, vx, vy, inside):
     return torch.from_numpy(tr)
 
 
-def build(dst, ref_root, cfg=CFG):
+def _synthetic_video(dst, T, H, W):
+    """Frames of dino_tracker_amd.synth.synth_video (content moving 4.2, 2.1 px per frame) and an elliptic foreground mask
+    moving with it, as PNG files."""
+    from PIL import Image
+    video = synth.synth_video(T, H, W, seed=1)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for t in range(T):
+        Image.fromarray((video[t].permute(1, 2, 0).numpy() * 255).astype(np.uint8)).save(os.path.join(dst, "video", f"{t:05d}.png"))
+        cx, cy = 0.6 * W - 4.2 * t, 0.55 * H - 2.1 * t
+        m = (((xx - cx) / (0.22 * W)) ** 2 + ((yy - cy) / (0.3 * H)) ** 2) <= 1.0
+        Image.fromarray((m * 255).astype(np.uint8)).save(os.path.join(dst, "masks", f"{t:05d}.png"))
+
+
+def build(dst, ref_root, cfg=CFG, overrides=None, synthetic_video=False):
+    """`overrides`: entries of train.yaml to replace (default: the small-batch settings of the parity fixture);
+    `synthetic_video`: generated frames + masks instead of the reference's horsejump clip (any T, any size)."""
     T, C, H, W = cfg["T"], cfg["C"], cfg["H"], cfg["W"]
     src = os.path.join(ref_root, "dataset", "horsejump")
     for sub in ("video", "masks"):
         os.makedirs(os.path.join(dst, sub), exist_ok=True)
+        if synthetic_video:
+            continue
         for f in sorted(os.listdir(os.path.join(src, sub)))[:T]:
             shutil.copy(os.path.join(src, sub, f), os.path.join(dst, sub, f))
+    if synthetic_video:
+        _synthetic_video(dst, T, H, W)
     ph, pw = (H - 14) // 7 + 1, (W - 14) // 7 + 1
     os.makedirs(os.path.join(dst, "dino_embeddings"), exist_ok=True)
     torch.save(synth.synth_features(T, C, ph, pw, seed=cfg["feat_seed"]), os.path.join(dst, "dino_embeddings", "dino_embed_video.pt"))
@@ -77,11 +96,14 @@ def build(dst, ref_root, cfg=CFG):
     torch.save(bb, os.path.join(dst, "dino_best_buddies", "dino_best_buddies_filtered.pt"))
     with open(os.path.join(ref_root, "config", "train.yaml")) as fh:
         conf = yaml.safe_load(fh.read())
-    conf.update(video_resh=H, video_resw=W, train_batch_size=48, batch_n_frames=3, total_iterations=cfg["total_iterations"],
-                checkpoint_interval=1000, apply_cyc_after=0, apply_cl_ref_after=0, cyc_n_frames=2,
-                cyc_batch_size_per_frame=24, cl_n_frames=2, cl_points_per_pair=24,
-                # larger weights than config/train.yaml so that every term moves the total visibly in three steps
-                lambda_cl_dino_bb=0.01, lambda_cl_ref_bb=0.01, lambda_emb_norm=0.01, lambda_angle=0.01)
+    conf.update(video_resh=H, video_resw=W, total_iterations=cfg["total_iterations"], checkpoint_interval=100000,
+                apply_cyc_after=0, apply_cl_ref_after=0)
+    if overrides is None:
+        overrides = dict(train_batch_size=48, batch_n_frames=3, cyc_n_frames=2, cyc_batch_size_per_frame=24, cl_n_frames=2,
+                         cl_points_per_pair=24, checkpoint_interval=1000,
+                         # larger weights than config/train.yaml so that every term moves the total visibly in three steps
+                         lambda_cl_dino_bb=0.01, lambda_cl_ref_bb=0.01, lambda_emb_norm=0.01, lambda_angle=0.01)
+    conf.update(overrides)
     path = os.path.join(dst, "train.yaml")
     with open(path, "w") as fh:
         yaml.safe_dump(conf, fh)

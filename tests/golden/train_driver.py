@@ -17,6 +17,7 @@ import json
 import os
 import runpy
 import sys
+import time
 
 import torch
 
@@ -42,6 +43,7 @@ if not torch.cuda.is_available():
     torch.Tensor.cuda = lambda self, *a, **k: self
 
 LOSSES = []
+STAMPS = []  # wall clock at the end of every iteration (after its .item() reads: the device is idle)
 
 
 def _dump():
@@ -49,7 +51,7 @@ def _dump():
     if path:
         with open(path, "w") as fh:
             json.dump({"names": ["total", "of", "cl_dino_bb", "cl_refiner", "emb_norm_reg", "angle_reg", "cyc"],
-                       "losses": LOSSES}, fh)
+                       "losses": LOSSES, "seconds": STAMPS}, fh)
 
 
 atexit.register(_dump)
@@ -69,7 +71,22 @@ if __name__ == "__main__":
 
     def update_losses(self, *vals):
         LOSSES.append([float(v) for v in vals])
+        STAMPS.append(time.time())
         return _update(self, *vals)
 
     dino_tracker.DINOTracker.update_losses = update_losses
-    runpy.run_path(script, run_name="__main__")
+    prof_path = os.environ.get("DTK_TRAIN_CPROFILE")
+    if prof_path:  # where does the HOST spend an iteration
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        try:
+            runpy.run_path(script, run_name="__main__")
+        finally:
+            pr.disable()
+            with open(prof_path, "w") as fh:
+                pstats.Stats(pr, stream=fh).sort_stats("cumulative").print_stats(70)
+                pstats.Stats(pr, stream=fh).sort_stats("tottime").print_stats(40)
+    else:
+        runpy.run_path(script, run_name="__main__")

@@ -32,41 +32,49 @@ def _randomise(module, seed):
 
 
 def test_delta_dino_train_mode_matches_reference():
-    """Forward value, gradients of all 16 parameter tensors and of the input, running statistics after two steps."""
+    """Forward value, gradients of all 16 parameter tensors and of the input, running statistics after two steps.  The
+    gradient of this chain (four conv + batch-statistics BatchNorm + ReLU stages) is ill-conditioned in float32 -- two
+    float32 evaluations with different summation orders differ by ~1e-3 -- so the arbiter is the REFERENCE run in float64:
+    this implementation (float32, convs as unfold + GEMM) must be as close to it as the reference's own float32 run is."""
+    import copy
     ref = ref_harness.load()
     C, H, W = 32, 70, 98
     theirs = ref.delta_dino.DeltaDINO(channels=[3, 64, 128, 256, C], vit_stride=7)
     _randomise(theirs, 0)
     ours = DeltaDINO(channels=[3, 64, 128, 256, C], vit_stride=7)
     ours.load_state_dict(theirs.state_dict())
-    theirs.train()
-    ours.train()
+    exact = copy.deepcopy(theirs).double()
+    for m in (theirs, ours, exact):
+        m.train()
     g = torch.Generator().manual_seed(1)
     h, w = (H - 14) // 7 + 1, (W - 14) // 7 + 1
     vit = torch.zeros(3, C, h, w)
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max().clamp(min=1e-30))
     for step in range(2):
-        x_t = torch.rand(3, 3, H, W, generator=g).requires_grad_()
-        x_o = x_t.detach().clone().requires_grad_()
-        y_t = theirs(x_t, vit)
-        y_o = ours(x_o, vit)
-        assert y_o.shape == y_t.shape == (3, C, h, w)
-        assert (y_o - y_t).abs().max() <= 2e-5 * y_t.abs().max()
-        cot = torch.randn(y_t.shape, generator=g)
-        theirs.zero_grad()
-        ours.zero_grad()
-        (y_t * cot).sum().backward()
-        (y_o * cot).sum().backward()
-        assert (x_o.grad - x_t.grad).abs().max() <= 1e-4 * x_t.grad.abs().max()
-        grads_t = dict((n, p.grad) for n, p in theirs.named_parameters())
-        for (n, p_t), (_, p_o) in zip(theirs.named_parameters(), ours.named_parameters()):
-            scale = p_t.grad.abs().max()
+        x = torch.rand(3, 3, H, W, generator=g)
+        cot = torch.randn(3, C, h, w, generator=g)
+        res = []
+        for m, dt in ((exact, torch.float64), (theirs, torch.float32), (ours, torch.float32)):
+            xi = x.to(dt).requires_grad_()
+            y = m(xi, vit.to(dt))
+            assert y.shape == (3, C, h, w)
+            m.zero_grad()
+            (y * cot.to(dt)).sum().backward()
+            res.append((y.detach(), xi.grad, dict((n, p.grad) for n, p in m.named_parameters())))
+        (y_e, dx_e, gp_e), (y_t, dx_t, gp_t), (y_o, dx_o, gp_o) = res
+        assert rel(y_o, y_e) <= 3 * rel(y_t, y_e) + 1e-6
+        assert rel(dx_o, dx_e) <= 3 * rel(dx_t, dx_e) + 1e-6
+        for n in gp_e:
+            scale = gp_e[n].abs().max()
             if re.fullmatch(r"layers\.(0|4|8|12)\.bias", n):
                 # a conv bias in front of a train-mode BatchNorm has gradient exactly 0 (the batch mean is subtracted):
-                # both sides hold rounding noise of the weight gradient's magnitude
-                scale = grads_t[n.replace("bias", "weight")].abs().max()
-                assert p_t.grad.abs().max() <= 1e-3 * scale and p_o.grad.abs().max() <= 1e-3 * scale, n
+                # both float32 runs hold rounding noise far below the weight gradient's magnitude
+                wscale = gp_e[n.replace("bias", "weight")].abs().max()
+                assert scale <= 1e-9 * wscale and gp_t[n].abs().max() <= 1e-3 * wscale and gp_o[n].abs().max() <= 1e-3 * wscale, n
                 continue
-            assert (p_o.grad - p_t.grad).abs().max() <= 2e-4 * scale + 1e-7, n
+            e_o = float((gp_o[n].double() - gp_e[n]).abs().max() / scale)
+            e_t = float((gp_t[n].double() - gp_e[n]).abs().max() / scale)
+            assert e_o <= 3 * e_t + 1e-5, (n, e_o, e_t)
     sd_t, sd_o = theirs.state_dict(), ours.state_dict()
     assert list(sd_t.keys()) == list(sd_o.keys())
     for k in sd_t:
