@@ -225,6 +225,71 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// ---- BlurPool (antialiased_cnns.BlurPool, filt_size 4, stride 2, reflect padding (1, 2, 1, 2)) ----------------------------
+// y[o] = sum_i f[i] x[refl(2 o + i - 1)] per axis, f = [1, 3, 3, 1] / 8, refl(-1) = 1, refl(n) = n - 2, refl(n + 1) = n - 3.
+// One thread per output (forward) / per input (backward: the transposed operator as a gather -- an input position is read
+// by at most two outputs directly and, within three cells of the far border or at index 1, by the reflected taps too).
+__device__ __forceinline__ int refl(int p, int n) { return p < 0 ? -p : (p >= n ? 2 * n - 2 - p : p); }
+__device__ __forceinline__ float blur_tap(int i) { return (i == 0 || i == 3) ? 0.125f : 0.375f; }
+
+__global__ __launch_bounds__(256) void blurpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long planes,
+                                                           int H, int W, int Ho, int Wo) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= planes * Ho * Wo) return;
+    const int ox = (int)(idx % Wo);
+    const long long t = idx / Wo;
+    const int oy = (int)(t % Ho);
+    const float* xp = x + (t / Ho) * (long long)H * W;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float* row = xp + (long long)refl(2 * oy + i - 1, H) * W;
+        float r = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r = fmaf(blur_tap(j), row[refl(2 * ox + j - 1, W)], r);
+        acc = fmaf(blur_tap(i), r, acc);
+    }
+    y[idx] = acc;
+}
+
+// the outputs o and weights through which input position p (of n, output length no) is read: at most 6 entries
+__device__ __forceinline__ int blur_adjoint(int p, int n, int no, int (&o)[6], float (&wgt)[6]) {
+    int cnt = 0;
+    auto add = [&](int q) {  // padded-axis position q in [-1, n + 1] that maps onto p
+        // q = 2 o + i - 1, i in 0..3  ->  o in [(q - 2) / 2, (q + 1) / 2]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int num = q + 1 - i;
+            if (num >= 0 && !(num & 1) && (num >> 1) < no) { o[cnt] = num >> 1; wgt[cnt] = blur_tap(i); ++cnt; }
+        }
+    };
+    add(p);
+    if (p == 1) add(-1);
+    if (p == n - 2) add(n);
+    if (p == n - 3) add(n + 1);
+    return cnt;
+}
+
+__global__ __launch_bounds__(256) void blurpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long long planes,
+                                                           int H, int W, int Ho, int Wo) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= planes * H * W) return;
+    const int px = (int)(idx % W);
+    const long long t = idx / W;
+    const int py = (int)(t % H);
+    const float* gp = dy + (t / H) * (long long)Ho * Wo;
+    int oy[6], ox[6];
+    float wy[6], wx[6];
+    const int ny = blur_adjoint(py, H, Ho, oy, wy), nx = blur_adjoint(px, W, Wo, ox, wx);
+    float acc = 0.f;
+    for (int a = 0; a < ny; ++a) {
+        float r = 0.f;
+        for (int b = 0; b < nx; ++b) r = fmaf(wx[b], gp[(long long)oy[a] * Wo + ox[b]], r);
+        acc = fmaf(wy[a], r, acc);
+    }
+    dx[idx] = acc;
+}
+
 int slices(int N, int C, int HW) {
     const long long L = (long long)N * HW;
     long long S = 4096 / (C > 0 ? C : 1);  // ~16 workgroups per CU over all channels
@@ -270,5 +335,25 @@ extern "C" int dtk_batchnorm_train_backward(const float* x, const float* dy, con
                part, N, C, HW, S);
     DTK_LAUNCH("bn_bwd_apply", bn_bwd_apply_kernel, dim3(S, C), dim3(256), 0, st, x, dy, gamma, beta, save_mean, save_rstd, relu,
                part, dx, dgamma, dbeta, N, C, HW, S);
+    return DTK_OK;
+}
+
+extern "C" int dtk_blurpool_forward(const float* x, float* y, int64_t planes, int32_t H, int32_t W, void* stream) {
+    DTK_REQUIRE(x && y, "dtk_blurpool_forward: null pointer");
+    DTK_REQUIRE(planes > 0 && H >= 4 && W >= 4, "dtk_blurpool_forward: bad shape %lld x %d x %d (reflection needs >= 4)", (long long)planes, H, W);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)planes * Ho * Wo;
+    DTK_LAUNCH("blurpool_fwd", blurpool_fwd_kernel, dim3(dtk_cdiv(total, 256)), dim3(256), 0, dtk_stream(stream), x, y,
+               (long long)planes, H, W, Ho, Wo);
+    return DTK_OK;
+}
+
+extern "C" int dtk_blurpool_backward(const float* dy, float* dx, int64_t planes, int32_t H, int32_t W, void* stream) {
+    DTK_REQUIRE(dy && dx, "dtk_blurpool_backward: null pointer");
+    DTK_REQUIRE(planes > 0 && H >= 4 && W >= 4, "dtk_blurpool_backward: bad shape %lld x %d x %d", (long long)planes, H, W);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)planes * H * W;
+    DTK_LAUNCH("blurpool_bwd", blurpool_bwd_kernel, dim3(dtk_cdiv(total, 256)), dim3(256), 0, dtk_stream(stream), dy, dx,
+               (long long)planes, H, W, Ho, Wo);
     return DTK_OK;
 }

@@ -242,3 +242,21 @@ def batchnorm_train_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Ten
                                              _p(beta, torch.float32), _p(mean, torch.float32), _p(rstd, torch.float32),
                                              int(relu), _p(dx), _p(dgamma), _p(dbeta), N, C, H * W, _p(ws), nb, _stream()))
     return dx, dgamma, dbeta
+
+
+def blurpool_forward(x: torch.Tensor) -> torch.Tensor:
+    """BlurPool (filt 4, stride 2, reflect) of x [N,C,H,W] (dtk_blurpool_forward)."""
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    check(lib().dtk_blurpool_forward(_p(x, torch.float32), _p(y), N * C, H, W, _stream()))
+    return y
+
+
+def blurpool_backward(dy: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """Adjoint of blurpool_forward: dy [N,C,Ho,Wo] -> dx [N,C,H,W] (dtk_blurpool_backward)."""
+    N, C, Ho, Wo = dy.shape
+    if (Ho, Wo) != ((H - 1) // 2 + 1, (W - 1) // 2 + 1):
+        raise RuntimeError(f"blurpool_backward: {Ho}x{Wo} is not the pooled size of {H}x{W}")
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    check(lib().dtk_blurpool_backward(_p(dy, torch.float32), _p(dx), N * C, H, W, _stream()))
+    return dx

@@ -29,10 +29,27 @@ EPS = 1e-8  # models/tracker.py:14, conv_norm.py:35, tracker_head.py:86
 
 
 # ---- Delta-DINO ----------------------------------------------------------------------------------------------------------
+class _BlurPool(torch.autograd.Function):
+    """csrc/train.hip: one gather kernel forward, one (the adjoint, also a gather) backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import ops
+        ctx.hw = x.shape[-2:]
+        return ops.blurpool_forward(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        return ops.blurpool_backward(dy.contiguous(), *ctx.hw)
+
+
 def blurpool(x: torch.Tensor, filt: torch.Tensor, stride: int = 2) -> torch.Tensor:
     """antialiased_cnns.BlurPool(filt_size 4, reflect): pad (left 1, right 2, top 1, bottom 2), depthwise 4 x 4 binomial
-    filter at `stride`.  The filter is separable and the same for every channel (outer([1,3,3,1]) / 64, the module's `filt`
-    buffer): two passes of four strided views each -- plain elementwise kernels, no convolution library."""
+    filter at `stride` (the same outer([1,3,3,1]) / 64 for every channel: the module's `filt` buffer).  On the device: the
+    hand-written kernels; on host tensors (CPU parity tests) two separable passes over strided views."""
+    if x.is_cuda and stride == 2 and filt.shape[-1] == 4:
+        return _BlurPool.apply(x)
     a = filt[0, 0].sum(dim=1)
     a = (a / a.sum()).tolist()  # the 1-D factor, [1, 3, 3, 1] / 8
     xp = F.pad(x, (1, 2, 1, 2), mode="reflect")
@@ -198,12 +215,32 @@ def normalized_weight(weight: torch.Tensor) -> torch.Tensor:
     return weight / s
 
 
+def _shifted_planes(x: torch.Tensor) -> torch.Tensor:
+    """[B, h, w] -> [B, 9, h, w]: plane 3 dy + dx holds x shifted so that cell (r, c) reads x[r + dy - 1, c + dx - 1] (zero
+    outside): the unfolded 3 x 3 neighbourhood of every cell for the whole batch in one copy kernel."""
+    h, w = x.shape[-2:]
+    xp = F.pad(x, (1, 1, 1, 1))
+    return torch.stack([xp[:, dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3)], dim=1)
+
+
 def head_logits(head, x: torch.Tensor) -> torch.Tensor:
-    """cnn_refiner (tracker_head.py:47-58): [B, 1, h, w] -> [B, 1, h, w]; both 3 x 3 convolutions as matrix products
-    (conv2d_gemm): 1 -> 16 over the unfolded map, 16 -> 1 over the unfolded hidden planes."""
+    """cnn_refiner (tracker_head.py:47-58): [B, 1, h, w] -> [B, 1, h, w], as two matrix products over the whole batch:
+        hidden[16] = relu(W1[16 x 9] . neighbourhood(x) + b1)
+        P[9]       = W2[9 x 16] . hidden          (per-cell projection onto the nine taps of the second conv)
+        z(r, c)    = b2 + sum_tap P[tap](r + dy - 1, c + dx - 1)
+    -- the formulation of the inference kernels (csrc/track_mfma.hip, refine_head_kernel)."""
     c0, c2 = head.cnn_refiner[0], head.cnn_refiner[2]
-    y = conv2d_gemm(x, normalized_weight(c0.weight), c0.bias, c0.padding)
-    return conv2d_gemm(torch.relu(y), normalized_weight(c2.weight), c2.bias, c2.padding)
+    b, _, h, w = x.shape
+    w1 = normalized_weight(c0.weight).reshape(c0.out_channels, 9)
+    w2 = normalized_weight(c2.weight).reshape(c2.in_channels, 9)
+    hid = torch.einsum("ot,bthw->bohw", w1, _shifted_planes(x[:, 0]))
+    if c0.bias is not None:
+        hid = hid + c0.bias[None, :, None, None]
+    planes = F.pad(torch.einsum("ct,bchw->bthw", w2, torch.relu(hid)), (1, 1, 1, 1))
+    z = sum(planes[:, 3 * dy + dx, dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3))
+    if c2.bias is not None:
+        z = z + c2.bias[0]
+    return z[:, None]
 
 
 def soft_argmax(p: torch.Tensor, peak: torch.Tensor, patch: int, stride: int, radius: float) -> torch.Tensor:

@@ -279,6 +279,12 @@ int dtk_batchnorm_train_backward(const float* x, const float* dy, const float* g
                                  float* dbeta, int32_t N, int32_t C, int32_t HW, void* workspace, size_t workspace_bytes,
                                  void* stream);
 
+/* BlurPool of the Delta-DINO CNN (antialiased_cnns.BlurPool(channels, stride=2): filt_size 4, reflect padding, depthwise
+ * outer([1,3,3,1]) / 64; models/networks/delta_dino.py:43-44) and its adjoint.  x / dx: [planes][H][W], y / dy:
+ * [planes][(H-1)/2+1][(W-1)/2+1], planes = N * C; H, W >= 4. */
+int dtk_blurpool_forward(const float* x, float* y, int64_t planes, int32_t H, int32_t W, void* stream);
+int dtk_blurpool_backward(const float* dy, float* dx, int64_t planes, int32_t H, int32_t W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

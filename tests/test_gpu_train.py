@@ -212,3 +212,27 @@ def test_batchnorm_train_kernels(shape, relu):
         assert rel(bn.bias.grad, bn64.bias.grad) < 2e-2
     assert torch.isfinite(y).all() and torch.isfinite(xd.grad).all()
     assert float(m64.abs().max()) > 1 and float(v64.min()) > 0
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 63, 427), (1, 3, 4, 4), (3, 2, 5, 6), (2, 4, 238, 427), (1, 2, 119, 214), (1, 1, 7, 4)])
+def test_blurpool_kernels(shape):
+    """csrc/train.hip blur-pool and its adjoint against the depthwise-convolution statement of antialiased_cnns.BlurPool
+    (reflect pad (1, 2, 1, 2), outer([1,3,3,1]) / 64, stride 2) in float64 on the host, odd and even plane sizes."""
+    from dino_tracker_amd import train_ops
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g)
+    a = torch.tensor([1.0, 3.0, 3.0, 1.0], dtype=torch.float64)
+    filt = (a[:, None] * a[None, :] / 64.0)[None, None].repeat(shape[1], 1, 1, 1)
+    x64 = x.double().requires_grad_()
+    y64 = torch.nn.functional.conv2d(torch.nn.functional.pad(x64, (1, 2, 1, 2), mode="reflect"), filt, stride=2, groups=shape[1])
+    cot = torch.randn(y64.shape, generator=g)
+    (y64 * cot.double()).sum().backward()
+    xd = x.cuda().requires_grad_()
+    y = train_ops.blurpool(xd, filt.float().cuda())
+    assert y.shape == y64.shape
+    (y * cot.cuda()).sum().backward()
+    assert (y.detach().cpu().double() - y64.detach()).abs().max() < 1e-6
+    assert (xd.grad.cpu().double() - x64.grad).abs().max() < 1e-6
+    # and the host statement used by the CPU parity tests (strided views) is the same operator
+    yh = train_ops.blurpool(x, filt.float())
+    assert (yh.double() - y64.detach()).abs().max() < 1e-6
