@@ -90,3 +90,37 @@ def test_launcher_fails_loudly_when_a_hot_module_is_not_the_overlay(tmp_path):
     r = subprocess.run([sys.executable, "-m", "dino_tracker_amd.run", str(root / "sneaky.py")], capture_output=True,
                        text=True, env=dict(os.environ, PYTHONPATH=ROOT), cwd=str(tmp_path), timeout=300)
     assert r.returncode != 0 and "did not resolve to the overlay" in r.stderr
+
+
+def test_run_videos_partitions_data_paths_over_ranks(tmp_path):
+    """dino_tracker_amd.run_videos: rank r of a world-size-3 launch runs the script once per data path v = r (mod 3), each
+    as a plain single-GPU process pinned to GPU LOCAL_RANK, with the script's own arguments passed through."""
+    import json
+    import subprocess
+    import sys
+    script = tmp_path / "fake_train.py"
+    script.write_text("import argparse, json, os\n"
+                      "p = argparse.ArgumentParser(); p.add_argument('--data-path'); p.add_argument('--config')\n"
+                      "a = p.parse_args()\n"
+                      "json.dump({'config': a.config, 'gpu': os.environ.get('HIP_VISIBLE_DEVICES'),\n"
+                      "           'world': os.environ.get('WORLD_SIZE')}, open(os.path.join(a.data_path, 'done.json'), 'w'))\n")
+    paths = []
+    for i in range(7):
+        d = tmp_path / f"video{i}"
+        d.mkdir()
+        paths.append(str(d))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for rank in range(3):
+        env = dict(os.environ, PYTHONPATH=root, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="3")
+        r = subprocess.run([sys.executable, "-m", "dino_tracker_amd.run_videos", str(script), "--data-paths"] + paths +
+                           ["--", "--config", "c.yaml"], env=env, capture_output=True, text=True, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr[-2000:]
+    for i, d in enumerate(paths):
+        rec = json.load(open(os.path.join(d, "done.json")))
+        assert rec == {"config": "c.yaml", "gpu": str(i % 3), "world": None}, (i, rec)
+    # a failing video makes its rank fail, the others still run
+    bad = tmp_path / "bad.py"
+    bad.write_text("import sys\nsys.exit(3 if 'video1' in sys.argv[2] else 0)\n")
+    r = subprocess.run([sys.executable, "-m", "dino_tracker_amd.run_videos", str(bad), "--data-paths"] + paths[:3],
+                       env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 1 and "video1" in r.stderr
