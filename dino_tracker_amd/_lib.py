@@ -111,10 +111,11 @@ SIGNATURES = {
     "dtk_blurpool_forward": (c_int, [c_void_p, c_void_p, ctypes.c_int64, c_int, c_int, c_void_p]),
     "dtk_blurpool_backward": (c_int, [c_void_p, c_void_p, ctypes.c_int64, c_int, c_int, c_void_p]),
     "dtk_batchnorm_workspace_bytes": (c_size_t, [c_int]),
-    "dtk_batchnorm_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
-                                            c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "dtk_batchnorm_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                            c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
+                                            c_void_p]),
     "dtk_batchnorm_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
-                                             c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+                                             c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
 }
 
 _LIB = None

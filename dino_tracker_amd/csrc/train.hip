@@ -130,9 +130,9 @@ __device__ __forceinline__ Moments channel_moments(const float* __restrict__ par
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ part,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                       float momentum, float eps, int relu, float* __restrict__ y,
-                                                       float* __restrict__ save_mean, float* __restrict__ save_rstd, int N,
-                                                       int C, int HW, int S) {
+                                                       const float* __restrict__ pre_bias, float momentum, float eps, int relu,
+                                                       float* __restrict__ y, float* __restrict__ save_mean,
+                                                       float* __restrict__ save_rstd, int N, int C, int HW, int S) {
     const int c = blockIdx.y, s = blockIdx.x;
     const Moments m = channel_moments(part, c, S);  // every wave recomputes it: S <= 64 loads, no barrier
     const float var = m.m2 / m.n;
@@ -140,7 +140,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     if (s == 0 && threadIdx.x == 0) {
         save_mean[c] = m.mean;
         save_rstd[c] = rstd;
-        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m.mean;
+        // a per-channel bias added in front of the layer (the conv's) shifts the batch mean and nothing else
+        const float shift = pre_bias ? pre_bias[c] : 0.f;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (m.mean + shift);
         if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m.m2 / fmaxf(m.n - 1.f, 1.f));
     }
     const float a = rstd * gamma[c], b = beta[c], mu = m.mean;  // y = (x - mu) a + b: the subtraction first (exact for x near mu)
@@ -160,14 +162,14 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restric
                                                           const float* __restrict__ save_mean,
                                                           const float* __restrict__ save_rstd, int relu,
                                                           float* __restrict__ part, int N, int C, int HW, int S) {
-    __shared__ float sm[4][2];
+    __shared__ float sm[4][3];
     const int c = blockIdx.y, s = blockIdx.x;
     const float mean = save_mean[c], rstd = save_rstd[c], ga = gamma[c], be = beta[c];
     const float fa = rstd * ga;  // y = (x - mean) fa + beta in bn_apply_kernel
     const long long L = (long long)N * HW;
     long long lo, hi;
     slice_bounds(L, S, s, &lo, &hi);
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
     Cursor cur(min(lo + threadIdx.x, L - 1), c, C, HW);
     for (long long e = lo + threadIdx.x; e < hi; e += 256, cur.advance(256)) {
         const size_t ad = cur.addr;
@@ -177,15 +179,18 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restric
         if (relu && !(fmaf(xv - mean, fa, be) > 0.f)) g = 0.f;  // the forward's own expression: same mask to the bit
         s1 += g;
         s2 = fmaf(g, xh, s2);
+        s3 += xh;
     }
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
-    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = s1; sm[threadIdx.x >> 6][1] = s2; }
+    s3 = wave_sum(s3);
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = s1; sm[threadIdx.x >> 6][1] = s2; sm[threadIdx.x >> 6][2] = s3; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float* p = part + ((size_t)c * S + s) * 2;
+        float* p = part + ((size_t)c * S + s) * 3;
         p[0] = (sm[0][0] + sm[1][0]) + (sm[2][0] + sm[3][0]);
         p[1] = (sm[0][1] + sm[1][1]) + (sm[2][1] + sm[3][1]);
+        p[2] = (sm[0][2] + sm[1][2]) + (sm[2][2] + sm[3][2]);
     }
 }
 
@@ -195,18 +200,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ save_mean,
                                                            const float* __restrict__ save_rstd, int relu,
                                                            const float* __restrict__ part, float* __restrict__ dx,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C,
-                                                           int HW, int S) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ dpre_bias, int N, int C, int HW, int S) {
     const int c = blockIdx.y, s = blockIdx.x;
     const int lane = threadIdx.x & 63;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (lane < S) {
-        const float* p = part + ((size_t)c * S + lane) * 2;
-        s1 = p[0]; s2 = p[1];
+        const float* p = part + ((size_t)c * S + lane) * 3;
+        s1 = p[0]; s2 = p[1]; s3 = p[2];
     }
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
-    if (s == 0 && threadIdx.x == 0) { dbeta[c] = s1; dgamma[c] = s2; }
+    s3 = wave_sum(s3);
+    if (s == 0 && threadIdx.x == 0) {
+        dbeta[c] = s1;
+        dgamma[c] = s2;
+        // gradient of a bias added in front of the layer = sum of dx = gamma rstd (s1 - L s1/L - s2/L sum(xhat)): zero in
+        // exact arithmetic (the batch mean is subtracted), in float32 the rounding residue of sum(xhat)
+        if (dpre_bias) dpre_bias[c] = -gamma[c] * save_rstd[c] * (s2 / (float)((long long)N * HW)) * s3;
+    }
     const float mean = save_mean[c], rstd = save_rstd[c], ga = gamma[c], be = beta[c];
     const float fa = rstd * ga;
     const long long L = (long long)N * HW;
@@ -304,8 +316,9 @@ int slices(int N, int C, int HW) {
 
 extern "C" size_t dtk_batchnorm_workspace_bytes(int32_t C) { return (size_t)(C > 0 ? C : 0) * 64 * 3 * sizeof(float); }
 
-extern "C" int dtk_batchnorm_train_forward(const float* x, const float* gamma, const float* beta, float* running_mean,
-                                           float* running_var, float momentum, float eps, int32_t relu, float* y,
+extern "C" int dtk_batchnorm_train_forward(const float* x, const float* gamma, const float* beta, const float* pre_bias,
+                                           float* running_mean, float* running_var, float momentum, float eps, int32_t relu,
+                                           float* y,
                                            float* save_mean, float* save_rstd, int32_t N, int32_t C, int32_t HW,
                                            void* workspace, size_t workspace_bytes, void* stream) {
     DTK_REQUIRE(x && gamma && beta && y && save_mean && save_rstd && workspace, "dtk_batchnorm_train_forward: null pointer");
@@ -316,14 +329,14 @@ extern "C" int dtk_batchnorm_train_forward(const float* x, const float* gamma, c
     float* part = static_cast<float*>(workspace);
     DTK_LAUNCH("bn_stats", bn_stats_kernel, dim3(S, C), dim3(256), 0, st, x, part, N, C, HW, S);
     DTK_LAUNCH("bn_apply", bn_apply_kernel, dim3(S, C), dim3(256), 0, st, x, part, gamma, beta, running_mean, running_var,
-               momentum, eps, relu, y, save_mean, save_rstd, N, C, HW, S);
+               pre_bias, momentum, eps, relu, y, save_mean, save_rstd, N, C, HW, S);
     return DTK_OK;
 }
 
 extern "C" int dtk_batchnorm_train_backward(const float* x, const float* dy, const float* gamma, const float* beta,
                                             const float* save_mean, const float* save_rstd, int32_t relu, float* dx,
-                                            float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t HW, void* workspace,
-                                            size_t workspace_bytes, void* stream) {
+                                            float* dgamma, float* dbeta, float* dpre_bias, int32_t N, int32_t C, int32_t HW,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
     DTK_REQUIRE(x && dy && gamma && beta && save_mean && save_rstd && dx && dgamma && dbeta && workspace,
                 "dtk_batchnorm_train_backward: null pointer");
     DTK_REQUIRE(N > 0 && C > 0 && HW > 0, "dtk_batchnorm_train_backward: bad shape %d x %d x %d", N, C, HW);
@@ -334,7 +347,7 @@ extern "C" int dtk_batchnorm_train_backward(const float* x, const float* dy, con
     DTK_LAUNCH("bn_bwd_sums", bn_bwd_sums_kernel, dim3(S, C), dim3(256), 0, st, x, dy, gamma, beta, save_mean, save_rstd, relu,
                part, N, C, HW, S);
     DTK_LAUNCH("bn_bwd_apply", bn_bwd_apply_kernel, dim3(S, C), dim3(256), 0, st, x, dy, gamma, beta, save_mean, save_rstd, relu,
-               part, dx, dgamma, dbeta, N, C, HW, S);
+               part, dx, dgamma, dbeta, dpre_bias, N, C, HW, S);
     return DTK_OK;
 }
 

@@ -214,7 +214,8 @@ def profile_collect() -> Dict[str, Tuple[float, int]]:
 
 
 def batchnorm_train_forward(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: Optional[torch.Tensor],
-                            running_var: Optional[torch.Tensor], momentum: float, eps: float, relu: bool):
+                            running_var: Optional[torch.Tensor], momentum: float, eps: float, relu: bool,
+                            pre_bias: Optional[torch.Tensor] = None):
     """Train-mode BatchNorm2d (+ fused ReLU) over x [N,C,H,W]: returns (y, save_mean, save_rstd); the running statistics
     are updated in place (dtk_batchnorm_train_forward)."""
     N, C, H, W = x.shape
@@ -224,24 +225,27 @@ def batchnorm_train_forward(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Te
     nb = int(lib().dtk_batchnorm_workspace_bytes(C))
     ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
     check(lib().dtk_batchnorm_train_forward(_p(x, torch.float32), _p(gamma, torch.float32), _p(beta, torch.float32),
-                                            _p(running_mean, torch.float32), _p(running_var, torch.float32), float(momentum),
+                                            _p(pre_bias, torch.float32), _p(running_mean, torch.float32),
+                                            _p(running_var, torch.float32), float(momentum),
                                             float(eps), int(relu), _p(y), _p(mean), _p(rstd), N, C, H * W, _p(ws), nb, _stream()))
     return y, mean, rstd
 
 
 def batchnorm_train_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, mean: torch.Tensor,
-                             rstd: torch.Tensor, relu: bool):
-    """(dx, dgamma, dbeta) of batchnorm_train_forward (dtk_batchnorm_train_backward)."""
+                             rstd: torch.Tensor, relu: bool, want_pre_bias: bool = False):
+    """(dx, dgamma, dbeta, dpre_bias or None) of batchnorm_train_forward (dtk_batchnorm_train_backward)."""
     N, C, H, W = x.shape
     dx = torch.empty_like(x)
     dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    dpre = torch.empty(C, dtype=torch.float32, device=x.device) if want_pre_bias else None
     nb = int(lib().dtk_batchnorm_workspace_bytes(C))
     ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
     check(lib().dtk_batchnorm_train_backward(_p(x, torch.float32), _p(dy, torch.float32), _p(gamma, torch.float32),
                                              _p(beta, torch.float32), _p(mean, torch.float32), _p(rstd, torch.float32),
-                                             int(relu), _p(dx), _p(dgamma), _p(dbeta), N, C, H * W, _p(ws), nb, _stream()))
-    return dx, dgamma, dbeta
+                                             int(relu), _p(dx), _p(dgamma), _p(dbeta), _p(dpre), N, C, H * W, _p(ws), nb,
+                                             _stream()))
+    return dx, dgamma, dbeta, dpre
 
 
 def blurpool_forward(x: torch.Tensor) -> torch.Tensor:

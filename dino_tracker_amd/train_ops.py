@@ -59,11 +59,76 @@ def blurpool(x: torch.Tensor, filt: torch.Tensor, stride: int = 2) -> torch.Tens
     return sum(a[k] * rows[:, :, :, k:k + stride * (wo - 1) + 1:stride] for k in range(4))
 
 
+_WORKSPACE = {}
+
+
+def _workspace(name: str, numel: int, like: torch.Tensor) -> torch.Tensor:
+    """Persistent scratch (per device and name), grown on demand: the unfolded operands of the convolutions are the largest
+    tensors of a training step (5 GB each at full size) -- kept out of the caching allocator, whose blocks the reference's
+    loop releases every iteration (torch.cuda.empty_cache(), dino_tracker.py:406)."""
+    key = (name, like.device, like.dtype)
+    buf = _WORKSPACE.get(key)
+    if buf is None or buf.numel() < numel:
+        _WORKSPACE[key] = buf = torch.empty(numel, dtype=like.dtype, device=like.device)
+    return buf[:numel]
+
+
+class _ConvGemm(torch.autograd.Function):
+    """Stride-1 convolution = unfold + matrix product, with the unfolded input RECOMPUTED in the backward (into the same
+    persistent scratch) instead of being saved: forward  Y_n = W [Cout, K] . cols_n [K, L];  backward  dW = sum_n dY_n .
+    cols_n^T,  dcols_n = W^T . dY_n -> col2im -> adjoint of the padding."""
+
+    @staticmethod
+    def forward(ctx, x, weight, padding, dilation, padding_mode):
+        n, cin, h, w = x.shape
+        cout, _, kh, kw = weight.shape
+        xp = F.pad(x, (padding,) * 4, mode=padding_mode) if padding and padding_mode != "zeros" else x
+        zpad = padding if padding_mode == "zeros" else 0
+        ho, wo = xp.shape[-2] + 2 * zpad - dilation * (kh - 1), xp.shape[-1] + 2 * zpad - dilation * (kw - 1)
+        k = cin * kh * kw
+        cols = _workspace("cols", n * k * ho * wo, x).view(n, k, ho * wo)
+        torch.ops.aten.im2col.out(xp, [kh, kw], [dilation, dilation], [zpad, zpad], [1, 1], out=cols)
+        y = torch.matmul(weight.reshape(cout, k), cols).view(n, cout, ho, wo)
+        ctx.save_for_backward(x, weight)
+        ctx.conf = (padding, dilation, padding_mode, zpad, ho, wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        padding, dilation, padding_mode, zpad, ho, wo = ctx.conf
+        n, cin, h, w = x.shape
+        cout, _, kh, kw = weight.shape
+        k = cin * kh * kw
+        dy = dy.reshape(n, cout, ho * wo)
+        dw = dx = None
+        xp = F.pad(x, (padding,) * 4, mode=padding_mode) if padding and padding_mode != "zeros" else x
+        if ctx.needs_input_grad[1]:
+            cols = _workspace("cols", n * k * ho * wo, x).view(n, k, ho * wo)
+            torch.ops.aten.im2col.out(xp, [kh, kw], [dilation, dilation], [zpad, zpad], [1, 1], out=cols)
+            dw = torch.matmul(dy, cols.transpose(1, 2)).sum(dim=0).view_as(weight)
+        if ctx.needs_input_grad[0]:
+            dcols = _workspace("dcols", n * k * ho * wo, x).view(n, k, ho * wo)
+            torch.matmul(weight.reshape(cout, k).t(), dy, out=dcols)
+            dxp = F.fold(dcols, xp.shape[-2:], (kh, kw), dilation=dilation, padding=zpad)
+            if xp is x:
+                dx = dxp
+            elif padding_mode == "reflect":
+                dx = torch.ops.aten.reflection_pad2d_backward(dxp, x, [padding] * 4)
+            else:
+                raise NotImplementedError(padding_mode)
+        return dx, dw, None, None, None
+
+
 def conv2d_gemm(x: torch.Tensor, weight: torch.Tensor, bias, padding: int, dilation: int = 1, padding_mode: str = "zeros"):
     """Stride-1 convolution as ONE matrix product over the unfolded input ([Cout, Cin k k] x [Cin k k, H W] per frame):
     forward and both backward products run on the BLAS GEMM kernels, im2col / col2im on plain copy kernels.  (The
     convolution library's per-call solver selection costs the host ~0.3 s per forward call and seconds per backward call on
-    this stack -- 40 s per training iteration, against 0.05 s of kernels.)"""
+    this stack -- 40 s per training iteration, against 0.05 s of kernels.)  On the device the unfolded operands live in
+    persistent scratch and are recomputed in the backward (_ConvGemm); host tensors take the autograd-traced form."""
+    if x.is_cuda:
+        y = _ConvGemm.apply(x, weight, padding, dilation, padding_mode)
+        return y if bias is None else y + bias[None, :, None, None]
     n, cin, h, w = x.shape
     cout, _, kh, kw = weight.shape
     if padding and padding_mode != "zeros":
@@ -111,27 +176,30 @@ class _BatchNormTrain(torch.autograd.Function):
     whose mean is large against their spread (5e-3 relative output error measured on Delta-DINO's second layer)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, pre_bias, running_mean, running_var, momentum, eps, relu):
         from . import ops
         x = x.contiguous()
+        pb = None if pre_bias is None else pre_bias.detach().contiguous()
         y, mean, rstd = ops.batchnorm_train_forward(x, gamma.detach().contiguous(), beta.detach().contiguous(), running_mean,
-                                                    running_var, momentum, eps, relu)
+                                                    running_var, momentum, eps, relu, pb)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
-        ctx.relu = relu
+        ctx.relu, ctx.has_pre = relu, pre_bias is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from . import ops
         x, gamma, beta, mean, rstd = ctx.saved_tensors
-        dx, dgamma, dbeta = ops.batchnorm_train_backward(x, dy.contiguous(), gamma.detach().contiguous(),
-                                                         beta.detach().contiguous(), mean, rstd, ctx.relu)
-        return dx, dgamma, dbeta, None, None, None, None, None
+        dx, dgamma, dbeta, dpre = ops.batchnorm_train_backward(x, dy.contiguous(), gamma.detach().contiguous(),
+                                                               beta.detach().contiguous(), mean, rstd, ctx.relu, ctx.has_pre)
+        return dx, dgamma, dbeta, dpre, None, None, None, None, None
 
 
-def batchnorm_train(bn: torch.nn.BatchNorm2d, x: torch.Tensor, relu: bool) -> torch.Tensor:
+def batchnorm_train(bn: torch.nn.BatchNorm2d, x: torch.Tensor, relu: bool, pre_bias=None) -> torch.Tensor:
     """nn.BatchNorm2d.forward in training mode (+ ReLU) on the device kernels; bookkeeping as torch's module does it
-    (num_batches_tracked, momentum None = cumulative average)."""
+    (num_batches_tracked, momentum None = cumulative average).  `pre_bias`: the bias of the convolution in front, which the
+    caller has NOT added to x (it only shifts the batch mean: the kernels account for it in running_mean and return its
+    gradient, the float32 residue of an exact zero) -- saves the (n, C, H, W) broadcast add and its reduction."""
     momentum = 0.0 if bn.momentum is None else bn.momentum
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
@@ -139,26 +207,32 @@ def batchnorm_train(bn: torch.nn.BatchNorm2d, x: torch.Tensor, relu: bool) -> to
             momentum = 1.0 / float(bn.num_batches_tracked)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    return _BatchNormTrain.apply(x, bn.weight, bn.bias, rm, rv, momentum, bn.eps, relu)
+    return _BatchNormTrain.apply(x, bn.weight, bn.bias, pre_bias, rm, rv, momentum, bn.eps, relu)
 
 
 def delta_dino_residual(delta_dino, frames: torch.Tensor, h: int, w: int, vit_patch: int = 14) -> torch.Tensor:
     """DeltaDINO.forward (delta_dino.py:53-61) in training mode -> the aligned residual [n, C, h, w].  Convolutions as
-    unfold + GEMM (conv2d_gemm), blur-pools as strided views; on the device every BatchNorm2d -- with the ReLU that follows
-    it -- runs on csrc/train.hip, forward and backward.  On host tensors (the CPU parity tests of this arithmetic) the
-    BatchNorm2d modules themselves run."""
+    unfold + GEMM (conv2d_gemm); on the device every BatchNorm2d -- with the ReLU that follows it and the bias of the conv in
+    front of it -- and every blur-pool run on csrc/train.hip, forward and backward.  On host tensors (the CPU parity tests
+    of this arithmetic) the BatchNorm2d modules themselves run."""
     x = frames
     layers = list(delta_dino.layers)
+    fused_bn = x.is_cuda
     i = 0
+    pending_bias = None  # a conv bias handed to the BatchNorm behind it instead of being added to the conv output
     while i < len(layers):
         layer = layers[i]
-        if isinstance(layer, torch.nn.BatchNorm2d) and layer.training and x.is_cuda and layer.affine:
-            relu = i + 1 < len(layers) and isinstance(layers[i + 1], torch.nn.ReLU)
-            x = batchnorm_train(layer, x, relu)
-            i += 2 if relu else 1
-            continue
+        nxt = layers[i + 1] if i + 1 < len(layers) else None
         if isinstance(layer, torch.nn.Conv2d):
-            x = conv2d_gemm(x, layer.weight, layer.bias, layer.padding[0], layer.dilation[0], layer.padding_mode)
+            to_bn = fused_bn and isinstance(nxt, torch.nn.BatchNorm2d) and nxt.training and nxt.affine
+            x = conv2d_gemm(x, layer.weight, None if to_bn else layer.bias, layer.padding[0], layer.dilation[0],
+                            layer.padding_mode)
+            pending_bias = layer.bias if to_bn else None
+        elif isinstance(layer, torch.nn.BatchNorm2d) and layer.training and fused_bn and layer.affine:
+            relu = isinstance(nxt, torch.nn.ReLU)
+            x = batchnorm_train(layer, x, relu, pending_bias)
+            pending_bias = None
+            i += 1 if relu else 0
         else:
             x = layer(x)
         i += 1

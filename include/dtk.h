@@ -267,17 +267,21 @@ int dtk_tapvid_counts(const float* pred_tracks, const uint8_t* pred_occluded, co
  *   save_mean / save_rstd [C] for the backward; running_mean / running_var [C] (nullable) are updated in place with
  *   `momentum` and the UNBIASED batch variance, as torch does.  Statistics by pairwise (Chan) merging of exact small-group
  *   moments -- no E[x^2] - E[x]^2.
- * backward: dx, dgamma [C], dbeta [C] from dy (the gradient w.r.t. the ReLU'd output when relu != 0).
+ * pre_bias [C] (nullable): the bias of the convolution in front of the layer (delta_dino.py:29-31), NOT added to x by the
+ *   caller: a per-channel constant only shifts the batch mean, so it enters running_mean and nothing else -- the layer
+ *   never makes the (n, C, H, W) pass that adds it.
+ * backward: dx, dgamma [C], dbeta [C] from dy (the gradient w.r.t. the ReLU'd output when relu != 0); dpre_bias [C]
+ *   (nullable) = sum of dx = the gradient of pre_bias: zero in exact arithmetic, the float32 rounding residue here.
  * workspace: dtk_batchnorm_workspace_bytes(C) bytes of device memory. */
 size_t dtk_batchnorm_workspace_bytes(int32_t C);
-int dtk_batchnorm_train_forward(const float* x, const float* gamma, const float* beta, float* running_mean,
-                                float* running_var, float momentum, float eps, int32_t relu, float* y, float* save_mean,
-                                float* save_rstd, int32_t N, int32_t C, int32_t HW, void* workspace, size_t workspace_bytes,
-                                void* stream);
+int dtk_batchnorm_train_forward(const float* x, const float* gamma, const float* beta, const float* pre_bias,
+                                float* running_mean, float* running_var, float momentum, float eps, int32_t relu, float* y,
+                                float* save_mean, float* save_rstd, int32_t N, int32_t C, int32_t HW, void* workspace,
+                                size_t workspace_bytes, void* stream);
 int dtk_batchnorm_train_backward(const float* x, const float* dy, const float* gamma, const float* beta,
                                  const float* save_mean, const float* save_rstd, int32_t relu, float* dx, float* dgamma,
-                                 float* dbeta, int32_t N, int32_t C, int32_t HW, void* workspace, size_t workspace_bytes,
-                                 void* stream);
+                                 float* dbeta, float* dpre_bias, int32_t N, int32_t C, int32_t HW, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 
 /* BlurPool of the Delta-DINO CNN (antialiased_cnns.BlurPool(channels, stride=2): filt_size 4, reflect padding, depthwise
  * outer([1,3,3,1]) / 64; models/networks/delta_dino.py:43-44) and its adjoint.  x / dx: [planes][H][W], y / dy:

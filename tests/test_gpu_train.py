@@ -212,6 +212,20 @@ def test_batchnorm_train_kernels(shape, relu):
         assert rel(bn.bias.grad, bn64.bias.grad) < 2e-2
     assert torch.isfinite(y).all() and torch.isfinite(xd.grad).all()
     assert float(m64.abs().max()) > 1 and float(v64.min()) > 0
+    # a conv bias handed to the layer instead of being added to x: same output, running_mean shifted by it, gradient ~ 0
+    bn2 = torch.nn.BatchNorm2d(c)
+    bn2.load_state_dict({k: v.float() for k, v in bn64.state_dict().items()})
+    bn2.num_batches_tracked.zero_()
+    with torch.no_grad():
+        bn2.running_mean.copy_(torch.zeros(c))
+    bn2 = bn2.cuda().train()
+    pre = (torch.randn(c, generator=g) * 2.0).cuda().requires_grad_()
+    x2 = x.cuda().requires_grad_()
+    y2 = train_ops.batchnorm_train(bn2, x2, relu, pre)
+    (y2 * cot.cuda()).sum().backward()
+    assert torch.equal(y2, y)
+    assert torch.allclose(bn2.running_mean.cpu(), 0.1 * (m64.float() + pre.detach().cpu()), rtol=1e-5, atol=1e-6)
+    assert pre.grad.abs().max() <= 1e-3 * cot.abs().sum(dim=(0, 2, 3)).max()
 
 
 @pytest.mark.parametrize("shape", [(2, 5, 63, 427), (1, 3, 4, 4), (3, 2, 5, 6), (2, 4, 238, 427), (1, 2, 119, 214), (1, 1, 7, 4)])
