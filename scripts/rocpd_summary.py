@@ -26,3 +26,35 @@ for name, n, tot, mn, mx in rows:
         short = re.sub(r"\(.*", "", name)[:60]
     print(f"| {short} | {n} | {tot / 1e6:.3f} | {tot / n / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | {100.0 * tot / total:.1f} |")
 print(f"\ntotal kernel time {total / 1e6:.1f} ms over {sum(r[1] for r in rows)} dispatches")
+
+if "--gaps" in sys.argv:
+    # idle time of the device between consecutive dispatches (start_i - latest end so far), charged to the kernel that ends
+    # the gap: where the host fails to keep the queue full
+    disp = db.execute(f"""select s.{name_col}, d.start, d.end from rocpd_kernel_dispatch d
+                          join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start""").fetchall()
+    if "--gaps-window" in sys.argv:  # KERNEL FIRST LAST: from the FIRST-th to the LAST-th dispatch of KERNEL (0-based)
+        i = sys.argv.index("--gaps-window")
+        key, first, last = sys.argv[i + 1], int(sys.argv[i + 2]), int(sys.argv[i + 3])
+        marks = [k for k, d in enumerate(disp) if key in d[0]]
+        disp = disp[marks[first]:marks[last]]
+        print(f"\n(window: dispatches {marks[first]} .. {marks[last]}, between occurrences {first} and {last} of `{key}`)")
+    gaps = {}
+    busy_end = disp[0][2]
+    idle = 0
+    for name, st, en in disp[1:]:
+        g = st - busy_end
+        if g > 0:
+            idle += g
+            m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name) or re.match(r"_ZN4att2(\d+)", name) or re.match(r"_Z(\d+)", name)
+            short = name[m.end():m.end() + int(m.group(1))] if m else re.sub(r"\(.*", "", name)[:50]
+            a = gaps.setdefault(short, [0, 0, 0])
+            a[0] += 1
+            a[1] += g
+            a[2] = max(a[2], g)
+        busy_end = max(busy_end, en)
+    span = busy_end - disp[0][1]
+    print(f"\ndevice idle between dispatches: {idle / 1e6:.1f} ms of a {span / 1e6:.1f} ms span ({100.0 * idle / span:.1f} %)")
+    print("| gap ends at kernel | gaps | total ms | max us |")
+    print("|---|---:|---:|---:|")
+    for k, (n, tot, mx) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:14]:
+        print(f"| {k} | {n} | {tot / 1e6:.3f} | {mx / 1e3:.1f} |")
