@@ -46,10 +46,14 @@ def test_head_forward_golden(name):
     head = MG.build_inputs(cfg)[2]
     th = TrackerHead(patch_size=14, step_h=7, step_w=7, video_h=cfg["H"], video_w=cfg["W"])
     th.load_state_dict(head)
-    th = th.cuda()
+    th = th.cuda().eval()  # inference kernels (a module in training mode with autograd on takes the differentiable path)
     maps = torch.relu(torch.from_numpy(gold["head_maps"])).cuda()
     out = th(maps).cpu().numpy()
     assert np.abs(out - gold["head_out"]).max() < 2e-6
+    th.train()
+    out_train = th(maps)  # train_ops.head_forward: same numbers, with an autograd graph into the head's parameters
+    assert out_train.requires_grad and np.abs(out_train.detach().cpu().numpy() - gold["head_out"]).max() < 2e-5
+    th.eval()
     # random maps incl. plateaus / exact ties -> first-index argmax, vs the oracle
     g = torch.Generator().manual_seed(7)
     rnd = torch.rand(16, 1, *maps.shape[-2:], generator=g)
