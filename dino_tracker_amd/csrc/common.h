@@ -56,20 +56,43 @@ static inline int dtk_cdiv(long long a, long long b) { return (int)((a + b - 1) 
 #ifdef __HIPCC__
 constexpr int WAVE = 64;
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+// Wave-wide all-reduce without an LDS round trip (the __shfl_xor butterfly compiles to six ds_bpermute_b32, ~100 cycles of
+// latency each -- 90 of them made refine_head latency-bound): four DPP steps inside a row of 16 lanes (quad permutes, then
+// the half-row and row mirrors pair up the partial sums), then v_permlane16_swap / v_permlane32_swap (gfx950) for the rows.
+// Every lane ends with the result.  (The swap results are copied to scalars before the bit cast: hipcc / ROCm 7.2 reads
+// element 0 for both when the cast is applied to the vector elements directly.)
+template <int CTRL>
+__device__ __forceinline__ int dtk_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <class Op>
+__device__ __forceinline__ int wave_allreduce_bits(int v, Op op) {
+    v = op(v, dtk_dpp<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = op(v, dtk_dpp<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = op(v, dtk_dpp<0x141>(v));   // row_half_mirror: lane i <-> 7 - i of each 8
+    v = op(v, dtk_dpp<0x140>(v));   // row_mirror:      lane i <-> 15 - i of each 16
+    {
+        const auto sw = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+        const unsigned a = sw[0], b = sw[1];
+        v = op((int)a, (int)b);
+    }
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+        const unsigned a = sw[0], b = sw[1];
+        v = op((int)a, (int)b);
+    }
     return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    return __int_as_float(wave_allreduce_bits(__float_as_int(v), [](int a, int b) {
+        return __float_as_int(__int_as_float(a) + __int_as_float(b));
+    }));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
-    return v;
+    return __int_as_float(wave_allreduce_bits(__float_as_int(v), [](int a, int b) {
+        return __float_as_int(fmaxf(__int_as_float(a), __int_as_float(b)));
+    }));
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+    return wave_allreduce_bits(v, [](int a, int b) { return a + b; });
 }
 // effective source count: min(M, *dM) when a device-side count is supplied
 __device__ __forceinline__ int dtk_active(int M, const int32_t* dM) {

@@ -2,6 +2,26 @@
 #pragma once
 #include "common.h"
 
+// Lane 0 of the wave that summed the disk: zero-mass fallback (tracker_head.py:86-94), centre of mass, RangeNormalizer.
+__device__ __forceinline__ void dtk_softargmax_finish(const dtk_geom& g, float sq, float sqx, float sqy, float cnt, float sx,
+                                                      float sy, int normalized, float* out2) {
+    if (sq < 1e-8f) {  // q <- (q + 1/|mask|) * mask
+        const float uni = 1.f / cnt;
+        sqx = sqx + uni * sx;
+        sqy = sqy + uni * sy;
+        sq = sq + uni * cnt;
+    }
+    const float xh = sqx / sq, yh = sqy / sq;
+    float vx = 2.f * (xh / (float)(g.video_w - 1)) - 1.f;  // RangeNormalizer.forward, dst=(-1,1)
+    float vy = 2.f * (yh / (float)(g.video_h - 1)) - 1.f;
+    if (!normalized) {  // RangeNormalizer.unnormalize, src=(-1,1)
+        vx = ((vx + 1.f) / 2.f) * (float)(g.video_w - 1);
+        vy = ((vy + 1.f) / 2.f) * (float)(g.video_h - 1);
+    }
+    out2[0] = vx;
+    out2[1] = vy;
+}
+
 // Shared with the MFMA path: finish one source from its (exact fp32) refined logits inside the disk.
 // Runs on ONE wave.  zfun(row, col) returns z at a cell; zmax / Z are the softmax statistics of the whole map.
 // Returns through lane 0.  (tracker_head.py:68-98,112,121 + model_inference.py:52)
@@ -29,22 +49,5 @@ __device__ __forceinline__ void dtk_disk_softargmax(const dtk_geom& g, int kstar
     sq = wave_sum(sq); sqx = wave_sum(sqx); sqy = wave_sum(sqy);
     cnt = wave_sum(cnt); sx = wave_sum(sx); sy = wave_sum(sy);
     if (sq_report) *sq_report = sq;  // same value on every lane: lets the caller detect an undecidable fallback test
-    if (lane == 0) {
-        if (sq < 1e-8f) {  // tracker_head.py:86-94: q <- (q + 1/|mask|) * mask
-            const float uni = 1.f / cnt;
-            sqx = sqx + uni * sx;
-            sqy = sqy + uni * sy;
-            sq = sq + uni * cnt;
-        }
-        const float xh = sqx / sq, yh = sqy / sq;
-        float vx = 2.f * (xh / (float)(g.video_w - 1)) - 1.f;  // RangeNormalizer.forward, dst=(-1,1)
-        float vy = 2.f * (yh / (float)(g.video_h - 1)) - 1.f;
-        if (!normalized) {  // RangeNormalizer.unnormalize, src=(-1,1)
-            vx = ((vx + 1.f) / 2.f) * (float)(g.video_w - 1);
-            vy = ((vy + 1.f) / 2.f) * (float)(g.video_h - 1);
-        }
-        out2[0] = vx;
-        out2[1] = vy;
-    }
+    if (lane == 0) dtk_softargmax_finish(g, sq, sqx, sqy, cnt, sx, sy, normalized, out2);
 }
-

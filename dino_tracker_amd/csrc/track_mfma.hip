@@ -1231,7 +1231,7 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
                                                           const int32_t* __restrict__ dM, int normalized) {
     __shared__ float s_x[4][WX * WX + 3];
     constexpr int PN = (WH * WH + 15) / 16 * 16;  // cells per tap plane
-    __shared__ float s_p[4][9 * PN];
+    __shared__ float s_p[4][9 * PN + 16];  // + a dummy row: the D rows of GEMM2 that are not taps are written there
     __shared__ float s_z[4][WZ * WZ + 7];
     __shared__ float s_out[4][2];
     const int ph = g.ph, pw = g.pw;
@@ -1248,6 +1248,7 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
         const int rr = kr - (RD + 2) + j / WX, cc = kc - (RD + 2) + j % WX;
         sx[j] = (rr >= 0 && rr < ph && cc >= 0 && cc < pw) ? xg[j] : 0.f;  // zero padding of conv1
     }
+    if (lane < 2) sx[WX * WX + lane] = lane == 0 ? 1.f : 0.f;  // the bias row of GEMM1 and its zero rows read these
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---- the refiner on the matrix cores (f32-input MFMA 16x16x4: fp32 products, fp32 accumulation), 16 hidden cells
@@ -1258,45 +1259,72 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
     // channels {4g' + kp}: lane group g' then simply supplies its register kp.  The per-tap planes go to LDS and
     //   z[zy][zx] = b2 + sum_tap P[tap][(zy + dy) * WH + zx + dx]
     // is nine LDS reads per logit instead of 144.
+    // The kernel is bound by instruction issue (~1900 instructions per source, 7 of 87 per group being MFMAs, before this
+    // form), so everything that does not depend on the group is per-lane state computed once: LDS indices of the three
+    // B-operand reads (a tap of the 3x3 neighbourhood, or the constant 1 / 0 slots behind the window), the four P-plane
+    // write indices (non-tap D rows go to a dummy row), the cell walk p -> p + 16 as additions, and the "hidden cell inside
+    // the map" test as two bit masks.
     const float b2 = head[304];
     const int gq = lane >> 4, jq = lane & 15;
-    float a1[3], a2[4], xconst[3];
-    int xoff[3];
+    typedef __attribute__((address_space(3))) float lds_f32;
+    float a1[3], a2[4];
+    const lds_f32* xptr[3];   // B-operand read of GEMM1 for this group
+    int xmov[3];              // 1: a tap of the neighbourhood (moves with the cell), 0: a constant slot
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
         const int kk = 4 * ks + gq;
         a1[ks] = kk < 9 ? head[jq * 9 + kk] : (kk == 9 ? head[144 + jq] : 0.f);
-        xoff[ks] = kk < 9 ? (kk / 3) * WX + (kk % 3) : -1;
-        xconst[ks] = kk == 9 ? 1.f : 0.f;
+        xmov[ks] = kk < 9 ? 1 : 0;
+        const int idx = kk < 9 ? (kk / 3) * WX + (kk % 3) : (kk == 9 ? WX * WX : WX * WX + 1);
+        xptr[ks] = (const lds_f32*)sx + idx;
+    }
+    float* Pb = s_p[w];
+    lds_f32* pptr[4];
+    int pinc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int tap = 4 * gq + r;
+        pptr[r] = (lds_f32*)Pb + (tap < 9 ? tap * PN + jq : 9 * PN + jq);
+        pinc[r] = tap < 9 ? 16 : 0;
     }
 #pragma unroll
     for (int kp = 0; kp < 4; ++kp) a2[kp] = jq < 9 ? head[160 + (4 * gq + kp) * 9 + jq] : 0.f;
-    float* Pb = s_p[w];
+    // hidden cell (hy, hx) of the window is cell (kr - (RD+1) + hy, kc - (RD+1) + hx) of the map: bit hy / hx set when inside
+    auto inside_mask = [](int k0, int n) -> unsigned {  // k0 = map coordinate of window index 0
+        const int lo = max(0, -k0), hi = min(WH - 1, n - 1 - k0);
+        return hi >= lo ? ((2u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+    };
+    const unsigned rmask = inside_mask(kr - (RD + 1), ph), cmask = inside_mask(kc - (RD + 1), pw);
+    int hy = jq >= WH ? 1 : 0, hx = jq >= WH ? jq - WH : jq;  // cell p = jq of group 0
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) xptr[ks] += xmov[ks] * (hy * WX + hx);  // its top-left tap in the x window
 #pragma unroll 1
     for (int grp = 0; grp < (WH * WH + 15) / 16; ++grp) {
-        const int p = grp * 16 + jq;  // hidden cell of this lane's column
-        const int pc = min(p, WH * WH - 1);
-        const int hy = pc / WH, hx = pc - hy * WH;  // window coords of its centre in the x window: (hy+1, hx+1)
-        const int hr = kr - (RD + 1) + hy, hc = kc - (RD + 1) + hx;
-        const bool in = hr >= 0 && hr < ph && hc >= 0 && hc < pw;
-        const float* xb = sx + hy * WX + hx;
+        // (cells p >= WH*WH of the last group read past the window and land in the planes' padding: never used)
+        const bool in = ((rmask >> hy) & (cmask >> hx) & 1u) != 0;  // hidden outside the map is zero (conv2's padding)
         f4 d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-            const float xv = xoff[ks] >= 0 ? xb[xoff[ks]] : xconst[ks];
-            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], xv, d1, 0, 0, 0);
-        }
+        for (int ks = 0; ks < 3; ++ks) d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], *xptr[ks], d1, 0, 0, 0);
         f4 d2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kp = 0; kp < 4; ++kp) {
-            const float hv = in ? fmaxf(d1[kp], 0.f) : 0.f;  // hidden outside the map is zero (conv2's padding)
+            float relu;  // one v_max_f32 (fmaxf compiles to a canonicalising v_max x, x first); NaN -> 0 like fmaxf
+            asm("v_max_f32 %0, 0, %1" : "=v"(relu) : "v"(d1[kp]));
+            const float hv = in ? relu : 0.f;
             d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[kp], hv, d2, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int tap = 4 * gq + r;
-            if (tap < 9 && p < WH * WH) Pb[tap * PN + p] = d2[r];
+            *pptr[r] = d2[r];
+            pptr[r] += pinc[r];
         }
+        // p -> p + 16 = one row down and 16 - WH columns right, wrapping once at most
+        const bool wrap = hx + 16 - WH >= WH;
+        hx += wrap ? 16 - 2 * WH : 16 - WH;
+        hy += wrap ? 2 : 1;
+        const int step = wrap ? 2 * WX + 16 - 2 * WH : WX + 16 - WH;  // words in the x window
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) xptr[ks] += xmov[ks] * step;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1323,12 +1351,22 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
         // with hmax = relu(b1 + P1 amax), hmin = relu(b1 + N1 amax) per channel (hmin must not be used where a hidden
         // tap can be padding: 0 < hmin there).  If exp(zw) / Z_ub exceeds the 1e-8 threshold the result is the plain
         // ratio, in which the statistics cancel.
+        // the disk cells of this lane (two slots of the WZ x WZ window), shared by the certificate and the soft arg-max
+        float zv[2], cx[2], cy[2];
+        bool okc[2];
         float zw = -INFINITY;
-        for (int j = lane; j < WZ * WZ; j += WAVE) {
-            const int r = kr - RD + j / WZ, c = kc - RD + j % WZ;
-            if (r < 0 || r >= ph || c < 0 || c >= pw) continue;
+        const float half = (float)(g.patch / 2);
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const int j = lane + WAVE * sl;
+            const int jr = j / WZ, jc = j - jr * WZ;
+            const int r = kr - RD + jr, c = kc - RD + jc;
             const float dx = (float)((c - kc) * g.stride), dy = (float)((r - kr) * g.stride);
-            if (sqrtf(dx * dx + dy * dy) <= g.radius) zw = fmaxf(zw, zb[j]);
+            okc[sl] = j < WZ * WZ && r >= 0 && r < ph && c >= 0 && c < pw && sqrtf(dx * dx + dy * dy) <= g.radius;
+            zv[sl] = okc[sl] ? zb[min(j, WZ * WZ - 1)] : -INFINITY;
+            cx[sl] = (float)(c * g.stride) + half;
+            cy[sl] = (float)(r * g.stride) + half;
+            zw = fmaxf(zw, zv[sl]);
         }
         zw = wave_max(zw);
         const float* cf = zerr + 8;  // = wpk + 160: P1, N1, W2p, W2n per channel
@@ -1353,9 +1391,19 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
             }
             return;
         }
-        float sq = 0.f;
-        dtk_disk_softargmax(g, k, zw, 1.f, zfun, normalized, s_out[w], &sq);  // sq >= 1: the fallback branch is dead
+        // softmax statistics (zw, 1): the ratio is independent of them, and sq >= 1 -- the zero-mass branch is dead
+        float sq = 0.f, sqx = 0.f, sqy = 0.f, cnt = 0.f, sxs = 0.f, sys = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+            if (okc[sl]) {
+                const float q = expf(zv[sl] - zw);
+                sq += q; sqx += q * cx[sl]; sqy += q * cy[sl];
+                cnt += 1.f; sxs += cx[sl]; sys += cy[sl];
+            }
+        sq = wave_sum(sq); sqx = wave_sum(sqx); sqy = wave_sum(sqy);
+        cnt = wave_sum(cnt); sxs = wave_sum(sxs); sys = wave_sum(sys);
         if (lane == 0) {
+            dtk_softargmax_finish(g, sq, sqx, sqy, cnt, sxs, sys, normalized, s_out[w]);
             const int oi = out_idx ? out_idx[m] : m;
             out_xy[2 * (size_t)oi] = s_out[w][0];
             out_xy[2 * (size_t)oi + 1] = s_out[w][1];
