@@ -1229,9 +1229,10 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
                                                           const float* __restrict__ zerr, Redo redo, Redo uncert,
                                                           int fast, int m0, int count, int M,
                                                           const int32_t* __restrict__ dM, int normalized) {
-    __shared__ float s_x[4][WX * WX + 3];
+    constexpr int XP = 16;  // pitch of the x window in LDS: 15 columns + a column of ones (the bias row of GEMM1)
+    __shared__ float s_x[4][WX * XP + 16];
     constexpr int PN = (WH * WH + 15) / 16 * 16;  // cells per tap plane
-    __shared__ float s_p[4][9 * PN + 16];  // + a dummy row: the D rows of GEMM2 that are not taps are written there
+    __shared__ float s_p[4][9 * PN];
     __shared__ float s_z[4][WZ * WZ + 7];
     __shared__ float s_out[4][2];
     const int ph = g.ph, pw = g.pw;
@@ -1244,67 +1245,72 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
     const int kr = k / pw, kc = k % pw;
     const float* xg = xwin + (size_t)i * WX * WX;
     float* sx = s_x[w];
-    for (int j = lane; j < WX * WX; j += WAVE) {
-        const int rr = kr - (RD + 2) + j / WX, cc = kc - (RD + 2) + j % WX;
-        sx[j] = (rr >= 0 && rr < ph && cc >= 0 && cc < pw) ? xg[j] : 0.f;  // zero padding of conv1
+    const int gq = lane >> 4, jq = lane & 15;
+    // This kernel is bound by INSTRUCTION ISSUE (the round-1 form: ~1900 instructions per source, 77 of them MFMAs; at 4
+    // cycles per wave64 instruction that is its whole run time), so the code below is organised to be short: no integer
+    // divisions, no per-group index arithmetic, no predicated stores.
+    // bit i of inside(k0, n, len): window index i <-> map coordinate k0 + i lies inside [0, n)
+    auto inside = [](int k0, int n, int len) -> unsigned {
+        const int lo = max(0, -k0), hi = min(len - 1, n - 1 - k0);
+        return hi >= lo ? ((2u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+    };
+    // x window: lane (gq, jq) loads column jq of rows gq, gq + 4, gq + 8, gq + 12; column 15 holds 1.0 in every row
+    {
+        const unsigned xr = inside(kr - (RD + 2), ph, WX), xc = inside(kc - (RD + 2), pw, WX);
+        const bool colin = (xc >> jq) & 1u;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            const int jr = gq + 4 * sl;
+            if (jr < WX) {
+                float v = jq == WX ? 1.f : 0.f;  // zero padding of conv1 outside the map
+                if (colin && ((xr >> jr) & 1u)) v = xg[jr * WX + jq];
+                sx[jr * XP + jq] = v;
+            }
+        }
     }
-    if (lane < 2) sx[WX * WX + lane] = lane == 0 ? 1.f : 0.f;  // the bias row of GEMM1 and its zero rows read these
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // ---- the refiner on the matrix cores (f32-input MFMA 16x16x4: fp32 products, fp32 accumulation), 16 hidden cells
-    // per pass:
-    //   GEMM1  H^T[16 ch][16 px] = W1e[16 ch][12] . Xe[12][16 px]     k = tap 0..8, k = 9: bias row (1.0), 10, 11: zero
-    //   GEMM2  P[tap][16 px]     = W2[tap][16 ch] . relu(H^T)         (taps 9..15 of the 16 rows are zero)
+    // ---- the refiner on the matrix cores (f32-input MFMA 16x16x4: fp32 products, fp32 accumulation), one ROW of the
+    // 13 x 13 hidden window per pass (lanes jq = 13..15 of a 16-lane group compute values nobody reads):
+    //   GEMM1  H^T[16 ch][16 px] = W1e[16 ch][12] . Xe[12][16 px]     k = tap 0..8, k = 9: bias (the column of ones), 10, 11: 0
+    //   GEMM2  P[tap][16 px]     = W2[tap][16 ch] . relu(H^T)         rows 9..15 repeat taps 0..6
     // D of GEMM1 -- lane (g, j): channels 4g + r of cell j -- feeds GEMM2 as its B operand when k-step kp is given the
     // channels {4g' + kp}: lane group g' then simply supplies its register kp.  The per-tap planes go to LDS and
     //   z[zy][zx] = b2 + sum_tap P[tap][(zy + dy) * WH + zx + dx]
-    // is nine LDS reads per logit instead of 144.
-    // The kernel is bound by instruction issue (~1900 instructions per source, 7 of 87 per group being MFMAs, before this
-    // form), so everything that does not depend on the group is per-lane state computed once: LDS indices of the three
-    // B-operand reads (a tap of the 3x3 neighbourhood, or the constant 1 / 0 slots behind the window), the four P-plane
-    // write indices (non-tap D rows go to a dummy row), the cell walk p -> p + 16 as additions, and the "hidden cell inside
-    // the map" test as two bit masks.
+    // is nine LDS reads per logit instead of 144.  With a row per pass every LDS address is a per-lane constant plus an
+    // immediate: a pass is 3 reads, 7 MFMAs, 4 relu + 4 selects (hidden cells outside the map are conv2's zero padding)
+    // and 4 stores.  The repeated rows of GEMM2 store the same values to the same addresses as the originals (no
+    // predicate); the stores of lanes 13..15 land on the first cells of the next row and are overwritten by that row's
+    // pass (same wave, program order), or in the plane's padding after the last row.
     const float b2 = head[304];
-    const int gq = lane >> 4, jq = lane & 15;
     typedef __attribute__((address_space(3))) float lds_f32;
     float a1[3], a2[4];
-    const lds_f32* xptr[3];   // B-operand read of GEMM1 for this group
-    int xmov[3];              // 1: a tap of the neighbourhood (moves with the cell), 0: a constant slot
+    const lds_f32* xptr[3];
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
         const int kk = 4 * ks + gq;
-        a1[ks] = kk < 9 ? head[jq * 9 + kk] : (kk == 9 ? head[144 + jq] : 0.f);
-        xmov[ks] = kk < 9 ? 1 : 0;
-        const int idx = kk < 9 ? (kk / 3) * WX + (kk % 3) : (kk == 9 ? WX * WX : WX * WX + 1);
-        xptr[ks] = (const lds_f32*)sx + idx;
+        const float wv = head[kk < 9 ? jq * 9 + kk : 144 + jq];
+        a1[ks] = kk <= 9 ? wv : 0.f;
+        xptr[ks] = (const lds_f32*)sx + (kk < 9 ? (kk / 3) * XP + (kk % 3) + jq : WX);  // a tap, or the column of ones
     }
     float* Pb = s_p[w];
     lds_f32* pptr[4];
-    int pinc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int tap = 4 * gq + r;
-        pptr[r] = (lds_f32*)Pb + (tap < 9 ? tap * PN + jq : 9 * PN + jq);
-        pinc[r] = tap < 9 ? 16 : 0;
+        pptr[r] = (lds_f32*)Pb + (tap < 9 ? tap : tap - 9) * PN + jq;
     }
 #pragma unroll
-    for (int kp = 0; kp < 4; ++kp) a2[kp] = jq < 9 ? head[160 + (4 * gq + kp) * 9 + jq] : 0.f;
-    // hidden cell (hy, hx) of the window is cell (kr - (RD+1) + hy, kc - (RD+1) + hx) of the map: bit hy / hx set when inside
-    auto inside_mask = [](int k0, int n) -> unsigned {  // k0 = map coordinate of window index 0
-        const int lo = max(0, -k0), hi = min(WH - 1, n - 1 - k0);
-        return hi >= lo ? ((2u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
-    };
-    const unsigned rmask = inside_mask(kr - (RD + 1), ph), cmask = inside_mask(kc - (RD + 1), pw);
-    int hy = jq >= WH ? 1 : 0, hx = jq >= WH ? jq - WH : jq;  // cell p = jq of group 0
+    for (int kp = 0; kp < 4; ++kp) a2[kp] = head[160 + (4 * gq + kp) * 9 + (jq < 9 ? jq : jq - 9)];
+    // hidden cell (hy, hx) of the window is cell (kr - (RD+1) + hy, kc - (RD+1) + hx) of the map
+    const unsigned rmask = __builtin_amdgcn_readfirstlane(inside(kr - (RD + 1), ph, WH));
+    const bool colok = (inside(kc - (RD + 1), pw, WH) >> jq) & 1u;
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) xptr[ks] += xmov[ks] * (hy * WX + hx);  // its top-left tap in the x window
-#pragma unroll 1
-    for (int grp = 0; grp < (WH * WH + 15) / 16; ++grp) {
-        // (cells p >= WH*WH of the last group read past the window and land in the planes' padding: never used)
-        const bool in = ((rmask >> hy) & (cmask >> hx) & 1u) != 0;  // hidden outside the map is zero (conv2's padding)
+    for (int hy = 0; hy < WH; ++hy) {
+        const bool in = colok & (((rmask >> hy) & 1u) != 0);
         f4 d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], *xptr[ks], d1, 0, 0, 0);
+        for (int ks = 0; ks < 3; ++ks) d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], xptr[ks][hy * XP], d1, 0, 0, 0);
         f4 d2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kp = 0; kp < 4; ++kp) {
@@ -1314,17 +1320,7 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
             d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[kp], hv, d2, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            *pptr[r] = d2[r];
-            pptr[r] += pinc[r];
-        }
-        // p -> p + 16 = one row down and 16 - WH columns right, wrapping once at most
-        const bool wrap = hx + 16 - WH >= WH;
-        hx += wrap ? 16 - 2 * WH : 16 - WH;
-        hy += wrap ? 2 : 1;
-        const int step = wrap ? 2 * WX + 16 - 2 * WH : WX + 16 - WH;  // words in the x window
-#pragma unroll
-        for (int ks = 0; ks < 3; ++ks) xptr[ks] += xmov[ks] * step;
+        for (int r = 0; r < 4; ++r) pptr[r][hy * WH] = d2[r];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

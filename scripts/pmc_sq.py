@@ -1,0 +1,39 @@
+"""Where the waves of each kernel spend their cycles, from ONE rocprofv3 PMC pass with the SQ counters
+    SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES
+(MI355X_MICROARCH.md, PMC section: WAIT_ANY = wave parked on s_waitcnt / barrier, WAIT_INST_ANY = issue stall, ACTIVE_INST_ANY
+= issuing; the three are disjoint and sum to WAVE_CYCLES; SQ counters are in quad-cycles, MFMA_BUSY in cycles).
+
+Usage: python scripts/pmc_sq.py <pmc.db> > profiles/<round>_pmc_sq.md"""
+import re
+import sqlite3
+import sys
+
+db = sqlite3.connect(sys.argv[1])
+ks = [r[1] for r in db.execute("pragma table_info(rocpd_info_kernel_symbol)")]
+name_col = "kernel_name" if "kernel_name" in ks else ks[-1]
+rows = db.execute(f"""select s.{name_col}, p.name, count(*), sum(e.value) from rocpd_pmc_event e
+                      join rocpd_info_pmc p on e.pmc_id = p.id
+                      join rocpd_kernel_dispatch d on e.event_id = d.event_id
+                      join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by 1, 2""").fetchall()
+dur = dict(db.execute(f"""select s.{name_col}, sum(d.end - d.start) from rocpd_kernel_dispatch d
+                          join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by 1""").fetchall())
+tab = {}
+for kn, cn, n, v in rows:
+    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", kn) or re.match(r"_ZN4att2(\d+)", kn) or re.match(r"_Z(\d+)", kn)
+    short = kn[m.end():m.end() + int(m.group(1))] if m else re.sub(r"\(.*", "", kn)[:40]
+    t = tab.setdefault(short, {"launches": n, "ns": 0})
+    t[cn] = t.get(cn, 0.0) + v
+    t["ns"] = max(t["ns"], dur.get(kn, 0))
+print("| kernel | launches | ms (this pass) | parked % | issue-stall % | issuing % | VALU issue % | VALU instr / wave | MFMA pipe busy % of kernel time |")
+print("|---|---:|---:|---:|---:|---:|---:|---:|---:|")
+for k, t in sorted(tab.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:16]:
+    wc = t.get("SQ_WAVE_CYCLES", 0.0)
+    if wc <= 0:
+        continue
+    pct = lambda c: 100.0 * t.get(c, 0.0) / wc
+    waves = max(t.get("SQ_WAVES", 0.0), 1.0)
+    # MFMA_BUSY is summed over the 1024 SIMDs of the chip; kernel time in cycles at ~2.1 GHz
+    busy = 100.0 * t.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * t["ns"] * 2.1) if t["ns"] else 0.0
+    print(f"| {k} | {t['launches']} | {t['ns'] / 1e6:.2f} | {pct('SQ_WAIT_ANY'):.1f} | {pct('SQ_WAIT_INST_ANY'):.1f} | "
+          f"{pct('SQ_ACTIVE_INST_ANY'):.1f} | {pct('SQ_ACTIVE_INST_VALU'):.1f} | {t.get('SQ_INSTS_VALU', 0.0) / waves:.0f} | {busy:.1f} |")
+print("\n(percentages of SQ_WAVE_CYCLES; `MFMA pipe busy` assumes 1024 SIMDs and 2.1 GHz under load: an estimate)")
