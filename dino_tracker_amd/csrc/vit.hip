@@ -273,7 +273,9 @@ __device__ __forceinline__ int gswz(int row, int piece) {
 
 // (Round 2 measured two LDS-DMA forms of this main loop on fc2, K = 1536: 64-wide stages, two in flight, two barriers per
 // stage: 17.9 ms; 32-wide stages in a ring of four, three in flight, one barrier per stage: 20.0 ms; this register-staged
-// form: 17.1-17.5 ms.  Kept.)
+// form: 17.1-17.5 ms.  Kept.  The SQ counters (profiles/r02_pmc_sq.md) show why it is slow -- 64 % of the wave cycles
+// parked, MFMA pipe 27 % busy: one k-step of prefetch does not cover the HBM latency -- but TWO k-steps of register
+// prefetch need 150 VGPRs = 3 waves per SIMD instead of 4 and measured 18.7 ms; forced to 128 VGPRs the loop spills.)
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
                                                         long long M, int N, int K, GemmEpi e) {
