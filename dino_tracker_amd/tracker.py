@@ -318,6 +318,17 @@ class Tracker(nn.Module):
         return self.get_point_predictions_from_embeddings(source_embeddings, frame_embeddings, target_frame_indices)
 
     # ---- test-time training ---------------------------------------------------------------
+    def train(self, mode: bool = True):
+        """nn.Module.train; leaving training mode also releases the convolution scratch of the training step (10 GB at
+        full size) and the per-batch tensors the loss terms read."""
+        super().train(mode)
+        if not mode:
+            from . import train_ops
+            train_ops.release_scratch()
+            self.frame_embeddings = self.raw_embeddings = self.residual_embeddings = None
+        return self
+
+
     def _forward_train(self, inp, use_raw_features=False):
         """tracker.py:303-325 in training mode: refine the batch's frames with gradients, keep the tensors the loss
         terms of dino_tracker.py read (`frame_embeddings`, `raw_embeddings`, `residual_embeddings`)."""

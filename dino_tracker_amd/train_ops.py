@@ -73,6 +73,11 @@ def _workspace(name: str, numel: int, like: torch.Tensor) -> torch.Tensor:
     return buf[:numel]
 
 
+def release_scratch() -> None:
+    """Drop the persistent scratch (Tracker.eval() calls this: inference needs none of it)."""
+    _WORKSPACE.clear()
+
+
 class _ConvGemm(torch.autograd.Function):
     """Stride-1 convolution = unfold + matrix product, with the unfolded input RECOMPUTED in the backward (into the same
     persistent scratch) instead of being saved: forward  Y_n = W [Cout, K] . cols_n [K, L];  backward  dW = sum_n dY_n .

@@ -158,7 +158,9 @@ def test_training_step_on_device_matches_host():
         assert cyc[key].shape[0] == k
     preds = trk.get_cycle_consistent_preds(frames_set_t.to(dev), masks)
     assert preds["source_target_coords"].requires_grad and preds["source_target_coords"].shape[1] == 2
+    assert train_ops._WORKSPACE  # the unfolded conv operands of the step
     trk.eval()
+    assert not train_ops._WORKSPACE and trk.frame_embeddings is None  # released with the training mode
 
 
 @pytest.mark.parametrize("shape,relu", [((4, 64, 63, 427), True), ((3, 128, 32, 214), True), ((8, 256, 16, 107), True),
