@@ -41,8 +41,13 @@ if "--gaps" in sys.argv:
     gaps = {}
     busy_end = disp[0][2]
     idle = 0
+    big = []
+    prev_name = disp[0][0]
     for name, st, en in disp[1:]:
         g = st - busy_end
+        if g > 2_000_000:
+            big.append((g, prev_name, name))
+        prev_name = name if en >= busy_end else prev_name
         if g > 0:
             idle += g
             m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name) or re.match(r"_ZN4att2(\d+)", name) or re.match(r"_Z(\d+)", name)
@@ -58,3 +63,6 @@ if "--gaps" in sys.argv:
     print("|---|---:|---:|---:|")
     for k, (n, tot, mx) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:14]:
         print(f"| {k} | {n} | {tot / 1e6:.3f} | {mx / 1e3:.1f} |")
+    strip = lambda n: re.sub(r"\(.*", "", n)[:90]
+    for g, a, b in big:
+        print("\ngap of %.1f ms between `%s` and `%s`" % (g / 1e6, strip(a), strip(b)))
