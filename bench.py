@@ -79,6 +79,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # one GPU per rank; a launcher that already narrowed the visible devices to one per rank leaves index 0 only
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     dist = None
