@@ -467,6 +467,108 @@ __device__ __forceinline__ f2 gelu2(f2 x) {
     return __builtin_elementwise_fma(hx, e, hx);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// wide-tile GEMM for N = 384 and long K (fc2 of ViT-S: K = 1536):  C[M][384] = A[M][K] . Wt[384][K]^T, EPI_DELTA epilogue
+//
+// The 128x128 kernel above is bound by memory LATENCY, not bandwidth: a CU streams 16 KB per k-step and would need
+// ~200 KB in flight to cover ~1.5 us, its 16 waves stage 64 KB (SQ counters: waves parked 64 %, MFMA pipe 27 % busy).
+// Here one workgroup of 8 waves owns 256 rows x ALL 384 columns: A is read exactly once (no column tiles), a k-step
+// moves 40 KB for 6.3 MFLOP (2.4x fewer bytes per flop), and the tiles arrive by LDS-DMA (global_load_lds_dwordx4, no
+// staging registers) into a ring of three 40 KB stages, two of them in flight -- 80 KB per CU against the ~93 KB that
+// Little's law asks for at this intensity.  LDS image = the 128x128 kernel's (row-major, four 16-byte pieces per row,
+// piece XOR-swizzled by gswz), produced by giving every DMA lane the matching SOURCE address.  One barrier per k-step.
+// Wave grid 2 x 4, wave tile 128 x 96 = 8 x 6 MFMA 16x16x32 tiles: 192 accumulator registers, two waves per SIMD.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int WD_M = 256, WD_N = 384, WD_STAGES = 3;
+constexpr int WD_A_BYTES = WD_M * 64, WD_B_BYTES = WD_N * 64, WD_STAGE_BYTES = WD_A_BYTES + WD_B_BYTES;
+constexpr int WD_REQ = (WD_M + WD_N) / 16 / 8;  // DMA requests per wave and stage (16 rows of 64 B each): 5
+
+__global__ __launch_bounds__(512, 2) void gemm_wide_delta_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
+                                                                 long long M, int K, GemmEpi e) {
+    __shared__ __attribute__((aligned(1024))) unsigned char stages[WD_STAGES * WD_STAGE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long m0 = (long long)blockIdx.x * WD_M;
+    const int wr = w >> 2, wc = w & 3;  // wave tile: rows wr*128.., columns wc*96..
+    const int fj = lane & 15, fg = lane >> 4;
+    // ---- DMA sources: request q = 5 w + i covers 16 rows (A rows 16q.. for q < 16, Wt rows 16(q-16).. otherwise); lane
+    // (row 16q' + lane/4, slot lane%4) fetches the piece that gswz puts in that slot
+    const bf16_t* src[WD_REQ];
+    unsigned dst[WD_REQ];
+#pragma unroll
+    for (int i = 0; i < WD_REQ; ++i) {
+        const int q = w * WD_REQ + i;
+        const bool isA = q < WD_M / 16;
+        const int row = (isA ? q : q - WD_M / 16) * 16 + (lane >> 2);
+        const int piece = (lane & 3) ^ ((0x1230 >> (((row >> 2) & 3) * 4)) & 3);
+        const long long grow = isA ? min(m0 + row, M - 1) : (long long)row;  // Wt has exactly WD_N rows
+        src[i] = (isA ? A : Wt) + grow * K + piece * 8;
+        dst[i] = (isA ? 0 : WD_A_BYTES) + (isA ? q : q - WD_M / 16) * 1024;
+    }
+    const unsigned lds0 = (unsigned)(size_t)&stages[0];
+    const int nk = K / GK;
+    auto issue = [&](int ks, int buf) {
+        const int kk = min(ks, nk - 1);  // past the end: a harmless repeat keeps the request count per stage uniform
+#pragma unroll
+        for (int i = 0; i < WD_REQ; ++i)
+            ws_glds16(src[i] + (size_t)kk * GK, __builtin_amdgcn_readfirstlane(lds0 + buf * WD_STAGE_BYTES + dst[i]));
+    };
+    f4 acc[8][6];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 6; ++ni) acc[mi][ni] = f4{0.f, 0.f, 0.f, 0.f};
+    // fragment addresses: row (tile row 16 mi + fj) -> uint4 index row * 4 + (fg ^ f(row)); f depends on fj only
+    const int fsw = (0x1230 >> (((fj >> 2) & 3) * 4)) & 3;
+    const unsigned a_off = ((wr * 128 + fj) * 4 + (fg ^ fsw)) * 16;
+    const unsigned b_off = WD_A_BYTES + ((wc * 96 + fj) * 4 + (fg ^ fsw)) * 16;
+    issue(0, 0);
+    issue(1, 1);
+    ws_wait<WD_REQ>();  // stage 0 landed (stage 1 may still fly)
+    __syncthreads();
+    int buf = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        const int nxt2 = buf == 0 ? 2 : buf - 1;  // (buf + 2) % 3: the stage consumed in the previous iteration
+        issue(ks + 2, nxt2);
+        const unsigned char* sb = stages + buf * WD_STAGE_BYTES;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            bf8 af[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                af[mi] = *reinterpret_cast<const bf8*>(sb + a_off + (half * 4 + mi) * 1024);
+#pragma unroll
+            for (int ni = 0; ni < 6; ++ni) {
+                const bf8 bfr = *reinterpret_cast<const bf8*>(sb + b_off + ni * 1024);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[half * 4 + mi][ni] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr, acc[half * 4 + mi][ni], 0, 0, 0);
+            }
+        }
+        ws_wait<WD_REQ>();  // stage ks + 1 landed; the requests of ks + 2 stay in flight
+        __syncthreads();
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    ws_wait<0>();
+    // D fragment: lane (fg, fj) holds rows 4*fg + r (r = 0..3), column fj of each 16x16 tile
+#pragma unroll
+    for (int ni = 0; ni < 6; ++ni) {
+        const int n = wc * 96 + ni * 16 + fj;
+        const float bias = e.bias ? e.bias[n] : 0.f;
+        const float gm = e.gamma[n];
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const long long mb = m0 + wr * 128 + mi * 16 + fg * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long m = mb + r;
+                if (m < M) e.delta[m * WD_N + n] = (bf16_t)(gm * (acc[mi][ni][r] + bias));
+            }
+        }
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_ws_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
                                                       long long M, int N, GemmEpi e, int tiles_per_chunk) {
@@ -847,8 +949,13 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
             }
             e = GemmEpi{};
             e.bias = L.fc2_b; e.delta = delta; e.gamma = L.ls2;
-            DTK_LAUNCH("vit_gemm_fc2", (gemm_bf16_kernel<EPI_DELTA>), dim3(gemm_grid(D, rows)), dim3(256), 0,
-                       st, hid, reinterpret_cast<const bf16_t*>(L.fc2_w), rows, D, 4 * D, e);
+            if (ws_ok && D == WD_N) {  // (ws_ok: the fast-path GEMMs are on, dtk_vit_model.flags)
+                DTK_LAUNCH("vit_gemm_fc2", gemm_wide_delta_kernel, dim3(dtk_cdiv(rows, WD_M)), dim3(512), 0, st, hid,
+                           reinterpret_cast<const bf16_t*>(L.fc2_w), rows, 4 * D, e);
+            } else {
+                DTK_LAUNCH("vit_gemm_fc2", (gemm_bf16_kernel<EPI_DELTA>), dim3(gemm_grid(D, rows)), dim3(256), 0,
+                           st, hid, reinterpret_cast<const bf16_t*>(L.fc2_w), rows, D, 4 * D, e);
+            }
         }
         if (m->depth > 0)  // the last MLP's residual update
             DTK_LAUNCH("vit_layernorm", layernorm_kernel, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x, (const bf16_t*)delta,
