@@ -271,6 +271,62 @@ __device__ __forceinline__ int gswz(int row, int piece) {
     return row * 4 + (piece ^ f);
 }
 
+// Epilogue of one 16x16 D tile: lane (fg, fj) holds rows mb .. mb+3 of column n (a[r]).  Shared by the tiled kernels.
+template <int EPI>
+__device__ __forceinline__ void gemm_store_tile(const f4& a, long long mb, int n, float bias, long long M, int N,
+                                                const GemmEpi& e) {
+    if (EPI == EPI_QKV) {
+        const int which = n / e.D, rem = n - which * e.D;
+        const int head = rem >> 6, dh = rem & 63;
+        const int frame = (int)(mb / e.S);  // the 4 rows of a fragment may straddle two frames: handle per row
+        (void)frame;
+        if (which == 2) {
+            // V transposed: 4 consecutive tokens -> 8 contiguous bytes when they stay inside one frame
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long m = mb + r;
+                if (m < M) {
+                    const int f = (int)(m / e.S), s = (int)(m - (long long)f * e.S);
+                    e.vt[(((size_t)f * e.heads + head) * 64 + dh) * e.Sp + s] = (bf16_t)(a[r] + bias);
+                }
+            }
+        } else {
+            bf16_t* dst = which == 0 ? e.q : e.k;
+            const float sc = which == 0 ? e.qscale : 1.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long m = mb + r;
+                if (m < M) {
+                    const int f = (int)(m / e.S), s = (int)(m - (long long)f * e.S);
+                    dst[(((size_t)f * e.heads + head) * e.Sp + s) * 64 + dh] = (bf16_t)((a[r] + bias) * sc);
+                }
+            }
+        }
+    } else if (EPI == EPI_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long long m = mb + r;
+            if (m < M) {
+                const float v = a[r] + bias;
+                e.out[m * N + n] = (bf16_t)(0.5f * v * (1.f + erff(v * 0.70710678118654752f)));
+            }
+        }
+    } else if (EPI == EPI_F32) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long long m = mb + r;
+            if (m < M) e.out_f32[m * N + n] = a[r] + bias;
+        }
+    } else {
+        const float gm = e.gamma[n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long long m = mb + r;
+            if (m < M) e.delta[m * N + n] = (bf16_t)(gm * (a[r] + bias));
+        }
+    }
+}
+
 // (Round 2 measured two LDS-DMA forms of this main loop on fc2, K = 1536: 64-wide stages, two in flight, two barriers per
 // stage: 17.9 ms; 32-wide stages in a ring of four, three in flight, one barrier per stage: 20.0 ms; this register-staged
 // form: 17.1-17.5 ms.  Kept.  The SQ counters (profiles/r02_pmc_sq.md) show why it is slow -- 64 % of the wave cycles
@@ -357,56 +413,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const long long mb = m0 + wr * 64 + mi * 16 + fg * 4;
-            if (EPI == EPI_QKV) {
-                const int which = n / e.D, rem = n - which * e.D;
-                const int head = rem >> 6, dh = rem & 63;
-                const int frame = (int)(mb / e.S);  // the 4 rows of a fragment may straddle two frames: handle per row
-                (void)frame;
-                if (which == 2) {
-                    // V transposed: 4 consecutive tokens -> 8 contiguous bytes when they stay inside one frame
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const long long m = mb + r;
-                        if (m < M) {
-                            const int f = (int)(m / e.S), s = (int)(m - (long long)f * e.S);
-                            e.vt[(((size_t)f * e.heads + head) * 64 + dh) * e.Sp + s] = (bf16_t)(acc[mi][ni][r] + bias);
-                        }
-                    }
-                } else {
-                    bf16_t* dst = which == 0 ? e.q : e.k;
-                    const float sc = which == 0 ? e.qscale : 1.f;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const long long m = mb + r;
-                        if (m < M) {
-                            const int f = (int)(m / e.S), s = (int)(m - (long long)f * e.S);
-                            dst[(((size_t)f * e.heads + head) * e.Sp + s) * 64 + dh] = (bf16_t)((acc[mi][ni][r] + bias) * sc);
-                        }
-                    }
-                }
-            } else if (EPI == EPI_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const long long m = mb + r;
-                    if (m < M) {
-                        const float v = acc[mi][ni][r] + bias;
-                        e.out[m * N + n] = (bf16_t)(0.5f * v * (1.f + erff(v * 0.70710678118654752f)));
-                    }
-                }
-            } else if (EPI == EPI_F32) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const long long m = mb + r;
-                    if (m < M) e.out_f32[m * N + n] = acc[mi][ni][r] + bias;
-                }
-            } else {
-                const float gm = e.gamma[n];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const long long m = mb + r;
-                    if (m < M) e.delta[m * N + n] = (bf16_t)(gm * (acc[mi][ni][r] + bias));
-                }
-            }
+            gemm_store_tile<EPI>(acc[mi][ni], mb, n, bias, M, N, e);
         }
     }
 }
@@ -566,6 +573,102 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_delta_kernel(const bf16_t* _
                 if (m < M) e.delta[m * WD_N + n] = (bf16_t)(gm * (acc[mi][ni][r] + bias));
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the same pipeline as a 256 x 256 tile for the GEMMs of wider models (N a multiple of 256: D = 768 / 1024 and their qkv
+// / MLP widths), all epilogues.  Stage = 16 KB of A + 16 KB of B, ring of FOUR stages with three in flight (96 KB per
+// CU); wave grid 2 x 4, wave tile 128 x 64 = 8 x 4 MFMA tiles (128 accumulator registers).  Block order as in
+// gemm_bf16_kernel: the column tiles of a row block run back to back on one XCD.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int W2_M = 256, W2_N = 256, W2_STAGES = 4, W2_STAGE_BYTES = (W2_M + W2_N) * 64;
+constexpr int W2_REQ = (W2_M + W2_N) / 16 / 8;  // 4 DMA requests per wave and stage
+
+inline unsigned gemm_wide_grid(int N, long long rows) {
+    const long long ncol = N / W2_N, nrow = dtk_cdiv(rows, W2_M);
+    return (unsigned)(dtk_cdiv(nrow, 8) * 8 * ncol);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
+                                                           long long M, int N, int K, GemmEpi e) {
+    __shared__ __attribute__((aligned(1024))) unsigned char stages[W2_STAGES * W2_STAGE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ncol = N / W2_N;
+    const long long nrow = (M + W2_M - 1) / W2_M;
+    const long long kb = blockIdx.x >> 3;
+    const long long row_blk = (kb / ncol) * 8 + (blockIdx.x & 7);
+    if (row_blk >= nrow) return;
+    const long long m0 = row_blk * W2_M;
+    const int n0 = (int)(kb % ncol) * W2_N;
+    const int wr = w >> 2, wc = w & 3;  // wave tile: rows wr*128.., columns wc*64..
+    const int fj = lane & 15, fg = lane >> 4;
+    const bf16_t* src[W2_REQ];
+    unsigned dst[W2_REQ];
+#pragma unroll
+    for (int i = 0; i < W2_REQ; ++i) {
+        const int q = w * W2_REQ + i;  // 0..15: A rows 16q.., 16..31: Wt rows n0 + 16(q-16)..
+        const bool isA = q < W2_M / 16;
+        const int row = (isA ? q : q - W2_M / 16) * 16 + (lane >> 2);
+        const int piece = (lane & 3) ^ ((0x1230 >> (((row >> 2) & 3) * 4)) & 3);
+        const long long grow = isA ? min(m0 + row, M - 1) : (long long)(n0 + row);
+        src[i] = (isA ? A : Wt) + grow * K + piece * 8;
+        dst[i] = (isA ? 0 : W2_M * 64) + (isA ? q : q - W2_M / 16) * 1024;
+    }
+    const unsigned lds0 = (unsigned)(size_t)&stages[0];
+    const int nk = K / GK;
+    auto issue = [&](int ks, int buf) {
+        const int kk = min(ks, nk - 1);
+#pragma unroll
+        for (int i = 0; i < W2_REQ; ++i)
+            ws_glds16(src[i] + (size_t)kk * GK, __builtin_amdgcn_readfirstlane(lds0 + buf * W2_STAGE_BYTES + dst[i]));
+    };
+    f4 acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f4{0.f, 0.f, 0.f, 0.f};
+    const int fsw = (0x1230 >> (((fj >> 2) & 3) * 4)) & 3;
+    const unsigned a_off = ((wr * 128 + fj) * 4 + (fg ^ fsw)) * 16;
+    const unsigned b_off = W2_M * 64 + ((wc * 64 + fj) * 4 + (fg ^ fsw)) * 16;
+    issue(0, 0);
+    issue(1, 1);
+    issue(2, 2);
+    ws_wait<2 * W2_REQ>();  // stage 0 landed
+    __syncthreads();
+    int buf = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        issue(ks + 3, (buf + 3) & 3);  // the stage consumed in the previous iteration
+        const unsigned char* sb = stages + buf * W2_STAGE_BYTES;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            bf8 af[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                af[mi] = *reinterpret_cast<const bf8*>(sb + a_off + (half * 4 + mi) * 1024);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const bf8 bfr = *reinterpret_cast<const bf8*>(sb + b_off + ni * 1024);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[half * 4 + mi][ni] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr, acc[half * 4 + mi][ni], 0, 0, 0);
+            }
+        }
+        ws_wait<2 * W2_REQ>();  // stage ks + 1 landed; ks + 2 and ks + 3 stay in flight
+        __syncthreads();
+        buf = (buf + 1) & 3;
+    }
+    ws_wait<0>();
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wc * 64 + ni * 16 + fj;
+        const float bias = e.bias ? e.bias[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+            gemm_store_tile<EPI>(acc[mi][ni], m0 + wr * 128 + mi * 16 + fg * 4, n, bias, M, N, e);
     }
 }
 
@@ -897,6 +1000,8 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
             const int tpc = (int)dtk_cdiv(tiles, chunks);
             return std::make_pair(dim3(colwg, (unsigned)dtk_cdiv(tiles, tpc)), tpc);
         };
+        // GEMMs of widths without a weight-stationary form: the 256 x 256 DMA kernel when the shape allows, else 128 x 128
+        const bool wide_ok = !(m->flags & DTK_VIT_TILED_GEMMS) && D % W2_N == 0;
         for (int l = 0; l < m->depth; ++l) {
             const dtk_vit_layer& L = m->layers[l];
             GemmEpi e{};
@@ -915,6 +1020,9 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
                 const auto gr = ws_grid(3 * D);
                 DTK_LAUNCH("vit_gemm_qkv", (gemm_ws_kernel<EPI_QKV>), gr.first, dim3(256), 0, st, xn,
                            reinterpret_cast<const bf16_t*>(L.qkv_w), rows, 3 * D, e, gr.second);
+            } else if (wide_ok) {
+                DTK_LAUNCH("vit_gemm_qkv", (gemm_wide_kernel<EPI_QKV>), dim3(gemm_wide_grid(3 * D, rows)), dim3(512), 0, st, xn,
+                           reinterpret_cast<const bf16_t*>(L.qkv_w), rows, 3 * D, D, e);
             } else {
                 DTK_LAUNCH("vit_gemm_qkv", (gemm_bf16_kernel<EPI_QKV>), dim3(gemm_grid(3 * D, rows)),
                            dim3(256), 0, st, xn, reinterpret_cast<const bf16_t*>(L.qkv_w), rows, 3 * D, D, e);
@@ -931,6 +1039,9 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
                 const auto gr = ws_grid(D);
                 DTK_LAUNCH("vit_gemm_proj", (gemm_ws_kernel<EPI_DELTA>), gr.first, dim3(256), 0, st, ao,
                            reinterpret_cast<const bf16_t*>(L.proj_w), rows, D, e, gr.second);
+            } else if (wide_ok) {
+                DTK_LAUNCH("vit_gemm_proj", (gemm_wide_kernel<EPI_DELTA>), dim3(gemm_wide_grid(D, rows)), dim3(512), 0, st, ao,
+                           reinterpret_cast<const bf16_t*>(L.proj_w), rows, D, D, e);
             } else {
                 DTK_LAUNCH("vit_gemm_proj", (gemm_bf16_kernel<EPI_DELTA>), dim3(gemm_grid(D, rows)), dim3(256),
                            0, st, ao, reinterpret_cast<const bf16_t*>(L.proj_w), rows, D, D, e);
@@ -943,6 +1054,9 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
                 const auto gr = ws_grid(4 * D);
                 DTK_LAUNCH("vit_gemm_fc1", (gemm_ws_kernel<EPI_GELU>), gr.first, dim3(256), 0, st, xn,
                            reinterpret_cast<const bf16_t*>(L.fc1_w), rows, 4 * D, e, gr.second);
+            } else if (wide_ok) {
+                DTK_LAUNCH("vit_gemm_fc1", (gemm_wide_kernel<EPI_GELU>), dim3(gemm_wide_grid(4 * D, rows)), dim3(512), 0, st, xn,
+                           reinterpret_cast<const bf16_t*>(L.fc1_w), rows, 4 * D, D, e);
             } else {
                 DTK_LAUNCH("vit_gemm_fc1", (gemm_bf16_kernel<EPI_GELU>), dim3(gemm_grid(4 * D, rows)),
                            dim3(256), 0, st, xn, reinterpret_cast<const bf16_t*>(L.fc1_w), rows, 4 * D, D, e);
@@ -952,6 +1066,9 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
             if (ws_ok && D == WD_N) {  // (ws_ok: the fast-path GEMMs are on, dtk_vit_model.flags)
                 DTK_LAUNCH("vit_gemm_fc2", gemm_wide_delta_kernel, dim3(dtk_cdiv(rows, WD_M)), dim3(512), 0, st, hid,
                            reinterpret_cast<const bf16_t*>(L.fc2_w), rows, 4 * D, e);
+            } else if (wide_ok) {
+                DTK_LAUNCH("vit_gemm_fc2", (gemm_wide_kernel<EPI_DELTA>), dim3(gemm_wide_grid(D, rows)), dim3(512), 0, st, hid,
+                           reinterpret_cast<const bf16_t*>(L.fc2_w), rows, D, 4 * D, e);
             } else {
                 DTK_LAUNCH("vit_gemm_fc2", (gemm_bf16_kernel<EPI_DELTA>), dim3(gemm_grid(D, rows)), dim3(256), 0,
                            st, hid, reinterpret_cast<const bf16_t*>(L.fc2_w), rows, D, 4 * D, e);
