@@ -53,8 +53,12 @@ def parse():
                     help="vit: features come from the (random-weight) ViT on the synthetic video; synthetic: the "
                          "feature-level generator with dense anchors (worst case for the tracker stage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-queries", type=int, default=4, help="queries of the CPU sample (SURVEY 8d: K = 4, full T)")
-    ap.add_argument("--cpu-vit-frames", type=int, default=1, help="frames the oracle's ViT / Delta-DINO legs are timed on")
+    ap.add_argument("--cpu-queries", type=int, default=4, help="queries of the TIMED CPU sample (SURVEY 8d: K = 4, full T)")
+    ap.add_argument("--parity-queries", type=int, default=16,
+                    help="queries of parity_sample (>= --cpu-queries; the extra ones go through the oracle untimed)")
+    ap.add_argument("--cpu-vit-frames", type=int, default=2,
+                    help="frames the oracle's ViT / Delta-DINO legs are timed on (also the from-the-video parity leg)")
+    ap.add_argument("--operands", default="fp16", choices=["fp16", "bf16"], help="operand type of the ViT's matrix units")
     return ap.parse_args()
 
 
@@ -127,7 +131,7 @@ def main():
     # no DINOv2 checkpoint exists offline: seeded random weights of the named architecture; LayerScale mean 0.1 keeps
     # the untrained encoder from collapsing all tokens onto one vector (synth.make_vit_weights)
     vit_sd = synth.make_vit_weights(model_name, seed=2, layerscale=0.1)
-    ex = VitExtractor(model_name, stride=7, device=dev, state_dict=vit_sd)
+    ex = VitExtractor(model_name, stride=7, device=dev, state_dict=vit_sd, operand_dtype=args.operands)
     if args.features == "vit":
         feats0 = ex.encode(videos[0])
     else:
@@ -215,14 +219,16 @@ def main():
         else:
             roofline = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": None, "traffic": None}
-        # HBM-side bytes per launch of that kernel from the committed PMC passes (scripts/pmc_traffic.py)
-        for prof_file in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        # HBM-side bytes per launch of that kernel: NOT measured by this process (PMC counters need a rocprofv3 wrapper
+        # around it) -- read from the newest committed PMC pass of the same command (scripts/pmc_traffic.py)
+        for prof_file in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", prof_file)) as fh:
                     tr = json.load(fh)["kernels"].get(dom)
                 if tr:
                     roofline["traffic"] = tr["bytes_per_launch"]
-                    roofline["traffic_note"] = f"bytes per launch, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE (profiles/{prof_file})"
+                    roofline["traffic_source"] = f"committed file profiles/{prof_file} (a separate rocprofv3 --pmc pass of this command on the builder's box), not this run"
+                    roofline["traffic_note"] = "bytes per launch, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes"
                     break
             except (OSError, ValueError, KeyError):
                 pass
@@ -240,39 +246,87 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and "track" in stages:
         from oracle import ref_algo as A
         nq = max(1, min(N, args.cpu_queries))
-        sel = torch.linspace(0, N - 1, nq).long()
+        npar = max(nq, min(N, args.parity_queries))
+        sel = torch.linspace(0, N - 1, npar).long()
+        timed = torch.linspace(0, npar - 1, nq).long()          # the timed K queries, spread over the parity sample
+        rest = torch.tensor([i for i in range(npar) if i not in set(timed.tolist())], dtype=torch.long)
         q_cpu = queries.cpu()[sel]
         one_video(videos[0])                                 # the state the sample is compared against
         refined_cpu = trk.refined_features.cpu()
+        # torch's CPU kernels on maps of 67 x 121 lose time to thread fan-out on a many-core host: time a slice of the
+        # first pass at a few thread counts and run the oracle at the fastest (reported as `cores`)
+        ncore = torch.get_num_threads()
+        best_thr, best_t = ncore, None
+        probe_src = refined_cpu[0].reshape(C, -1).t()[:128].contiguous()
+        for thr in sorted({ncore, 64, 32, 16, 8}):
+            if thr > ncore:
+                continue
+            torch.set_num_threads(thr)
+            c0 = time.perf_counter()
+            A.track(probe_src, refined_cpu, torch.zeros(128, dtype=torch.long), head, H, W)
+            el = time.perf_counter() - c0
+            if best_t is None or el < best_t:
+                best_thr, best_t = thr, el
+        torch.set_num_threads(best_thr)
         c0 = time.perf_counter()
-        rt, ro, cs_cpu, _ = A.infer(refined_cpu, q_cpu, head, H, W, return_aux=True)
+        rt_t, ro_t, cs_t, _ = A.infer(refined_cpu, q_cpu[timed], head, H, W, return_aux=True)
         t_query = (time.perf_counter() - c0) / nq
-        a_bar = float((cs_cpu >= 0.7).sum()) / nq
+        a_bar = float((cs_t >= 0.7).sum()) / nq
+        rt = torch.zeros(npar, T, 2)
+        ro = torch.zeros(npar, T, dtype=torch.bool)
+        cs_all = torch.zeros(npar, T)
+        rt[timed], ro[timed], cs_all[timed] = rt_t, ro_t, cs_t
+        if rest.numel():
+            r2, o2, c2, _ = A.infer(refined_cpu, q_cpu[rest], head, H, W, return_aux=True)
+            rt[rest], ro[rest], cs_all[rest] = r2, o2, c2
+        torch.set_num_threads(ncore)
         nf = max(1, min(T, args.cpu_vit_frames))
         vcpu = videos[0][:nf].cpu()
         c0 = time.perf_counter()
         dino_cpu = torch.stack([A.vit_tokens(vcpu[i:i + 1], vit_sd, model_name) for i in range(nf)]) if args.features == "vit" else None
         t_vit = (time.perf_counter() - c0) / nf if dino_cpu is not None else 0.0
+        from_video = None
         if dino_cpu is None:
             dino_cpu = trk.dino_embed_video[:nf].cpu()
         c0 = time.perf_counter()
-        A.refine_features(vcpu, dino_cpu, delta)
+        refined_nf = A.refine_features(vcpu, dino_cpu, delta)
         t_delta = (time.perf_counter() - c0) / nf
         total = T * t_vit + T * t_delta + N * t_query
-        cpu = {"value": round(N * T / total, 3), "unit": "query-points*frames/s", "cores": torch.get_num_threads(),
+        cpu = {"value": round(N * T / total, 3), "unit": "query-points*frames/s", "cores": best_thr,
                "kind": "port",
-               "sample": f"oracle (fp32 torch restatement of the reference; the un-modified reference is not on this box): "
+               "sample": f"oracle (fp32 torch restatement of the reference; the un-modified reference is not on this box, its "
+                         f"literal per-call path is ~T x more expensive: profiles/r03_cpu_reference_literal.json): "
                          f"infer on {nq} of the {N} queries at full T={T} with all their anchors ({a_bar:.1f} per query) "
-                         f"{t_query:.2f} s/query; ViT {t_vit:.2f} s/frame and Delta-DINO {t_delta:.2f} s/frame on {nf} frame(s); "
+                         f"{t_query:.2f} s/query on {best_thr} threads (fastest of 8..{ncore}); ViT {t_vit:.2f} s/frame and "
+                         f"Delta-DINO {t_delta:.2f} s/frame on {nf} frame(s), {ncore} threads; "
                          f"N T / (T t_vit + T t_delta + N t_query), SURVEY 8d",
                "t_query_s": round(t_query, 3), "t_vit_s": round(t_vit, 3), "t_delta_s": round(t_delta, 3),
-               "anchors_per_query": round(a_bar, 2)}
+               "anchors_per_query": round(a_bar, 2), "host_threads": ncore}
         tg, og = mi.infer(queries[sel.to(dev)])
-        parity = {"queries": nq, "frames": T, "correlation_maps": int(nq * T + float((cs_cpu >= 0.7).sum()) * T),
+        parity = {"queries": npar, "frames": T, "correlation_maps": int(npar * T + float((cs_all >= 0.7).sum()) * T),
                   "max_dxy_px": round(float((tg.cpu() - rt).abs().max()), 6),
                   "occ_mismatch": int((og.cpu() != ro).sum()), "occ_flags": int(ro.numel()),
                   "tiers": dict(trk.last_track_stats),
                   "note": "HIP infer vs oracle infer on the same refined volume (the one the timed step produced)"}
+        if args.features == "vit" and nf >= 2:
+            # from the VIDEO: the first nf frames through oracle ViT -> oracle refine -> oracle infer against the device's
+            # ViT -> Delta-DINO -> infer on the same frames (what the 16-bit operands of P1 add; tests assert it at T = 8)
+            dev_feat = trk.dino_embed_video[:nf].cpu()
+            f_rel = float((dev_feat - dino_cpu).norm() / dino_cpu.norm())
+            qv = q_cpu.clone()
+            qv[:, 2] = 0
+            rv, ov = A.infer(refined_nf, qv, head, H, W)
+            trk2 = Tracker(video=videos[0][:nf], dino_features=ex.encode(videos[0][:nf]), dino_patch_size=14, stride=7,
+                           device=dev, track_method=method)
+            trk2.tracker_head.load_state_dict(head)
+            trk2.delta_dino.load_state_dict(delta)
+            trk2.to(dev).eval()
+            mi2 = ModelInference(trk2, RangeNormalizer((W, H, nf), device=dev), 0.7, 0.6)
+            tv, ovd = mi2.infer(qv.to(dev))
+            parity["from_video"] = {"frames": nf, "queries": npar, "feature_rel_err_P1": round(f_rel, 7),
+                                    "max_dxy_px": round(float((tv.cpu() - rv).abs().max()), 6),
+                                    "occ_mismatch": int((ovd.cpu() != ov).sum()),
+                                    "note": "video -> HIP ViT/Delta-DINO/infer vs video -> oracle ViT/refine/infer"}
 
     if rank == 0:
         out = {
@@ -280,7 +334,7 @@ def main():
             "unit": "query-points*frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if (qpar or args.videos > 0) else "weak",
-            "vs_baseline": None, "dtype": ("mixed: bf16 ViT, split-f16 convs (fp32-grade), " + ("f32 tracker" if method == ops.TRACK_EXACT
+            "vs_baseline": None, "dtype": (f"mixed: {args.operands} ViT operands, split-f16 convs (fp32-grade), " + ("f32 tracker" if method == ops.TRACK_EXACT
                                                                        else "f16 candidates + f32 deciders in the tracker")
                       + "; f32 accumulate"),
             "data": "synthetic",

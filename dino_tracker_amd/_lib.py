@@ -42,10 +42,12 @@ class VitModel(ctypes.Structure):
     _fields_ = [("D", ctypes.c_int32), ("heads", ctypes.c_int32), ("depth", ctypes.c_int32), ("patch", ctypes.c_int32),
                 ("stride", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("flags", ctypes.c_int32),
                 ("patch_w", c_void_p), ("patch_b", c_void_p),
-                ("cls_pos", c_void_p), ("pos", c_void_p), ("mean_std", c_void_p), ("layers", ctypes.POINTER(VitLayer))]
+                ("cls_pos", c_void_p), ("pos", c_void_p), ("mean_std", c_void_p), ("layers", ctypes.POINTER(VitLayer)),
+                ("overflow", c_void_p)]
 
 
-VIT_TILED_GEMMS = 1  # dtk_vit_model.flags
+VIT_TILED_GEMMS, VIT_BF16, VIT_CHECK_RANGE = 1, 2, 4  # dtk_vit_model.flags
+OPERAND_F16, OPERAND_BF16 = 0, 1
 
 
 class TrackOpts(ctypes.Structure):
@@ -78,7 +80,7 @@ SIGNATURES = {
     "dtk_vit_workspace_bytes": (c_size_t, [ctypes.POINTER(VitModel), c_int, c_int, c_int]),
     "dtk_vit_forward": (c_int, [ctypes.POINTER(VitModel), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_size_t, c_void_p]),
-    "dtk_vit_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dtk_vit_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dtk_delta_dino_packed_floats": (c_size_t, [c_int, c_int]),
     "dtk_delta_dino_pack": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                     c_void_p, c_void_p]),

@@ -43,6 +43,12 @@ __device__ __forceinline__ Moments wave_merge(Moments m) {
         other.m2 = __shfl_xor(m.m2, o, WAVE);
         m = merge(m, other);
     }
+    // merge(a, b) is not symmetric in rounding, so the lanes of a butterfly can end a few ulps apart: every lane takes
+    // lane 0's result, so that the forward's normalisation, the saved statistics and the backward's recomputed ReLU mask
+    // all use bit-identical moments
+    m.n = __shfl(m.n, 0, WAVE);
+    m.mean = __shfl(m.mean, 0, WAVE);
+    m.m2 = __shfl(m.m2, 0, WAVE);
     return m;
 }
 

@@ -4,26 +4,63 @@
 // -> +res), output = residual stream after the last requested block (no final norm), CLS included.
 //
 //   patch_embed_kernel  exact fp32 implicit GEMM on the f32-input MFMA (K = 3*14*14 = 588), mean/std fused in the load
-//   layernorm_kernel    one wave per token, fp32 statistics, bf16 output
-//   gemm_bf16_kernel    C = A W^T on MFMA 16x16x32 bf16 (fp32 accumulate), 128x128 tiles, LDS double-buffered, with
+//   layernorm_kernel    one wave per token, fp32 statistics, 16-bit output
+//   gemm_tiled_kernel   C = A W^T on MFMA 16x16x32 (fp32 accumulate), 128x128 tiles, LDS double-buffered, with
 //                       fused epilogues: QKV split (Q pre-scaled by log2(e)/sqrt(d), V written transposed), GELU,
 //                       LayerScale + residual add into the fp32 stream
-//   attention2_kernel   (vit_attention2.h) flash attention, d_head = 64: S^T = K Q^T and O^T = V^T P^T on MFMA 32x32x16 bf16 so
+//   attention2_kernel   (vit_attention2.h) flash attention, d_head = 64: S^T = K Q^T and O^T = V^T P^T on MFMA 32x32x16 so
 //                       that every per-query quantity is lane-local; K / V^T tiles by LDS-DMA into XOR-swizzled images,
 //                       16 waves per CU, exp2-domain softmax with optimistic exponentials (guarded), XCD-aware grid
-// Residual stream fp32, matrix operands bf16 (the reference runs fp32; parity is stated at feature level).
+// Residual stream fp32.  Matrix operands (LN output, Q / K / V^T / P, attention output, MLP hidden, the pending residual
+// update, the weights) are a template parameter T: _Float16 by default since round 3 -- the same MFMA rate as bf16 with
+// 8x less operand rounding (fp16 range: activations saturate at +-65504, FP16_OVFL mode, and set the model's overflow
+// word) -- or __bf16 with DTK_VIT_BF16 (the reference runs fp32; parity is stated in DESIGN.md section 4).
 #include <stdlib.h>
 #include <utility>
 #include "common.h"
+
+#define ATT2_NS att2_f16
+#define ATT2_T _Float16
+#define ATT2_F16 1
+#define ATT2_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
 #include "vit_attention2.h"
+#undef ATT2_NS
+#undef ATT2_T
+#undef ATT2_F16
+#undef ATT2_MFMA
+#define ATT2_NS att2_bf16
+#define ATT2_T __bf16
+#define ATT2_F16 0
+#define ATT2_MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#include "vit_attention2.h"
+#undef ATT2_NS
+#undef ATT2_T
+#undef ATT2_F16
+#undef ATT2_MFMA
 
 namespace {
 
-typedef __bf16 bf16_t;
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+
+// operand-type plumbing of the templated kernels below
+template <typename T> struct Vec {
+    typedef T t8 __attribute__((ext_vector_type(8)));
+    typedef T t4 __attribute__((ext_vector_type(4)));
+};
+template <typename T> struct IsF16 { static constexpr bool value = false; };
+template <> struct IsF16<_Float16> { static constexpr bool value = true; };
+__device__ __forceinline__ f4 mfma16(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f4 mfma16(bf8 a, bf8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f16v mfma32(h8 a, h8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f16v mfma32(bf8 a, bf8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+template <typename T> __device__ __forceinline__ void operand_mode() {
+    if (IsF16<T>::value) att2c::fp16_saturate_mode();  // overflowing fp16 results clamp to +-65504 instead of +-inf
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // patch embedding: tokens[f][1 + r*pw + c][:] = W . patch(r,c) + b + pos[r*pw + c];  tokens[f][0] = cls_pos
@@ -79,9 +116,6 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
 // consecutive tokens of one patch row (a wave 32 of them) x 96 output features and walks K = 784 in seven chunks of two
 // kernel rows; per chunk the two pixel rows (903 px) and the 96 x 112 weight slab (both planes) are staged in LDS.
 // ---------------------------------------------------------------------------------------------------------------
-typedef _Float16 half_t;
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 constexpr int PE_P = 14, PE_S = 7, PE_TOK = 128, PE_NF = 96;
 constexpr int PE_ROWPX = (PE_TOK - 1) * PE_S + PE_P;  // 903 pixels of one kernel row for 128 tokens
 constexpr int PE_K = PE_P * PE_P * 4;                 // 784
@@ -194,9 +228,15 @@ __global__ __launch_bounds__(256) void patch_embed_split_kernel(const h4v* __res
 // ---------------------------------------------------------------------------------------------------------------
 // LayerNorm: fp32 row -> bf16 row (A operand of the next GEMM); one wave per token
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, const T* __restrict__ delta,
                                                         const float* __restrict__ gam, const float* __restrict__ bet,
-                                                        bf16_t* __restrict__ y, long long rows, int D, float eps) {
+                                                        T* __restrict__ y, long long rows, int D, float eps,
+                                                        int* __restrict__ overflow) {
+    typedef typename Vec<T>::t8 T8;
+    typedef typename Vec<T>::t4 T4;
+    (void)sizeof(T8); (void)sizeof(T4);
+    operand_mode<T>();
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -205,19 +245,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
     // the previous projection / MLP, written by the GEMM epilogue) is applied here: x += delta
     float4 v[4];
     float s = 0.f;
+    bool sat = false;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int c = lane * 4 + it * 256;
         if (c < D) {
             v[it] = *reinterpret_cast<const float4*>(p + c);
             if (delta) {
-                const bf4 d = *reinterpret_cast<const bf4*>(delta + row * D + c);
-                v[it].x += (float)d[0]; v[it].y += (float)d[1]; v[it].z += (float)d[2]; v[it].w += (float)d[3];
+                const T4 d = *reinterpret_cast<const T4*>(delta + row * D + c);
+                const float d0 = (float)d[0], d1 = (float)d[1], d2 = (float)d[2], d3 = (float)d[3];
+                // a saturated (or non-finite) residual update: the fp16 range was exceeded upstream
+                if (IsF16<T>::value) sat |= !(fmaxf(fmaxf(fabsf(d0), fabsf(d1)), fmaxf(fabsf(d2), fabsf(d3))) < 65504.f);
+                v[it].x += d0; v[it].y += d1; v[it].z += d2; v[it].w += d3;
                 *reinterpret_cast<float4*>(p + c) = v[it];
             }
             s += (v[it].x + v[it].y) + (v[it].z + v[it].w);
         }
     }
+    if (IsF16<T>::value && overflow && __any(sat) && lane == 0) atomicOr(overflow, 1);
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
@@ -229,15 +274,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
     if (!y) return;  // final residual update only
-    bf16_t* o = y + row * D;
+    T* o = y + row * D;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int c = lane * 4 + it * 256;
         if (c < D) {
             const float4 g = *reinterpret_cast<const float4*>(gam + c), b = *reinterpret_cast<const float4*>(bet + c);
-            bf4 r = {(bf16_t)((v[it].x - mean) * rstd * g.x + b.x), (bf16_t)((v[it].y - mean) * rstd * g.y + b.y),
-                     (bf16_t)((v[it].z - mean) * rstd * g.z + b.z), (bf16_t)((v[it].w - mean) * rstd * g.w + b.w)};
-            *reinterpret_cast<bf4*>(o + c) = r;
+            T4 r = {(T)((v[it].x - mean) * rstd * g.x + b.x), (T)((v[it].y - mean) * rstd * g.y + b.y),
+                     (T)((v[it].z - mean) * rstd * g.z + b.z), (T)((v[it].w - mean) * rstd * g.w + b.w)};
+            *reinterpret_cast<T4*>(o + c) = r;
         }
     }
 }
@@ -248,19 +293,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
 constexpr int GM = 128, GN = 128, GK = 32;
 enum { EPI_QKV = 0, EPI_GELU = 1, EPI_DELTA = 2, EPI_F32 = 3 };
 
+template <typename T>
 struct GemmEpi {
     const float* bias;   // [N]
     // EPI_QKV
-    bf16_t* q;           // [F][heads][Sp][64]
-    bf16_t* k;           // [F][heads][Sp][64]
-    bf16_t* vt;          // [F][heads][64][Sp]
+    T* q;           // [F][heads][Sp][64]
+    T* k;           // [F][heads][Sp][64]
+    T* vt;          // [F][heads][64][Sp]
     int S, Sp, heads, D;
     float qscale;
     // EPI_GELU
-    bf16_t* out;         // [M][N]
+    T* out;         // [M][N]
     // EPI_DELTA
     int no_store;        // DTK_DEV builds: skip the stores of the weight-stationary kernel (DTK_DEBUG & 65536)
-    bf16_t* delta;       // [M][N] bf16: gamma * (A W^T + bias), added to the fp32 residual stream by the next LayerNorm
+    T* delta;       // [M][N] bf16: gamma * (A W^T + bias), added to the fp32 residual stream by the next LayerNorm
     const float* gamma;  // [N] LayerScale
     // EPI_F32 (tiled kernel only)
     float* out_f32;      // [M][N] fp32: A W^T + bias (the qkv facet output)
@@ -272,9 +318,9 @@ __device__ __forceinline__ int gswz(int row, int piece) {
 }
 
 // Epilogue of one 16x16 D tile: lane (fg, fj) holds rows mb .. mb+3 of column n (a[r]).  Shared by the tiled kernels.
-template <int EPI>
+template <typename T, int EPI>
 __device__ __forceinline__ void gemm_store_tile(const f4& a, long long mb, int n, float bias, long long M, int N,
-                                                const GemmEpi& e) {
+                                                const GemmEpi<T>& e) {
     if (EPI == EPI_QKV) {
         const int which = n / e.D, rem = n - which * e.D;
         const int head = rem >> 6, dh = rem & 63;
@@ -287,18 +333,18 @@ __device__ __forceinline__ void gemm_store_tile(const f4& a, long long mb, int n
                 const long long m = mb + r;
                 if (m < M) {
                     const int f = (int)(m / e.S), s = (int)(m - (long long)f * e.S);
-                    e.vt[(((size_t)f * e.heads + head) * 64 + dh) * e.Sp + s] = (bf16_t)(a[r] + bias);
+                    e.vt[(((size_t)f * e.heads + head) * 64 + dh) * e.Sp + s] = (T)(a[r] + bias);
                 }
             }
         } else {
-            bf16_t* dst = which == 0 ? e.q : e.k;
+            T* dst = which == 0 ? e.q : e.k;
             const float sc = which == 0 ? e.qscale : 1.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const long long m = mb + r;
                 if (m < M) {
                     const int f = (int)(m / e.S), s = (int)(m - (long long)f * e.S);
-                    dst[(((size_t)f * e.heads + head) * e.Sp + s) * 64 + dh] = (bf16_t)((a[r] + bias) * sc);
+                    dst[(((size_t)f * e.heads + head) * e.Sp + s) * 64 + dh] = (T)((a[r] + bias) * sc);
                 }
             }
         }
@@ -308,7 +354,7 @@ __device__ __forceinline__ void gemm_store_tile(const f4& a, long long mb, int n
             const long long m = mb + r;
             if (m < M) {
                 const float v = a[r] + bias;
-                e.out[m * N + n] = (bf16_t)(0.5f * v * (1.f + erff(v * 0.70710678118654752f)));
+                e.out[m * N + n] = (T)(0.5f * v * (1.f + erff(v * 0.70710678118654752f)));
             }
         }
     } else if (EPI == EPI_F32) {
@@ -322,7 +368,7 @@ __device__ __forceinline__ void gemm_store_tile(const f4& a, long long mb, int n
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long long m = mb + r;
-            if (m < M) e.delta[m * N + n] = (bf16_t)(gm * (a[r] + bias));
+            if (m < M) e.delta[m * N + n] = (T)(gm * (a[r] + bias));
         }
     }
 }
@@ -332,9 +378,13 @@ __device__ __forceinline__ void gemm_store_tile(const f4& a, long long mb, int n
 // form: 17.1-17.5 ms.  Kept.  The SQ counters (profiles/r02_pmc_sq.md) show why it is slow -- 64 % of the wave cycles
 // parked, MFMA pipe 27 % busy: one k-step of prefetch does not cover the HBM latency -- but TWO k-steps of register
 // prefetch need 150 VGPRs = 3 waves per SIMD instead of 4 and measured 18.7 ms; forced to 128 VGPRs the loop spills.)
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
-                                                        long long M, int N, int K, GemmEpi e) {
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm_tiled_kernel(const T* __restrict__ A, const T* __restrict__ Wt,
+                                                         long long M, int N, int K, GemmEpi<T> e) {
+    typedef typename Vec<T>::t8 T8;
+    typedef typename Vec<T>::t4 T4;
+    (void)sizeof(T8); (void)sizeof(T4);
+    operand_mode<T>();
     __shared__ uint4 As[2][GM * 4];
     __shared__ uint4 Bs[2][GN * 4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -354,10 +404,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     // clamp loader rows so that ragged M / N never read out of bounds (results of clamped rows are not stored)
     const long long ar0 = min(m0 + lrow, M - 1), ar1 = min(m0 + lrow + 64, M - 1);
     const int br0 = min(n0 + lrow, N - 1), br1 = min(n0 + lrow + 64, N - 1);
-    const bf16_t* a0 = A + ar0 * K + lpiece * 8;
-    const bf16_t* a1 = A + ar1 * K + lpiece * 8;
-    const bf16_t* b0 = Wt + (size_t)br0 * K + lpiece * 8;
-    const bf16_t* b1 = Wt + (size_t)br1 * K + lpiece * 8;
+    const T* a0 = A + ar0 * K + lpiece * 8;
+    const T* a1 = A + ar1 * K + lpiece * 8;
+    const T* b0 = Wt + (size_t)br0 * K + lpiece * 8;
+    const T* b1 = Wt + (size_t)br1 * K + lpiece * 8;
     f4 acc[4][4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -379,22 +429,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
             rb0 = *reinterpret_cast<const uint4*>(b0 + (ks + 1) * GK);
             rb1 = *reinterpret_cast<const uint4*>(b1 + (ks + 1) * GK);
         }
-        bf8 af[4], bfr[4];
+        T8 af[4], bfr[4];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const uint4 v = As[cur][gswz(wr * 64 + mi * 16 + fj, fg)];
-            af[mi] = *reinterpret_cast<const bf8*>(&v);
+            af[mi] = *reinterpret_cast<const T8*>(&v);
         }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const uint4 v = Bs[cur][gswz(wc * 64 + ni * 16 + fj, fg)];
-            bfr[ni] = *reinterpret_cast<const bf8*>(&v);
+            bfr[ni] = *reinterpret_cast<const T8*>(&v);
         }
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = mfma16(af[mi], bfr[ni], acc[mi][ni]);
         if (ks + 1 < nk) {
             As[cur ^ 1][gswz(lrow, lpiece)] = ra0;
             As[cur ^ 1][gswz(lrow + 64, lpiece)] = ra1;
@@ -413,7 +463,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const long long mb = m0 + wr * 64 + mi * 16 + fg * 4;
-            gemm_store_tile<EPI>(acc[mi][ni], mb, n, bias, M, N, e);
+            gemm_store_tile<T, EPI>(acc[mi][ni], mb, n, bias, M, N, e);
         }
     }
 }
@@ -492,8 +542,13 @@ constexpr int WD_M = 256, WD_N = 384, WD_STAGES = 3;
 constexpr int WD_A_BYTES = WD_M * 64, WD_B_BYTES = WD_N * 64, WD_STAGE_BYTES = WD_A_BYTES + WD_B_BYTES;
 constexpr int WD_REQ = (WD_M + WD_N) / 16 / 8;  // DMA requests per wave and stage (16 rows of 64 B each): 5
 
-__global__ __launch_bounds__(512, 2) void gemm_wide_delta_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
-                                                                 long long M, int K, GemmEpi e) {
+template <typename T>
+__global__ __launch_bounds__(512, 2) void gemm_wide_delta_kernel(const T* __restrict__ A, const T* __restrict__ Wt,
+                                                                 long long M, int K, GemmEpi<T> e) {
+    typedef typename Vec<T>::t8 T8;
+    typedef typename Vec<T>::t4 T4;
+    (void)sizeof(T8); (void)sizeof(T4);
+    operand_mode<T>();
     __shared__ __attribute__((aligned(1024))) unsigned char stages[WD_STAGES * WD_STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -502,7 +557,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_delta_kernel(const bf16_t* _
     const int fj = lane & 15, fg = lane >> 4;
     // ---- DMA sources: request q = 5 w + i covers 16 rows (A rows 16q.. for q < 16, Wt rows 16(q-16).. otherwise); lane
     // (row 16q' + lane/4, slot lane%4) fetches the piece that gswz puts in that slot
-    const bf16_t* src[WD_REQ];
+    const T* src[WD_REQ];
     unsigned dst[WD_REQ];
 #pragma unroll
     for (int i = 0; i < WD_REQ; ++i) {
@@ -542,17 +597,17 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_delta_kernel(const bf16_t* _
         const unsigned char* sb = stages + buf * WD_STAGE_BYTES;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            bf8 af[4];
+            T8 af[4];
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
-                af[mi] = *reinterpret_cast<const bf8*>(sb + a_off + (half * 4 + mi) * 1024);
+                af[mi] = *reinterpret_cast<const T8*>(sb + a_off + (half * 4 + mi) * 1024);
 #pragma unroll
             for (int ni = 0; ni < 6; ++ni) {
-                const bf8 bfr = *reinterpret_cast<const bf8*>(sb + b_off + ni * 1024);
+                const T8 bfr = *reinterpret_cast<const T8*>(sb + b_off + ni * 1024);
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
                     acc[half * 4 + mi][ni] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr, acc[half * 4 + mi][ni], 0, 0, 0);
+                        mfma16(af[mi], bfr, acc[half * 4 + mi][ni]);
             }
         }
         ws_wait<WD_REQ>();  // stage ks + 1 landed; the requests of ks + 2 stay in flight
@@ -572,7 +627,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_delta_kernel(const bf16_t* _
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const long long m = mb + r;
-                if (m < M) e.delta[m * WD_N + n] = (bf16_t)(gm * (acc[mi][ni][r] + bias));
+                if (m < M) e.delta[m * WD_N + n] = (T)(gm * (acc[mi][ni][r] + bias));
             }
         }
     }
@@ -582,7 +637,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_delta_kernel(const bf16_t* _
 // the same pipeline as a 256 x 256 tile for the GEMMs of wider models (N a multiple of 256: D = 768 / 1024 and their qkv
 // / MLP widths), all epilogues.  Stage = 16 KB of A + 16 KB of B, ring of FOUR stages with three in flight (96 KB per
 // CU); wave grid 2 x 4, wave tile 128 x 64 = 8 x 4 MFMA tiles (128 accumulator registers).  Block order as in
-// gemm_bf16_kernel: the column tiles of a row block run back to back on one XCD.
+// gemm_tiled_kernel: the column tiles of a row block run back to back on one XCD.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int W2_M = 256, W2_N = 256, W2_STAGES = 4, W2_STAGE_BYTES = (W2_M + W2_N) * 64;
 constexpr int W2_REQ = (W2_M + W2_N) / 16 / 8;  // 4 DMA requests per wave and stage
@@ -592,9 +647,13 @@ inline unsigned gemm_wide_grid(int N, long long rows) {
     return (unsigned)(dtk_cdiv(nrow, 8) * 8 * ncol);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
-                                                           long long M, int N, int K, GemmEpi e) {
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const T* __restrict__ A, const T* __restrict__ Wt,
+                                                           long long M, int N, int K, GemmEpi<T> e) {
+    typedef typename Vec<T>::t8 T8;
+    typedef typename Vec<T>::t4 T4;
+    (void)sizeof(T8); (void)sizeof(T4);
+    operand_mode<T>();
     __shared__ __attribute__((aligned(1024))) unsigned char stages[W2_STAGES * W2_STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -607,7 +666,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16_t* __restr
     const int n0 = (int)(kb % ncol) * W2_N;
     const int wr = w >> 2, wc = w & 3;  // wave tile: rows wr*128.., columns wc*64..
     const int fj = lane & 15, fg = lane >> 4;
-    const bf16_t* src[W2_REQ];
+    const T* src[W2_REQ];
     unsigned dst[W2_REQ];
 #pragma unroll
     for (int i = 0; i < W2_REQ; ++i) {
@@ -646,17 +705,17 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16_t* __restr
         const unsigned char* sb = stages + buf * W2_STAGE_BYTES;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            bf8 af[4];
+            T8 af[4];
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
-                af[mi] = *reinterpret_cast<const bf8*>(sb + a_off + (half * 4 + mi) * 1024);
+                af[mi] = *reinterpret_cast<const T8*>(sb + a_off + (half * 4 + mi) * 1024);
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                const bf8 bfr = *reinterpret_cast<const bf8*>(sb + b_off + ni * 1024);
+                const T8 bfr = *reinterpret_cast<const T8*>(sb + b_off + ni * 1024);
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
                     acc[half * 4 + mi][ni] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr, acc[half * 4 + mi][ni], 0, 0, 0);
+                        mfma16(af[mi], bfr, acc[half * 4 + mi][ni]);
             }
         }
         ws_wait<2 * W2_REQ>();  // stage ks + 1 landed; ks + 2 and ks + 3 stay in flight
@@ -670,13 +729,17 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const bf16_t* __restr
         const float bias = e.bias ? e.bias[n] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi)
-            gemm_store_tile<EPI>(acc[mi][ni], m0 + wr * 128 + mi * 16 + fg * 4, n, bias, M, N, e);
+            gemm_store_tile<T, EPI>(acc[mi][ni], m0 + wr * 128 + mi * 16 + fg * 4, n, bias, M, N, e);
     }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_ws_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
-                                                      long long M, int N, GemmEpi e, int tiles_per_chunk) {
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm_ws_kernel(const T* __restrict__ A, const T* __restrict__ Wt,
+                                                      long long M, int N, GemmEpi<T> e, int tiles_per_chunk) {
+    typedef typename Vec<T>::t8 T8;
+    typedef typename Vec<T>::t4 T4;
+    (void)sizeof(T8); (void)sizeof(T4);
+    operand_mode<T>();
     __shared__ __attribute__((aligned(1024))) unsigned char toks[3][WS_TILE_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char stage[4][2][WS_UNIT_BYTES];  // per wave: two staging units
     __shared__ __attribute__((aligned(16))) float s_bias[4][64], s_gamma[4][64];
@@ -691,13 +754,13 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const bf16_t* __restrict__
     // weights: MFMA row i of row tile t carries output feature n0 + 32 t + nl(i), nl chosen so that D row
     // (r & 3) + 8 (r >> 2) + 4 h  <->  feature 16 h + r
     const int nl = (j & 3) + 4 * (j >> 3) + 16 * ((j >> 2) & 1);
-    bf8 wf[2][WS_KS];
+    T8 wf[2][WS_KS];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int row = min(n0 + t * 32 + nl, N - 1);
-        const bf16_t* wp = Wt + (size_t)row * WS_K + h * 8;
+        const T* wp = Wt + (size_t)row * WS_K + h * 8;
 #pragma unroll
-        for (int ks = 0; ks < WS_KS; ++ks) wf[t][ks] = *reinterpret_cast<const bf8*>(wp + ks * 16);
+        for (int ks = 0; ks < WS_KS; ++ks) wf[t][ks] = *reinterpret_cast<const T8*>(wp + ks * 16);
     }
     {
         const int n = min(n0 + lane, N - 1);
@@ -722,7 +785,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const bf16_t* __restrict__
         for (int gg = 0; gg < 2; ++gg) {
             const int g = 2 * w + gg;
             const long long m = min((tile0 + n) * WS_ROWS + 4 * g + l_tt, M - 1);
-            const bf16_t* gp = A + m * WS_K + ((l_pp - g) & 15) * 8;
+            const T* gp = A + m * WS_K + ((l_pp - g) & 15) * 8;
 #pragma unroll
             for (int c = 0; c < 3; ++c)
                 ws_glds16(gp + c * 128, __builtin_amdgcn_readfirstlane(lds_base + buf * WS_TILE_BYTES + (g * 3 + c) * 1024));
@@ -745,34 +808,34 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const bf16_t* __restrict__
         v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
         const bool ok = m_ep < M && nb < N && !DTK_DBG(e.no_store, 3);
         if (EPI == EPI_GELU) {
-            bf8 o;
+            T8 o;
 #pragma unroll
             for (int r = 0; r < 8; r += 2) {
                 const f2 g = gelu2(f2{v[r], v[r + 1]});
-                o[r] = (bf16_t)g[0];
-                o[r + 1] = (bf16_t)g[1];
+                o[r] = (T)g[0];
+                o[r + 1] = (T)g[1];
             }
             // (staging the GELU output for whole-line stores measured slower than these scattered 16-byte stores)
-            if (ok) *reinterpret_cast<bf8*>(e.out + m_ep * N + nb) = o;
+            if (ok) *reinterpret_cast<T8*>(e.out + m_ep * N + nb) = o;
         } else if (EPI == EPI_DELTA) {
             const float4 g0 = *reinterpret_cast<const float4*>(&s_gamma[w][fl]), g1 = *reinterpret_cast<const float4*>(&s_gamma[w][fl + 4]);
-            bf8 o = {(bf16_t)(v[0] * g0.x), (bf16_t)(v[1] * g0.y), (bf16_t)(v[2] * g0.z), (bf16_t)(v[3] * g0.w),
-                     (bf16_t)(v[4] * g1.x), (bf16_t)(v[5] * g1.y), (bf16_t)(v[6] * g1.z), (bf16_t)(v[7] * g1.w)};
-            *reinterpret_cast<bf8*>(&stage[w][0][0] + j * WS_PITCH + fl * 2) = o;
+            T8 o = {(T)(v[0] * g0.x), (T)(v[1] * g0.y), (T)(v[2] * g0.z), (T)(v[3] * g0.w),
+                     (T)(v[4] * g1.x), (T)(v[5] * g1.y), (T)(v[6] * g1.z), (T)(v[7] * g1.w)};
+            *reinterpret_cast<T8*>(&stage[w][0][0] + j * WS_PITCH + fl * 2) = o;
         } else {
             const int dh = fl;  // 0..63 inside the head
             if (which == 2) {
                 // V^T[f][head][dh][s]: consecutive lanes are consecutive tokens
                 if (ok) {
-                    bf16_t* vp = e.vt + (((size_t)f_ep * e.heads + head) * 64 + dh) * e.Sp + s_ep;
+                    T* vp = e.vt + (((size_t)f_ep * e.heads + head) * 64 + dh) * e.Sp + s_ep;
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) vp[(size_t)r * e.Sp] = (bf16_t)v[r];
+                    for (int r = 0; r < 8; ++r) vp[(size_t)r * e.Sp] = (T)v[r];
                 }
             } else {
-                bf8 o;
+                T8 o;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) o[r] = (bf16_t)(v[r] * qsc);
-                *reinterpret_cast<bf8*>(&stage[w][0][0] + j * WS_PITCH + fl * 2) = o;
+                for (int r = 0; r < 8; ++r) o[r] = (T)(v[r] * qsc);
+                *reinterpret_cast<T8*>(&stage[w][0][0] + j * WS_PITCH + fl * 2) = o;
             }
         }
     };
@@ -795,7 +858,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const bf16_t* __restrict__
                         } else {
                             int f = f0_fl, sp = s0_fl + row;  // a tile crosses at most one frame end
                             if (sp >= e.S) { sp -= e.S; ++f; }
-                            bf16_t* dst = which == 0 ? e.q : e.k;
+                            T* dst = which == 0 ? e.q : e.k;
                             *reinterpret_cast<uint4*>(dst + (((size_t)f * e.heads + head) * e.Sp + sp) * 64 + piece * 8) = val;
                         }
                     }
@@ -822,16 +885,16 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const bf16_t* __restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) accN[t][r] = 0.f;
         const unsigned char* base = &toks[0][0] + buf * WS_TILE_BYTES;
-        bf8 b[3];
-        b[0] = *reinterpret_cast<const bf8*>(base + frag_off[0]);
-        b[1] = *reinterpret_cast<const bf8*>(base + frag_off[1]);
+        T8 b[3];
+        b[0] = *reinterpret_cast<const T8*>(base + frag_off[0]);
+        b[1] = *reinterpret_cast<const T8*>(base + frag_off[1]);
 #pragma unroll
         for (int ks = 0; ks < WS_KS; ++ks) {
             if (ks + 2 < WS_KS)
-                b[(ks + 2) % 3] = *reinterpret_cast<const bf8*>(base + frag_off[(ks + 2) & 7] + ((ks + 2) >> 3) * 1024);
+                b[(ks + 2) % 3] = *reinterpret_cast<const T8*>(base + frag_off[(ks + 2) & 7] + ((ks + 2) >> 3) * 1024);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                accN[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][ks], b[ks % 3], accN[t], 0, 0, 0);
+                accN[t] = mfma32(wf[t][ks], b[ks % 3], accN[t]);
             // the tile staged during the previous step leaves first: its stores have the whole step to retire
             if (have_flush && ks == 0) flush();
             if (have_prev && ks % 6 == 2) epi8(accP, (ks / 6) >> 1, (ks / 6) & 1);
@@ -894,7 +957,7 @@ __global__ __launch_bounds__(256) void drop_cls_kernel(const float* __restrict__
 // (their weights are loaded once per chunk); 30 frames of 67x121 tokens need ~2.6 GB of workspace
 constexpr int VIT_FRAME_BATCH = 30;
 
-// 1-D grid of gemm_bf16_kernel: 8 row blocks (one per XCD) x all column tiles per group
+// 1-D grid of gemm_tiled_kernel: 8 row blocks (one per XCD) x all column tiles per group
 inline unsigned gemm_grid(int N, long long rows) {
     const long long ncol = dtk_cdiv(N, GN), nrow = dtk_cdiv(rows, GM);
     return (unsigned)(dtk_cdiv(nrow, 8) * 8 * ncol);
@@ -925,40 +988,57 @@ VitPlan vit_plan(const dtk_vit_model* m, int ph, int pw, int frames) {
     return p;
 }
 
-}  // namespace
 
-extern "C" size_t dtk_vit_workspace_bytes(const dtk_vit_model* m, int video_h, int video_w, int frames) {
-    if (!m || frames <= 0) return 0;
-    const int ph = 1 + (video_h - m->patch) / m->stride, pw = 1 + (video_w - m->patch) / m->stride;
-    return vit_plan(m, ph, pw, frames).total;
+// attention launch per operand type (the kernel lives in a per-type namespace of vit_attention2.h)
+template <typename T> struct Att;
+template <> struct Att<_Float16> {
+    static int launch(const _Float16* q, const _Float16* k, const _Float16* vt, _Float16* o, int S, int Sp, int heads, int D,
+                      int FH, hipStream_t st) {
+        int QB;
+        const unsigned grid = att2c::attention2_grid(FH, S, 1, &QB);
+        DTK_LAUNCH("vit_attention", (att2_f16::attention2_kernel<1>), dim3(grid), dim3(512), 0, st, q, k, vt, o, S, Sp, heads,
+                   D, FH, QB);
+        return DTK_OK;
+    }
+};
+template <> struct Att<__bf16> {
+    static int launch(const __bf16* q, const __bf16* k, const __bf16* vt, __bf16* o, int S, int Sp, int heads, int D, int FH,
+                      hipStream_t st) {
+        int QB;
+        const unsigned grid = att2c::attention2_grid(FH, S, 1, &QB);
+        DTK_LAUNCH("vit_attention", (att2_bf16::attention2_kernel<1>), dim3(grid), dim3(512), 0, st, q, k, vt, o, S, Sp, heads,
+                   D, FH, QB);
+        return DTK_OK;
+    }
+};
+
+// |x| >= 65504 or non-finite anywhere in a 16-bit tensor -> *flag |= bit (DTK_VIT_CHECK_RANGE: every intermediate tensor)
+template <typename T>
+__global__ __launch_bounds__(256) void range_scan_kernel(const T* __restrict__ p, long long n8, int* __restrict__ flag, int bit) {
+    typedef typename Vec<T>::t8 T8;
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const T8 v = reinterpret_cast<const T8*>(p)[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bad |= !(fabsf((float)v[e]) < 65504.f);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, bit);
 }
 
-extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int nframes, int video_h, int video_w,
-                               float* tokens_out, float* feat_out, float* qkv_out, void* workspace,
-                               size_t workspace_bytes, void* stream) {
-    DTK_REQUIRE(m && frames && workspace && (tokens_out || feat_out || qkv_out), "dtk_vit_forward: null pointer");
-    DTK_REQUIRE(!qkv_out || m->depth > 0, "dtk_vit_forward: qkv_out needs at least one block");
-    DTK_REQUIRE(m->D > 0 && m->heads > 0 && m->D == m->heads * 64, "dtk_vit_forward: d_head must be 64 (D=%d heads=%d)",
-                m->D, m->heads);
-    DTK_REQUIRE(m->D % 32 == 0 && m->depth >= 0 && m->layers, "dtk_vit_forward: bad model");
-    DTK_REQUIRE(video_h >= m->patch && video_w >= m->patch, "dtk_vit_forward: frame smaller than a patch");
-    const int ph = 1 + (video_h - m->patch) / m->stride, pw = 1 + (video_w - m->patch) / m->stride;
+template <typename T>
+int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_h, int video_w, float* tokens_out,
+            float* feat_out, float* qkv_out, unsigned char* ws, const VitPlan& p, int ph, int pw, hipStream_t st) {
     const int HW = ph * pw, D = m->D;
-    const VitPlan p = vit_plan(m, ph, pw, nframes);
-    if (workspace_bytes < p.total) {
-        dtk_set_error("dtk_vit_forward: workspace %zu B < required %zu B", workspace_bytes, p.total);
-        return DTK_E_WORKSPACE;
-    }
-    hipStream_t st = dtk_stream(stream);
-    unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
     float* x = reinterpret_cast<float*>(ws + p.x);
-    bf16_t* xn = reinterpret_cast<bf16_t*>(ws + p.xn);
-    bf16_t* q = reinterpret_cast<bf16_t*>(ws + p.q);
-    bf16_t* k = reinterpret_cast<bf16_t*>(ws + p.k);
-    bf16_t* vt = reinterpret_cast<bf16_t*>(ws + p.vt);
-    bf16_t* ao = reinterpret_cast<bf16_t*>(ws + p.ao);
-    bf16_t* hid = reinterpret_cast<bf16_t*>(ws + p.hid);
-    bf16_t* delta = reinterpret_cast<bf16_t*>(ws + p.delta);
+    T* xn = reinterpret_cast<T*>(ws + p.xn);
+    T* q = reinterpret_cast<T*>(ws + p.q);
+    T* k = reinterpret_cast<T*>(ws + p.k);
+    T* vt = reinterpret_cast<T*>(ws + p.vt);
+    T* ao = reinterpret_cast<T*>(ws + p.ao);
+    T* hid = reinterpret_cast<T*>(ws + p.hid);
+    T* delta = reinterpret_cast<T*>(ws + p.delta);
+    int* ovf = m->overflow;
+    const bool scan = ovf && (m->flags & DTK_VIT_CHECK_RANGE);
     const int S = p.S, Sp = p.Sp;
     // Q/K/V^T padding rows (s >= S) must be finite zeros: they are read by the last KV tile
     {
@@ -968,6 +1048,10 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
     for (int f0 = 0; f0 < nframes; f0 += p.FB) {
         const int nf = (nframes - f0) < p.FB ? (nframes - f0) : p.FB;
         const long long rows = (long long)nf * S;
+        auto scan_range = [&](const T* t, long long n, int bit) -> int {
+            if (scan) DTK_LAUNCH("vit_range_scan", range_scan_kernel<T>, dim3(1024), dim3(256), 0, st, t, n / 8, ovf, bit);
+            return DTK_OK;
+        };
         const bool pe_fits = (size_t)nf * video_h * video_w * 16 <= p.delta - p.hid &&
                              (size_t)D * PE_K * 4 <= p.total - p.delta;
         if (m->patch == PE_P && m->stride == PE_S && pe_fits) {
@@ -1006,79 +1090,80 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
         const bool wide_ok = !(m->flags & DTK_VIT_TILED_GEMMS) && D % W2_N == 0;
         for (int l = 0; l < m->depth; ++l) {
             const dtk_vit_layer& L = m->layers[l];
-            GemmEpi e{};
-            DTK_LAUNCH("vit_layernorm", layernorm_kernel, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x,
-                       l ? delta : (const bf16_t*)nullptr, L.ln1_w, L.ln1_b, xn, rows, D, m->ln_eps);
+            const T* qkv_w = reinterpret_cast<const T*>(L.qkv_w);
+            const T* proj_w = reinterpret_cast<const T*>(L.proj_w);
+            const T* fc1_w = reinterpret_cast<const T*>(L.fc1_w);
+            const T* fc2_w = reinterpret_cast<const T*>(L.fc2_w);
+            GemmEpi<T> e{};
+            DTK_LAUNCH("vit_layernorm", layernorm_kernel<T>, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x,
+                       l ? delta : (const T*)nullptr, L.ln1_w, L.ln1_b, xn, rows, D, m->ln_eps, ovf);
             if (qkv_out && l == m->depth - 1) {  // the qkv hook of the reference (models/extractor.py:107-118), fp32 out
                 e.bias = L.qkv_b; e.out_f32 = qkv_out + (size_t)f0 * S * 3 * D;
-                DTK_LAUNCH("vit_gemm_qkv_facet", (gemm_bf16_kernel<EPI_F32>), dim3(gemm_grid(3 * D, rows)), dim3(256), 0, st,
-                           xn, reinterpret_cast<const bf16_t*>(L.qkv_w), rows, 3 * D, D, e);
-                e = GemmEpi{};
+                DTK_LAUNCH("vit_gemm_qkv_facet", (gemm_tiled_kernel<T, EPI_F32>), dim3(gemm_grid(3 * D, rows)), dim3(256), 0, st,
+                           xn, qkv_w, rows, 3 * D, D, e);
+                e = GemmEpi<T>{};
             }
             e.bias = L.qkv_b; e.q = q; e.k = k; e.vt = vt; e.S = S; e.Sp = Sp; e.heads = m->heads; e.D = D;
             e.qscale = 0.125f * 1.4426950408889634f;
             e.no_store = dbg_ns;
             if (ws_ok) {
                 const auto gr = ws_grid(3 * D);
-                DTK_LAUNCH("vit_gemm_qkv", (gemm_ws_kernel<EPI_QKV>), gr.first, dim3(256), 0, st, xn,
-                           reinterpret_cast<const bf16_t*>(L.qkv_w), rows, 3 * D, e, gr.second);
+                DTK_LAUNCH("vit_gemm_qkv", (gemm_ws_kernel<T, EPI_QKV>), gr.first, dim3(256), 0, st, xn, qkv_w, rows, 3 * D, e,
+                           gr.second);
             } else if (wide_ok) {
-                DTK_LAUNCH("vit_gemm_qkv", (gemm_wide_kernel<EPI_QKV>), dim3(gemm_wide_grid(3 * D, rows)), dim3(512), 0, st, xn,
-                           reinterpret_cast<const bf16_t*>(L.qkv_w), rows, 3 * D, D, e);
+                DTK_LAUNCH("vit_gemm_qkv", (gemm_wide_kernel<T, EPI_QKV>), dim3(gemm_wide_grid(3 * D, rows)), dim3(512), 0, st,
+                           xn, qkv_w, rows, 3 * D, D, e);
             } else {
-                DTK_LAUNCH("vit_gemm_qkv", (gemm_bf16_kernel<EPI_QKV>), dim3(gemm_grid(3 * D, rows)),
-                           dim3(256), 0, st, xn, reinterpret_cast<const bf16_t*>(L.qkv_w), rows, 3 * D, D, e);
+                DTK_LAUNCH("vit_gemm_qkv", (gemm_tiled_kernel<T, EPI_QKV>), dim3(gemm_grid(3 * D, rows)), dim3(256), 0, st, xn,
+                           qkv_w, rows, 3 * D, D, e);
             }
-            {
-                int QB;
-                const unsigned agrid = att2::attention2_grid(nf * m->heads, S, 1, &QB);
-                DTK_LAUNCH("vit_attention", (att2::attention2_kernel<1>), dim3(agrid), dim3(512), 0, st, q, k, vt, ao, S, Sp,
-                           m->heads, D, nf * m->heads, QB);
-            }
-            e = GemmEpi{};
+            if (scan_range(q, (long long)(p.ao - p.q) / 2, 2)) return DTK_E_HIP;
+            if (Att<T>::launch(q, k, vt, ao, S, Sp, m->heads, D, nf * m->heads, st)) return DTK_E_HIP;
+            e = GemmEpi<T>{};
             e.bias = L.proj_b; e.delta = delta; e.gamma = L.ls1; e.no_store = dbg_ns;
             if (ws_ok) {
                 const auto gr = ws_grid(D);
-                DTK_LAUNCH("vit_gemm_proj", (gemm_ws_kernel<EPI_DELTA>), gr.first, dim3(256), 0, st, ao,
-                           reinterpret_cast<const bf16_t*>(L.proj_w), rows, D, e, gr.second);
+                DTK_LAUNCH("vit_gemm_proj", (gemm_ws_kernel<T, EPI_DELTA>), gr.first, dim3(256), 0, st, ao, proj_w, rows, D, e,
+                           gr.second);
             } else if (wide_ok) {
-                DTK_LAUNCH("vit_gemm_proj", (gemm_wide_kernel<EPI_DELTA>), dim3(gemm_wide_grid(D, rows)), dim3(512), 0, st, ao,
-                           reinterpret_cast<const bf16_t*>(L.proj_w), rows, D, D, e);
+                DTK_LAUNCH("vit_gemm_proj", (gemm_wide_kernel<T, EPI_DELTA>), dim3(gemm_wide_grid(D, rows)), dim3(512), 0, st, ao,
+                           proj_w, rows, D, D, e);
             } else {
-                DTK_LAUNCH("vit_gemm_proj", (gemm_bf16_kernel<EPI_DELTA>), dim3(gemm_grid(D, rows)), dim3(256),
-                           0, st, ao, reinterpret_cast<const bf16_t*>(L.proj_w), rows, D, D, e);
+                DTK_LAUNCH("vit_gemm_proj", (gemm_tiled_kernel<T, EPI_DELTA>), dim3(gemm_grid(D, rows)), dim3(256), 0, st, ao,
+                           proj_w, rows, D, D, e);
             }
-            DTK_LAUNCH("vit_layernorm", layernorm_kernel, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x, (const bf16_t*)delta,
-                       L.ln2_w, L.ln2_b, xn, rows, D, m->ln_eps);
-            e = GemmEpi{};
+            DTK_LAUNCH("vit_layernorm", layernorm_kernel<T>, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x, (const T*)delta,
+                       L.ln2_w, L.ln2_b, xn, rows, D, m->ln_eps, ovf);
+            e = GemmEpi<T>{};
             e.bias = L.fc1_b; e.out = hid; e.no_store = dbg_ns;
             if (ws_ok) {
                 const auto gr = ws_grid(4 * D);
-                DTK_LAUNCH("vit_gemm_fc1", (gemm_ws_kernel<EPI_GELU>), gr.first, dim3(256), 0, st, xn,
-                           reinterpret_cast<const bf16_t*>(L.fc1_w), rows, 4 * D, e, gr.second);
+                DTK_LAUNCH("vit_gemm_fc1", (gemm_ws_kernel<T, EPI_GELU>), gr.first, dim3(256), 0, st, xn, fc1_w, rows, 4 * D, e,
+                           gr.second);
             } else if (wide_ok) {
-                DTK_LAUNCH("vit_gemm_fc1", (gemm_wide_kernel<EPI_GELU>), dim3(gemm_wide_grid(4 * D, rows)), dim3(512), 0, st, xn,
-                           reinterpret_cast<const bf16_t*>(L.fc1_w), rows, 4 * D, D, e);
+                DTK_LAUNCH("vit_gemm_fc1", (gemm_wide_kernel<T, EPI_GELU>), dim3(gemm_wide_grid(4 * D, rows)), dim3(512), 0, st,
+                           xn, fc1_w, rows, 4 * D, D, e);
             } else {
-                DTK_LAUNCH("vit_gemm_fc1", (gemm_bf16_kernel<EPI_GELU>), dim3(gemm_grid(4 * D, rows)),
-                           dim3(256), 0, st, xn, reinterpret_cast<const bf16_t*>(L.fc1_w), rows, 4 * D, D, e);
+                DTK_LAUNCH("vit_gemm_fc1", (gemm_tiled_kernel<T, EPI_GELU>), dim3(gemm_grid(4 * D, rows)), dim3(256), 0, st, xn,
+                           fc1_w, rows, 4 * D, D, e);
             }
-            e = GemmEpi{};
+            if (scan_range(hid, rows * 4 * D, 4)) return DTK_E_HIP;
+            e = GemmEpi<T>{};
             e.bias = L.fc2_b; e.delta = delta; e.gamma = L.ls2;
             if (ws_ok && D == WD_N) {  // (ws_ok: the fast-path GEMMs are on, dtk_vit_model.flags)
-                DTK_LAUNCH("vit_gemm_fc2", gemm_wide_delta_kernel, dim3(dtk_cdiv(rows, WD_M)), dim3(512), 0, st, hid,
-                           reinterpret_cast<const bf16_t*>(L.fc2_w), rows, 4 * D, e);
+                DTK_LAUNCH("vit_gemm_fc2", gemm_wide_delta_kernel<T>, dim3(dtk_cdiv(rows, WD_M)), dim3(512), 0, st, hid, fc2_w,
+                           rows, 4 * D, e);
             } else if (wide_ok) {
-                DTK_LAUNCH("vit_gemm_fc2", (gemm_wide_kernel<EPI_DELTA>), dim3(gemm_wide_grid(D, rows)), dim3(512), 0, st, hid,
-                           reinterpret_cast<const bf16_t*>(L.fc2_w), rows, D, 4 * D, e);
+                DTK_LAUNCH("vit_gemm_fc2", (gemm_wide_kernel<T, EPI_DELTA>), dim3(gemm_wide_grid(D, rows)), dim3(512), 0, st, hid,
+                           fc2_w, rows, D, 4 * D, e);
             } else {
-                DTK_LAUNCH("vit_gemm_fc2", (gemm_bf16_kernel<EPI_DELTA>), dim3(gemm_grid(D, rows)), dim3(256), 0,
-                           st, hid, reinterpret_cast<const bf16_t*>(L.fc2_w), rows, D, 4 * D, e);
+                DTK_LAUNCH("vit_gemm_fc2", (gemm_tiled_kernel<T, EPI_DELTA>), dim3(gemm_grid(D, rows)), dim3(256), 0, st, hid,
+                           fc2_w, rows, D, 4 * D, e);
             }
         }
         if (m->depth > 0)  // the last MLP's residual update
-            DTK_LAUNCH("vit_layernorm", layernorm_kernel, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x, (const bf16_t*)delta,
-                       (const float*)nullptr, (const float*)nullptr, (bf16_t*)nullptr, rows, D, m->ln_eps);
+            DTK_LAUNCH("vit_layernorm", layernorm_kernel<T>, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x, (const T*)delta,
+                       (const float*)nullptr, (const float*)nullptr, (T*)nullptr, rows, D, m->ln_eps, ovf);
         if (tokens_out)
             DTK_HIP(hipMemcpyAsync(tokens_out + (size_t)f0 * S * D, x, (size_t)rows * D * sizeof(float),
                                    hipMemcpyDeviceToDevice, st));
@@ -1091,16 +1176,48 @@ extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int 
     return DTK_OK;
 }
 
+}  // namespace
+
+extern "C" size_t dtk_vit_workspace_bytes(const dtk_vit_model* m, int video_h, int video_w, int frames) {
+    if (!m || frames <= 0) return 0;
+    const int ph = 1 + (video_h - m->patch) / m->stride, pw = 1 + (video_w - m->patch) / m->stride;
+    return vit_plan(m, ph, pw, frames).total;
+}
+
+extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int nframes, int video_h, int video_w,
+                               float* tokens_out, float* feat_out, float* qkv_out, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    DTK_REQUIRE(m && frames && workspace && (tokens_out || feat_out || qkv_out), "dtk_vit_forward: null pointer");
+    DTK_REQUIRE(!qkv_out || m->depth > 0, "dtk_vit_forward: qkv_out needs at least one block");
+    DTK_REQUIRE(m->D > 0 && m->heads > 0 && m->D == m->heads * 64, "dtk_vit_forward: d_head must be 64 (D=%d heads=%d)",
+                m->D, m->heads);
+    DTK_REQUIRE(m->D % 32 == 0 && m->depth >= 0 && m->layers, "dtk_vit_forward: bad model");
+    DTK_REQUIRE(video_h >= m->patch && video_w >= m->patch, "dtk_vit_forward: frame smaller than a patch");
+    const int ph = 1 + (video_h - m->patch) / m->stride, pw = 1 + (video_w - m->patch) / m->stride;
+    const VitPlan p = vit_plan(m, ph, pw, nframes);
+    if (workspace_bytes < p.total) {
+        dtk_set_error("dtk_vit_forward: workspace %zu B < required %zu B", workspace_bytes, p.total);
+        return DTK_E_WORKSPACE;
+    }
+    hipStream_t st = dtk_stream(stream);
+    unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
+    if (m->flags & DTK_VIT_BF16)
+        return vit_run<__bf16>(m, frames, nframes, video_h, video_w, tokens_out, feat_out, qkv_out, ws, p, ph, pw, st);
+    return vit_run<_Float16>(m, frames, nframes, video_h, video_w, tokens_out, feat_out, qkv_out, ws, p, ph, pw, st);
+}
+
 // The attention stage on its own (tests drive its guard / safe-pass logic with crafted operands; layouts as inside
 // dtk_vit_forward).
 extern "C" int dtk_vit_attention(const void* q, const void* k, const void* vt, void* out, int frames, int heads, int S,
-                                 int Sp, void* stream) {
+                                 int Sp, int operand_type, void* stream) {
     DTK_REQUIRE(q && k && vt && out, "dtk_vit_attention: null pointer");
     DTK_REQUIRE(frames > 0 && heads > 0 && S > 0 && Sp >= S && Sp % 64 == 0, "dtk_vit_attention: bad sizes (Sp %% 64 == 0, Sp >= S)");
-    int QB;
-    const unsigned agrid = att2::attention2_grid(frames * heads, S, 1, &QB);
-    DTK_LAUNCH("vit_attention", (att2::attention2_kernel<1>), dim3(agrid), dim3(512), 0, dtk_stream(stream),
-               reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k), reinterpret_cast<const bf16_t*>(vt),
-               reinterpret_cast<bf16_t*>(out), S, Sp, heads, heads * 64, frames * heads, QB);
-    return DTK_OK;
+    DTK_REQUIRE(operand_type == DTK_OPERAND_F16 || operand_type == DTK_OPERAND_BF16, "dtk_vit_attention: operand_type");
+    if (operand_type == DTK_OPERAND_BF16)
+        return Att<__bf16>::launch(reinterpret_cast<const __bf16*>(q), reinterpret_cast<const __bf16*>(k),
+                                   reinterpret_cast<const __bf16*>(vt), reinterpret_cast<__bf16*>(out), S, Sp, heads,
+                                   heads * 64, frames * heads, dtk_stream(stream));
+    return Att<_Float16>::launch(reinterpret_cast<const _Float16*>(q), reinterpret_cast<const _Float16*>(k),
+                                 reinterpret_cast<const _Float16*>(vt), reinterpret_cast<_Float16*>(out), S, Sp, heads,
+                                 heads * 64, frames * heads, dtk_stream(stream));
 }

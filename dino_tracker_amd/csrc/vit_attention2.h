@@ -1,6 +1,15 @@
-// vit_attention2.h -- flash attention for d_head = 64, second generation (round 2).
+// vit_attention2.h -- flash attention for d_head = 64, second generation (round 2; operand type a parameter since round 3).
 //
-// What changed against attention_kernel (vit.hip), and why (profiles/r01_bench_kernel_trace.md: 0.37 of the MFMA peak):
+// Included once per operand type (no include guard): the includer defines
+//   ATT2_NS    namespace of this instantiation            (att2_f16 / att2_bf16)
+//   ATT2_T     operand type of Q / K / V^T / P / O        (_Float16 / __bf16)
+//   ATT2_F16   1 when ATT2_T is _Float16
+//   ATT2_MFMA  the 32x32x16 MFMA builtin for that type
+// fp16 is the default of the library since round 3: the same MFMA rate as bf16 with 8x less operand rounding (round 2's
+// end-to-end error from the VIDEO, p99 1.4e-3 px, was the bf16 operands of P1).  fp16's narrow exponent range is what the
+// guards of MODE 1 below are sized for.
+//
+// What changed against attention_kernel (round 1), and why (profiles/r01_bench_kernel_trace.md: 0.37 of the MFMA peak):
 //   * 8 (or 16) waves per CU instead of 4: a workgroup is 512 threads = 8 waves x 32 queries, compiled for <= 128 VGPRs so
 //     that TWO workgroups share a CU (4 waves per SIMD).  With d_head = 64 the softmax costs ~3.5 VALU instructions per
 //     score against 0.5 MFMA: one wave per SIMD can hide ~4-5 issue slots under a 32x32x16 MFMA (MI355X_MICROARCH.md,
@@ -17,21 +26,17 @@
 //   * workgroup -> (frame, head, query block) mapping keeps all query blocks of one (frame, head) on one XCD (blocks are
 //     dispatched round-robin over the 8 XCDs), so that its 2 MB of K / V^T are fetched from HBM once and re-read from that
 //     XCD's 4 MB L2 by the other blocks (round 1: 4.5x the algorithmic HBM traffic, PMC).
-// The arithmetic is the one of attention_kernel: exp2-domain online softmax, deferred maximum (threshold 8), raw v_exp_f32,
-// scores arriving as s - m through the C operand of the first MFMA, bf16 P, fp32 accumulation.
-#pragma once
+// Arithmetic: exp2-domain online softmax, raw v_exp_f32, 16-bit P (RTN pack: v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32), fp32
+// accumulation of O and of the row sums.
+#ifndef ATT2_NS
+#error "define ATT2_NS, ATT2_T, ATT2_F16 and ATT2_MFMA before including vit_attention2.h"
+#endif
 
-namespace att2 {
-
-typedef __bf16 bf16_t;
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+#ifndef DTK_ATT2_COMMON
+#define DTK_ATT2_COMMON
+namespace att2c {
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f16v __attribute__((ext_vector_type(16)));
-
-constexpr int TILE_KEYS = 64;
-constexpr int TILE_BYTES = 2 * TILE_KEYS * 64 * 2;  // K tile (64 keys x 64 d) + V^T tile (64 d x 64 keys), bf16
-constexpr int NBUF = 3;
 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
@@ -58,21 +63,49 @@ __device__ __forceinline__ void halves(float x, float& lo_all, float& hi_all) {
 }
 template <int N>
 __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+// MODE register bit 23 (FP16_OVFL): an fp16 result that overflows is clamped to +-65504 instead of becoming +-inf
+// (conversions included), so that a rare out-of-range activation saturates instead of poisoning everything downstream.
+__device__ __forceinline__ void fp16_saturate_mode() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
+
+inline unsigned attention2_grid(int FH, int S, int QT, int* qb_out) {
+    const int QB = (S + 256 * QT - 1) / (256 * QT);
+    *qb_out = QB;
+    return (unsigned)(((FH + 7) / 8) * 8 * QB);
+}
+}  // namespace att2c
+#endif
+
+namespace ATT2_NS {
+using namespace att2c;
+
+typedef ATT2_T op_t;
+typedef ATT2_T op8 __attribute__((ext_vector_type(8)));
+typedef ATT2_T op4 __attribute__((ext_vector_type(4)));
+constexpr bool F16 = ATT2_F16 != 0;
+// MODE 1 thresholds on a lane's part (32 keys) of a tile's row sum: at RESC_T the reference moves up after the tile; at
+// POISON_T a P entry may have left the operand type's range (fp16: 65504), the row is redone by the safe pass
+constexpr float RESC_T = F16 ? 0x1p9f : 0x1p40f;
+constexpr float POISON_T = F16 ? 0x1p15f : 0x1p120f;
+constexpr float LOW_T = F16 ? 0x1p-7f : 0x1p-100f;  // a final row sum below this has lost P's precision (fp16 subnormals)
+
+constexpr int TILE_KEYS = 64;
+constexpr int TILE_BYTES = 2 * TILE_KEYS * 64 * 2;  // K tile (64 keys x 64 d) + V^T tile (64 d x 64 keys), bf16
+constexpr int NBUF = 3;
 
 // Safe pass of ONE wave (rare: only after a poisoned row sum, MODE 1): queries q0 .. q0+nq-1 of one (frame, head) again,
 // 32 at a time, with a running maximum per 64-key tile; fragments come straight from global memory in the layouts of the
 // main loop (K rows permuted so that a lane holds 8 consecutive keys per 16-key group), no LDS, no barriers.
-__device__ __noinline__ void safe_pass(const bf16_t* Qb, const bf16_t* Kb, const bf16_t* Vb, bf16_t* Ob, int q0, int nq, int S,
+__device__ __noinline__ void safe_pass(const op_t* Qb, const op_t* Kb, const op_t* Vb, op_t* Ob, int q0, int nq, int S,
                                        int Sp, int D) {
     const int lane = threadIdx.x & 63, lq = lane & 31, hi = lane >> 5;
     const int krow = (lq & 19) | ((lq & 4) << 1) | ((lq & 8) >> 1);
     const int ntiles = (S + 63) / 64;
 #pragma unroll 1
     for (int qq = q0; qq < q0 + nq; qq += 32) {
-        bf8 qf[4];
+        op8 qf[4];
         const int qrow = min(qq + lq, Sp - 1);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf8*>(Qb + (size_t)qrow * 64 + ks * 16 + hi * 8);
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const op8*>(Qb + (size_t)qrow * 64 + ks * 16 + hi * 8);
         f16v oa[2];
         float m = -3e38f;
         f2 l = {0.f, 0.f};
@@ -89,8 +122,8 @@ __device__ __noinline__ void safe_pass(const bf16_t* Qb, const bf16_t* Kb, const
                 for (int r = 0; r < 16; ++r) s2[b][r] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const bf8 kf = *reinterpret_cast<const bf8*>(Kb + (size_t)(t * 64 + b * 32 + krow) * 64 + ks * 16 + hi * 8);
-                    s2[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s2[b], 0, 0, 0);
+                    const op8 kf = *reinterpret_cast<const op8*>(Kb + (size_t)(t * 64 + b * 32 + krow) * 64 + ks * 16 + hi * 8);
+                    s2[b] = ATT2_MFMA(kf, qf[ks], s2[b], 0, 0, 0);
                 }
             }
             float tm = -3e38f;
@@ -113,17 +146,17 @@ __device__ __noinline__ void safe_pass(const bf16_t* Qb, const bf16_t* Kb, const
                 for (int r = 0; r < 16; ++r) oa[db][r] *= alpha;
 #pragma unroll
             for (int bj = 0; bj < 4; ++bj) {
-                bf8 pfr;
+                op8 pfr;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float pv = __builtin_amdgcn_exp2f(s2[bj >> 1][8 * (bj & 1) + e] - m);
                     l[e & 1] += pv;
-                    pfr[e] = (bf16_t)pv;
+                    pfr[e] = (op_t)pv;
                 }
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    const bf8 vf = *reinterpret_cast<const bf8*>(Vb + (size_t)(db * 32 + lq) * Sp + t * 64 + bj * 16 + hi * 8);
-                    oa[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfr, oa[db], 0, 0, 0);
+                    const op8 vf = *reinterpret_cast<const op8*>(Vb + (size_t)(db * 32 + lq) * Sp + t * 64 + bj * 16 + hi * 8);
+                    oa[db] = ATT2_MFMA(vf, pfr, oa[db], 0, 0, 0);
                 }
             }
         }
@@ -131,15 +164,15 @@ __device__ __noinline__ void safe_pass(const bf16_t* Qb, const bf16_t* Kb, const
         const float inv = 1.f / (lh + __shfl_xor(lh, 32, 64));
         const int qi = qq + lq;
         if (qi < S) {
-            bf16_t* orow = Ob + (size_t)qi * D;
+            op_t* orow = Ob + (size_t)qi * D;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
                     const int d = db * 32 + 8 * rq + 4 * hi;
-                    bf4 v = {(bf16_t)(oa[db][4 * rq + 0] * inv), (bf16_t)(oa[db][4 * rq + 1] * inv),
-                             (bf16_t)(oa[db][4 * rq + 2] * inv), (bf16_t)(oa[db][4 * rq + 3] * inv)};
-                    *reinterpret_cast<bf4*>(orow + d) = v;
+                    op4 v = {(op_t)(oa[db][4 * rq + 0] * inv), (op_t)(oa[db][4 * rq + 1] * inv),
+                             (op_t)(oa[db][4 * rq + 2] * inv), (op_t)(oa[db][4 * rq + 3] * inv)};
+                    *reinterpret_cast<op4*>(orow + d) = v;
                 }
         }
     }
@@ -153,20 +186,26 @@ __device__ __noinline__ void safe_pass(const bf16_t* Qb, const bf16_t* Kb, const
 // MODE 0: running maximum per tile (deferred rescale, threshold 8), as in round 1.
 // MODE 1: OPTIMISTIC exponentials.  With d_head = 64 the softmax costs as many VALU cycles as the tile costs MFMA cycles
 //   (PMC: SQ_ACTIVE_INST_VALU 3.5 M cycles per SIMD against 2.9 M of SQ_VALU_MFMA_BUSY_CYCLES per launch), and a third of
-//   them only maintain the running maximum.  Any reference m gives the same softmax as long as 2^(s - m) neither overflows
-//   nor underflows to an all-zero row (P is bf16 = fp32's exponent range, O and l accumulate in fp32).  So the reference
-//   starts at 0 -- p = exp2(s), no subtraction at all -- and a guard on the tile's row sum (one compare per tile:
-//   not (sum < 2^40), which also catches inf / NaN) makes the wave move the reference up by an exact power of two AFTER the
-//   tile's PV product (nothing has overflowed yet: 2^40 is 87 binades below fp32's limit); from then on that wave
-//   subtracts its reference like MODE 0 does.  A score more than 120 above the reference in ONE step (83 nats), or a row
-//   whose scores all sit 100 binades below 0, poisons the row sum (NaN / 0) instead; a wave that finds such a sum at the end
-//   redoes its queries in a safe pass (running maximum per tile, operands read straight from global memory, no barriers).
-//   tests/test_gpu_p1.py forces all three events.
+//   them only maintain the running maximum.  Any reference m gives the same softmax as long as 2^(s - m) stays inside the
+//   range in which P keeps its precision: bf16 has fp32's exponent range; fp16 (the default) ends at 65504 above and has
+//   full precision down to 2^-14 only.  So the reference is ESTIMATED ONCE per query -- the maximum of its scores against
+//   the first 64 keys (which hold the CLS token) and against the 32 keys of its own wave (which hold its own key: the
+//   self score is the usual row maximum of a trained ViT), i.e. a lower bound of the row maximum, hence p_max >= 1 -- and
+//   is kept at exactly 0 (p = exp2(s), no subtraction at all) while every estimate of the wave is within +-3.  After that
+//   only a guard on the tile's row sum runs (one compare per tile: not (a lane's 32-key part < RESC_T), which also catches
+//   inf / NaN): the wave moves the reference up by an exact power of two AFTER the tile's PV product -- nothing has
+//   overflowed yet while the part stays below POISON_T (fp16: RESC_T = 2^9, POISON_T = 2^15: every p < 65504) -- and from
+//   then on subtracts its reference.  A part beyond POISON_T in ONE step (fp16: a score 15 binades = 10 nats above
+//   everything the row has seen; bf16: 120 binades) poisons the row sum instead; a wave that finds a poisoned or a tiny
+//   (< LOW_T) sum at the end redoes its queries in a safe pass (running maximum per tile, operands read straight from
+//   global memory, no barriers).  The reference never exceeds the row maximum by more than 6 binades (a rescale sets it to
+//   floor(log2(tile sum)) <= log2(64 p_max)), so p_max >= 2^-6 and the entries that matter at 11 bits are normal numbers.
+//   tests/test_gpu_p1.py forces all of these events.
 template <int QT, int ABL = 0, int MODE = 1, bool PIN = true, bool PRIO = false>
-__global__ __launch_bounds__(512, QT == 1 ? 4 : 2) void attention2_kernel(const bf16_t* __restrict__ Q,
-                                                                          const bf16_t* __restrict__ Kg,
-                                                                          const bf16_t* __restrict__ Vt,
-                                                                          bf16_t* __restrict__ O, int S, int Sp, int heads,
+__global__ __launch_bounds__(512, QT == 1 ? 4 : 2) void attention2_kernel(const op_t* __restrict__ Q,
+                                                                          const op_t* __restrict__ Kg,
+                                                                          const op_t* __restrict__ Vt,
+                                                                          op_t* __restrict__ O, int S, int Sp, int heads,
                                                                           int D, int FH, int QB) {
     __shared__ __attribute__((aligned(1024))) unsigned char tiles[NBUF][TILE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -179,15 +218,15 @@ __global__ __launch_bounds__(512, QT == 1 ? 4 : 2) void attention2_kernel(const 
     const int frame = fh / heads, head = fh - frame * heads;
     const int q0 = qb * (256 * QT) + w * (32 * QT);
     const int lq = lane & 31, hi = lane >> 5;
-    const bf16_t* Qb = Q + (size_t)fh * Sp * 64;
-    const bf16_t* Kb = Kg + (size_t)fh * Sp * 64;
-    const bf16_t* Vb = Vt + (size_t)fh * 64 * Sp;
+    const op_t* Qb = Q + (size_t)fh * Sp * 64;
+    const op_t* Kb = Kg + (size_t)fh * Sp * 64;
+    const op_t* Vb = Vt + (size_t)fh * 64 * Sp;
 
     // ---- DMA source of this lane: wave w fills rows 8w .. 8w+7 of the K tile and of the V^T tile (one request each);
     // LDS slot (row, piece') holds global piece  piece' ^ ((row >> 1) & 7)
     const int lrow = w * 8 + (lane >> 3), lpc = (lane & 7) ^ ((lrow >> 1) & 7);
-    const bf16_t* ksrc = Kb + (size_t)lrow * 64 + lpc * 8;        // + t * 64 * 64
-    const bf16_t* vsrc = Vb + (size_t)lrow * Sp + lpc * 8;        // + t * 64
+    const op_t* ksrc = Kb + (size_t)lrow * 64 + lpc * 8;        // + t * 64 * 64
+    const op_t* vsrc = Vb + (size_t)lrow * Sp + lpc * 8;        // + t * 64
     const unsigned lds_base = (unsigned)(size_t)&tiles[0][0];
     auto issue = [&](int t, int buf) {
         if ((ABL & 2) && t > 1) return;
@@ -196,13 +235,13 @@ __global__ __launch_bounds__(512, QT == 1 ? 4 : 2) void attention2_kernel(const 
     };
 
     // Q^T fragments (B operand): lane (query lq, hi) holds d = 16*ks + 8*hi .. +7 for ks = 0..3
-    bf8 qf[QT][4];
+    op8 qf[QT][4];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const int qrow = min(q0 + qt * 32 + lq, Sp - 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-            qf[qt][ks] = *reinterpret_cast<const bf8*>(Qb + (size_t)qrow * 64 + ks * 16 + hi * 8);
+            qf[qt][ks] = *reinterpret_cast<const op8*>(Qb + (size_t)qrow * 64 + ks * 16 + hi * 8);
     }
     const int ntiles = (S + 63) / 64;
     issue(0, 0);
@@ -211,7 +250,8 @@ __global__ __launch_bounds__(512, QT == 1 ? 4 : 2) void attention2_kernel(const 
     f16v o[QT][2];  // O^T accumulators: d-block db: rows d = 32*db + (r&3) + 8*(r>>2) + 4*hi, column = query lq
     float m_run[QT];
     f2 l_run[QT];
-    bool has_m = false;  // MODE 1, wave-uniform: a guard has tripped, the reference of some query is not 0 any more
+    bool has_m = false;  // MODE 1, wave-uniform: the reference of some query of the wave is not 0
+    if (F16) fp16_saturate_mode();
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         m_run[qt] = 0.f;
@@ -237,7 +277,43 @@ __global__ __launch_bounds__(512, QT == 1 ? 4 : 2) void attention2_kernel(const 
     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[qt][ks]));
-    vm_wait<2>();   // tile 0 landed (this wave's two requests of tile 1 may still fly)
+    // MODE 1: the reference estimate (see above), before the main loop so that the loop itself carries none of it: scores
+    // of the wave's queries against keys 0..63 and against the wave's OWN 32 keys (rows q0 + 32 qt ..), K fragments straight
+    // from global memory (any row order: only the maximum is used)
+    if (MODE == 1 && !(ABL & 8)) {
+        bool far = false;
+        float est[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float tm = -3e38f;
+#pragma unroll
+            for (int blk = 0; blk < 3; ++blk) {
+                const int kr0 = blk < 2 ? blk * 32 : q0 + qt * 32;
+                const op_t* kp = Kb + (size_t)min(kr0 + lq, Sp - 1) * 64 + hi * 8;
+                op8 kf[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const op8*>(kp + ks * 16);
+                f16v so = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) so = ATT2_MFMA(kf[ks], qf[qt][ks], so, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kr0 + (r & 3) + 8 * (r >> 2) + 4 * hi;  // D row of the MFMA = key row of the block
+                    tm = fmaxf(tm, key < S ? so[r] : -3e38f);
+                }
+            }
+            float a, b;
+            halves(tm, a, b);
+            est[qt] = fmaxf(a, b);
+            far |= __any(!(fabsf(est[qt]) <= 3.f));
+        }
+        if (far) {
+            has_m = true;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) m_run[qt] = est[qt];
+        }
+    }
+    vm_wait<0>();   // tiles 0 and 1 landed
     __syncthreads();
 
     int buf = 0;
@@ -251,14 +327,14 @@ __global__ __launch_bounds__(512, QT == 1 ? 4 : 2) void attention2_kernel(const 
         // with sched_barrier): left alone, hipcc under the 128-VGPR cap issues ds_read -> s_waitcnt lgkmcnt(0) -> MFMA one
         // fragment at a time and every MFMA eats a full LDS latency (measured: -21 % when the reads are taken away).
         auto ldk = [&](int f) {  // K fragment f: d step ks = f >> 1 of key block b = f & 1 (accumulators alternate)
-            return *reinterpret_cast<const bf8*>((ABL & 4) ? tb + lane * 16 : tb + (koff[f & 1] ^ ((f >> 1) << 5)));
+            return *reinterpret_cast<const op8*>((ABL & 4) ? tb + lane * 16 : tb + (koff[f & 1] ^ ((f >> 1) << 5)));
         };
         auto ldv = [&](int g) {  // V^T fragment g: key group bj = g >> 1 (b = bj >> 1, j = bj & 1) of d-block db = g & 1
-            return *reinterpret_cast<const bf8*>((ABL & 4) ? tb + 8192 + lane * 16 : tb + (voff[g & 1] ^ ((g >> 1) << 5)));
+            return *reinterpret_cast<const op8*>((ABL & 4) ? tb + 8192 + lane * 16 : tb + (voff[g & 1] ^ ((g >> 1) << 5)));
         };
         // ---- S^T = K Q^T : two 32-key blocks x four 16-wide d steps ----
         f16v sc[QT][2];
-        bf8 kr[4], vr[4];
+        op8 kr[4], vr[4];
         auto scores = [&]() {
             const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // inline constant C
             kr[0] = ldk(0); kr[1] = ldk(1); kr[2] = ldk(2);
@@ -268,7 +344,7 @@ __global__ __launch_bounds__(512, QT == 1 ? 4 : 2) void attention2_kernel(const 
                 if (f + 3 < 8) kr[(f + 3) & 3] = ldk(f + 3);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
-                    sc[qt][f & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[f & 3], qf[qt][f >> 1],
+                    sc[qt][f & 1] = ATT2_MFMA(kr[f & 3], qf[qt][f >> 1],
                                                                             f < 2 ? zero16 : sc[qt][f & 1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -288,7 +364,7 @@ __global__ __launch_bounds__(512, QT == 1 ? 4 : 2) void attention2_kernel(const 
         };
         scores();
         // ---- online softmax (exp2 domain; Q carries log2(e)/sqrt(d)) : everything per query is lane-local ----
-        bf8 pf[QT][4];  // P^T fragments: [query tile][16-key group bj]
+        op8 pf[QT][4];  // P^T fragments: [query tile][16-key group bj]
         float lsum[QT];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
@@ -324,8 +400,8 @@ __global__ __launch_bounds__(512, QT == 1 ? 4 : 2) void attention2_kernel(const 
                         if (sub) sv += nm;
                         const f2 p = (ABL & 1) ? sv * f2{0.01f, 0.01f} : f2{__builtin_amdgcn_exp2f(sv[0]), __builtin_amdgcn_exp2f(sv[1])};
                         lt += p;
-                        pf[qt][bj][e] = (bf16_t)p[0];
-                        pf[qt][bj][e + 1] = (bf16_t)p[1];
+                        pf[qt][bj][e] = (op_t)p[0];
+                        pf[qt][bj][e + 1] = (op_t)p[1];
                     }
                 return lt;
             };
@@ -349,7 +425,7 @@ __global__ __launch_bounds__(512, QT == 1 ? 4 : 2) void attention2_kernel(const 
         bool resc = false;
         if (MODE == 1 && !(ABL & 8)) {
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) resc |= __any(!(lsum[qt] < 0x1p40f));
+            for (int qt = 0; qt < QT; ++qt) resc |= __any(!(lsum[qt] < RESC_T));
         }
         // ---- O^T += V^T P^T : A fragment of (d-block db, keys 16 bj + 8hi .. +7) = one 16-byte read ----
         vr[0] = ldv(0); vr[1] = ldv(1); vr[2] = ldv(2);
@@ -359,20 +435,20 @@ __global__ __launch_bounds__(512, QT == 1 ? 4 : 2) void attention2_kernel(const 
             if (g + 3 < 8) vr[(g + 3) & 3] = ldv(g + 3);
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt)
-                o[qt][g & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr[g & 3], pf[qt][g >> 1], o[qt][g & 1], 0, 0, 0);
+                o[qt][g & 1] = ATT2_MFMA(vr[g & 3], pf[qt][g >> 1], o[qt][g & 1], 0, 0, 0);
             if (PIN) __builtin_amdgcn_sched_barrier(0);
         }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
-        if (MODE == 1 && resc) {  // rare: a row sum of this tile passed 2^40 -> move the reference up by a power of two
+        if (MODE == 1 && resc) {  // rare: a row sum of this tile passed RESC_T -> move the reference up by a power of two
             asm volatile("; guard tripped" ::: "memory");
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 float a, b;
                 halves(lsum[qt], a, b);
                 const float tot = a + b;  // both key halves
-                if (!(tot < 0x1p120f)) {
+                if (!(a < POISON_T && b < POISON_T)) {
                     l_run[qt] = f2{__builtin_nanf(""), __builtin_nanf("")};  // beyond repair here: safe pass at the end
-                } else if (tot >= 0x1p40f) {
+                } else if (tot >= RESC_T) {
                     const float k = floorf(__builtin_amdgcn_logf(tot));  // v_log_f32 = log2
                     const float alpha = __builtin_amdgcn_exp2f(-k);      // exact power of two
                     m_run[qt] += k;
@@ -398,7 +474,7 @@ __global__ __launch_bounds__(512, QT == 1 ? 4 : 2) void attention2_kernel(const 
         float a, b;
         halves(l_half, a, b);
         l_tot[qt] = a + b;
-        if (MODE == 1) redo |= __any(!(l_tot[qt] > 0x1p-100f && l_tot[qt] < 0x1p120f));
+        if (MODE == 1) redo |= __any(!(l_tot[qt] > LOW_T && l_tot[qt] < 0x1p120f));
     }
     if (MODE == 1 && redo && !(ABL & 8)) {
         // rare: see safe_pass (kept out of line so that it costs the main loop no registers)
@@ -410,24 +486,18 @@ __global__ __launch_bounds__(512, QT == 1 ? 4 : 2) void attention2_kernel(const 
         const float inv = 1.f / l_tot[qt];
         const int qi = q0 + qt * 32 + lq;
         if (qi < S) {
-            bf16_t* orow = O + ((size_t)frame * S + qi) * D + head * 64;
+            op_t* orow = O + ((size_t)frame * S + qi) * D + head * 64;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
                     const int d = db * 32 + 8 * rq + 4 * hi;
-                    bf4 v = {(bf16_t)(o[qt][db][4 * rq + 0] * inv), (bf16_t)(o[qt][db][4 * rq + 1] * inv),
-                             (bf16_t)(o[qt][db][4 * rq + 2] * inv), (bf16_t)(o[qt][db][4 * rq + 3] * inv)};
-                    *reinterpret_cast<bf4*>(orow + d) = v;
+                    op4 v = {(op_t)(o[qt][db][4 * rq + 0] * inv), (op_t)(o[qt][db][4 * rq + 1] * inv),
+                             (op_t)(o[qt][db][4 * rq + 2] * inv), (op_t)(o[qt][db][4 * rq + 3] * inv)};
+                    *reinterpret_cast<op4*>(orow + d) = v;
                 }
         }
     }
 }
 
-inline unsigned attention2_grid(int FH, int S, int QT, int* qb_out) {
-    const int QB = (S + 256 * QT - 1) / (256 * QT);
-    *qb_out = QB;
-    return (unsigned)(((FH + 7) / 8) * 8 * QB);
-}
-
-}  // namespace att2
+}  // namespace ATT2_NS

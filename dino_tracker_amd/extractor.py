@@ -9,8 +9,13 @@ weights are a plain state dict in upstream facebookresearch/dinov2 naming (`patc
 Anything else raises: there is no silent fallback.
 Facets: `tokens` (block outputs, models/extractor.py:137-150) is the hot path.  The qkv hook output of a block
 (models/extractor.py:107-118) comes from the same device program (`qkv_out` of dtk_vit_forward: fp32 output of the
-bf16-operand GEMM), so the key / query / value getters (:224-267) are reshapes of it like in the reference; the
+16-bit-operand GEMM), so the key / query / value getters (:224-267) are reshapes of it like in the reference; the
 attention-map facet and the key self-similarity are small torch expressions over it (not on the hot path).
+
+Operand type of the matrix units: IEEE fp16 by default (`operand_dtype="fp16"`; the residual stream, the statistics and
+every accumulation are fp32) -- the same MFMA rate as bf16 with 8x less operand rounding.  fp16 ends at 65504: activations
+beyond that SATURATE on the device and set an overflow word, which `encode` turns into a RuntimeError naming
+`operand_dtype="bf16"` (fp32's range, 8 mantissa bits) as the way out.
 """
 from __future__ import annotations
 
@@ -24,7 +29,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from ._lib import VIT_TILED_GEMMS, VitLayer, VitModel, check, lib
+from ._lib import VIT_BF16, VIT_CHECK_RANGE, VIT_TILED_GEMMS, VitLayer, VitModel, check, lib
 from .synth import VIT_CONFIGS, make_vit_weights
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
@@ -36,8 +41,12 @@ class VitExtractor(nn.Module):
     KEY_LIST = [BLOCK_KEY, ATTN_KEY, PATCH_IMD_KEY, QKV_KEY]
 
     def __init__(self, model_name, stride, device, state_dict: Optional[Dict[str, torch.Tensor]] = None,
-                 random_seed: Optional[int] = None):
+                 random_seed: Optional[int] = None, operand_dtype: str = "fp16", check_range: bool = False):
         super().__init__()
+        if operand_dtype not in ("fp16", "bf16"):
+            raise ValueError(f"operand_dtype {operand_dtype!r}: 'fp16' or 'bf16'")
+        self.operand_dtype = operand_dtype
+        self.check_range = check_range  # also scan Q / K / V and the MLP hidden of every block for saturation (slower)
         if model_name not in VIT_CONFIGS:
             raise NotImplementedError(f"{model_name}: the HIP encoder covers dinov2_vit{{s,b,l}}14 (d_head 64)")
         self.model_name, self.stride, self.device = model_name, stride, device
@@ -69,8 +78,13 @@ class VitExtractor(nn.Module):
             self._keep.append(t)
             return t.data_ptr()
 
-        def b16(name):
-            t = sd[name].to(torch.bfloat16).contiguous()
+        wdt = torch.float16 if self.operand_dtype == "fp16" else torch.bfloat16
+
+        def b16(name):  # matrix weights in the operand type of the MFMA kernels
+            w = sd[name]
+            if wdt == torch.float16 and float(w.abs().max()) >= 65504.0:
+                raise RuntimeError(f"{name}: |w| reaches the fp16 limit; use operand_dtype='bf16'")
+            t = w.to(wdt).contiguous()
             self._keep.append(t)
             return t.data_ptr()
 
@@ -120,10 +134,13 @@ class VitExtractor(nn.Module):
         ms = torch.tensor((IMAGENET_MEAN + IMAGENET_STD) if normalize else (0.0, 0.0, 0.0, 1.0, 1.0, 1.0),
                           dtype=torch.float32, device=self.device)
         D = self.cfg["dim"]
-        m = VitModel(D, self.cfg["heads"], layer + 1, patch, self.stride, 1e-6, VIT_TILED_GEMMS if self.tiled_gemms else 0,
+        flags = (VIT_TILED_GEMMS if self.tiled_gemms else 0) | (VIT_BF16 if self.operand_dtype == "bf16" else 0) | \
+            (VIT_CHECK_RANGE if self.check_range else 0)
+        overflow = torch.zeros(1, dtype=torch.int32, device=self.device)
+        m = VitModel(D, self.cfg["heads"], layer + 1, patch, self.stride, 1e-6, flags,
                      self._sd["patch_embed.proj.weight"].data_ptr(),
                      self._sd["patch_embed.proj.bias"].data_ptr(), cls_pos.data_ptr(), pos.data_ptr(), ms.data_ptr(),
-                     ctypes.cast(self._layers, ctypes.POINTER(VitLayer)))
+                     ctypes.cast(self._layers, ctypes.POINTER(VitLayer)), overflow.data_ptr())
         ws_bytes = int(lib().dtk_vit_workspace_bytes(m, H, W, n))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
         S = ph * pw + 1
@@ -135,6 +152,11 @@ class VitExtractor(nn.Module):
         check(lib().dtk_vit_forward(m, ops._p(frames), n, H, W, ops._p(tokens), ops._p(feat), ops._p(qkv), ops._p(ws),
                                     ws_bytes, ops._stream()))
         torch.cuda.current_stream().synchronize()  # `ms`, `ws` must outlive the launches
+        self.last_overflow = int(overflow.item())
+        if self.last_overflow:
+            what = [n for b, n in ((1, "a residual update"), (2, "Q / K / V"), (4, "the MLP hidden")) if self.last_overflow & b]
+            raise RuntimeError(f"dtk_vit_forward: {' and '.join(what)} left the fp16 range (saturated at 65504); "
+                               "construct the extractor with operand_dtype='bf16'")
         return {"tokens": tokens, "feat": feat, "qkv": qkv}[want]
 
     def get_feature_from_input(self, input_img, layers: List[int]):  # models/extractor.py:137-150

@@ -228,6 +228,11 @@ def batchnorm_train_forward(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Te
                                             _p(pre_bias, torch.float32), _p(running_mean, torch.float32),
                                             _p(running_var, torch.float32), float(momentum),
                                             float(eps), int(relu), _p(y), _p(mean), _p(rstd), N, C, H * W, _p(ws), nb, _stream()))
+    # the kernel wrote the running statistics through raw pointers: tell torch (consumers that cache by `_version`, e.g.
+    # delta_dino.weights_key -> the packed eval-mode BN constants, must see the change)
+    for buf in (running_mean, running_var):
+        if buf is not None:
+            torch.autograd.graph.increment_version(buf)
     return y, mean, rstd
 
 

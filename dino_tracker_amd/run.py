@@ -53,6 +53,23 @@ def check_resolution() -> None:
         raise SystemExit("dino_tracker_amd.run: these modules did not resolve to the overlay:\n  " + "\n  ".join(wrong))
 
 
+def precheck_resolution() -> None:
+    """Where WOULD the hot-path modules come from with the path as configured?  (importlib.util.find_spec imports the
+    parent packages -- PEP 420 namespaces here -- but not the modules themselves.)"""
+    import importlib.util
+    wrong = []
+    for name in HOT_MODULES:
+        try:
+            spec = importlib.util.find_spec(name)
+        except (ImportError, ValueError):
+            spec = None
+        origin = getattr(spec, "origin", None) if spec is not None else None
+        if origin and not os.path.abspath(origin).startswith(OVERLAY + os.sep):
+            wrong.append(f"{name} -> {origin}")
+    if wrong:
+        raise SystemExit("dino_tracker_amd.run: these modules would not resolve to the overlay:\n  " + "\n  ".join(wrong))
+
+
 def main(argv: list) -> None:
     extra = []
     while argv and argv[0] == "--path":
@@ -70,10 +87,19 @@ def main(argv: list) -> None:
         if name in HOT_MODULES or name in ("models", "data", "models.networks"):
             del sys.modules[name]
     sys.argv = [script] + argv[1:]
+    precheck_resolution()  # before the script runs: a mis-resolved path must not execute the PyTorch reference first
+    ok = False
     try:
         runpy.run_path(script, run_name="__main__")
+        ok = True
     finally:
-        check_resolution()
+        if ok:
+            check_resolution()
+        else:  # never replace the script's own exception / traceback
+            try:
+                check_resolution()
+            except SystemExit as e:
+                print(e, file=sys.stderr)
 
 
 if __name__ == "__main__":

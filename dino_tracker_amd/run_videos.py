@@ -37,6 +37,23 @@ def parse(argv):
     return extra, script, paths, script_args
 
 
+def pin_local_gpu(env: dict, local: int) -> None:
+    """One GPU per rank: entry `local` of whatever device list the job was already restricted to (a scheduler's
+    ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES), or plain index `local` when there is none."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        cur = [d for d in env.get(var, "").split(",") if d.strip()]
+        if cur:
+            if local >= len(cur):
+                raise SystemExit(f"dino_tracker_amd.run_videos: LOCAL_RANK {local} but {var}={env[var]}")
+            env[var] = cur[local].strip()
+            for other in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+                if other != var:
+                    env.pop(other, None)
+            return
+    # ROCR_VISIBLE_DEVICES narrows what HIP enumerates: HIP indices are relative to it, so `local` is already right
+    env["HIP_VISIBLE_DEVICES"] = str(local)
+
+
 def main(argv) -> int:
     extra, script, paths, script_args = parse(argv)
     rank = int(os.environ.get("RANK", "0"))
@@ -44,7 +61,7 @@ def main(argv) -> int:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     env = dict(os.environ)
     if world > 1:
-        env["HIP_VISIBLE_DEVICES"] = str(local)
+        pin_local_gpu(env, local)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK",
               "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)  # the per-video process is a plain single-GPU run

@@ -38,12 +38,16 @@ def infer_benchmark(model_inference, query_points: Mapping[int, Sequence], devic
 def metrics_from_counts(counts: Sequence[int]) -> Dict[str, float]:
     """eval/metrics.py:84-146: ratios of the 18 counts, then the means over the five thresholds."""
     ev, occ_eq, vis = counts[0], counts[1], counts[2]
-    m = {"occlusion_accuracy": occ_eq / ev}
+
+    def ratio(a, b):  # a video without evaluated / visible points: nan, like numpy's 0/0 in eval/metrics.py, not an exception
+        return a / b if b else float("nan")
+
+    m = {"occlusion_accuracy": ratio(occ_eq, ev)}
     fr, ja = [], []
     for i, th in enumerate(THRESHOLDS):
         correct, tp, fp = counts[3 + 3 * i], counts[4 + 3 * i], counts[5 + 3 * i]
-        m[f"pts_within_{th}"] = correct / vis
-        m[f"jaccard_{th}"] = tp / (vis + fp)
+        m[f"pts_within_{th}"] = ratio(correct, vis)
+        m[f"jaccard_{th}"] = ratio(tp, vis + fp)
         fr.append(m[f"pts_within_{th}"])
         ja.append(m[f"jaccard_{th}"])
     m["average_jaccard"] = sum(ja) / len(ja)

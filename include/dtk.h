@@ -68,19 +68,21 @@ int dtk_unpack_features(const float* thwc, float* chw, int T, int C, int HW, voi
 int dtk_feature_norms(const float* thwc, float* norms, int T, int C, int HW, void* stream);
 
 /* ---- P1: DINOv2 ViT encoder as driven by VitExtractor (models/extractor.py:23-150, utils.py:33-72) -----------------
- * Host-side structs of DEVICE pointers.  Matrix weights are bf16 in nn.Linear layout [out][in]; vectors are fp32.
+ * Host-side structs of DEVICE pointers.  Matrix weights are 16-bit in nn.Linear layout [out][in], in the model's OPERAND
+ * TYPE: IEEE fp16 by default (round 3: the same MFMA rate as bf16 with 8x less operand rounding -- round 2's end-to-end
+ * error from the video was the bf16 operands), bf16 with DTK_VIT_BF16; vectors are fp32.
  * Upstream facebookresearch/dinov2 parameter names are given for each field (blocks.{i}.*). */
 typedef struct dtk_vit_layer {
     const float *ln1_w, *ln1_b;   /* norm1.weight / .bias */
-    const void* qkv_w;            /* attn.qkv.weight  bf16 [3D][D] */
+    const void* qkv_w;            /* attn.qkv.weight  16-bit [3D][D] */
     const float* qkv_b;           /* attn.qkv.bias    [3D] */
-    const void* proj_w;           /* attn.proj.weight bf16 [D][D] */
+    const void* proj_w;           /* attn.proj.weight 16-bit [D][D] */
     const float* proj_b;          /* attn.proj.bias */
     const float* ls1;             /* ls1.gamma */
     const float *ln2_w, *ln2_b;   /* norm2.* */
-    const void* fc1_w;            /* mlp.fc1.weight bf16 [4D][D] */
+    const void* fc1_w;            /* mlp.fc1.weight 16-bit [4D][D] */
     const float* fc1_b;
-    const void* fc2_w;            /* mlp.fc2.weight bf16 [D][4D] */
+    const void* fc2_w;            /* mlp.fc2.weight 16-bit [D][4D] */
     const float* fc2_b;
     const float* ls2;             /* ls2.gamma */
 } dtk_vit_layer;
@@ -90,16 +92,25 @@ typedef struct dtk_vit_model {
     int32_t depth;                /* number of blocks to run = hooked layer + 1 (models/extractor.py:137-150) */
     int32_t patch, stride;        /* 14, 7 (models/extractor.py:41-55) */
     float ln_eps;                 /* 1e-6 */
-    int32_t flags;                /* 0, or DTK_VIT_TILED_GEMMS: run the K = 384 GEMMs on the tiled kernel too (cross-check) */
+    int32_t flags;                /* 0 or a combination of the DTK_VIT_* bits below */
     const float* patch_w;         /* patch_embed.proj.weight fp32 [D][3][patch][patch] */
     const float* patch_b;         /* patch_embed.proj.bias */
     const float* cls_pos;         /* cls_token + pos_embed[0]  [D] */
     const float* pos;             /* interpolated patch position encoding [ph*pw][D] (models/extractor.py:57-85) */
     const float* mean_std;        /* ImageNet mean[3], std[3] (utils.py:46) */
     const dtk_vit_layer* layers;  /* HOST array of `depth` entries */
+    int32_t* overflow;            /* DEVICE word or NULL; OR-ed with 1 when a residual update (projection / MLP output) reached
+                                   * the fp16 limit 65504 or is not finite, with 2 / 4 when Q, K, V / the MLP hidden did
+                                   * (the latter two only with DTK_VIT_CHECK_RANGE).  The caller zeroes it.  fp16 activations
+                                   * SATURATE (FP16_OVFL mode) instead of becoming inf; a non-zero word means the features
+                                   * are not trustworthy and the model should be run with DTK_VIT_BF16. */
 } dtk_vit_model;
 
-#define DTK_VIT_TILED_GEMMS 1
+#define DTK_VIT_TILED_GEMMS 1   /* run the K = 384 GEMMs on the tiled kernel too (cross-check in the tests) */
+#define DTK_VIT_BF16 2          /* operand type bf16 instead of fp16 (weights must then be bf16) */
+#define DTK_VIT_CHECK_RANGE 4   /* scan Q / K / V^T and the MLP hidden of every block for saturated values (costs a pass) */
+#define DTK_OPERAND_F16 0
+#define DTK_OPERAND_BF16 1
 
 /* frames [n][3][video_h][video_w] fp32 in [0,1] -> block output of layer depth-1 (before the final norm):
  * tokens_out [n][1 + ph*pw][D] (CLS first; what get_feature_from_input returns) and/or
@@ -113,14 +124,15 @@ int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int nframes, in
                     void* stream);
 
 /* The multi-head self-attention stage of a block on its own, d_head = 64 (what runs between the QKV and the projection
- * GEMMs inside dtk_vit_forward; upstream Attention.forward, hooked by models/extractor.py:101-104).  bf16 operands:
+ * GEMMs inside dtk_vit_forward; upstream Attention.forward, hooked by models/extractor.py:101-104).  Operands in
+ * `operand_type` (DTK_OPERAND_F16 / DTK_OPERAND_BF16):
  *   q  [frames][heads][Sp][64]   queries, ALREADY multiplied by log2(e) / sqrt(64) (the softmax runs in the exp2 domain)
  *   k  [frames][heads][Sp][64]   keys; rows S .. Sp-1 must be finite (zero)
  *   vt [frames][heads][64][Sp]   values, transposed; columns S .. Sp-1 must be finite (zero)
  *   out[frames][S][heads*64]     softmax(q k^T) v, heads concatenated (the input of attn.proj)
  * Sp = S rounded up to a multiple of 64 (dtk_vit_forward uses 128). */
 int dtk_vit_attention(const void* q, const void* k, const void* vt, void* out, int frames, int heads, int S, int Sp,
-                      void* stream);
+                      int operand_type, void* stream);
 
 /* ---- P2: Delta-DINO refinement (models/tracker.py:113-135; models/networks/delta_dino.py:53-61;
  *      models/utils.py:7-45), fp32-grade on the fp16 MFMA (operands split into hi + lo halves, 3 products) ----------

@@ -1,7 +1,8 @@
-"""End-to-end error of the bf16 ViT: video -> HIP ViT -> HIP Delta-DINO -> HIP infer, against the fp32 oracle run on the
-same VIDEO (oracle ViT -> oracle refine -> oracle infer).  north_star's 1e-3 px is stated on identical inputs; the
-P3 / P2 tests hold it on identical FEATURES, this script measures what the bf16 operands of P1 add on top.
-Writes gpurun_out/e2e_error.json (copied to profiles/ by hand).  Usage: python scripts/e2e_error.py [H W T nq]"""
+"""End-to-end error from the VIDEO: video -> HIP ViT -> HIP Delta-DINO -> HIP infer, against the fp32 oracle run on the
+same video (oracle ViT -> oracle refine -> oracle infer).  north_star's 1e-3 px is stated on identical inputs; the
+P3 / P2 tests hold it on identical FEATURES, this script measures what the 16-bit operands of P1 add on top (fp16 by
+default since round 3; `bf16` as fifth argument gives the round-2 arithmetic for comparison).
+Writes gpurun_out/e2e_error_*.json (copied to profiles/ by hand).  Usage: python scripts/e2e_error.py [H W T nq [fp16|bf16]]"""
 import json
 import os
 import sys
@@ -21,7 +22,7 @@ from dino_tracker_amd.tracker import Tracker  # noqa: E402
 from oracle import ref_algo as A  # noqa: E402
 
 
-def run(H, W, T, nq, layerscale=0.1, seed=2000):
+def run(H, W, T, nq, layerscale=0.1, seed=2000, operand_dtype="fp16"):
     dev = "cuda:0"
     name = "dinov2_vits14"
     sd = synth.make_vit_weights(name, seed=2, layerscale=layerscale)
@@ -29,7 +30,7 @@ def run(H, W, T, nq, layerscale=0.1, seed=2000):
     head = synth.synth_head_weights(3)
     delta = synth.synth_delta_dino_weights(384, seed=4)
     queries = synth.grid_queries(nq, nq, H, W, 0, margin=min(60.0, H / 6))
-    ex = VitExtractor(name, stride=7, device=dev, state_dict=sd)
+    ex = VitExtractor(name, stride=7, device=dev, state_dict=sd, operand_dtype=operand_dtype)
     feat = ex.encode(video)
     trk = Tracker(video=video.to(dev), dino_features=feat, dino_patch_size=14, stride=7, device=dev)
     trk.tracker_head.load_state_dict(head)
@@ -52,7 +53,8 @@ def run(H, W, T, nq, layerscale=0.1, seed=2000):
     err_same = (traj.cpu() - rt_same).norm(dim=-1).reshape(-1)
     q = torch.tensor([0.5, 0.9, 0.99, 1.0])
     return {
-        "config": f"{W}x{H}x{T}, {nq * nq} queries, ViT-S/14 random weights (LayerScale {layerscale}), seed {seed}",
+        "config": f"{W}x{H}x{T}, {nq * nq} queries, ViT-S/14 random weights (LayerScale {layerscale}), seed {seed}, "
+                  f"{operand_dtype} operands",
         "feature_rel_err_P1": rel,
         "px_err_vs_oracle_on_same_video": {"p50": err.quantile(q[0]).item(), "p90": err.quantile(q[1]).item(),
                                            "p99": err.quantile(q[2]).item(), "max": err.max().item(),
@@ -67,8 +69,9 @@ def run(H, W, T, nq, layerscale=0.1, seed=2000):
 
 if __name__ == "__main__":
     a = [int(x) for x in sys.argv[1:5]] if len(sys.argv) >= 5 else [238, 322, 6, 4]
-    out = [run(*a)]
+    dt = sys.argv[5] if len(sys.argv) > 5 else "fp16"
+    out = [run(*a, operand_dtype=dt)]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"e2e_error_{a[0]}x{a[1]}x{a[2]}.json"), "w") as fh:
+    with open(os.path.join(ROOT, "gpurun_out", f"e2e_error_{a[0]}x{a[1]}x{a[2]}_{dt}.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out, indent=1))

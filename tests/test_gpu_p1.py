@@ -1,6 +1,7 @@
 """-m gpu: DINOv2 ViT encoder (P1) through the C-ABI vs the fp32 oracle restatement (seeded random weights).
-The device path uses bf16 matrix operands (fp32 accumulate / residual stream), the oracle fp32, so parity is stated
-at feature level: per-token cosine similarity >= 0.999 and relative Frobenius error <= 2e-2."""
+The device path uses fp16 matrix operands by default (fp32 accumulate / residual stream; bf16 on request), the oracle
+fp32, so parity is stated at feature level: per-token cosine similarity >= 0.999999 and relative Frobenius error
+<= 3e-4 for fp16 (measured ~1e-4: twelve blocks of 2^-12 operand rounding), 0.999 / 2e-2 for bf16 (measured 1e-3)."""
 import pytest
 import torch
 
@@ -11,7 +12,10 @@ from oracle import ref_algo as A
 pytestmark = pytest.mark.gpu
 
 
-def _check(got, ref, cos_min=0.999, rel_max=2e-2):
+BF16_TOL = dict(cos_min=0.999, rel_max=2e-2)
+
+
+def _check(got, ref, cos_min=0.999999, rel_max=3e-4):
     got, ref = got.float().cpu(), ref.float().cpu()
     cos = torch.nn.functional.cosine_similarity(got, ref, dim=-1)
     rel = (got - ref).norm() / ref.norm()
@@ -57,7 +61,7 @@ def test_patch_embedding_is_fp32_grade(vits, shape):
 
 def test_weight_stationary_gemm_matches_tiled_gemm():
     """The K = 384 GEMMs (QKV, projection, fc1) run on the weight-stationary kernel; dtk_vit_model.flags =
-    DTK_VIT_TILED_GEMMS sends them to the tiled kernel instead.  Both use bf16 operands, so after all 12 blocks the
+    DTK_VIT_TILED_GEMMS sends them to the tiled kernel instead.  Both use the same 16-bit operands, so after all 12 blocks the
     features must agree far more closely than either agrees with the fp32 oracle (differences: accumulation order, erf
     polynomial vs erff).  Run with the benchmark's LayerScale (0.1)."""
     sd = synth.make_vit_weights("dinov2_vits14", seed=2, layerscale=0.1)
@@ -67,7 +71,7 @@ def test_weight_stationary_gemm_matches_tiled_gemm():
     ex.tiled_gemms = True
     b = ex.encode(video).cpu()
     assert not torch.equal(a, b)  # two different kernels did run
-    _check(a, b, cos_min=0.9999, rel_max=1e-2)
+    _check(a, b, cos_min=0.999999, rel_max=3e-4)
 
 
 def test_full_resolution_first_blocks(vits):
@@ -123,7 +127,8 @@ def test_attention_large_logits_force_rescale():
     video = synth.synth_video(1, 238, 322, seed=76)  # 33 x 45 = 1485 tokens: 24 key tiles
     feat = ex.encode(video, layer=0)
     ref = A.vit_tokens(video, sd, "dinov2_vits14", layer=0).permute(1, 2, 0).reshape(-1, d)
-    _check(feat[0], ref, cos_min=0.998, rel_max=3e-2)
+    # 16-bit Q / K move a score by ~2^-11 |s| (|s| reaches tens here), i.e. P by a few 1e-3 relative
+    _check(feat[0], ref, cos_min=0.9999, rel_max=5e-3)
 
 
 # ---- against the un-modified reference extractor (tests/golden/p1_small.npz, written by make_golden.py) -----------------
@@ -161,7 +166,7 @@ def test_cls_row_and_layer_mean_match_reference_golden():
     assert tok.shape == gold.shape
     _check(tok[0], gold[0])
     cls_err = (tok[0, 0] - gold[0, 0]).norm() / gold[0, 0].norm()
-    assert cls_err < 2e-2, cls_err  # the CLS token itself, not just "finite"
+    assert cls_err < 5e-4, cls_err  # the CLS token itself, not just "finite"
 
 
 def test_qkv_facets_match_reference_golden():
@@ -177,24 +182,24 @@ def test_qkv_facets_match_reference_golden():
     x = ((video - m) / s).cuda()
     qkv = ex.get_qkv_feature_from_input(x)
     assert len(qkv) == 12
-    _check(qkv[1][0].cpu(), torch.from_numpy(g["qkv_l1"])[0], cos_min=0.9995, rel_max=2e-2)
+    _check(qkv[1][0].cpu(), torch.from_numpy(g["qkv_l1"])[0], cos_min=0.99999, rel_max=1e-3)
     keys = get_dino_features_video(video.cuda(), model_name=MG.P1_CASE["model"], facet="keys", stride=7, layer=3,
                                    device="cuda:0", state_dict=sd)
     gk = torch.from_numpy(g["keys_l3"])
     assert keys.shape == gk.shape
-    _check(keys[0].permute(1, 2, 0).reshape(-1, 384), gk[0].permute(1, 2, 0).reshape(-1, 384), cos_min=0.9995)
+    _check(keys[0].permute(1, 2, 0).reshape(-1, 384), gk[0].permute(1, 2, 0).reshape(-1, 384), cos_min=0.99999, rel_max=1e-3)
     q = ex.get_queries_from_input(x, layers=[1])
     v = ex.get_values_from_input(x, layers=[1])
     gq = torch.from_numpy(g["qkv_l1"]).reshape(1, 222, 3, 384)
-    _check(q[0].cpu(), gq[0, :, 0], cos_min=0.9995)
-    _check(v[0].cpu(), gq[0, :, 2], cos_min=0.9995)
+    _check(q[0].cpu(), gq[0, :, 0], cos_min=0.99999, rel_max=1e-3)
+    _check(v[0].cpu(), gq[0, :, 2], cos_min=0.99999, rel_max=1e-3)
     ssim = ex.get_keys_self_sim_from_input(x, layer_num=1).cpu()
-    assert (ssim - torch.from_numpy(g["keys_self_sim_l1"])).abs().max() < 2e-2
+    assert (ssim - torch.from_numpy(g["keys_self_sim_l1"])).abs().max() < 2e-3
     attn = ex.get_attn_feature_from_input(x)[1]
     assert attn.shape == (1, 6, 222, 222) and (attn.sum(-1) - 1).abs().max() < 1e-4
     ref_attn = torch.softmax((gq[:, :, 0].reshape(1, 222, 6, 64).permute(0, 2, 1, 3) * 0.125)
                              @ gq[:, :, 1].reshape(1, 222, 6, 64).permute(0, 2, 3, 1), dim=-1)
-    assert (attn.cpu() - ref_attn).abs().max() < 5e-3
+    assert (attn.cpu() - ref_attn).abs().max() < 1e-3
 
 
 def test_full_resolution_all_blocks_bench_weights():
@@ -209,14 +214,18 @@ def test_full_resolution_all_blocks_bench_weights():
     print(f"full-res 12 blocks, bench weights: min token cos {cos:.6f}, rel Frobenius {rel:.3e}")
 
 
-def test_attention_guards_and_safe_pass():
-    """dtk_vit_attention alone on crafted bf16 operands vs an fp64 softmax on the SAME operands.  The kernel exponentiates
-    scores optimistically against a reference that starts at 0 (vit_attention2.h, MODE 1); the rows below force every
-    branch of that logic: (5) scores up to +-60 -> row sums beyond 2^40 -> power-of-two rescale of O / l; (6) scores of
-    +-300 -> inf -> poisoned sum -> safe pass; (7) about -300 for EVERY key -> all-zero row -> safe pass; and ordinary
-    rows that share their wave with them.  S is not a multiple of the 64-key tile (masked tail)."""
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_attention_guards_and_safe_pass(dt):
+    """dtk_vit_attention alone on crafted 16-bit operands vs an fp64 softmax on the SAME operands, for both operand types.
+    The kernel exponentiates scores optimistically against a reference it estimates once from the first 64 keys and the
+    wave's own 32 keys (vit_attention2.h, MODE 1); the rows below force every branch of that logic: (5) scores up to +-60 ->
+    tile row sums beyond RESC_T -> power-of-two rescale of O / l, or beyond POISON_T -> safe pass (fp16: 2^9 / 2^15, bf16:
+    2^40 / 2^120); (6) scores of +-300 -> poisoned sum -> safe pass; (7) about -300 for EVERY key -> an estimate far
+    below 0; (8) a row whose large scores all sit in LATE tiles: the estimate is low and the sums jump past POISON_T in one
+    step (fp16); and ordinary rows that share their wave with them.  S is not a multiple of the 64-key tile (masked tail)."""
     from dino_tracker_amd import ops
-    from dino_tracker_amd._lib import check, lib
+    from dino_tracker_amd._lib import OPERAND_BF16, OPERAND_F16, check, lib
+    tdt = torch.float16 if dt == "fp16" else torch.bfloat16
     g = torch.Generator().manual_seed(11)
     F, Hh, S = 1, 2, 1000
     Sp = 1024
@@ -233,11 +242,16 @@ def test_attention_guards_and_safe_pass():
     q[0, 0, 7] *= 0.01
     q[0, 0, 7, 0] = -6.0
     q[0, 1, 700] *= 120.0   # a poisoned row in another wave / head, late in the sweep
-    qb, kb, vb = q.bfloat16(), k.bfloat16(), v.bfloat16()
+    # (8) head 1, row 300: channel 1 of the keys 640.. is large and the query looks along it: scores ~ +40 there, ~0 before
+    k[0, 1, 640:S, 1] += 20.0
+    q[0, 1, 300] *= 0.05
+    q[0, 1, 300, 1] = 2.0
+    qb, kb, vb = q.to(tdt), k.to(tdt), v.to(tdt)
     vt = vb.transpose(2, 3).contiguous()  # [F][H][64][Sp]
-    out = torch.empty(F, S, Hh * 64, dtype=torch.bfloat16, device="cuda")
+    out = torch.empty(F, S, Hh * 64, dtype=tdt, device="cuda")
     qd, kd, vd = qb.cuda().contiguous(), kb.cuda().contiguous(), vt.cuda().contiguous()
-    check(lib().dtk_vit_attention(ops._p(qd), ops._p(kd), ops._p(vd), ops._p(out), F, Hh, S, Sp, ops._stream()))
+    check(lib().dtk_vit_attention(ops._p(qd), ops._p(kd), ops._p(vd), ops._p(out), F, Hh, S, Sp,
+                                  OPERAND_F16 if dt == "fp16" else OPERAND_BF16, ops._stream()))
     s = qb.double()[:, :, :S] @ kb.double()[:, :, :S].transpose(2, 3)            # exp2-domain scores
     p = torch.softmax(s * 0.6931471805599453, dim=-1)
     ref = (p @ vb.double()[:, :, :S]).permute(0, 2, 1, 3).reshape(F, S, Hh * 64)
@@ -246,9 +260,99 @@ def test_attention_guards_and_safe_pass():
     err = (got - ref).abs().amax(dim=-1)[0]
     scale = ref.abs().amax(dim=-1)[0].clamp(min=0.05)
     rel = err / scale
-    # bf16 P and bf16 output: 2^-8 of the row's largest output, every row, incl. the crafted ones
-    assert rel.max() < 6e-3, (int(rel.argmax()), rel.max().item())
-    for row in (5, 6, 7, 700):
-        assert p[0, row // 1000 if row == 700 else 0].max() > 0  # (rows exist)
+    # 16-bit P and 16-bit output: 2^-8 (bf16) / 2^-11 (fp16) of the row's largest output, every row, incl. the crafted ones
+    tol = 6e-3 if dt == "bf16" else 1e-3
+    assert rel.max() < tol, (int(rel.argmax()), rel.max().item())
     # the crafted rows really are extreme: near one-hot / far from the reference 0
     assert s[0, 0, 6].abs().max() > 200 and s[0, 0, 7].max() < -150 and s[0, 0, 5].abs().max() > 45
+    assert s[0, 1, 300, 640:].min() > 30 and s[0, 1, 300, :96].max() < 8
+
+
+# ---- operand types and the fp16 range ---------------------------------------------------------------------------------
+def test_bf16_operands_on_request(vits):
+    """operand_dtype='bf16' (DTK_VIT_BF16): the round-2 arithmetic, kept for activations beyond fp16's range."""
+    sd, ex16 = vits
+    exb = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd, operand_dtype="bf16")
+    video = synth.synth_video(2, 140, 210, seed=79)
+    a, b = ex16.encode(video).cpu(), exb.encode(video).cpu()
+    assert not torch.equal(a, b)
+    for t in range(2):
+        ref = A.vit_tokens(video[t:t + 1], sd, "dinov2_vits14").permute(1, 2, 0).reshape(-1, 384)
+        c16, r16 = _check(a[t], ref)
+        cb, rb = _check(b[t], ref, **BF16_TOL)
+        print(f"frame {t}: fp16 rel {r16:.2e}, bf16 rel {rb:.2e}")
+        assert r16 < 0.4 * rb  # fp16 operands are what buys the end-to-end 1e-3 px
+
+
+def _outlier_weights(scale_fc2=1.0):
+    """ViT-S weights with the features of a trained DINOv2 the seeded initialisation lacks: 'massive activations' (a few
+    tokens whose residual stream carries 1e3-scale values in a few channels, here planted through the position
+    encoding of 5 grid cells and the CLS token), LayerNorm gains up to 8, LayerScale up to 3, and one block whose MLP
+    output is large (fc2 x scale_fc2)."""
+    sd = {k: v.clone() for k, v in synth.make_vit_weights("dinov2_vits14", seed=12, layerscale=0.5).items()}
+    g = torch.Generator().manual_seed(13)
+    pe = sd["pos_embed"]  # [1, 1 + 37*37, 384]
+    for cell in (0, 1, 400, 401 + 37, 1369):
+        ch = torch.randint(0, 384, (3,), generator=g)
+        pe[0, cell, ch] += torch.tensor([1500.0, -900.0, 600.0])
+    for i in range(12):
+        sd[f"blocks.{i}.norm1.weight"] *= 1.0 + 7.0 * torch.rand(384, generator=g) ** 4
+        sd[f"blocks.{i}.ls2.gamma"] *= 1.0 + 5.0 * torch.rand(384, generator=g) ** 4
+    sd["blocks.2.attn.qkv.weight"][:768] *= 1.5   # sharper attention in one block (scores to +-100 binades)
+    sd["blocks.3.mlp.fc2.weight"] *= scale_fc2
+    return sd
+
+
+def test_outlier_tokens_stay_in_fp16_range():
+    """1e3-scale outlier tokens in the fp32 residual stream, large gains, a peaked-attention block and an MLP whose output is
+    ~1e3: every 16-bit tensor must stay finite and un-saturated (overflow word 0, also with the full range scan) and the
+    features must match the fp32 oracle at the fp16 tolerance relative to the token norms."""
+    sd = _outlier_weights(scale_fc2=300.0)
+    ex = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd, check_range=True)
+    video = synth.synth_video(2, 238, 322, seed=80)
+    tok = ex.encode(video, layer=5, want="tokens").cpu()
+    assert ex.last_overflow == 0 and torch.isfinite(tok).all()
+    for t in range(2):
+        ref = A.vit_tokens(video[t:t + 1], sd, "dinov2_vits14", layer=5)
+        ref = ref.permute(1, 2, 0).reshape(-1, 384)
+        assert ref.abs().max() > 500  # the outliers are there
+        # (16-bit Q / K move a score by ~2^-12 |s|, and |s| reaches 100 here: the tolerance is 3x the plain one)
+        cos, rel = _check(tok[t, 1:], ref, cos_min=0.99999, rel_max=1e-3)
+        print(f"outlier frame {t}: max |x| {ref.abs().max().item():.0f}, min cos {cos:.7f}, rel {rel:.2e}")
+
+
+def test_fp16_saturation_is_reported_and_bf16_is_the_way_out():
+    """An MLP output beyond 65504 cannot be an fp16 residual update: the device saturates it (no inf / NaN downstream),
+    sets the overflow word, and `encode` raises naming operand_dtype='bf16' -- which then runs (bf16 tolerance)."""
+    sd = _outlier_weights(scale_fc2=3.0e5)
+    video = synth.synth_video(1, 140, 210, seed=81)
+    ex = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd)
+    with pytest.raises(RuntimeError, match="operand_dtype='bf16'"):
+        ex.encode(video, layer=4)
+    assert ex.last_overflow & 1
+    exb = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd, operand_dtype="bf16")
+    feat = exb.encode(video, layer=4).cpu()
+    ref = A.vit_tokens(video, sd, "dinov2_vits14", layer=4).permute(1, 2, 0).reshape(-1, 384)
+    assert torch.isfinite(feat).all()
+    _check(feat[0], ref, **BF16_TOL)
+
+
+# ---- ViT-L/14: the reference's shipped configuration (config/preprocessing.yaml:10-13), no reference checkout needed --------
+def test_vitl_layer15_full_resolution_and_all_24_blocks():
+    """dinov2_vitl14 (D = 1024, 16 heads, K = 1024 / 4096 GEMMs on gemm_wide_kernel): one 476 x 854 synthetic frame to the
+    hooked block 15 -- what preprocessing/save_dino_embed_video.py computes per frame -- and one small frame through all
+    24 blocks, against the fp32 oracle."""
+    sd = synth.make_vit_weights("dinov2_vitl14", seed=6, layerscale=0.1)
+    ex = VitExtractor("dinov2_vitl14", stride=7, device="cuda:0", state_dict=sd)
+    video = synth.synth_video(1, 476, 854, seed=82)
+    feat = ex.encode(video, layer=15).cpu()
+    assert feat.shape == (1, 67 * 121, 1024)
+    ref = A.vit_tokens(video, sd, "dinov2_vitl14", layer=15).permute(1, 2, 0).reshape(-1, 1024)
+    cos, rel = _check(feat[0], ref)
+    print(f"ViT-L block 15 at 476x854: min token cos {cos:.7f}, rel {rel:.2e}")
+    small = synth.synth_video(2, 140, 210, seed=83)
+    tok = ex.encode(small, want="tokens").cpu()  # layer None = 23
+    for t in range(2):
+        r = A.vit_tokens(small[t:t + 1], sd, "dinov2_vitl14").permute(1, 2, 0).reshape(-1, 1024)
+        cos, rel = _check(tok[t, 1:], r)
+        print(f"ViT-L 24 blocks, frame {t}: min token cos {cos:.7f}, rel {rel:.2e}")

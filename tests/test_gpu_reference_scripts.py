@@ -164,16 +164,20 @@ def test_device_metrics_random_tracks_first_and_strided():
 
 
 def test_end_to_end_from_the_video():
-    """video -> HIP ViT (bf16 operands) -> HIP Delta-DINO -> HIP infer vs the fp32 oracle on the same VIDEO (benchmark
-    weights, 322 x 238 x 5, 9 queries).  north_star's 1e-3 px is stated on identical inputs; P2 / P3 hold it on identical
-    features, and this test bounds what the bf16 ViT adds (measured: median 5e-4, max 1.1-1.4e-3 px, flags identical;
-    scripts/e2e_error.py, profiles/r02_e2e_error_*.json)."""
+    """north_star's bar on identical VIDEOS: video -> HIP ViT (fp16 operands) -> HIP Delta-DINO -> HIP infer vs the fp32
+    oracle on the same video (oracle ViT -> oracle refine -> oracle infer), benchmark weights, 854 x 476, T = 8, 64 grid
+    queries: every predicted position within 1e-3 px, every occlusion flag identical.  (Round 2, bf16 operands: p99
+    1.4e-3 px, 22 % of the points beyond 1e-3.)  scripts/e2e_error.py is the measurement; profiles/r03_e2e_error_*.json."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import e2e_error
-    r = e2e_error.run(238, 322, 5, 3)
+    r = e2e_error.run(476, 854, 8, 8)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "e2e_error_test_476x854x8.json"), "w") as fh:
+        json.dump(r, fh, indent=1)
     px = r["px_err_vs_oracle_on_same_video"]
-    assert r["feature_rel_err_P1"] < 3e-3
-    assert px["p50"] < 1e-3 and px["max"] < 3e-3, px
+    print("end to end from the video:", json.dumps(px), "P1 feature rel err", r["feature_rel_err_P1"])
+    assert r["feature_rel_err_P1"] < 3e-4
+    assert px["max"] <= 1e-3, px
     assert r["occ_mismatch_same_video"] == 0
     assert r["px_err_vs_oracle_on_same_features"]["max"] < 1e-3
 

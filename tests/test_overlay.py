@@ -3,6 +3,8 @@ while non-hot-path modules still come from the reference checkout when it is pre
 script file sitting in a reference-shaped directory, which is the case `python script.py` + PYTHONPATH gets wrong
 (the script's directory precedes PYTHONPATH): that is what `python -m dino_tracker_amd.run` is for."""
 import os
+
+import pytest
 import subprocess
 import sys
 import textwrap
@@ -124,3 +126,45 @@ def test_run_videos_partitions_data_paths_over_ranks(tmp_path):
     r = subprocess.run([sys.executable, "-m", "dino_tracker_amd.run_videos", str(bad), "--data-paths"] + paths[:3],
                        env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 1 and "video1" in r.stderr
+
+
+def test_run_videos_pins_the_local_gpu_inside_an_existing_restriction():
+    """a job already restricted to some GPUs (HIP_VISIBLE_DEVICES=4,5,6,7 from a scheduler) must hand rank r entry r
+    of THAT list, not device r."""
+    from dino_tracker_amd.run_videos import pin_local_gpu
+    env = {"HIP_VISIBLE_DEVICES": "4,5,6,7"}
+    pin_local_gpu(env, 2)
+    assert env["HIP_VISIBLE_DEVICES"] == "6"
+    env = {"CUDA_VISIBLE_DEVICES": "1, 3"}
+    pin_local_gpu(env, 1)
+    assert env == {"CUDA_VISIBLE_DEVICES": "3"}
+    env = {"ROCR_VISIBLE_DEVICES": "2,3"}
+    pin_local_gpu(env, 1)
+    assert env["HIP_VISIBLE_DEVICES"] == "1" and env["ROCR_VISIBLE_DEVICES"] == "2,3"
+    env = {}
+    pin_local_gpu(env, 5)
+    assert env == {"HIP_VISIBLE_DEVICES": "5"}
+    with pytest.raises(SystemExit):
+        pin_local_gpu({"HIP_VISIBLE_DEVICES": "0,1"}, 3)
+
+
+def test_tapvid_metrics_of_an_empty_video_are_nan_not_an_exception():
+    """eval/metrics.py divides numpy scalars (nan + a warning when a video has no evaluated / visible points)."""
+    import math
+    from dino_tracker_amd.tapvid import metrics_from_counts
+    m = metrics_from_counts([0] * 18)
+    assert all(math.isnan(v) for v in m.values())
+    m = metrics_from_counts([10, 5, 0] + [0] * 15)
+    assert m["occlusion_accuracy"] == 0.5 and math.isnan(m["average_jaccard"])
+
+
+def test_launcher_refuses_a_path_that_resolves_to_the_reference_before_running_it(tmp_path):
+    """the resolution check runs BEFORE the script (it used to run in `finally`, after the whole reference path
+    had executed), and an exception of the script itself is not replaced."""
+    import subprocess, sys  # noqa: E401
+    fake = tmp_path / "models"
+    fake.mkdir()
+    (tmp_path / "boom.py").write_text("raise ValueError('the script ran')\n")
+    r = subprocess.run([sys.executable, "-m", "dino_tracker_amd.run", str(tmp_path / "boom.py")], capture_output=True,
+                       text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode != 0 and "the script ran" in r.stderr and "ValueError" in r.stderr
