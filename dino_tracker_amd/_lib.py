@@ -101,6 +101,9 @@ SIGNATURES = {
                           c_void_p, c_size_t, c_void_p]),
     "dtk_argmax_cells": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "dtk_bb_nms_workspace_bytes": (c_size_t, [ctypes.POINTER(Geom), c_int]),
+    "dtk_bb_nms": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
+                           c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "dtk_feat_f16_bytes": (c_size_t, [ctypes.POINTER(Geom)]),
     "dtk_make_feat_f16": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p]),
     "dtk_traj_cos_sims": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

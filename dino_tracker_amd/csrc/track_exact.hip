@@ -442,3 +442,155 @@ int dtk_argmax_exact(const dtk_geom* g, const float* feat, const float* norms, c
     }
     return DTK_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// DINO best-buddy ambiguity ratio (second half): preprocessing_dino_bb/compute_dino_bb_nms.py:12-66.
+// Per source (a best-buddy cell of frame sf) the reference takes the affinity row against frame tf, its top-k (400)
+// entries, boxes of +-box_size px around their cell centres, torchvision batched_nms (greedy, descending score, a box is
+// dropped when its IoU with an already KEPT box exceeds the threshold), zeroes the dropped affinities and returns the two
+// largest entries of that masked list and r = second / first.
+// Only the first two kept boxes matter, and greedy NMS decides them without the full sweep: the arg-max is always kept,
+// and the next candidate in descending order that does not overlap IT is the second kept one (everything in between
+// overlaps the arg-max, the only kept box so far).  So per source:
+//   peak   = first maximum of the row (cell k*, value a)
+//   K      = the topk-th largest value of the row (exact: bit-wise bisection on an order-preserving integer key)
+//   b      = max { v[k] : v[k] >= K, k != k*, IoU(box_k, box_k*) <= thresh }      (second kept box, if any)
+//   nsupp  = # { k : v[k] >= K, k != k*, IoU(box_k, box_k*) > thresh }             (zeroed entries)
+//   top-2 of the multiset { a, b, 0 x min(nsupp, 2) }  ->  peak_affs[2], r = second / first.
+// IoU in fp32 exactly as torchvision's nms kernel computes it (boxes = centre -+ box_size, centres = patch/2 + stride *
+// cell: all integers, so also equal to the coordinate-offset form batched_nms uses for few boxes).
+// One workgroup per source over its fp32 map (corr_exact_kernel, no ReLU), rows in registers.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int NMS_VPT = 40;  // values per thread: HW <= 256 * 40 = 10240 cells
+
+__device__ __forceinline__ unsigned order_key(float v) {
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void bb_nms_kernel(dtk_geom g, const float* __restrict__ maps, int HWs, float box_half,
+                                                     float iou_thresh, int topk, float* __restrict__ peak_affs,
+                                                     float* __restrict__ r_out, int m0, int count) {
+    __shared__ float red[4];
+    __shared__ int redi[4];
+    __shared__ int s_cnt;
+    const int i = blockIdx.x;
+    if (i >= count) return;
+    const int tid = threadIdx.x, HW = g.ph * g.pw;
+    const float* map = maps + (size_t)i * HWs;
+    float v[NMS_VPT];
+    float best = -INFINITY;
+    int bi = INT_MAX;
+#pragma unroll
+    for (int j = 0; j < NMS_VPT; ++j) {
+        const int c = tid + 256 * j;
+        v[j] = c < HW ? map[c] : -INFINITY;
+        if (c < HW && v[j] > best) { best = v[j]; bi = c; }
+    }
+    // ---- first maximum (torch semantics: lowest index among equals) ----
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, WAVE);
+        const int oi = __shfl_xor(bi, o, WAVE);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { red[tid >> 6] = best; redi[tid >> 6] = bi; }
+    __syncthreads();
+    best = red[0]; bi = redi[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (red[w] > best || (red[w] == best && redi[w] < bi)) { best = red[w]; bi = redi[w]; }
+    // ---- K = key of the topk-th largest value: build it bit by bit, most significant first ----
+    unsigned K = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = K | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < NMS_VPT; ++j) c += (tid + 256 * j < HW && order_key(v[j]) >= cand) ? 1 : 0;
+        c = wave_sum_i(c);
+        __syncthreads();
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        if ((tid & 63) == 0) atomicAdd(&s_cnt, c);
+        __syncthreads();
+        if (s_cnt >= topk) K = cand;
+    }
+    // ---- second kept box / number of suppressed ones among the top-k ----
+    const float half = (float)(g.patch / 2), st = (float)g.stride;
+    const float pcx = half + st * (float)(bi % g.pw), pcy = half + st * (float)(bi / g.pw);
+    const float px1 = pcx - box_half, px2 = pcx + box_half, py1 = pcy - box_half, py2 = pcy + box_half;
+    const float parea = (px2 - px1) * (py2 - py1);
+    float b = -INFINITY;
+    int nsupp = 0;
+#pragma unroll
+    for (int j = 0; j < NMS_VPT; ++j) {
+        const int c = tid + 256 * j;
+        if (c < HW && c != bi && order_key(v[j]) >= K) {
+            const float cx = half + st * (float)(c % g.pw), cy = half + st * (float)(c / g.pw);
+            const float x1 = cx - box_half, x2 = cx + box_half, y1 = cy - box_half, y2 = cy + box_half;
+            const float iw = fmaxf(fminf(x2, px2) - fmaxf(x1, px1), 0.f), ih = fmaxf(fminf(y2, py2) - fmaxf(y1, py1), 0.f);
+            const float inter = iw * ih;
+            const float iou = inter / (parea + (x2 - x1) * (y2 - y1) - inter);
+            if (iou > iou_thresh) ++nsupp;
+            else b = fmaxf(b, v[j]);
+        }
+    }
+    b = wave_max(b);
+    nsupp = wave_sum_i(nsupp);
+    __syncthreads();
+    if ((tid & 63) == 0) { red[tid >> 6] = b; redi[tid >> 6] = nsupp; }
+    __syncthreads();
+    if (tid == 0) {
+        b = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        nsupp = redi[0] + redi[1] + redi[2] + redi[3];
+        // two largest of { best, b, 0 (nsupp >= 1), 0 (nsupp >= 2) }
+        float c4[4] = {best, b, nsupp >= 1 ? 0.f : -INFINITY, nsupp >= 2 ? 0.f : -INFINITY};
+        float t1 = -INFINITY, t2 = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (c4[q] > t1) { t2 = t1; t1 = c4[q]; }
+            else if (c4[q] > t2) t2 = c4[q];
+        }
+        peak_affs[2 * (size_t)(m0 + i)] = t1;
+        peak_affs[2 * (size_t)(m0 + i) + 1] = t2;
+        r_out[m0 + i] = t2 / t1;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t dtk_bb_nms_workspace_bytes(const dtk_geom* g, int M) { return dtk_track_exact_workspace_bytes(g, M); }
+
+extern "C" int dtk_bb_nms(const dtk_geom* g, const float* feat, const float* norms, const float* emb, const int32_t* src_row,
+                          const int32_t* tgt, float box_size, float iou_thresh, int topk, float* peak_affs, float* r, int M,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    DTK_REQUIRE(g && feat && norms && emb && tgt && peak_affs && r && workspace, "dtk_bb_nms: null pointer");
+    DTK_REQUIRE(M >= 0, "dtk_bb_nms: negative M");
+    if (M == 0) return DTK_OK;
+    DTK_REQUIRE(g->C % TK == 0, "dtk_bb_nms: C=%d must be a multiple of %d", g->C, TK);
+    const int HWs = exact_hws(g), HW = g->ph * g->pw;
+    DTK_REQUIRE(HW <= 256 * NMS_VPT, "dtk_bb_nms: %d cells per frame (max %d)", HW, 256 * NMS_VPT);
+    DTK_REQUIRE(topk >= 2 && topk <= HW, "dtk_bb_nms: topk=%d must be in [2, %d] (torch.topk)", topk, HW);
+    long long chunk = (long long)(workspace_bytes / ((size_t)(HWs + 1) * sizeof(float)));
+    if (chunk > M) chunk = M;
+    if (chunk > 65535LL * TM) chunk = 65535LL * TM;
+    if (chunk < 1) {
+        dtk_set_error("dtk_bb_nms: workspace of %zu B holds no map", workspace_bytes);
+        return DTK_E_WORKSPACE;
+    }
+    hipStream_t st = dtk_stream(stream);
+    float* maps = reinterpret_cast<float*>(workspace);
+    float* snorm = maps + (size_t)chunk * HWs;
+    for (long long m0 = 0; m0 < M; m0 += chunk) {
+        const int cnt = (int)((M - m0) < chunk ? (M - m0) : chunk);
+        DTK_LAUNCH("row_norms", row_norms_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, emb, src_row, snorm, (int)m0, cnt, M,
+                   (const int32_t*)nullptr, g->C);
+        DTK_LAUNCH("corr_exact", corr_exact_kernel, dim3(dtk_cdiv(HW, TN), dtk_cdiv(cnt, TM)), dim3(256), 0, st, *g, feat, norms,
+                   emb, src_row, tgt, snorm, maps, (int)m0, cnt, M, (const int32_t*)nullptr, HWs, 0);
+        DTK_LAUNCH("bb_nms", bb_nms_kernel, dim3(cnt), dim3(256), 0, st, *g, maps, HWs, box_size, iou_thresh, topk, peak_affs, r,
+                   (int)m0, cnt);
+    }
+    return DTK_OK;
+}

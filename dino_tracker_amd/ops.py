@@ -160,6 +160,23 @@ def argmax_cells(g: Geom, feat: torch.Tensor, norms: torch.Tensor, feat_f16: Opt
     return cell, cos
 
 
+def bb_nms(g: Geom, feat: torch.Tensor, norms: torch.Tensor, emb: torch.Tensor, src_row: Optional[torch.Tensor],
+           tgt: torch.Tensor, box_size: float = 50.0, iou_thresh: float = 0.2, topk: int = 400,
+           max_workspace_bytes: int = 1 << 30) -> Tuple[torch.Tensor, torch.Tensor]:
+    """dtk_bb_nms: (peak_affs [M, 2], r [M]) of preprocessing_dino_bb/compute_dino_bb_nms.py:12-44 for M sources."""
+    M = tgt.shape[0]
+    peak = torch.empty((M, 2), dtype=torch.float32, device=feat.device)
+    r = torch.empty(M, dtype=torch.float32, device=feat.device)
+    if M == 0:
+        return peak, r
+    nb = min(int(lib().dtk_bb_nms_workspace_bytes(g, M)), max_workspace_bytes)
+    ws = torch.empty(nb, dtype=torch.uint8, device=feat.device)
+    check(lib().dtk_bb_nms(g, _p(feat, torch.float32), _p(norms, torch.float32), _p(emb, torch.float32),
+                           _p(src_row, torch.int32), _p(tgt, torch.int32), float(box_size), float(iou_thresh), int(topk),
+                           _p(peak), _p(r), M, _p(ws), nb, _stream()))
+    return peak, r
+
+
 def traj_cos_sims(S: torch.Tensor, tq: torch.Tensor, N: int, T: int) -> torch.Tensor:
     C = S.shape[-1]
     cs = torch.empty((N, T), dtype=torch.float32, device=S.device)

@@ -232,6 +232,16 @@ int dtk_argmax_cells(const dtk_geom* g, const float* feat, const float* norms, c
                      const int32_t* src_row, const int32_t* tgt, int32_t* arg_cell, float* arg_cos, int M, int method,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* DINO best-buddy ambiguity ratio (preprocessing_dino_bb/compute_dino_bb_nms.py:12-66): for each source m
+ * (row src_row[m] of emb = the feature of a best-buddy cell) the cosine affinity row against frame tgt[m], its top-`topk`
+ * entries (:14), boxes of +-box_size px around their cell centres (:21-27), torchvision batched_nms at iou_thresh (:30),
+ * suppressed affinities zeroed (:34-36), then the two largest of the masked list -> peak_affs[m][0..1] (:38) and
+ * r[m] = second / first (:42).  fp32 everywhere (exact-path correlation).  Workspace: dtk_bb_nms_workspace_bytes. */
+size_t dtk_bb_nms_workspace_bytes(const dtk_geom* g, int M);
+int dtk_bb_nms(const dtk_geom* g, const float* feat, const float* norms, const float* emb, const int32_t* src_row,
+               const int32_t* tgt, float box_size, float iou_thresh, int topk, float* peak_affs, float* r, int M,
+               void* workspace, size_t workspace_bytes, void* stream);
+
 /* fp16 unit-norm copy of the feature volume consumed by DTK_TRACK_MFMA: f16[t][row][col][c] = 32 F/|F| with every map
  * row padded with zero cells to a multiple of 128 columns (an N-tile of the GEMM is one map row); C % 32 == 0. */
 size_t dtk_feat_f16_bytes(const dtk_geom* g);

@@ -416,3 +416,32 @@ def best_buddies_pair(fs: torch.Tensor, ft: torch.Tensor):
     rng = torch.arange(fs.shape[0])
     keep = rng == tmax[smax]
     return rng[keep], smax[keep], aff[rng[keep], smax[keep]]
+
+
+def bb_nms_ratio(aff: torch.Tensor, pw: int, box_size: float = 50.0, iou_thresh: float = 0.2, topk: int = 400,
+                 patch: int = 14, stride: int = 7):
+    """preprocessing_dino_bb/compute_dino_bb_nms.py:12-44 (`get_bb_sim_indices`) for affinity rows aff [B, HW] over a
+    token grid of width pw: (top2 [B, 2], r [B]).  Restated WITHOUT the NMS sweep: of the top-k entries the arg-max is
+    always kept by greedy NMS, and the second kept box is the best-scoring one whose IoU with the arg-max box is <= thresh
+    (everything scored in between overlaps the arg-max, the only box kept until then); suppressed entries count as 0
+    (`affs_filt * filt_idx_mask`, :36) and the answer is the top-2 of that masked list (:38).  Pinned against the
+    reference function run with a restated torchvision.ops.batched_nms (tests/test_oracle_vs_reference.py)."""
+    b, hw = aff.shape
+    vals, idx = torch.topk(aff, k=topk, dim=1)                      # sorted descending; [:, 0] is the arg-max
+    half = patch // 2
+    cx = (half + stride * (idx % pw)).float()
+    cy = (half + stride * (idx // pw)).float()
+    x1, x2, y1, y2 = cx - box_size, cx + box_size, cy - box_size, cy + box_size
+    iw = (torch.minimum(x2, x2[:, :1]) - torch.maximum(x1, x1[:, :1])).clamp(min=0)
+    ih = (torch.minimum(y2, y2[:, :1]) - torch.maximum(y1, y1[:, :1])).clamp(min=0)
+    inter = iw * ih
+    area = (x2 - x1) * (y2 - y1)
+    supp = inter / (area[:, :1] + area - inter) > iou_thresh
+    supp[:, 0] = False
+    neg = torch.full_like(vals, float("-inf"))
+    second = torch.where(~supp, vals, neg)[:, 1:].max(dim=1).values if topk > 1 else neg[:, 0]
+    nsupp = supp.sum(dim=1)
+    zero1 = torch.where(nsupp >= 1, torch.zeros(b), neg[:, 0])
+    zero2 = torch.where(nsupp >= 2, torch.zeros(b), neg[:, 0])
+    top2 = torch.stack([vals[:, 0], second, zero1, zero2], dim=1).topk(2, dim=1).values
+    return top2, top2[:, 1] / top2[:, 0]

@@ -347,3 +347,79 @@ def test_best_buddies(method):
             assert (e["cos_sims"].cpu() - cs).abs().max() < 2e-6
             total += si.numel()
     assert total > 100
+
+
+def test_best_buddies_nms_ratio():
+    """N4 second half: compute_dino_bb_nms.py on the device (dtk_bb_nms over all frame pairs in one call + compute_max_r by
+    index arithmetic) vs the oracle's restatement, which tests/test_oracle_vs_reference.py pins against the reference
+    functions.  Includes a source whose best competitor sits INSIDE the suppression zone of its peak (r must come from the
+    next one outside) and one whose row has a second, far-away copy of the peak (r ~ 1)."""
+    from dino_tracker_amd.best_buddies import compute_bb_nms_all, create_meshgrid, extract_best_buddies
+    Hs, Ws, T, C = 238, 322, 3, 64
+    ph, pw = 33, 45
+    feats = synth.synth_features(T, C, ph, pw, seed=67)
+    feats[1, :, 25, 40] = feats[1, :, 6, 5] * 1.01    # a far-away near-copy of a cell of frame 1 -> an ambiguous match, r ~ 1
+    bb = extract_best_buddies(feats, Hs, Ws, stride=7, device="cuda:0", method=ops.TRACK_EXACT)
+    out = compute_bb_nms_all({k: dict(v) for k, v in bb.items()}, feats, Hs, Ws, stride=7, box_size=50, iou_thresh=0.2,
+                             topk=400, device="cuda:0")
+    tm = feats.permute(0, 2, 3, 1).reshape(T, -1, C)
+    cell = lambda xy: (xy[:, 1].long() - 7) // 7 * pw + (xy[:, 0].long() - 7) // 7  # noqa: E731
+    raw = {}
+    for key, e in bb.items():
+        s, t = (int(x) for x in key.split("_"))
+        src = tm[s][cell(e["source_coords"].cpu())]
+        aff = (src @ tm[t].t()) / torch.clamp(src.norm(dim=1)[:, None] * tm[t].norm(dim=1)[None], min=1e-8)
+        raw[key] = A.bb_nms_ratio(aff, pw, 50.0, 0.2, 400)
+    n_amb = 0
+    for key, e in out.items():
+        s, t = key.split("_")
+        top2, r = raw[key]
+        assert e["peak_coords"] is None
+        assert (e["peak_affs"].cpu() - top2).abs().max() < 2e-6, key
+        # compute_max_r: the pair's r and the reverse pair's
+        rev = f"{t}_{s}"
+        where = torch.full((ph * pw,), -1, dtype=torch.long)
+        where[cell(bb[rev]["source_coords"].cpu())] = torch.arange(bb[rev]["source_coords"].shape[0])
+        j = where[cell(bb[key]["target_coords"].cpu())]
+        want = torch.maximum(r, raw[rev][1][j])
+        assert (e["r"].cpu() - want).abs().max() < 5e-6, key
+        n_amb += int((want > 0.97).sum())
+        assert (want > 0.05).float().mean() > 0.3 and (want < 0.9).float().mean() > 0.3
+    assert n_amb >= 1
+
+
+def test_bb_nms_kernel_edge_rows():
+    """dtk_bb_nms on crafted affinity rows (features = one-hot-ish so that the row IS the crafted vector): every other
+    top-k entry inside the zone (second = 0 from the zeroed entries), negative runner-up, fewer candidates outside the
+    zone than 2.  (Exact ties of scores are left out: torchvision's nms sorts them in no defined order.)"""
+    from dino_tracker_amd._lib import make_geom
+    Hs, Ws, C = 238, 322, 64
+    ph, pw, HW = 33, 45, 33 * 45
+    g = make_geom(2, C, Hs, Ws)
+    gen = torch.Generator().manual_seed(5)
+    # frame 1: unit vectors e_0 .. e_3 at four chosen cells, everything else orthogonal to the sources (components >= 8);
+    # a source's affinity row is then its own first four components (normalised) at those cells and exactly 0 elsewhere
+    f1 = torch.randn(HW, C, generator=gen)
+    f1[:, :8] = 0.0   # every other cell is orthogonal to the sources below: affinity exactly 0
+    special = {"peak": 10 * pw + 10, "near": 10 * pw + 12, "far": 25 * pw + 35, "far2": 3 * pw + 40}
+    for i, c in enumerate(special.values()):
+        f1[c] = 0
+        f1[c, i] = 1.0
+    feats = torch.zeros(2, HW, C)
+    feats[1] = f1
+    # sources (rows of emb): affinity with cell `k` ~ component k of the unit-normalised source
+    srcs = torch.zeros(4, C)
+    srcs[0, :4] = torch.tensor([1.0, 0.9, 0.0, 0.0])      # runner-up inside the zone only: second = 0 -> r = 0
+    srcs[1, :4] = torch.tensor([1.0, 0.9, 0.5, 0.2])      # runner-up inside the zone, far = 0.5 outside -> r = 0.5
+    srcs[2, :4] = torch.tensor([1.0, 0.0, -0.5, 0.0])     # negative far candidate
+    srcs[3, :4] = torch.tensor([0.2, 1.0, 0.3, 0.9])      # the peak is `near`; `peak` is in ITS zone, far2 = 0.9 is not
+    feat_d = feats.cuda().contiguous()
+    norms = feat_d.norm(dim=-1).contiguous()
+    emb = srcs.cuda().contiguous()
+    tgt = torch.ones(4, dtype=torch.int32, device="cuda")
+    peak, r = ops.bb_nms(g, feat_d, norms, emb, None, tgt, 50.0, 0.2, 400)
+    aff = (srcs @ f1.t()) / torch.clamp(srcs.norm(dim=1)[:, None] * f1.norm(dim=1)[None], min=1e-8)
+    top2, rr = A.bb_nms_ratio(aff, pw, 50.0, 0.2, 400)
+    assert (peak.cpu() - top2).abs().max() < 1e-6, (peak.cpu(), top2)
+    assert torch.allclose(r.cpu(), rr, atol=1e-6, equal_nan=True), (r.cpu(), rr)
+    assert float(rr[0]) == 0.0 and abs(float(rr[1]) - 0.5) < 1e-6 and float(rr[2]) == 0.0 and abs(float(rr[3]) - 0.9) < 1e-6
