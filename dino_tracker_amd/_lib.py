@@ -115,6 +115,12 @@ SIGNATURES = {
                                   c_int, c_int, c_int, c_void_p, c_void_p]),
     "dtk_blurpool_forward": (c_int, [c_void_p, c_void_p, ctypes.c_int64, c_int, c_int, c_void_p]),
     "dtk_blurpool_backward": (c_int, [c_void_p, c_void_p, ctypes.c_int64, c_int, c_int, c_void_p]),
+    "dtk_gemm_nt_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dtk_im2col": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                           ctypes.c_int64, c_void_p]),
+    "dtk_col2im": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dtk_transpose_f32": (c_int, [c_void_p, c_void_p, ctypes.c_int64, ctypes.c_int64, c_int, c_void_p]),
     "dtk_batchnorm_workspace_bytes": (c_size_t, [c_int]),
     "dtk_batchnorm_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                             c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,

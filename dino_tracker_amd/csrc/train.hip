@@ -376,3 +376,307 @@ extern "C" int dtk_blurpool_backward(const float* dy, float* dx, int64_t planes,
                (long long)planes, H, W, Ho, Wo);
     return DTK_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Convolutions of the training step as matrix products on the fp16 matrix cores, fp32-grade (round 3).
+//
+// Round 2 ran every convolution of the Delta-DINO CNN (forward, data gradient, weight gradient; delta_dino.py:29-31 under
+// autograd, dino_tracker.py:392-448) as ATen im2col / col2im + an fp32 library GEMM: 40 % of the iteration's kernel time at
+// fp32 vector rates.  Here:
+//   gemm_nt_split_kernel   C[m][n] (+)= sum_k A[m][k] B[n][k], both operands fp32 with the reduction index contiguous, split
+//                          x = hi + lo into fp16 halves WHILE they are staged into LDS (after a power-of-two operand scale
+//                          that keeps the halves normal numbers), product = hi.hi + hi.lo + lo.hi on MFMA 16x16x32 f16 with
+//                          fp32 accumulation -- the scheme of delta_dino.hip / refine_corr (2^-22 relative per operand,
+//                          tests/test_numeric_claims.py) -- 128 x 128 tiles, batched, optional split of the reduction over
+//                          workgroups (atomic accumulation) for the weight gradient whose reduction runs over all pixels.
+//   im2col_kernel          unfolded operand of a stride-1 k x k convolution with reflect (or zero) padding and dilation, in
+//                          either of the two layouts the three products need (below); col2im_kernel its adjoint as a GATHER
+//                          (incl. the adjoint of the reflect padding: a pixel near the border also collects what its mirror
+//                          images in the padding received), transpose_kernel for the operands that are reduction-major.
+//   forward        Y[cout][l]   = sum_k W[cout][k]  cols[l][k]          cols  = im2col layout 0  [L][Kp]
+//   weight grad    dW[cout][k]  = sum_l dY[cout][l] colsT[k][l]         colsT = im2col layout 1  [Kp][Lp], all frames and
+//                                                                       pixel chunks accumulate into one dW
+//   data grad      dcols[k][l]  = sum_c Wt[k][c]    dYt[l][c]  -> col2im   (Wt, dYt: transposes)
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+constexpr int GT = 128, GKS = 32, GRP = 40;  // tile side, k-step, LDS row pitch in halves (80 B: conflict-free fragments)
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                            float* __restrict__ C, int M, int N, int K, long long lda,
+                                                            long long ldb, long long ldc, long long sA, long long sB,
+                                                            long long sC, int split_k, int k_chunk, int accumulate,
+                                                            const float* __restrict__ scale_a, const float* __restrict__ scale_b) {
+    __shared__ __attribute__((aligned(16))) half_t Ah[GT * GRP], Al[GT * GRP], Bh[GT * GRP], Bl[GT * GRP];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int bz = blockIdx.z / split_k, ks = blockIdx.z - bz * split_k;
+    A += bz * sA;
+    B += bz * sB;
+    C += bz * sC;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int k0 = ks * k_chunk, k1 = min(K, k0 + k_chunk);
+    if (k0 >= k1) return;
+    const float sa = scale_a ? *scale_a : 1.f, sb = scale_b ? *scale_b : 1.f;
+    const int wr = w >> 1, wc = w & 1;  // wave tile 64 x 64
+    const int fj = lane & 15, fg = lane >> 4;
+    // loader: piece p = tid + 256 i (i < 4): row p >> 3 of the tile, floats 4 (p & 7) .. + 3 of the k-step
+    float4 ra[4], rb[4];
+    auto load = [&](int kk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = tid + 256 * i, row = p >> 3, kq = kk + (p & 7) * 4;
+            const int am = m0 + row, bn = n0 + row;
+            if (VEC) {  // rows 16-byte aligned and K a multiple of 4: whole pieces are inside or outside
+                ra[i] = (am < M && kq < k1) ? *reinterpret_cast<const float4*>(A + am * lda + kq) : float4{0.f, 0.f, 0.f, 0.f};
+                rb[i] = (bn < N && kq < k1) ? *reinterpret_cast<const float4*>(B + bn * ldb + kq) : float4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                float a[4], b[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[e] = (am < M && kq + e < k1) ? A[am * lda + kq + e] : 0.f;
+                    b[e] = (bn < N && kq + e < k1) ? B[bn * ldb + kq + e] : 0.f;
+                }
+                ra[i] = float4{a[0], a[1], a[2], a[3]};
+                rb[i] = float4{b[0], b[1], b[2], b[3]};
+            }
+        }
+    };
+    auto split_store = [&](half_t* hp, half_t* lp, int row, int kq, const float4& v, float s) {
+        const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+        h4v hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = (half_t)x[e];
+            lo[e] = (half_t)(x[e] - (float)hi[e]);
+        }
+        *reinterpret_cast<h4v*>(hp + row * GRP + kq) = hi;
+        *reinterpret_cast<h4v*>(lp + row * GRP + kq) = lo;
+    };
+    f4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f4{0.f, 0.f, 0.f, 0.f};
+    load(k0);
+    for (int kk = k0; kk < k1; kk += GKS) {
+        __syncthreads();  // the previous step's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = tid + 256 * i;
+            split_store(Ah, Al, p >> 3, (p & 7) * 4, ra[i], sa);
+            split_store(Bh, Bl, p >> 3, (p & 7) * 4, rb[i], sb);
+        }
+        __syncthreads();
+        if (kk + GKS < k1) load(kk + GKS);  // in flight under the MFMAs
+        h8 bh[4], bl[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            bh[ni] = *reinterpret_cast<const h8*>(&Bh[(wc * 64 + ni * 16 + fj) * GRP + fg * 8]);
+            bl[ni] = *reinterpret_cast<const h8*>(&Bl[(wc * 64 + ni * 16 + fj) * GRP + fg * 8]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const h8 ah = *reinterpret_cast<const h8*>(&Ah[(wr * 64 + mi * 16 + fj) * GRP + fg * 8]);
+            const h8 al = *reinterpret_cast<const h8*>(&Al[(wr * 64 + mi * 16 + fj) * GRP + fg * 8]);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                // D[i][j] = sum_k A_op[i][k] B_op[j][k]: first operand = rows m, second = rows n
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ni], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ni], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+    }
+    // D fragment: lane (fg, fj) holds rows 4 fg + r (r = 0..3) of column fj of each 16 x 16 tile
+    const float inv = 1.f / (sa * sb);
+    const bool atomic = split_k > 1 || accumulate == 2;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wc * 64 + ni * 16 + fj;
+            if (n >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wr * 64 + mi * 16 + fg * 4 + r;
+                if (m >= M) continue;
+                float* dst = C + m * ldc + n;
+                const float v = acc[mi][ni][r] * inv;
+                if (atomic) atomicAdd(dst, v);
+                else *dst = accumulate ? *dst + v : v;
+            }
+        }
+}
+
+// reflect-padded source index of padded coordinate q (torch 'reflect': no edge repeat)
+__device__ __forceinline__ int reflect_idx(int q, int pad, int n) {
+    int s = q - pad;
+    if (s < 0) s = -s;
+    if (s >= n) s = 2 * (n - 1) - s;
+    return s;
+}
+
+// layout 0: cols[f][l][Kp], one workgroup per 8 output pixels (a thread walks k with stride 32: coalesced 128-byte stores)
+// layout 1: cols[f][Kp][Lp], pixels contiguous
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ cols, int C, int H, int W,
+                                                     int ks, int pad, int dil, int reflect, int layout, int Kp, long long Lp) {
+    const int f = blockIdx.z;
+    const long long L = (long long)H * W;
+    const float* xf = x + (long long)f * C * L;
+    const int K = C * ks * ks;
+    if (layout == 0) {
+        float* cf = cols + (long long)f * L * Kp;
+        const long long l = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+        if (l >= L) return;
+        const int oy = (int)(l / W), ox = (int)(l - (long long)oy * W);
+        for (int k = threadIdx.x & 31; k < Kp; k += 32) {
+            float v = 0.f;
+            if (k < K) {
+                const int c = k / (ks * ks), rem = k - c * ks * ks, ky = rem / ks, kx = rem - ky * ks;
+                int sy = oy + ky * dil, sx = ox + kx * dil;  // padded coordinates
+                bool ok = true;
+                if (reflect) { sy = reflect_idx(sy, pad, H); sx = reflect_idx(sx, pad, W); }
+                else { sy -= pad; sx -= pad; ok = sy >= 0 && sy < H && sx >= 0 && sx < W; }
+                if (ok) v = xf[(long long)c * L + (long long)sy * W + sx];
+            }
+            cf[l * Kp + k] = v;
+        }
+    } else {
+        float* cf = cols + (long long)f * Kp * Lp;
+        const int k = blockIdx.y;
+        const long long l = (long long)blockIdx.x * 256 + threadIdx.x;
+        if (l >= Lp) return;
+        float v = 0.f;
+        if (k < K && l < L) {
+            const int oy = (int)(l / W), ox = (int)(l - (long long)oy * W);
+            const int c = k / (ks * ks), rem = k - c * ks * ks, ky = rem / ks, kx = rem - ky * ks;
+            int sy = oy + ky * dil, sx = ox + kx * dil;
+            bool ok = true;
+            if (reflect) { sy = reflect_idx(sy, pad, H); sx = reflect_idx(sx, pad, W); }
+            else { sy -= pad; sx -= pad; ok = sy >= 0 && sy < H && sx >= 0 && sx < W; }
+            if (ok) v = xf[(long long)c * L + (long long)sy * W + sx];
+        }
+        cf[(long long)k * Lp + l] = v;
+    }
+}
+
+// adjoint of im2col (layout 1 of the gradient: dcols[f][Kp][L]) as a gather: input pixel (c, y, x) sums, over its pre-images
+// (qy, qx) in the padded frame (itself and, within `pad` of a border, its mirror image) and over the k x k taps, the entry of
+// the output pixel (qy - ky dil, qx - kx dil) that read it.
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcols, float* __restrict__ dx, int C, int H, int W,
+                                                     int ks, int pad, int dil, int reflect, int Kp) {
+    const int f = blockIdx.z, c = blockIdx.y;
+    const long long L = (long long)H * W;
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= L) return;
+    const int y = (int)(p / W), xx = (int)(p - (long long)y * W);
+    const float* df = dcols + (long long)f * Kp * L;
+    int qy[2], qx[2], ny = 1, nx = 1;
+    qy[0] = y + pad;
+    qx[0] = xx + pad;
+    if (reflect) {
+        if (y >= 1 && y <= pad) qy[ny++] = pad - y;
+        else if (y <= H - 2 && y >= H - 1 - pad) qy[ny++] = pad + 2 * (H - 1) - y;
+        if (xx >= 1 && xx <= pad) qx[nx++] = pad - xx;
+        else if (xx <= W - 2 && xx >= W - 1 - pad) qx[nx++] = pad + 2 * (W - 1) - xx;
+    }
+    float s = 0.f;
+    for (int iy = 0; iy < ny; ++iy)
+        for (int ix = 0; ix < nx; ++ix)
+            for (int ky = 0; ky < ks; ++ky) {
+                const int oy = qy[iy] - ky * dil;
+                if (oy < 0 || oy >= H) continue;  // stride 1, "same" size: the output has H x W pixels
+                for (int kx = 0; kx < ks; ++kx) {
+                    const int ox = qx[ix] - kx * dil;
+                    if (ox < 0 || ox >= W) continue;
+                    s += df[(long long)((c * ks + ky) * ks + kx) * L + (long long)oy * W + ox];
+                }
+            }
+    dx[((long long)f * C + c) * L + p] = s;
+}
+
+// dst[b][c][r] = src[b][r][c]  (32 x 32 tiles through LDS)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, long long R, long long Cc) {
+    __shared__ float t[32][33];
+    const long long b = blockIdx.z;
+    const float* s = src + b * R * Cc;
+    float* d = dst + b * R * Cc;
+    const long long r0 = (long long)blockIdx.y * 32, c0 = (long long)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long r = r0 + ty + 8 * i, c = c0 + tx;
+        if (r < R && c < Cc) t[ty + 8 * i][tx] = s[r * Cc + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < R && c < Cc) d[c * R + r] = t[tx][ty + 8 * i];
+    }
+}
+
+}  // namespace
+
+extern "C" int dtk_gemm_nt_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb,
+                               int64_t ldc, int32_t batch, int64_t stride_a, int64_t stride_b, int64_t stride_c, int32_t split_k,
+                               int32_t accumulate, const float* scale_a, const float* scale_b, void* stream) {
+    DTK_REQUIRE(A && B && C, "dtk_gemm_nt_f32: null pointer");
+    DTK_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0 && split_k > 0, "dtk_gemm_nt_f32: bad sizes");
+    DTK_REQUIRE(lda >= K && ldb >= K && ldc >= N, "dtk_gemm_nt_f32: leading dimensions");
+    DTK_REQUIRE((long long)batch * split_k <= 65535, "dtk_gemm_nt_f32: batch * split_k > 65535");
+    int k_chunk = dtk_cdiv(dtk_cdiv(K, split_k), GKS) * GKS;
+    const bool vec = lda % 4 == 0 && ldb % 4 == 0 && K % 4 == 0 && stride_a % 4 == 0 && stride_b % 4 == 0 &&
+                     ((size_t)A & 15) == 0 && ((size_t)B & 15) == 0;
+    const dim3 grid(dtk_cdiv(N, GT), dtk_cdiv(M, GT), batch * split_k);
+    if (vec)
+        DTK_LAUNCH("train_gemm", gemm_nt_split_kernel<true>, grid, dim3(256), 0, dtk_stream(stream), A, B, C, M, N, K, (long long)lda,
+                   (long long)ldb, (long long)ldc, (long long)stride_a, (long long)stride_b, (long long)stride_c, split_k, k_chunk,
+                   accumulate, scale_a, scale_b);
+    else
+        DTK_LAUNCH("train_gemm", gemm_nt_split_kernel<false>, grid, dim3(256), 0, dtk_stream(stream), A, B, C, M, N, K, (long long)lda,
+                   (long long)ldb, (long long)ldc, (long long)stride_a, (long long)stride_b, (long long)stride_c, split_k, k_chunk,
+                   accumulate, scale_a, scale_b);
+    return DTK_OK;
+}
+
+extern "C" int dtk_im2col(const float* x, float* cols, int32_t n, int32_t C, int32_t H, int32_t W, int32_t ksize, int32_t pad,
+                          int32_t dil, int32_t reflect, int32_t layout, int32_t Kp, int64_t Lp, void* stream) {
+    DTK_REQUIRE(x && cols && n > 0 && C > 0 && H > 0 && W > 0 && ksize > 0, "dtk_im2col: bad arguments");
+    DTK_REQUIRE(2 * pad == dil * (ksize - 1), "dtk_im2col: only 'same' convolutions (2 pad == dil (k - 1))");
+    DTK_REQUIRE(!reflect || (pad < H && pad < W), "dtk_im2col: reflect padding needs pad < H, W");
+    DTK_REQUIRE(Kp >= C * ksize * ksize && (layout == 0 || Lp >= (long long)H * W), "dtk_im2col: Kp / Lp too small");
+    const long long L = (long long)H * W;
+    if (layout == 0)
+        DTK_LAUNCH("train_im2col", im2col_kernel, dim3(dtk_cdiv(L, 8), 1, n), dim3(256), 0, dtk_stream(stream), x, cols, C, H, W,
+                   ksize, pad, dil, reflect, 0, Kp, (long long)0);
+    else
+        DTK_LAUNCH("train_im2col", im2col_kernel, dim3(dtk_cdiv(Lp, 256), Kp, n), dim3(256), 0, dtk_stream(stream), x, cols, C, H,
+                   W, ksize, pad, dil, reflect, 1, Kp, (long long)Lp);
+    return DTK_OK;
+}
+
+extern "C" int dtk_col2im(const float* dcols, float* dx, int32_t n, int32_t C, int32_t H, int32_t W, int32_t ksize, int32_t pad,
+                          int32_t dil, int32_t reflect, int32_t Kp, void* stream) {
+    DTK_REQUIRE(dcols && dx && n > 0 && C > 0 && H > 0 && W > 0 && ksize > 0, "dtk_col2im: bad arguments");
+    DTK_REQUIRE(2 * pad == dil * (ksize - 1), "dtk_col2im: only 'same' convolutions (2 pad == dil (k - 1))");
+    DTK_REQUIRE(!reflect || (2 * pad < H && 2 * pad < W), "dtk_col2im: reflect padding needs 2 pad < H, W");
+    DTK_REQUIRE(Kp >= C * ksize * ksize && C <= 65535, "dtk_col2im: Kp too small / too many channels");
+    const long long L = (long long)H * W;
+    DTK_LAUNCH("train_col2im", col2im_kernel, dim3(dtk_cdiv(L, 256), C, n), dim3(256), 0, dtk_stream(stream), dcols, dx, C, H, W,
+               ksize, pad, dil, reflect, Kp);
+    return DTK_OK;
+}
+
+extern "C" int dtk_transpose_f32(const float* src, float* dst, int64_t rows, int64_t cols, int32_t batch, void* stream) {
+    DTK_REQUIRE(src && dst && rows > 0 && cols > 0 && batch > 0, "dtk_transpose_f32: bad arguments");
+    DTK_REQUIRE(dtk_cdiv(rows, 32) <= 65535 && batch <= 65535, "dtk_transpose_f32: too many row tiles / batches");
+    DTK_LAUNCH("train_transpose", transpose_kernel, dim3(dtk_cdiv(cols, 32), dtk_cdiv(rows, 32), batch), dim3(256), 0,
+               dtk_stream(stream), src, dst, (long long)rows, (long long)cols);
+    return DTK_OK;
+}

@@ -286,3 +286,30 @@ def blurpool_backward(dy: torch.Tensor, H: int, W: int) -> torch.Tensor:
     dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
     check(lib().dtk_blurpool_backward(_p(dy, torch.float32), _p(dx), N * C, H, W, _stream()))
     return dx
+
+
+# ---- N1: convolutions of the training step on the split-fp16 MFMA GEMM (csrc/train.hip) -----------------------------------
+def gemm_nt(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, M: int, N: int, K: int, lda: int, ldb: int, ldc: int,
+            batch: int = 1, stride_a: int = 0, stride_b: int = 0, stride_c: int = 0, split_k: int = 1, accumulate: int = 0,
+            scale_a: Optional[torch.Tensor] = None, scale_b: Optional[torch.Tensor] = None) -> None:
+    """dtk_gemm_nt_f32: C[b][m][n] (+)= sum_k A[b][m][k] B[b][n][k], fp32-grade on the fp16 matrix cores.  The tensors are
+    passed as flat storage + explicit leading dimensions / batch strides (in floats); scales are 1-element device tensors."""
+    check(lib().dtk_gemm_nt_f32(_p(A, torch.float32), _p(B, torch.float32), _p(C, torch.float32), M, N, K, lda, ldb, ldc, batch,
+                                stride_a, stride_b, stride_c, split_k, accumulate, _p(scale_a, torch.float32),
+                                _p(scale_b, torch.float32), _stream()))
+
+
+def im2col(x: torch.Tensor, cols: torch.Tensor, ksize: int, pad: int, dil: int, reflect: bool, layout: int, Kp: int,
+           Lp: int = 0) -> None:
+    n, C, H, W = x.shape
+    check(lib().dtk_im2col(_p(x, torch.float32), _p(cols, torch.float32), n, C, H, W, ksize, pad, dil, int(reflect), layout, Kp, Lp,
+                           _stream()))
+
+
+def col2im(dcols: torch.Tensor, dx: torch.Tensor, ksize: int, pad: int, dil: int, reflect: bool, Kp: int) -> None:
+    n, C, H, W = dx.shape
+    check(lib().dtk_col2im(_p(dcols, torch.float32), _p(dx, torch.float32), n, C, H, W, ksize, pad, dil, int(reflect), Kp, _stream()))
+
+
+def transpose_f32(src: torch.Tensor, dst: torch.Tensor, rows: int, cols: int, batch: int = 1) -> None:
+    check(lib().dtk_transpose_f32(_p(src, torch.float32), _p(dst, torch.float32), rows, cols, batch, _stream()))

@@ -125,6 +125,99 @@ class _ConvGemm(torch.autograd.Function):
         return dx, dw, None, None, None
 
 
+_SCALARS = {}
+
+
+def _scalar(value: float, device) -> torch.Tensor:
+    key = (float(value), str(device))
+    if key not in _SCALARS:
+        _SCALARS[key] = torch.full((1,), float(value), dtype=torch.float32, device=device)
+    return _SCALARS[key]
+
+
+W_SCALE = 256.0  # weights carry 2^8 into the fp16 split (their lo halves stay normal numbers), like the inference kernels
+
+
+def _pow2_scale(t: torch.Tensor) -> torch.Tensor:
+    """Device scalar 2^e with max |t| * 2^e in [2^9, 2^10]: the operand scale of a gradient tensor for the fp16 split (its
+    entries down to 2^-24 of the largest keep normal halves).  No host synchronisation."""
+    amax = t.abs().amax().clamp_min(1e-30)
+    return torch.exp2(torch.floor(10.0 - torch.log2(amax))).reshape(1)
+
+
+class _ConvMfma(torch.autograd.Function):
+    """Stride-1 'same' convolution (k x k, reflect or zero padding, dilation) on the hand-written kernels of csrc/train.hip
+    (round 3): im2col -> split-fp16 MFMA GEMM, forward, weight gradient and data gradient; fp32-grade (2^-22 relative per
+    operand).  The unfolded operands live in persistent scratch and are recomputed in the backward.
+        forward      Y[cout][l]  = sum_k W[cout][k]  cols[l][k]
+        weight grad  dW[cout][k] = sum_{frames, l} dY[cout][l] colsT[k][l]      (reduction split over workgroups, atomic adds)
+        data grad    dcols[k][l] = sum_c Wt[k][c] dYt[l][c]  -> col2im (with the adjoint of the reflect padding)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, padding, dilation, padding_mode):
+        from . import ops
+        n, cin, h, w = x.shape
+        cout, _, kh, kw = weight.shape
+        assert kh == kw and 2 * padding == dilation * (kh - 1) and padding_mode in ("reflect", "zeros")
+        k = cin * kh * kw
+        kp = (k + 31) // 32 * 32
+        L = h * w
+        x = x.contiguous()
+        cols = _workspace("cols", n * L * kp, x)
+        ops.im2col(x, cols, kh, padding, dilation, padding_mode == "reflect", 0, kp)
+        wp = torch.zeros(cout, kp, dtype=torch.float32, device=x.device)
+        wp[:, :k] = weight.detach().reshape(cout, k)
+        y = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
+        ops.gemm_nt(wp, cols, y, cout, L, kp, kp, kp, L, batch=n, stride_a=0, stride_b=L * kp, stride_c=cout * L,
+                    scale_a=_scalar(W_SCALE, x.device))
+        ctx.save_for_backward(x, weight)
+        ctx.conf = (padding, dilation, padding_mode, kp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        x, weight = ctx.saved_tensors
+        padding, dilation, padding_mode, kp = ctx.conf
+        n, cin, h, w = x.shape
+        cout, _, kh, kw = weight.shape
+        k = cin * kh * kw
+        L = h * w
+        dev = x.device
+        dy = dy.contiguous()
+        s_dy = _pow2_scale(dy)
+        dw = dx = None
+        if ctx.needs_input_grad[1]:
+            lp = (L + 31) // 32 * 32
+            colst = _workspace("cols", n * kp * lp, x)
+            ops.im2col(x, colst, kh, padding, dilation, padding_mode == "reflect", 1, kp, lp)
+            if lp != L:  # rows of dY padded to the same (aligned) length, zeros behind
+                dyp = torch.zeros(n, cout, lp, dtype=torch.float32, device=dev)
+                dyp[:, :, :L] = dy.reshape(n, cout, L)
+            else:
+                dyp = dy
+            dwp = torch.zeros(cout, kp, dtype=torch.float32, device=dev)
+            tiles = ((cout + 127) // 128) * ((kp + 127) // 128)
+            split = max(1, min(lp // 2048, 2048 // max(1, tiles * n), 65535 // n))
+            ops.gemm_nt(dyp, colst, dwp, cout, kp, lp, lp, lp, kp, batch=n, stride_a=cout * lp, stride_b=kp * lp, stride_c=0,
+                        split_k=split, accumulate=2, scale_a=s_dy)
+            dw = dwp[:, :k].reshape(weight.shape)
+        if ctx.needs_input_grad[0]:
+            wt = torch.zeros(kp, cout, dtype=torch.float32, device=dev)
+            wt[:k] = weight.detach().reshape(cout, k).t()
+            dyt = _workspace("dyt", n * L * cout, x)
+            ops.transpose_f32(dy, dyt, cout, L, batch=n)
+            dcols = _workspace("dcols", n * kp * L, x)
+            ops.gemm_nt(wt, dyt, dcols, kp, L, cout, cout, cout, L, batch=n, stride_a=0, stride_b=L * cout, stride_c=kp * L,
+                        scale_a=_scalar(W_SCALE, dev), scale_b=s_dy)
+            dx = torch.empty_like(x)
+            ops.col2im(dcols, dx, kh, padding, dilation, padding_mode == "reflect", kp)
+        return dx, dw, None, None, None
+
+
+USE_MFMA_CONVS = True  # device tensors: csrc/train.hip (_ConvMfma); False: round 2's unfold + library GEMM (_ConvGemm)
+
+
 def conv2d_gemm(x: torch.Tensor, weight: torch.Tensor, bias, padding: int, dilation: int = 1, padding_mode: str = "zeros"):
     """Stride-1 convolution as ONE matrix product over the unfolded input ([Cout, Cin k k] x [Cin k k, H W] per frame):
     forward and both backward products run on the BLAS GEMM kernels, im2col / col2im on plain copy kernels.  (The
@@ -132,7 +225,10 @@ def conv2d_gemm(x: torch.Tensor, weight: torch.Tensor, bias, padding: int, dilat
     this stack -- 40 s per training iteration, against 0.05 s of kernels.)  On the device the unfolded operands live in
     persistent scratch and are recomputed in the backward (_ConvGemm); host tensors take the autograd-traced form."""
     if x.is_cuda:
-        y = _ConvGemm.apply(x, weight, padding, dilation, padding_mode)
+        kh = weight.shape[-1]
+        same = weight.shape[-2] == kh and 2 * padding == dilation * (kh - 1) and padding_mode in ("reflect", "zeros")
+        fn = _ConvMfma if (USE_MFMA_CONVS and same and weight.shape[0] % 4 == 0) else _ConvGemm
+        y = fn.apply(x, weight, padding, dilation, padding_mode)
         return y if bias is None else y + bias[None, :, None, None]
     n, cin, h, w = x.shape
     cout, _, kh, kw = weight.shape

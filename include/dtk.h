@@ -311,6 +311,29 @@ int dtk_batchnorm_train_backward(const float* x, const float* dy, const float* g
 int dtk_blurpool_forward(const float* x, float* y, int64_t planes, int32_t H, int32_t W, void* stream);
 int dtk_blurpool_backward(const float* dy, float* dx, int64_t planes, int32_t H, int32_t W, void* stream);
 
+/* ---- N1: the convolutions of the training step as fp32-grade matrix products on the fp16 matrix cores ---------------------
+ * (models/networks/delta_dino.py:29-31 under autograd; dino_tracker.py:392-448).
+ * dtk_gemm_nt_f32:  C[b][m][n] (+)= sum_k A[b][m][k] * B[b][n][k]     (both operands with the reduction index contiguous)
+ *   fp32 in, fp32 out; every operand is split x = hi + lo (fp16) while it is staged and a product is hi.hi + hi.lo + lo.hi
+ *   with fp32 accumulation (2^-22 relative per operand).  scale_a / scale_b: DEVICE scalars (powers of two, NULL = 1) applied
+ *   before the split and divided out in the epilogue, so that small operands (gradients) keep normal fp16 halves.
+ *   batch b: operands b * stride_a / stride_b (0 = shared), output b * stride_c.  split_k > 1 cuts the reduction into chunks
+ *   whose partial sums are ATOMICALLY added to C; accumulate: 0 overwrite, 1 C += (single writer), 2 atomic add (several
+ *   batches writing the same C: stride_c = 0).  With split_k > 1 or accumulate 2 the caller zeroes / owns C's prior content.
+ * dtk_im2col: unfolded operand of a stride-1 'same' convolution (2 pad == dil (k - 1)), reflect or zero padding:
+ *   layout 0: cols[f][l][Kp]  (l = y W + x, k = (c ksize + ky) ksize + kx contiguous, zero-filled to Kp)
+ *   layout 1: cols[f][Kp][Lp] (pixels contiguous, zero-filled to Lp)
+ * dtk_col2im: adjoint of layout 1 with Lp = H W (incl. the adjoint of the reflect padding): dcols[f][Kp][H W] -> dx[f][C][H][W]
+ * dtk_transpose_f32: dst[b][c][r] = src[b][r][c]. */
+int dtk_gemm_nt_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb,
+                    int64_t ldc, int32_t batch, int64_t stride_a, int64_t stride_b, int64_t stride_c, int32_t split_k,
+                    int32_t accumulate, const float* scale_a, const float* scale_b, void* stream);
+int dtk_im2col(const float* x, float* cols, int32_t n, int32_t C, int32_t H, int32_t W, int32_t ksize, int32_t pad, int32_t dil,
+               int32_t reflect, int32_t layout, int32_t Kp, int64_t Lp, void* stream);
+int dtk_col2im(const float* dcols, float* dx, int32_t n, int32_t C, int32_t H, int32_t W, int32_t ksize, int32_t pad, int32_t dil,
+               int32_t reflect, int32_t Kp, void* stream);
+int dtk_transpose_f32(const float* src, float* dst, int64_t rows, int64_t cols, int32_t batch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

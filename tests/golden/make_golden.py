@@ -125,13 +125,20 @@ def run_reference_p1():
 
 
 # ---- configs 1 and 3: the reference's SCRIPTS, un-modified, on CPU ------------------------------------------------------
-def run_reference_scripts(only_cfg3=False):
+def run_reference_scripts(only_cfg3=False, synthetic=False):
     """inference_grid.py (config 1) and inference_benchmark.py + eval/metrics.py (configs 3-4) of the reference, run as
     __main__ through runpy with the CPU shims; their .npy outputs and the TAP-Vid metrics are the golden values the
-    `-m gpu` test compares the launcher-run HIP outputs with (tests/test_gpu_reference_scripts.py)."""
+    `-m gpu` test compares the launcher-run HIP outputs with (tests/test_gpu_reference_scripts.py).
+    synthetic=True: the same scripts on the synthetic-video data directories (ref_scripts_data.CFG1S / CFG3S), whose inputs
+    can be rebuilt WITHOUT the reference checkout -> ref_scripts_synth.npz, the golden of the twin tests."""
     import runpy
     import ref_scripts_data as D
     R = ref_harness.load()
+    if synthetic:
+        cfg1, cfg3 = D.CFG1S, D.CFG3S
+        build = lambda dst, ref, cfg: D.build_synth_data_dir(dst, cfg)  # noqa: E731
+    else:
+        cfg1, cfg3, build = D.CFG1, D.CFG3, D.build_data_dir
     ref = ref_harness.REFERENCE_ROOT
     out = {}
     tmp = tempfile.mkdtemp()
@@ -143,24 +150,24 @@ def run_reference_scripts(only_cfg3=False):
             old = np.load(os.path.join(OUT, "ref_scripts.npz"))
             out["cfg1_traj"], out["cfg1_occ"] = old["cfg1_traj"], old["cfg1_occ"]
         else:
-            d1 = D.build_data_dir(os.path.join(tmp, "cfg1"), ref, D.CFG1)
+            d1 = build(os.path.join(tmp, "cfg1"), ref, cfg1)
             sys.argv = ["inference_grid.py", "--config", os.path.join(ref, "config", "train.yaml"), "--data-path", d1,
-                        "--interval", str(D.CFG1["interval"])]
+                        "--interval", str(cfg1["interval"])]
             runpy.run_path(os.path.join(ref, "inference_grid.py"), run_name="__main__")
             out["cfg1_traj"] = np.load(os.path.join(d1, "grid_trajectories", "grid_trajectories.npy"))
             out["cfg1_occ"] = np.load(os.path.join(d1, "grid_occlusions", "grid_occlusions.npy"))
-        d3 = D.build_data_dir(os.path.join(tmp, "cfg3"), ref, D.CFG3)
+        d3 = build(os.path.join(tmp, "cfg3"), ref, cfg3)
         pkl = os.path.join(tmp, "tapvid_synth.pkl")
-        bench = D.build_tapvid_pickle(pkl, D.CFG3)
+        bench = D.build_tapvid_pickle(pkl, cfg3)
         sys.argv = ["inference_benchmark.py", "--config", os.path.join(ref, "config", "train.yaml"), "--data-path", d3,
-                    "--benchmark-pickle-path", pkl, "--video-id", str(D.CFG3["video_idx"])]
+                    "--benchmark-pickle-path", pkl, "--video-id", str(cfg3["video_idx"])]
         runpy.run_path(os.path.join(ref, "inference_benchmark.py"), run_name="__main__")
-        for f in D.CFG3["query_frames"]:
+        for f in cfg3["query_frames"]:
             out[f"cfg3_traj_{f}"] = np.load(os.path.join(d3, "trajectories", f"trajectories_{f}.npy"))
             out[f"cfg3_occ_{f}"] = np.load(os.path.join(d3, "occlusions", f"occlusion_preds_{f}.npy"))
         import eval.metrics as EM
         m = EM.compute_tapvid_metrics_for_video(os.path.join(d3, "trajectories"), os.path.join(d3, "occlusions"), bench,
-                                                D.CFG3["video_idx"], pred_video_sizes=[854, 476])
+                                                cfg3["video_idx"], pred_video_sizes=[854, 476])
         out["cfg3_metric_names"] = np.array(sorted(m))
         out["cfg3_metric_values"] = np.array([m[k] for k in sorted(m)], dtype=np.float64)
     finally:
@@ -226,14 +233,21 @@ if __name__ == "__main__":
         print("ref_train", res["losses"], os.path.getsize(path) // 1024, "KiB")
         if not names:
             sys.exit(0)
-    if "ref_scripts" in names or "ref_scripts_cfg3" in names:
+    if "ref_scripts" in names or "ref_scripts_cfg3" in names:  # (not "ref_scripts_synth": handled below)
         only3 = "ref_scripts_cfg3" in names
-        names = [n for n in names if not n.startswith("ref_scripts")]
+        names = [n for n in names if not n.startswith("ref_scripts") or n == "ref_scripts_synth"]
         res = run_reference_scripts(only_cfg3=only3)
         path = os.path.join(OUT, "ref_scripts.npz")
         np.savez_compressed(path, **res)
         print("ref_scripts", {k: v.shape for k, v in res.items()}, dict(zip(res["cfg3_metric_names"], res["cfg3_metric_values"])),
               os.path.getsize(path) // 1024, "KiB")
+    if "ref_scripts_synth" in names:
+        names.remove("ref_scripts_synth")
+        res = run_reference_scripts(synthetic=True)
+        path = os.path.join(OUT, "ref_scripts_synth.npz")
+        np.savez_compressed(path, **res)
+        print("ref_scripts_synth", {k: v.shape for k, v in res.items()},
+              dict(zip(res["cfg3_metric_names"], res["cfg3_metric_values"])), os.path.getsize(path) // 1024, "KiB")
     if "p1_small" in names:
         names.remove("p1_small")
         res = run_reference_p1()

@@ -68,3 +68,31 @@ def build_tapvid_pickle(path, cfg):
     with open(path, "wb") as fh:
         pickle.dump(data, fh)
     return data
+
+
+# ---- the same two configurations on a SYNTHETIC video (no reference checkout needed to rebuild the inputs) ----------------
+# Frames are dino_tracker_amd.synth.synth_video quantised to 8 bits and written as 854 x 476 PNGs (lossless, already at the
+# model resolution: the reference's LANCZOS resize to the same size returns the pixels unchanged), masks a centred rectangle.
+CFG1S = dict(T=8, C=1024, interval=80, feat_seed=23, head_seed=3, delta_seed=8, video_seed=310)
+CFG3S = dict(T=8, C=1024, feat_seed=24, head_seed=3, delta_seed=8, video_seed=311, video_idx=0, query_frames=(0, 3, 6),
+             per_frame=6)
+
+
+def build_synth_data_dir(dst, cfg):
+    from PIL import Image
+    T, C = cfg["T"], cfg["C"]
+    video = (synth.synth_video(T, 476, 854, seed=cfg["video_seed"]) * 255.0).round().clamp(0, 255).to(torch.uint8)
+    for sub in ("video", "masks"):
+        os.makedirs(os.path.join(dst, sub), exist_ok=True)
+    mask = np.zeros((476, 854), dtype=np.uint8)
+    mask[120:360, 250:600] = 255
+    for t in range(T):
+        Image.fromarray(video[t].permute(1, 2, 0).numpy()).save(os.path.join(dst, "video", f"{t:05d}.png"))
+        Image.fromarray(mask).save(os.path.join(dst, "masks", f"{t:05d}.png"))
+    os.makedirs(os.path.join(dst, "dino_embeddings"), exist_ok=True)
+    torch.save(synth.synth_features(T, C, 67, 121, seed=cfg["feat_seed"]), os.path.join(dst, "dino_embeddings", "dino_embed_video.pt"))
+    ck = os.path.join(dst, "models", "dino_tracker")
+    os.makedirs(ck, exist_ok=True)
+    torch.save(synth.synth_head_weights(cfg["head_seed"]), os.path.join(ck, "tracker_head_100.pt"))
+    torch.save(synth.synth_delta_dino_weights(C, cfg["delta_seed"]), os.path.join(ck, "delta_dino_100.pt"))
+    return dst

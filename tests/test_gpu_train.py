@@ -252,3 +252,42 @@ def test_blurpool_kernels(shape):
     # and the host statement used by the CPU parity tests (strided views) is the same operator
     yh = train_ops.blurpool(x, filt.float())
     assert (yh.double() - y64.detach()).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("case", [
+    dict(n=2, cin=3, cout=64, h=37, w=53, dil=1, mode="reflect"),      # layer 1: K = 75 -> padded to 96; H W not a multiple of 4
+    dict(n=3, cin=16, cout=32, h=30, w=41, dil=2, mode="reflect"),     # dilated layer (pad 4), ragged M / N tiles
+    dict(n=1, cin=8, cout=12, h=19, w=22, dil=1, mode="zeros"),
+    dict(n=2, cin=64, cout=128, h=60, w=107, dil=1, mode="reflect"),   # several k-steps and a split reduction in the weight grad
+])
+def test_conv_mfma_forward_and_gradients_match_float64(case):
+    """csrc/train.hip (im2col -> split-fp16 MFMA GEMM -> col2im) vs torch's convolution in float64 on the host: output, data
+    gradient (incl. the adjoint of the reflect padding at the borders) and weight gradient at fp32-rounding level.  Inputs with
+    a large common offset (like Delta-DINO's activations) and a gradient of small magnitude (1e-6: the operand scale)."""
+    from dino_tracker_amd import train_ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    n, cin, cout, h, w, dil, mode = (case[k] for k in ("n", "cin", "cout", "h", "w", "dil", "mode"))
+    pad = 2 * dil
+    x = (torch.randn(n, cin, h, w, generator=g) + 3.0).requires_grad_(True)
+    wt = (torch.randn(cout, cin, 5, 5, generator=g) * 0.05).requires_grad_(True)
+    dy = torch.randn(n, cout, h, w, generator=g) * 1e-6
+    xd, wd = x.detach().cuda().requires_grad_(True), wt.detach().cuda().requires_grad_(True)
+    y = train_ops._ConvMfma.apply(xd, wd, pad, dil, mode)
+    y.backward(dy.cuda())
+    x64, w64 = x.detach().double().requires_grad_(True), wt.detach().double().requires_grad_(True)
+    xp = F.pad(x64, (pad,) * 4, mode="reflect") if mode == "reflect" else x64
+    y64 = F.conv2d(xp, w64, None, padding=0 if mode == "reflect" else pad, dilation=dil)
+    y64.backward(dy.double())
+
+    def rel(a, b):
+        return float((a.double().cpu() - b).abs().max() / b.abs().max())
+
+    ry, rdx, rdw = rel(y.detach(), y64.detach()), rel(xd.grad, x64.grad), rel(wd.grad, w64.grad)
+    print(f"{case}: rel err y {ry:.2e} dx {rdx:.2e} dw {rdw:.2e}")
+    assert ry < 3e-6 and rdx < 3e-6 and rdw < 3e-6, (ry, rdx, rdw)
+    # and against round 2's unfold + library-GEMM path on the device
+    xd2, wd2 = x.detach().cuda().requires_grad_(True), wt.detach().cuda().requires_grad_(True)
+    y2 = train_ops._ConvGemm.apply(xd2, wd2, pad, dil, mode)
+    y2.backward(dy.cuda())
+    assert rel(y2.detach(), y64.detach()) < 1e-5
