@@ -521,8 +521,25 @@ __device__ __forceinline__ int reflect_idx(int q, int pad, int n) {
     return s;
 }
 
-// layout 0: cols[f][l][Kp], one workgroup per 8 output pixels (a thread walks k with stride 32: coalesced 128-byte stores)
-// layout 1: cols[f][Kp][Lp], pixels contiguous
+// one element of the unfolded operand: output pixel l, patch index k (k >= K: zero fill)
+__device__ __forceinline__ float im2col_value(const float* __restrict__ xf, long long l, int k, int K, int H, int W, int ks, int pad,
+                                              int dil, int reflect) {
+    if (k >= K) return 0.f;
+    const long long L = (long long)H * W;
+    const int oy = (int)(l / W), ox = (int)(l - (long long)oy * W);
+    const int c = k / (ks * ks), rem = k - c * ks * ks, ky = rem / ks, kx = rem - ky * ks;
+    int sy = oy + ky * dil, sx = ox + kx * dil;  // padded coordinates
+    if (reflect) { sy = reflect_idx(sy, pad, H); sx = reflect_idx(sx, pad, W); }
+    else {
+        sy -= pad; sx -= pad;
+        if (sy < 0 || sy >= H || sx < 0 || sx >= W) return 0.f;
+    }
+    return xf[(long long)c * L + (long long)sy * W + sx];
+}
+
+// layout 0: cols[f][l][Kp] -- 32 pixels x 32 patch indices per workgroup through an LDS tile: the frame is READ along the
+// pixels (consecutive lanes = consecutive x of one tap: coalesced) and the operand is WRITTEN along k (128-byte rows)
+// layout 1: cols[f][Kp][Lp], pixels contiguous on both sides: one thread per element
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ cols, int C, int H, int W,
                                                      int ks, int pad, int dil, int reflect, int layout, int Kp, long long Lp) {
     const int f = blockIdx.z;
@@ -530,38 +547,29 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
     const float* xf = x + (long long)f * C * L;
     const int K = C * ks * ks;
     if (layout == 0) {
+        __shared__ float t[32][33];
         float* cf = cols + (long long)f * L * Kp;
-        const long long l = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
-        if (l >= L) return;
-        const int oy = (int)(l / W), ox = (int)(l - (long long)oy * W);
-        for (int k = threadIdx.x & 31; k < Kp; k += 32) {
-            float v = 0.f;
-            if (k < K) {
-                const int c = k / (ks * ks), rem = k - c * ks * ks, ky = rem / ks, kx = rem - ky * ks;
-                int sy = oy + ky * dil, sx = ox + kx * dil;  // padded coordinates
-                bool ok = true;
-                if (reflect) { sy = reflect_idx(sy, pad, H); sx = reflect_idx(sx, pad, W); }
-                else { sy -= pad; sx -= pad; ok = sy >= 0 && sy < H && sx >= 0 && sx < W; }
-                if (ok) v = xf[(long long)c * L + (long long)sy * W + sx];
-            }
-            cf[l * Kp + k] = v;
+        const long long l0 = (long long)blockIdx.x * 32;
+        const int k0 = blockIdx.y * 32;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kk = ty + 8 * i;
+            const long long l = l0 + tx;
+            t[kk][tx] = l < L ? im2col_value(xf, l, k0 + kk, K, H, W, ks, pad, dil, reflect) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long l = l0 + ty + 8 * i;
+            if (l < L) cf[l * Kp + k0 + tx] = t[tx][ty + 8 * i];
         }
     } else {
         float* cf = cols + (long long)f * Kp * Lp;
         const int k = blockIdx.y;
         const long long l = (long long)blockIdx.x * 256 + threadIdx.x;
         if (l >= Lp) return;
-        float v = 0.f;
-        if (k < K && l < L) {
-            const int oy = (int)(l / W), ox = (int)(l - (long long)oy * W);
-            const int c = k / (ks * ks), rem = k - c * ks * ks, ky = rem / ks, kx = rem - ky * ks;
-            int sy = oy + ky * dil, sx = ox + kx * dil;
-            bool ok = true;
-            if (reflect) { sy = reflect_idx(sy, pad, H); sx = reflect_idx(sx, pad, W); }
-            else { sy -= pad; sx -= pad; ok = sy >= 0 && sy < H && sx >= 0 && sx < W; }
-            if (ok) v = xf[(long long)c * L + (long long)sy * W + sx];
-        }
-        cf[(long long)k * Lp + l] = v;
+        cf[(long long)k * Lp + l] = l < L ? im2col_value(xf, l, k, K, H, W, ks, pad, dil, reflect) : 0.f;
     }
 }
 
@@ -651,10 +659,11 @@ extern "C" int dtk_im2col(const float* x, float* cols, int32_t n, int32_t C, int
     DTK_REQUIRE(2 * pad == dil * (ksize - 1), "dtk_im2col: only 'same' convolutions (2 pad == dil (k - 1))");
     DTK_REQUIRE(!reflect || (pad < H && pad < W), "dtk_im2col: reflect padding needs pad < H, W");
     DTK_REQUIRE(Kp >= C * ksize * ksize && (layout == 0 || Lp >= (long long)H * W), "dtk_im2col: Kp / Lp too small");
+    DTK_REQUIRE(layout != 0 || (Kp % 32 == 0 && Kp / 32 <= 65535), "dtk_im2col: layout 0 needs Kp %% 32 == 0");
     const long long L = (long long)H * W;
     if (layout == 0)
-        DTK_LAUNCH("train_im2col", im2col_kernel, dim3(dtk_cdiv(L, 8), 1, n), dim3(256), 0, dtk_stream(stream), x, cols, C, H, W,
-                   ksize, pad, dil, reflect, 0, Kp, (long long)0);
+        DTK_LAUNCH("train_im2col", im2col_kernel, dim3(dtk_cdiv(L, 32), Kp / 32, n), dim3(256), 0, dtk_stream(stream), x, cols, C, H,
+                   W, ksize, pad, dil, reflect, 0, Kp, (long long)0);
     else
         DTK_LAUNCH("train_im2col", im2col_kernel, dim3(dtk_cdiv(Lp, 256), Kp, n), dim3(256), 0, dtk_stream(stream), x, cols, C, H,
                    W, ksize, pad, dil, reflect, 1, Kp, (long long)Lp);

@@ -109,17 +109,29 @@ def test_training_step_on_device_matches_host():
     s = train_ops.sample_bilinear(emb, torch.cat([nrm[:, :2], src[:, None].float()], dim=1))
     out_h = train_ops.head_forward(hd_h, torch.relu(train_ops.cosine_maps(s, emb, tgt))[:, None])
     (out_h * cot).sum().backward()
+    # the arbiter: the same step on the host in float64
+    dd_64, hd_64 = copy.deepcopy(dd_h).double(), copy.deepcopy(hd_h).double()
+    for m64 in (dd_64, hd_64):
+        m64.zero_grad()
+    raw64 = feats[idx].double()
+    emb64 = raw64 + dd_64(video[idx].double(), raw64)
+    s64 = train_ops.sample_bilinear(emb64, torch.cat([nrm[:, :2], src[:, None].float()], dim=1).double())
+    out_64 = train_ops.head_forward(hd_64, torch.relu(train_ops.cosine_maps(s64, emb64, tgt))[:, None])
+    (out_64 * cot.double()).sum().backward()
     assert (out.detach().cpu() - out_h.detach()).abs().max() < 5e-5
     assert (trk.frame_embeddings.detach().cpu() - emb.detach()).abs().max() < 1e-4 * emb.detach().abs().max()
-    errs = {}
-    for tag, mod_d, mod_h in (("delta_dino", trk.delta_dino, dd_h), ("tracker_head", trk.tracker_head, hd_h)):
+    errs, errs_dev64, errs_host64 = {}, {}, {}
+    for tag, mod_d, mod_h, mod_64 in (("delta_dino", trk.delta_dino, dd_h, dd_64), ("tracker_head", trk.tracker_head, hd_h, hd_64)):
         grads_h = dict((n, p.grad) for n, p in mod_h.named_parameters())
+        grads_64 = dict((n, p.grad) for n, p in mod_64.named_parameters())
         for n, p in mod_d.named_parameters():
             gh = grads_h[n]
             scale = gh.abs().max()
             if tag == "delta_dino" and n.endswith(".bias") and n.split(".")[1] in ("0", "4", "8", "12"):
                 scale = grads_h[n.replace("bias", "weight")].abs().max()  # exact gradient 0 (BatchNorm follows)
             errs[f"{tag}.{n}"] = float((p.grad.cpu() - gh).abs().max() / scale)
+            errs_dev64[f"{tag}.{n}"] = float((p.grad.cpu().double() - grads_64[n]).abs().max() / scale)
+            errs_host64[f"{tag}.{n}"] = float((gh.double() - grads_64[n]).abs().max() / scale)
     # a library conv on the device against the same conv in float64: how much of the difference is the kernels' own rounding
     xx = torch.randn(2, 64, 40, 60, generator=g)
     ww = torch.randn(128, 64, 5, 5, generator=g) * 0.05
@@ -128,14 +140,25 @@ def test_training_step_on_device_matches_host():
     errs["conv_fp32_host_vs_fp64"] = float((torch.nn.functional.conv2d(xx, ww, padding=2).double() - y64).abs().max() / y64.abs().max())
     os.makedirs(LOGDIR, exist_ok=True)
     with open(os.path.join(LOGDIR, "train_step_device_vs_host.json"), "w") as fh:
-        json.dump(errs, fh, indent=1)
+        json.dump({"device_vs_host_fp32": errs, "device_vs_host_fp64": errs_dev64, "host_fp32_vs_host_fp64": errs_host64,
+                   "note": "tracker_head.cnn_refiner.2.bias: the last conv's bias shifts every logit of a map alike, its exact "
+                           "gradient is 0 (softmax invariance) -- the entry is 0/0-like rounding residue, not an error"}, fh, indent=1)
     # device (library convs + csrc/train.hip BatchNorm, fp32) against host (fp32): four conv + batch-statistics BatchNorm +
     # ReLU stages amplify summation-order differences to ~1e-3 (the host chain itself is 1e-3 .. 7e-3 from a float64 chain,
     # profiles/r02_train_grad_check.txt).  The last conv's bias shifts every logit of a map alike: its exact gradient is 0.
     exact_zero = grads_h["cnn_refiner.2.bias"].abs().max() / grads_h["cnn_refiner.2.weight"].abs().max()
     assert exact_zero < 1e-4 and errs.pop("tracker_head.cnn_refiner.2.bias") >= 0
+    errs_dev64.pop("tracker_head.cnn_refiner.2.bias")
+    errs_host64.pop("tracker_head.cnn_refiner.2.bias")
     for k, v in errs.items():
-        assert v < (5e-3 if k.startswith("delta_dino") else 1e-4), (k, v)
+        if k.startswith("delta_dino"):
+            # four conv + batch-statistics BatchNorm + ReLU stages amplify fp32 rounding to 1e-3 .. 7e-3 of a gradient even on
+            # the host (errs_host64): the device chain (csrc/train.hip convolutions + BatchNorm) must be as close to the
+            # float64 chain as the host's float32 chain is, up to a factor 2
+            assert errs_dev64[k] < max(2.0 * errs_host64[k], 3e-3), (k, errs_dev64[k], errs_host64[k])
+            assert v < 2e-2, (k, v)
+        else:
+            assert v < 1e-4, (k, v)
     for n, b in trk.delta_dino.named_buffers():
         if "running" in n:
             assert torch.allclose(b.cpu(), dict(dd_h.named_buffers())[n], rtol=1e-4, atol=1e-6), n
