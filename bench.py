@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--cpu-vit-frames", type=int, default=2,
                     help="frames the oracle's ViT / Delta-DINO legs are timed on (also the from-the-video parity leg)")
     ap.add_argument("--operands", default="fp16", choices=["fp16", "bf16"], help="operand type of the ViT's matrix units")
+    ap.add_argument("--vit-frame-batch", type=int, default=0, help="frames per pass of the ViT encoder (0 = library default)")
+    ap.add_argument("--track-round", type=int, default=0, help="sources per round of dtk_track (0 = library default, 524288)")
     return ap.parse_args()
 
 
@@ -132,6 +134,7 @@ def main():
     # the untrained encoder from collapsing all tokens onto one vector (synth.make_vit_weights)
     vit_sd = synth.make_vit_weights(model_name, seed=2, layerscale=0.1)
     ex = VitExtractor(model_name, stride=7, device=dev, state_dict=vit_sd, operand_dtype=args.operands)
+    ex.frame_batch = args.vit_frame_batch
     if args.features == "vit":
         feats0 = ex.encode(videos[0])
     else:
@@ -141,6 +144,7 @@ def main():
     trk.tracker_head.load_state_dict(head)
     trk.delta_dino.load_state_dict(delta)
     trk.to(dev).eval()
+    trk.track_round_sources = args.track_round
     mi = ModelInference(trk, RangeNormalizer((W, H, T), device=dev), 0.7, 0.6)  # caches refined features once
     stats_acc = {"sources": 0, "whole_map_tier": 0, "exact_tier": 0, "syncs": 0}
 

@@ -43,7 +43,7 @@ class VitModel(ctypes.Structure):
                 ("stride", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("flags", ctypes.c_int32),
                 ("patch_w", c_void_p), ("patch_b", c_void_p),
                 ("cls_pos", c_void_p), ("pos", c_void_p), ("mean_std", c_void_p), ("layers", ctypes.POINTER(VitLayer)),
-                ("overflow", c_void_p)]
+                ("frame_batch", ctypes.c_int32), ("overflow", c_void_p)]
 
 
 VIT_TILED_GEMMS, VIT_BF16, VIT_CHECK_RANGE = 1, 2, 4  # dtk_vit_model.flags

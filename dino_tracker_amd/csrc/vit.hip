@@ -972,7 +972,8 @@ VitPlan vit_plan(const dtk_vit_model* m, int ph, int pw, int frames) {
     VitPlan p;
     p.S = ph * pw + 1;
     p.Sp = (p.S + 127) / 128 * 128;
-    p.FB = frames < VIT_FRAME_BATCH ? frames : VIT_FRAME_BATCH;
+    const int fb = m->frame_batch > 0 ? m->frame_batch : VIT_FRAME_BATCH;
+    p.FB = frames < fb ? frames : fb;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t off = 0;
     const size_t rows = (size_t)p.FB * p.S;

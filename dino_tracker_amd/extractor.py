@@ -47,6 +47,7 @@ class VitExtractor(nn.Module):
             raise ValueError(f"operand_dtype {operand_dtype!r}: 'fp16' or 'bf16'")
         self.operand_dtype = operand_dtype
         self.check_range = check_range  # also scan Q / K / V and the MLP hidden of every block for saturation (slower)
+        self.frame_batch = 0            # frames per pass of the encoder; 0 = the library's default
         if model_name not in VIT_CONFIGS:
             raise NotImplementedError(f"{model_name}: the HIP encoder covers dinov2_vit{{s,b,l}}14 (d_head 64)")
         self.model_name, self.stride, self.device = model_name, stride, device
@@ -140,7 +141,7 @@ class VitExtractor(nn.Module):
         m = VitModel(D, self.cfg["heads"], layer + 1, patch, self.stride, 1e-6, flags,
                      self._sd["patch_embed.proj.weight"].data_ptr(),
                      self._sd["patch_embed.proj.bias"].data_ptr(), cls_pos.data_ptr(), pos.data_ptr(), ms.data_ptr(),
-                     ctypes.cast(self._layers, ctypes.POINTER(VitLayer)), overflow.data_ptr())
+                     ctypes.cast(self._layers, ctypes.POINTER(VitLayer)), int(self.frame_batch), overflow.data_ptr())
         ws_bytes = int(lib().dtk_vit_workspace_bytes(m, H, W, n))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
         S = ph * pw + 1

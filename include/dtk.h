@@ -99,6 +99,7 @@ typedef struct dtk_vit_model {
     const float* pos;             /* interpolated patch position encoding [ph*pw][D] (models/extractor.py:57-85) */
     const float* mean_std;        /* ImageNet mean[3], std[3] (utils.py:46) */
     const dtk_vit_layer* layers;  /* HOST array of `depth` entries */
+    int32_t frame_batch;          /* frames per pass of the encoder (workspace grows with it); 0 = the library's default (30) */
     int32_t* overflow;            /* DEVICE word or NULL; OR-ed with 1 when a residual update (projection / MLP output) reached
                                    * the fp16 limit 65504 or is not finite, with 2 / 4 when Q, K, V / the MLP hidden did
                                    * (the latter two only with DTK_VIT_CHECK_RANGE).  The caller zeroes it.  fp16 activations

@@ -11,6 +11,24 @@ NAMES = {  # kernel function -> launch name used by bench.py (only kernels with 
     "patch_embed_split_kernel": "vit_patch_embed", "conv1_split_kernel": "dd_conv1", "gemm_wide_delta_kernel": "vit_gemm_fc2",
 }
 
+def function_name(kn):
+    """last component of an Itanium-mangled (possibly nested: _ZN <len><name> ... E) kernel name, templates dropped;
+    names that are already demangled lose their namespaces, template arguments and parameter list"""
+    if kn.startswith("_Z"):
+        i = 3 if kn.startswith("_ZN") else 2
+        last = None
+        while i < len(kn) and kn[i].isdigit():
+            j = i
+            while kn[j].isdigit():
+                j += 1
+            n = int(kn[i:j])
+            last = kn[j:j + n]
+            i = j + n
+        return last or kn[:40]
+    base = re.sub(r"<.*", "", kn.split("(")[0]).strip()
+    return base.split("::")[-1].split(" ")[-1]
+
+
 def per_kernel(path, counter):
     db = sqlite3.connect(path)
     ks = [r[1] for r in db.execute("pragma table_info(rocpd_info_kernel_symbol)")]
@@ -21,8 +39,7 @@ def per_kernel(path, counter):
                           join rocpd_info_kernel_symbol s on d.kernel_id = s.id where p.name = ? group by 1""", (counter,))
     out = {}
     for kn, n, v in rows:
-        m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", kn) or re.match(r"_ZN4att2(\d+)", kn) or re.match(r"_Z(\d+)", kn)
-        short = kn[m.end():m.end() + int(m.group(1))] if m else kn[:40]
+        short = function_name(kn)
         c = out.setdefault(short, [0, 0.0])
         c[0] += n; c[1] += v
     return out
