@@ -143,7 +143,11 @@ class VitExtractor(nn.Module):
                      self._sd["patch_embed.proj.bias"].data_ptr(), cls_pos.data_ptr(), pos.data_ptr(), ms.data_ptr(),
                      ctypes.cast(self._layers, ctypes.POINTER(VitLayer)), int(self.frame_batch), overflow.data_ptr())
         ws_bytes = int(lib().dtk_vit_workspace_bytes(m, H, W, n))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+        # the workspace (2.6 GB for 30 frames of 854 x 476) is kept between calls: handing it back to the caching allocator
+        # and asking again costs a device allocation (~25 ms) whenever the block has been split or released in between
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < ws_bytes or ws.device != torch.device(self.device):
+            self._ws = ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
         S = ph * pw + 1
         if want not in ("tokens", "feat", "qkv"):
             raise ValueError(want)
