@@ -8,6 +8,25 @@ import re
 import sqlite3
 import sys
 
+
+
+def function_name(kn):
+    """last component of an Itanium-mangled (possibly nested) kernel name, templates dropped (as in pmc_traffic.py)"""
+    if kn.startswith("_Z"):
+        i = 3 if kn.startswith("_ZN") else 2
+        last = None
+        while i < len(kn) and kn[i].isdigit():
+            j = i
+            while kn[j].isdigit():
+                j += 1
+            n = int(kn[i:j])
+            last = kn[j:j + n]
+            i = j + n
+        return last or kn[:40]
+    base = re.sub(r"<.*", "", kn.split("(")[0]).strip()
+    return base.split("::")[-1].split(" ")[-1]
+
+
 db = sqlite3.connect(sys.argv[1])
 ks = [r[1] for r in db.execute("pragma table_info(rocpd_info_kernel_symbol)")]
 name_col = "kernel_name" if "kernel_name" in ks else ks[-1]
@@ -19,8 +38,7 @@ dur = dict(db.execute(f"""select s.{name_col}, sum(d.end - d.start) from rocpd_k
                           join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by 1""").fetchall())
 tab = {}
 for kn, cn, n, v in rows:
-    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", kn) or re.match(r"_ZN4att2(\d+)", kn) or re.match(r"_Z(\d+)", kn)
-    short = kn[m.end():m.end() + int(m.group(1))] if m else re.sub(r"\(.*", "", kn)[:40]
+    short = function_name(kn)
     t = tab.setdefault(short, {"launches": n, "ns": 0})
     t[cn] = t.get(cn, 0.0) + v
     t["ns"] = max(t["ns"], dur.get(kn, 0))
