@@ -121,6 +121,10 @@ SIGNATURES = {
                            ctypes.c_int64, c_void_p]),
     "dtk_col2im": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dtk_transpose_f32": (c_int, [c_void_p, c_void_p, ctypes.c_int64, ctypes.c_int64, c_int, c_void_p]),
+    "dtk_resample2d_forward": (c_int, [c_void_p, c_void_p, ctypes.c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p]),
+    "dtk_resample2d_backward": (c_int, [c_void_p, c_void_p, ctypes.c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p]),
     "dtk_batchnorm_workspace_bytes": (c_size_t, [c_int]),
     "dtk_batchnorm_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                             c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,

@@ -335,6 +335,15 @@ int dtk_col2im(const float* dcols, float* dx, int32_t n, int32_t C, int32_t H, i
                int32_t reflect, int32_t Kp, void* stream);
 int dtk_transpose_f32(const float* src, float* dst, int64_t rows, int64_t cols, int32_t batch, void* stream);
 
+/* CNN -> ViT grid alignment of the training step (models/utils.py:7-45), forward and backward, as a separable two-tap
+ * resampling given by per-axis tables: destination index i reads source cells lo[i] and min(lo[i] + 1, n - 1) with weights
+ * 1 - whi[i] and whi[i].  src / dsrc [planes][hs][ws], dst / ddst [planes][hd][wd].  Backward tables per axis: int32
+ * ranges[4][n_src] = start, end of the destination indices whose LO is a, then start, end of those whose HI is a. */
+int dtk_resample2d_forward(const float* src, float* dst, int64_t planes, int32_t hs, int32_t ws, int32_t hd, int32_t wd,
+                           const int32_t* ylo, const float* ywhi, const int32_t* xlo, const float* xwhi, void* stream);
+int dtk_resample2d_backward(const float* ddst, float* dsrc, int64_t planes, int32_t hs, int32_t ws, int32_t hd, int32_t wd,
+                            const int32_t* yranges, const float* ywhi, const int32_t* xranges, const float* xwhi, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

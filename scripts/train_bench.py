@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--profile-dir", default="")
+    ap.add_argument("--rng-shim", action="store_true", help="keep train_driver's host-side random draws (parity runs; slow)")
     ap.add_argument("--data-dir", default="", help="reuse / create the synthetic inputs here (shared between the two sides)")
     a = ap.parse_args()
     ref = os.environ.get("DTK_REFERENCE_ROOT", "/root/reference")
@@ -59,6 +60,8 @@ def main():
     shims = os.path.join(ROOT, "oracle", "shims")
     tail = [os.path.join(ref, "train.py"), "--config", yml, "--data-path", d, "--seed", "2"]
     env = dict(os.environ, DTK_TRAIN_LOG=log)
+    if not a.rng_shim:
+        env["DTK_TRAIN_NO_RNG_SHIM"] = "1"  # time the loop with torch's own random generators (see train_driver.py)
     if a.side == "hip":
         cmd = [sys.executable, "-m", "dino_tracker_amd.run", "--path", shims, "--path", ref, drv] + tail
         env["PYTHONPATH"] = ROOT

@@ -3,7 +3,9 @@ both sides of the comparison (the reference's own modules on CPU when make_golde
 implementation on the device under `python -m dino_tracker_amd.run` in tests/test_gpu_train.py):
 
   * every random draw comes from torch's CPU generator: randperm / randint with a device argument and Tensor.multinomial
-    are computed on the host and moved, so that the CPU and the device run see the same indices;
+    are computed on the host and moved, so that the CPU and the device run see the same indices ($DTK_TRAIN_NO_RNG_SHIM=1
+    leaves torch's generators alone: scripts/train_bench.py times the loop that way -- the shim's host-side randperm of
+    ~400 k elements, 56 times per iteration, was 165 ms of round 2's "0.20 s per iteration");
   * DINOTracker.update_losses also appends its arguments (the seven loss values of the iteration) to a list that is written
     to $DTK_TRAIN_LOG as JSON at exit -- train() itself only logs every 100th iteration.
 On a machine without a GPU `Tensor.cuda()` is the identity (dino_tracker.py and models/utils.py call it unconditionally)
@@ -38,7 +40,8 @@ def multinomial(self, *args, **kw):
     return _multinomial(self.cpu(), *args, **kw).to(self.device)
 
 
-torch.randperm, torch.randint, torch.Tensor.multinomial = randperm, randint, multinomial
+if not os.environ.get("DTK_TRAIN_NO_RNG_SHIM"):  # timing runs keep torch's own generators (device draws stay on the device)
+    torch.randperm, torch.randint, torch.Tensor.multinomial = randperm, randint, multinomial
 if not torch.cuda.is_available():
     torch.Tensor.cuda = lambda self, *a, **k: self
 
@@ -75,8 +78,16 @@ if __name__ == "__main__":
         return _update(self, *vals)
 
     dino_tracker.DINOTracker.update_losses = update_losses
+    tprof_path = os.environ.get("DTK_TRAIN_TORCHPROF")
     prof_path = os.environ.get("DTK_TRAIN_CPROFILE")
-    if prof_path:  # where does the HOST spend an iteration
+    if tprof_path:  # per-operator HOST and device time of the whole run (torch.profiler), sorted by self CPU time
+        from torch.profiler import ProfilerActivity, profile
+        acts = [ProfilerActivity.CPU] + ([ProfilerActivity.CUDA] if torch.cuda.is_available() else [])
+        with profile(activities=acts, record_shapes=False) as prof:
+            runpy.run_path(script, run_name="__main__")
+        with open(tprof_path, "w") as fh:
+            fh.write(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=60, max_name_column_width=70))
+    elif prof_path:  # where does the HOST spend an iteration
         import cProfile
         import pstats
         pr = cProfile.Profile()
