@@ -313,3 +313,19 @@ def col2im(dcols: torch.Tensor, dx: torch.Tensor, ksize: int, pad: int, dil: int
 
 def transpose_f32(src: torch.Tensor, dst: torch.Tensor, rows: int, cols: int, batch: int = 1) -> None:
     check(lib().dtk_transpose_f32(_p(src, torch.float32), _p(dst, torch.float32), rows, cols, batch, _stream()))
+
+
+def resample2d_forward(src: torch.Tensor, dst: torch.Tensor, ylo, ywhi, xlo, xwhi) -> None:
+    """dtk_resample2d_forward: src [n, C, hs, ws] -> dst [n, C, hd, wd] through the per-axis two-tap tables."""
+    n, c, hs, ws = src.shape
+    hd, wd = dst.shape[-2:]
+    check(lib().dtk_resample2d_forward(_p(src, torch.float32), _p(dst, torch.float32), n * c, hs, ws, hd, wd, _p(ylo, torch.int32),
+                                       _p(ywhi, torch.float32), _p(xlo, torch.int32), _p(xwhi, torch.float32), _stream()))
+
+
+def resample2d_backward(ddst: torch.Tensor, dsrc: torch.Tensor, yranges, ywhi, xranges, xwhi) -> None:
+    n, c, hd, wd = ddst.shape
+    hs, ws = dsrc.shape[-2:]
+    check(lib().dtk_resample2d_backward(_p(ddst, torch.float32), _p(dsrc, torch.float32), n * c, hs, ws, hd, wd,
+                                        _p(yranges, torch.int32), _p(ywhi, torch.float32), _p(xranges, torch.int32),
+                                        _p(xwhi, torch.float32), _stream()))

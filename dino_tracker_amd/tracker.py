@@ -61,6 +61,7 @@ class Tracker(nn.Module):
         self._refined_key = None   # Delta-DINO parameter versions the cached refined volume was computed with
         self._workspace = None
         self.track_round_sources = 0          # dtk_track_opts.round_sources (0 = library default)
+        self.cyc_sampling = os.environ.get("DTK_CYC_SAMPLING", "device")  # see _cycle_point_sets
         self.track_tier = ops.TIER_AUTO       # dtk_track_opts.tier
         self.last_track_stats = None          # dtk_track_stats of the most recent dtk_track call (dict)
 
@@ -349,7 +350,15 @@ class Tracker(nn.Module):
     def _cycle_point_sets(self, frames_set_t, fg_masks):
         """Index plumbing of tracker.py:183-222: cyc_n_frames random (source, target) frame pairs of the batch and, per
         pair, cyc_batch_size_per_frame pixel positions of the source frame split foreground / background by the mask.
-        Random numbers are drawn in the reference's order (2 x randint, then randperm fg, randperm bg per pair)."""
+
+        `self.cyc_sampling` (default from $DTK_CYC_SAMPLING, "device"):
+          "device"     everything on the device, no host read: per pair one uniform key per pixel, the n_fg largest keys among
+                       the foreground pixels and the n_bg largest among the background ones = a uniformly random subset
+                       without replacement, which is what `coords[randperm(len)[:k]]` is (tracker.py:215-217);
+          "reference"  the reference's own sequence of draws (2 x randint, then a HOST randperm over the foreground and one
+                       over the background pixels of each pair): bit-identical index sets for identical seeds (the parity
+                       tests run this), at the price of 8 host permutations of up to 4e5 elements and ~20 device
+                       synchronisations per iteration."""
         n = frames_set_t.shape[0]
         dev = frames_set_t.device
         source_selector = torch.randint(n, (self.cyc_n_frames,), device=dev)
@@ -357,6 +366,22 @@ class Tracker(nn.Module):
         h, w = fg_masks.shape[-2:]
         n_fg = int(self.cyc_batch_size_per_frame * self.cyc_fg_points_ratio)
         n_bg = self.cyc_batch_size_per_frame - n_fg
+        if self.cyc_sampling == "device":
+            k = self.cyc_n_frames
+            src_t = frames_set_t[source_selector].long()                                  # [k] frame numbers
+            fg = (fg_masks[src_t.to(fg_masks.device)] > 0).reshape(k, h * w).to(dev)
+            keys = torch.rand(k, h * w, device=dev)
+            neg = torch.full_like(keys, -1.0)
+            pick_fg = torch.topk(torch.where(fg, keys, neg), min(n_fg, h * w), dim=1)
+            pick_bg = torch.topk(torch.where(fg, neg, keys), min(n_bg, h * w), dim=1)
+            cells = torch.cat([pick_fg.indices, pick_bg.indices], dim=1)                  # [k, n_fg + n_bg]
+            valid = torch.cat([pick_fg.values, pick_bg.values], dim=1) >= 0               # fewer pixels than asked for: dropped
+            t_col = src_t[:, None].expand_as(cells)
+            pts = torch.stack([(cells % w).float(), torch.div(cells, w, rounding_mode="floor").float(), t_col.float()], dim=2)
+            src_idx = source_selector[:, None].expand_as(cells)
+            tgt_idx = target_selector[:, None].expand_as(cells)
+            keep = valid.reshape(-1).nonzero()[:, 0]                                      # the one host read of this function
+            return pts.reshape(-1, 3)[keep], src_idx.reshape(-1)[keep].long(), tgt_idx.reshape(-1)[keep].long()
         pts, src_idx, tgt_idx = [], [], []
         for s_i, t_i in zip(source_selector.tolist(), target_selector.tolist()):
             source_t = int(frames_set_t[s_i])
@@ -385,7 +410,7 @@ class Tracker(nn.Module):
         tgt_xy = unnorm(self.get_point_predictions((src_pts, src_idx, tgt_idx, frames_set_t), emb))
         tgt_pts = torch.cat([tgt_xy, t_of[tgt_idx][:, None]], dim=1)
         back_xy = unnorm(self.get_point_predictions((tgt_pts, tgt_idx, src_idx, frames_set_t), emb))
-        keep = torch.norm(src_pts[:, :2] - back_xy[:, :2], dim=1) <= self.cyc_thresh
+        keep = (torch.norm(src_pts[:, :2] - back_xy[:, :2], dim=1) <= self.cyc_thresh).nonzero()[:, 0]  # ONE host read
         src_t, tgt_t = t_of[src_idx][keep], t_of[tgt_idx][keep]
         norm_t = lambda t: self.range_normalizer(t[:, None].repeat(1, 3), dst=(-1, 1), dims=[2])[:, 2]
         return {

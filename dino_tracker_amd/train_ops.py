@@ -264,8 +264,68 @@ def align_matrix(n_vit: int, n_cnn: int, vit_stride: int, vit_patch: int, cnn_st
     return m.to(device=device, dtype=dtype)
 
 
+def align_tables(n_vit: int, n_cnn: int, vit_stride: int, vit_patch: int, cnn_stride: int):
+    """The two-tap form of `align_matrix` along one axis, for the device kernels (dtk_resample2d_*): destination index i
+    reads source cells lo[i] and min(lo[i] + 1, n_cnn - 1) with weights 1 - whi[i], whi[i] -- same float32 arithmetic as
+    align_matrix -- and, for the backward gather, ranges[4][n_cnn]: start / end of the destination indices whose LO is a,
+    then start / end of those whose HI is a (lo and hi are non-decreasing)."""
+    px = torch.arange(n_vit, dtype=torch.float32) * vit_stride + vit_patch / 2.0
+    c_br = (n_cnn - 1) * cnn_stride
+    g = -1.0 - (1.0 / c_br) + (2.0 * px / c_br)
+    pos = (((g + 1.0) / 2.0) * (n_cnn - 1)).clamp(0, n_cnn - 1)
+    lo = pos.floor().clamp(max=n_cnn - 1)
+    whi = pos - lo
+    lo = lo.long()
+    hi = (lo + 1).clamp(max=n_cnn - 1)
+    assert bool((lo[1:] >= lo[:-1]).all()) and bool((hi[1:] >= hi[:-1]).all())
+    a = torch.arange(n_cnn)
+    ranges = torch.stack([torch.searchsorted(lo, a, right=False), torch.searchsorted(lo, a, right=True),
+                          torch.searchsorted(hi, a, right=False), torch.searchsorted(hi, a, right=True)])
+    return lo.to(torch.int32), whi.to(torch.float32), ranges.to(torch.int32).contiguous()
+
+
+_ALIGN_TABLES = {}
+
+
+def _align_tables_on(device, key):
+    k = (str(device),) + key
+    if k not in _ALIGN_TABLES:
+        _ALIGN_TABLES[k] = tuple(t.to(device) for t in align_tables(*key))
+    return _ALIGN_TABLES[k]
+
+
+class _AlignResample(torch.autograd.Function):
+    """CNN -> ViT grid alignment on csrc/train.hip (dtk_resample2d_forward / _backward): 4 reads per output, the backward a
+    gather.  (Round 2: two constant interpolation matrices as library GEMMs over 60 x 107 planes, 14 ms per iteration.)"""
+
+    @staticmethod
+    def forward(ctx, cnn, h, w, vit_stride, vit_patch, cnn_stride):
+        from . import ops
+        cnn = cnn.contiguous()
+        n, c, hc, wc = cnn.shape
+        ylo, ywhi, yr = _align_tables_on(cnn.device, (h, hc, vit_stride, vit_patch, cnn_stride))
+        xlo, xwhi, xr = _align_tables_on(cnn.device, (w, wc, vit_stride, vit_patch, cnn_stride))
+        out = torch.empty(n, c, h, w, dtype=torch.float32, device=cnn.device)
+        ops.resample2d_forward(cnn, out, ylo, ywhi, xlo, xwhi)
+        ctx.tables = (yr, ywhi, xr, xwhi, hc, wc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import ops
+        yr, ywhi, xr, xwhi, hc, wc = ctx.tables
+        dout = dout.contiguous()
+        n, c = dout.shape[:2]
+        dcnn = torch.empty(n, c, hc, wc, dtype=torch.float32, device=dout.device)
+        ops.resample2d_backward(dout, dcnn, yr, ywhi, xr, xwhi)
+        return dcnn, None, None, None, None, None
+
+
 def align_cnn_to_vit(cnn: torch.Tensor, h: int, w: int, vit_stride: int, vit_patch: int, cnn_stride: int) -> torch.Tensor:
-    """models/utils.py:7-45 as two matrix products: [n, C, hc, wc] -> [n, C, h, w]."""
+    """models/utils.py:7-45: [n, C, hc, wc] -> [n, C, h, w].  Device float32 tensors: the two-tap resampling kernels; host
+    tensors (and other dtypes): the same weights as two matrix products."""
+    if cnn.is_cuda and cnn.dtype == torch.float32 and cnn.shape[0] * cnn.shape[1] <= 65535:
+        return _AlignResample.apply(cnn, h, w, vit_stride, vit_patch, cnn_stride)
     my = align_matrix(h, cnn.shape[-2], vit_stride, vit_patch, cnn_stride, cnn.device, cnn.dtype)
     mx = align_matrix(w, cnn.shape[-1], vit_stride, vit_patch, cnn_stride, cnn.device, cnn.dtype)
     return torch.matmul(my, torch.matmul(cnn, mx.t()))
@@ -366,20 +426,18 @@ def sample_bilinear(emb: torch.Tensor, pts: torch.Tensor) -> torch.Tensor:
 # ---- correlation ------------------------------------------------------------------------------------------------------------
 def cosine_maps(src: torch.Tensor, frames: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
     """tracker.py:158-169: rho[b] = <src[b], frames[tgt[b]]> / max(|src[b]| |frames[tgt[b]]|, 1e-8) -> [B, h, w].
-    Sources are grouped by target frame: one matrix product per frame that is somebody's target."""
+    One batched product of every source with every frame of the set, of which each source keeps its target's map (what the
+    reference's einsum does, tracker.py:159-160): with n <= 8 frames in a training batch that is a few GFLOP, and -- unlike
+    grouping the sources by target frame, round 2's form -- it needs no host read of the target indices (every
+    `unique().tolist()` / `nonzero()` is a device synchronisation; they were 9 of the ~55 per iteration)."""
     n, c, h, w = frames.shape
     b = src.shape[0]
     tgt = tgt.long()
-    out = src.new_zeros(b, h * w)
     fl = frames.reshape(n, c, h * w)
-    snorm = src.norm(dim=1)
-    for f in torch.unique(tgt).tolist():  # one host read per call; n <= 8 frames in a training batch
-        sel = (tgt == f).nonzero()[:, 0]
-        ff = fl[f]
-        dots = src[sel] @ ff
-        den = (snorm[sel][:, None] * ff.norm(dim=0)[None, :]).clamp(min=EPS)
-        out = out.index_copy(0, sel, dots / den)
-    return out.reshape(b, h, w)
+    rows = torch.arange(b, device=src.device)
+    dots = torch.matmul(src, fl)[tgt, rows]                       # [n, B, HW] -> [B, HW]
+    den = (src.norm(dim=1)[:, None] * fl.norm(dim=1)[tgt]).clamp(min=EPS)
+    return (dots / den).reshape(b, h, w)
 
 
 # ---- tracker head -----------------------------------------------------------------------------------------------------------

@@ -72,21 +72,34 @@ if __name__ == "__main__":
 
     _update = dino_tracker.DINOTracker.update_losses
 
+    tprof_path = os.environ.get("DTK_TRAIN_TORCHPROF")
+    PROF = {}
+
     def update_losses(self, *vals):
         LOSSES.append([float(v) for v in vals])
         STAMPS.append(time.time())
+        if tprof_path:  # per-operator host / device time of iterations 3 .. 6 only (set-up and warm-up excluded)
+            if len(LOSSES) == 2:
+                from torch.profiler import ProfilerActivity, profile
+                acts = [ProfilerActivity.CPU] + ([ProfilerActivity.CUDA] if torch.cuda.is_available() else [])
+                PROF["p"] = profile(activities=acts, with_stack=bool(os.environ.get("DTK_TRAIN_TORCHPROF_STACK")))
+                PROF["p"].start()
+            elif len(LOSSES) == 6 and "p" in PROF:
+                PROF["p"].stop()
+                with open(tprof_path, "w") as fh:
+                    fh.write("iterations 3..6 (4 iterations)\n")
+                    fh.write(PROF["p"].key_averages().table(sort_by="self_cpu_time_total", row_limit=70, max_name_column_width=70))
+                    if os.environ.get("DTK_TRAIN_TORCHPROF_STACK"):
+                        fh.write("\n\nby source location (group_by_stack_n = 6)\n")
+                        fh.write(PROF["p"].key_averages(group_by_stack_n=6).table(sort_by="self_cpu_time_total", row_limit=60,
+                                                                                  max_name_column_width=50, max_src_column_width=110))
+                del PROF["p"]
         return _update(self, *vals)
 
     dino_tracker.DINOTracker.update_losses = update_losses
-    tprof_path = os.environ.get("DTK_TRAIN_TORCHPROF")
     prof_path = os.environ.get("DTK_TRAIN_CPROFILE")
-    if tprof_path:  # per-operator HOST and device time of the whole run (torch.profiler), sorted by self CPU time
-        from torch.profiler import ProfilerActivity, profile
-        acts = [ProfilerActivity.CPU] + ([ProfilerActivity.CUDA] if torch.cuda.is_available() else [])
-        with profile(activities=acts, record_shapes=False) as prof:
-            runpy.run_path(script, run_name="__main__")
-        with open(tprof_path, "w") as fh:
-            fh.write(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=60, max_name_column_width=70))
+    if False:
+        pass
     elif prof_path:  # where does the HOST spend an iteration
         import cProfile
         import pstats

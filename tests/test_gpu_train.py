@@ -37,8 +37,10 @@ def test_train_py_unmodified_three_iterations(tmp_path):
     cmd = [sys.executable, "-m", "dino_tracker_amd.run", "--path", os.path.join(ROOT, "oracle", "shims"), "--path", REF,
            os.path.join(ROOT, "tests", "golden", "train_driver.py"), os.path.join(REF, "train.py"),
            "--config", cfg, "--data-path", d, "--seed", "2"]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, PYTHONPATH=ROOT, DTK_TRAIN_LOG=log),
-                       cwd=REF, timeout=3000)
+    # DTK_CYC_SAMPLING=reference: the cycle-consistency point sets drawn in the reference's own order (host randperm), so
+    # that both sides see the same indices; the default ("device") draws an equivalent random subset on the device
+    r = subprocess.run(cmd, capture_output=True, text=True,
+                       env=dict(os.environ, PYTHONPATH=ROOT, DTK_TRAIN_LOG=log, DTK_CYC_SAMPLING="reference"), cwd=REF, timeout=3000)
     os.makedirs(LOGDIR, exist_ok=True)
     with open(os.path.join(LOGDIR, "cfg5_train.log"), "w") as fh:
         fh.write("$ " + " ".join(cmd) + "\n" + r.stdout[-6000:] + "\n--- stderr ---\n" + r.stderr[-6000:])
@@ -173,12 +175,21 @@ def test_training_step_on_device_matches_host():
     masks = torch.zeros(T, H, W, dtype=torch.uint8, device=dev)
     masks[:, 30:90, 60:150] = 255
     trk.cyc_n_frames, trk.cyc_batch_size_per_frame = 3, 32
-    cyc = trk.get_cycle_consistent_coords(frames_set_t.to(dev), masks)
-    k = cyc["source_points"].shape[0]
-    assert 0 < k <= 3 * 32
-    assert (torch.norm(cyc["source_points"][:, :2] - cyc["cycle_points"][:, :2], dim=1) <= trk.cyc_thresh).all()
-    for key in ("target_points", "source_frame_indices", "target_frame_indices", "source_times_normalized"):
-        assert cyc[key].shape[0] == k
+    for mode in ("device", "reference"):
+        trk.cyc_sampling = mode
+        cyc = trk.get_cycle_consistent_coords(frames_set_t.to(dev), masks)
+        k = cyc["source_points"].shape[0]
+        assert 0 < k <= 3 * 32, mode
+        assert (torch.norm(cyc["source_points"][:, :2] - cyc["cycle_points"][:, :2], dim=1) <= trk.cyc_thresh).all()
+        for key in ("target_points", "source_frame_indices", "target_frame_indices", "source_times_normalized"):
+            assert cyc[key].shape[0] == k
+        # the sampled sources honour the foreground / background split (70 % of 32 inside the mask) and lie on batch frames
+        pts, si, ti = trk._cycle_point_sets(frames_set_t.to(dev), masks)
+        assert pts.shape == (3 * 32, 3) and si.shape == ti.shape == (3 * 32,)
+        inside = (pts[:, 0] >= 60) & (pts[:, 0] < 150) & (pts[:, 1] >= 30) & (pts[:, 1] < 90)
+        assert int(inside.sum()) == 3 * int(32 * trk.cyc_fg_points_ratio), (mode, int(inside.sum()))
+        assert torch.equal(pts[:, 2], frames_set_t.to(dev)[si].float())
+        assert len(set(map(tuple, pts.cpu().tolist()))) >= 3 * 32 - 3  # without replacement inside a pair
     preds = trk.get_cycle_consistent_preds(frames_set_t.to(dev), masks)
     assert preds["source_target_coords"].requires_grad and preds["source_target_coords"].shape[1] == 2
     assert train_ops._WORKSPACE  # the unfolded conv operands of the step
