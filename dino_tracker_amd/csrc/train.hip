@@ -537,9 +537,11 @@ __device__ __forceinline__ float im2col_value(const float* __restrict__ xf, long
     return xf[(long long)c * L + (long long)sy * W + sx];
 }
 
-// layout 0: cols[f][l][Kp] -- 32 pixels x 32 patch indices per workgroup through an LDS tile: the frame is READ along the
-// pixels (consecutive lanes = consecutive x of one tap: coalesced) and the operand is WRITTEN along k (128-byte rows)
-// layout 1: cols[f][Kp][Lp], pixels contiguous on both sides: one thread per element
+// layout 0: cols[f][l][Kp] -- a workgroup owns 32 consecutive pixels and walks ALL patch indices in tiles of 32 through an
+// LDS transpose tile: the frame is READ along the pixels (consecutive lanes = consecutive x of one tap) and the operand is
+// WRITTEN along k, 128 bytes per pixel and tile, the 32 rows of a workgroup forming one contiguous 32 x Kp x 4 byte range.
+// (First form: one workgroup per 32 x 32 tile = 5 M workgroups of 1 K elements for the second layer: 1.2 TB/s.)
+// layout 1: cols[f][Kp][Lp], pixels contiguous on both sides: a workgroup owns 1024 pixels of 8 patch indices, 16-byte stores
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ cols, int C, int H, int W,
                                                      int ks, int pad, int dil, int reflect, int layout, int Kp, long long Lp) {
     const int f = blockIdx.z;
@@ -550,26 +552,36 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
         __shared__ float t[32][33];
         float* cf = cols + (long long)f * L * Kp;
         const long long l0 = (long long)blockIdx.x * 32;
-        const int k0 = blockIdx.y * 32;
         const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        const long long lr = l0 + tx;
+        for (int k0 = 0; k0 < Kp; k0 += 32) {
+            __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int kk = ty + 8 * i;
-            const long long l = l0 + tx;
-            t[kk][tx] = l < L ? im2col_value(xf, l, k0 + kk, K, H, W, ks, pad, dil, reflect) : 0.f;
-        }
-        __syncthreads();
+            for (int i = 0; i < 4; ++i) {
+                const int kk = ty + 8 * i;
+                t[kk][tx] = lr < L ? im2col_value(xf, lr, k0 + kk, K, H, W, ks, pad, dil, reflect) : 0.f;
+            }
+            __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long long l = l0 + ty + 8 * i;
-            if (l < L) cf[l * Kp + k0 + tx] = t[tx][ty + 8 * i];
+            for (int i = 0; i < 4; ++i) {
+                const long long l = l0 + ty + 8 * i;
+                if (l < L) cf[l * Kp + k0 + tx] = t[tx][ty + 8 * i];
+            }
         }
     } else {
         float* cf = cols + (long long)f * Kp * Lp;
-        const int k = blockIdx.y;
-        const long long l = (long long)blockIdx.x * 256 + threadIdx.x;
-        if (l >= Lp) return;
-        cf[(long long)k * Lp + l] = l < L ? im2col_value(xf, l, k, K, H, W, ks, pad, dil, reflect) : 0.f;
+        const long long l = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+        if (l >= Lp) return;  // Lp is a multiple of 4
+        for (int kk = 0; kk < 8; ++kk) {
+            const int k = blockIdx.y * 8 + kk;
+            if (k >= Kp) break;
+            float4 v;
+            v.x = l + 0 < L ? im2col_value(xf, l + 0, k, K, H, W, ks, pad, dil, reflect) : 0.f;
+            v.y = l + 1 < L ? im2col_value(xf, l + 1, k, K, H, W, ks, pad, dil, reflect) : 0.f;
+            v.z = l + 2 < L ? im2col_value(xf, l + 2, k, K, H, W, ks, pad, dil, reflect) : 0.f;
+            v.w = l + 3 < L ? im2col_value(xf, l + 3, k, K, H, W, ks, pad, dil, reflect) : 0.f;
+            *reinterpret_cast<float4*>(cf + (long long)k * Lp + l) = v;
+        }
     }
 }
 
@@ -659,14 +671,15 @@ extern "C" int dtk_im2col(const float* x, float* cols, int32_t n, int32_t C, int
     DTK_REQUIRE(2 * pad == dil * (ksize - 1), "dtk_im2col: only 'same' convolutions (2 pad == dil (k - 1))");
     DTK_REQUIRE(!reflect || (pad < H && pad < W), "dtk_im2col: reflect padding needs pad < H, W");
     DTK_REQUIRE(Kp >= C * ksize * ksize && (layout == 0 || Lp >= (long long)H * W), "dtk_im2col: Kp / Lp too small");
-    DTK_REQUIRE(layout != 0 || (Kp % 32 == 0 && Kp / 32 <= 65535), "dtk_im2col: layout 0 needs Kp %% 32 == 0");
+    DTK_REQUIRE(layout != 0 || Kp % 32 == 0, "dtk_im2col: layout 0 needs Kp %% 32 == 0");
+    DTK_REQUIRE(layout == 0 || (Lp % 4 == 0 && ((size_t)cols & 15) == 0), "dtk_im2col: layout 1 needs Lp %% 4 == 0 and 16-byte alignment");
     const long long L = (long long)H * W;
     if (layout == 0)
-        DTK_LAUNCH("train_im2col", im2col_kernel, dim3(dtk_cdiv(L, 32), Kp / 32, n), dim3(256), 0, dtk_stream(stream), x, cols, C, H,
-                   W, ksize, pad, dil, reflect, 0, Kp, (long long)0);
+        DTK_LAUNCH("train_im2col", im2col_kernel, dim3(dtk_cdiv(L, 32), 1, n), dim3(256), 0, dtk_stream(stream), x, cols, C, H, W,
+                   ksize, pad, dil, reflect, 0, Kp, (long long)0);
     else
-        DTK_LAUNCH("train_im2col", im2col_kernel, dim3(dtk_cdiv(Lp, 256), Kp, n), dim3(256), 0, dtk_stream(stream), x, cols, C, H,
-                   W, ksize, pad, dil, reflect, 1, Kp, (long long)Lp);
+        DTK_LAUNCH("train_im2col", im2col_kernel, dim3(dtk_cdiv(Lp, 1024), dtk_cdiv(Kp, 8), n), dim3(256), 0, dtk_stream(stream), x,
+                   cols, C, H, W, ksize, pad, dil, reflect, 1, Kp, (long long)Lp);
     return DTK_OK;
 }
 
