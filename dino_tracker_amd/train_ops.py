@@ -456,6 +456,29 @@ def _shifted_planes(x: torch.Tensor) -> torch.Tensor:
     return torch.stack([xp[:, dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3)], dim=1)
 
 
+class _TapContract(torch.autograd.Function):
+    """y[b, o, k] = sum_t w[o, t] x[b, t, k] for a TINY weight matrix (16 x 9 / 9 x 16) and B maps of k = h w cells.
+    The point is the backward: autograd's einsum gradient computes dw as ONE product with a 16 x 9 output and a reduction
+    over all B h w = 4e6 positions, which the GEMM library runs on a handful of workgroups (2.3 ms per call, six calls = 14 ms
+    of a training iteration: `Cijk_..._MT16x16x512` in profiles/r03_train_kernel_trace.md).  Here dw is a batched product per
+    map -- B independent 16 x 9 results -- and a sum over the batch."""
+
+    @staticmethod
+    def forward(ctx, w, x):
+        ctx.save_for_backward(w, x)
+        return torch.matmul(w, x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        w, x = ctx.saved_tensors
+        dw = dx = None
+        if ctx.needs_input_grad[0]:
+            dw = torch.bmm(dy, x.transpose(1, 2)).sum(dim=0)
+        if ctx.needs_input_grad[1]:
+            dx = torch.matmul(w.t(), dy)
+        return dw, dx
+
+
 def head_logits(head, x: torch.Tensor) -> torch.Tensor:
     """cnn_refiner (tracker_head.py:47-58): [B, 1, h, w] -> [B, 1, h, w], as two matrix products over the whole batch:
         hidden[16] = relu(W1[16 x 9] . neighbourhood(x) + b1)
@@ -466,10 +489,11 @@ def head_logits(head, x: torch.Tensor) -> torch.Tensor:
     b, _, h, w = x.shape
     w1 = normalized_weight(c0.weight).reshape(c0.out_channels, 9)
     w2 = normalized_weight(c2.weight).reshape(c2.in_channels, 9)
-    hid = torch.einsum("ot,bthw->bohw", w1, _shifted_planes(x[:, 0]))
+    hid = _TapContract.apply(w1, _shifted_planes(x[:, 0]).reshape(b, 9, h * w)).reshape(b, c0.out_channels, h, w)
     if c0.bias is not None:
         hid = hid + c0.bias[None, :, None, None]
-    planes = F.pad(torch.einsum("ct,bchw->bthw", w2, torch.relu(hid)), (1, 1, 1, 1))
+    planes = _TapContract.apply(w2.t(), torch.relu(hid).reshape(b, c2.in_channels, h * w)).reshape(b, 9, h, w)
+    planes = F.pad(planes, (1, 1, 1, 1))
     z = sum(planes[:, 3 * dy + dx, dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3))
     if c2.bias is not None:
         z = z + c2.bias[0]
