@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256) void head_exact_kernel(dtk_geom g, const float
                                                          const float* __restrict__ maps, int HWs,
                                                          const int32_t* __restrict__ out_idx,
                                                          float* __restrict__ out_xy, int m0, int count, int M,
-                                                         const int32_t* __restrict__ dM, int normalized) {
+                                                         const int32_t* __restrict__ dM, int normalized,
+                                                         float* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int HW = g.ph * g.pw, pw = g.pw, ph = g.ph;
     const int HWp = (HW + 3) & ~3;
@@ -283,7 +284,16 @@ __global__ __launch_bounds__(256) void head_exact_kernel(dtk_geom g, const float
     zs = block_sum(zs, red);
     if (tid < 64) {
         auto zfun = [&](int r, int c) { return sz[r * pw + c]; };
-        dtk_disk_softargmax(g, kstar, zm, zs, zfun, normalized, out_xy + 2 * (size_t)(out_idx ? out_idx[m] : m));
+        float sq = 0.f;
+        dtk_disk_softargmax(g, kstar, zm, zs, zfun, normalized, out_xy + 2 * (size_t)(out_idx ? out_idx[m] : m), &sq);
+        // what the backward of the training step needs again (dtk_head_backward): arg-max cell, softmax statistics, disk mass
+        if (stats && tid == 0) {
+            float* st = stats + 4 * (size_t)i;
+            st[0] = __int_as_float(kstar);
+            st[1] = zm;
+            st[2] = zs;
+            st[3] = sq;
+        }
     }
 }
 
@@ -374,7 +384,7 @@ int dtk_track_exact(const dtk_geom* g, const float* feat, const float* norms, co
         DTK_LAUNCH("corr_exact", corr_exact_kernel, dim3(dtk_cdiv(HW, TN), dtk_cdiv(cnt, TM)), dim3(256), 0, st, *g, feat,
                            norms, emb, src_row, tgt, snorm, maps, (int)m0, cnt, M, dM, HWs, 1);
         DTK_LAUNCH("head_exact", head_exact_kernel, dim3(cnt), dim3(256), lds, st, *g, head, maps, HWs, out_idx, out_xy,
-                           (int)m0, cnt, M, dM, normalized);
+                           (int)m0, cnt, M, dM, normalized, (float*)nullptr);
     }
     return DTK_OK;
 }
@@ -389,7 +399,231 @@ extern "C" int dtk_head_forward(const dtk_geom* g, const float* head, const floa
     DTK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head_exact_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     DTK_LAUNCH("head_exact", head_exact_kernel, dim3(B), dim3(256), lds, dtk_stream(stream), *g, head, maps, g->ph * g->pw,
-                       (const int32_t*)nullptr, out_xy, 0, B, B, (const int32_t*)nullptr, normalized);
+                       (const int32_t*)nullptr, out_xy, 0, B, B, (const int32_t*)nullptr, normalized, (float*)nullptr);
+    return DTK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// TrackerHead.forward / backward of the TRAINING step (tracker_head.py:68-121 under autograd, dino_tracker.py:392-448).
+// Forward = head_exact_kernel, which also leaves per-map statistics (arg-max cell, softmax maximum and partition sum, disk
+// mass).  The backward is LOCAL: with x^ = sum_D q X / sum_D q over the disk D around the arg-max and q = softmax(z) on D,
+//     dz_k = p_k (dq_k - sum_{j in D} p_j dq_j),   dq_k = [gx (X_k - x^) + gy (Y_k - y^)] / sum_D q   (k in D, else 0)
+// and the subtracted mean vanishes identically when no zero-mass fallback fired (sum_D p_j (X_j - x^) = 0): logits outside the
+// disk do not move the output.  So dz lives on the disk (<= 81 cells), the hidden gradient on its 13 x 13 neighbourhood, the
+// input gradient on 15 x 15 -- the windows of the inference kernel refine_head.  One wave per map, windows in LDS:
+// recompute hidden and logits of the window, then the two transposed 3 x 3 convolutions and the four parameter gradients
+// (per-map partials, summed by the caller: deterministic).  Maps whose fallback fired (disk mass < 1e-8: dz is dense) are
+// not handled here: the caller checks `stats` and takes the autograd path for such a batch.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int HB_RD = 5, HB_WX = 2 * HB_RD + 5, HB_WH = 2 * HB_RD + 3, HB_WZ = 2 * HB_RD + 1;  // 15, 13, 11
+
+__global__ __launch_bounds__(256) void head_backward_kernel(dtk_geom g, const float* __restrict__ head,
+                                                            const float* __restrict__ maps, const float* __restrict__ stats,
+                                                            const float* __restrict__ gout, float* __restrict__ dmaps,
+                                                            float* __restrict__ dhead, int B, int normalized) {
+    constexpr int NH = HB_WH * HB_WH, NZ = HB_WZ * HB_WZ, XP = HB_WX + 1;
+    __shared__ float s_x[4][HB_WX * XP];
+    __shared__ float s_h[4][DTK_HEAD_HIDDEN * NH];   // hidden activations of the window, later their gradients
+    __shared__ unsigned char s_m[4][DTK_HEAD_HIDDEN * NH];  // relu' of the hidden pre-activation (0 also outside the map)
+    __shared__ float s_z[4][NZ], s_dz[4][NZ];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + w;
+    if (b >= B) return;  // wave-uniform; only wave-level barriers below
+    const int ph = g.ph, pw = g.pw, HW = ph * pw;
+    const float* st = stats + 4 * (size_t)b;
+    const int kstar = __float_as_int(st[0]);
+    const float zmax = st[1], Z = st[2];
+    const int kr = kstar / pw, kc = kstar % pw;
+    const float* map = maps + (size_t)b * HW;
+    const float* w1 = head;
+    const float* b1 = head + 144;
+    const float* w2 = head + 160;
+    const float b2 = head[304];
+    float* sx = s_x[w];
+    float* sh = s_h[w];
+    unsigned char* sm = s_m[w];
+    float* sz = s_z[w];
+    float* sdz = s_dz[w];
+    auto wsync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // x window: rows kr - 7 .. kr + 7, columns kc - 7 .. kc + 7 (zero outside the map: conv1's padding)
+    for (int i = lane; i < HB_WX * HB_WX; i += WAVE) {
+        const int jr = i / HB_WX, jc = i - jr * HB_WX;
+        const int r = kr - (HB_RD + 2) + jr, c = kc - (HB_RD + 2) + jc;
+        sx[jr * XP + jc] = (r >= 0 && r < ph && c >= 0 && c < pw) ? map[r * pw + c] : 0.f;
+    }
+    wsync();
+    // hidden window: cell (hy, hx) = map cell (kr - 6 + hy, kc - 6 + hx); outside the map it is conv2's zero padding
+    for (int i = lane; i < NH; i += WAVE) {
+        const int hy = i / HB_WH, hx = i - hy * HB_WH;
+        const int r = kr - (HB_RD + 1) + hy, c = kc - (HB_RD + 1) + hx;
+        const bool in = r >= 0 && r < ph && c >= 0 && c < pw;
+        float x9[9];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) x9[dy * 3 + dx] = sx[(hy + dy) * XP + hx + dx];
+#pragma unroll
+        for (int ch = 0; ch < DTK_HEAD_HIDDEN; ++ch) {
+            float a = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) a = fmaf(w1[ch * 9 + t], x9[t], a);
+            a += b1[ch];
+            const bool pos = in && a > 0.f;
+            sh[ch * NH + i] = pos ? a : 0.f;
+            sm[ch * NH + i] = pos ? 1 : 0;
+        }
+    }
+    wsync();
+    // logits of the 11 x 11 window: cell (zy, zx) = map cell (kr - 5 + zy, kc - 5 + zx) = hidden cell (zy + 1, zx + 1)
+    for (int i = lane; i < NZ; i += WAVE) {
+        const int zy = i / HB_WZ, zx = i - zy * HB_WZ;
+        float a = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < DTK_HEAD_HIDDEN; ++ch)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) a = fmaf(w2[ch * 9 + dy * 3 + dx], sh[ch * NH + (zy + dy) * HB_WH + zx + dx], a);
+        sz[i] = a + b2;
+    }
+    wsync();
+    // disk: masses, centre, dq, dz
+    const float half = (float)(g.patch / 2);
+    float p_[2], cx[2], cy[2];
+    bool ok[2];
+    float sq = 0.f, sqx = 0.f, sqy = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int i = lane + WAVE * sl;
+        const int zy = i / HB_WZ, zx = i - zy * HB_WZ;
+        const int r = kr - HB_RD + zy, c = kc - HB_RD + zx;
+        const float dx = (float)((c - kc) * g.stride), dy = (float)((r - kr) * g.stride);
+        ok[sl] = i < NZ && r >= 0 && r < ph && c >= 0 && c < pw && sqrtf(dx * dx + dy * dy) <= g.radius;
+        p_[sl] = ok[sl] ? expf(sz[min(i, NZ - 1)] - zmax) / Z : 0.f;
+        cx[sl] = (float)(c * g.stride) + half;
+        cy[sl] = (float)(r * g.stride) + half;
+        sq += p_[sl]; sqx += p_[sl] * cx[sl]; sqy += p_[sl] * cy[sl];
+    }
+    sq = wave_sum(sq); sqx = wave_sum(sqx); sqy = wave_sum(sqy);
+    const float xh = sqx / sq, yh = sqy / sq;
+    float gx = gout[2 * (size_t)b], gy = gout[2 * (size_t)b + 1];
+    if (normalized) { gx *= 2.f / (float)(g.video_w - 1); gy *= 2.f / (float)(g.video_h - 1); }
+    float dq[2], cbar = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        dq[sl] = ok[sl] ? (gx * (cx[sl] - xh) + gy * (cy[sl] - yh)) / sq : 0.f;
+        cbar += p_[sl] * dq[sl];
+    }
+    cbar = wave_sum(cbar);  // zero up to rounding (no fallback here)
+    float db2 = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int i = lane + WAVE * sl;
+        const float dz = ok[sl] ? p_[sl] * (dq[sl] - cbar) : 0.f;
+        if (i < NZ) sdz[i] = dz;
+        db2 += dz;
+    }
+    db2 = wave_sum(db2);
+    wsync();
+    float* dh = dhead + 305 * (size_t)b;
+    // dW2[ch][t] = sum_k dz_k hid[ch][k + t]
+    for (int o = lane; o < DTK_HEAD_HIDDEN * 9; o += WAVE) {
+        const int ch = o / 9, t = o - ch * 9, dy = t / 3, dx = t - dy * 3;
+        float a = 0.f;
+        for (int i = 0; i < NZ; ++i) {
+            const int zy = i / HB_WZ, zx = i - zy * HB_WZ;
+            a = fmaf(sdz[i], sh[ch * NH + (zy + dy) * HB_WH + zx + dx], a);
+        }
+        dh[160 + o] = a;
+    }
+    if (lane == 0) dh[304] = db2;
+    wsync();
+    // dhid_pre[ch][m] = relu'(.) sum_t w2[ch][t] dz[m - t]   (hidden cell m = (hy, hx); dz cell = (hy - dy, hx - dx) in z coordinates)
+    for (int i = lane; i < NH; i += WAVE) {
+        const int hy = i / HB_WH, hx = i - hy * HB_WH;
+        float dzt[9];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int zy = hy - dy, zx = hx - dx;  // z cell whose tap (dy, dx) reads this hidden cell
+                dzt[dy * 3 + dx] = (zy >= 0 && zy < HB_WZ && zx >= 0 && zx < HB_WZ) ? sdz[zy * HB_WZ + zx] : 0.f;
+            }
+#pragma unroll
+        for (int ch = 0; ch < DTK_HEAD_HIDDEN; ++ch) {
+            float a = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) a = fmaf(w2[ch * 9 + t], dzt[t], a);
+            sh[ch * NH + i] = sm[ch * NH + i] ? a : 0.f;
+        }
+    }
+    wsync();
+    // db1[ch], dW1[ch][t] = sum_m dhid_pre[ch][m] x[m + t]
+    for (int o = lane; o < DTK_HEAD_HIDDEN * 10; o += WAVE) {
+        const int ch = o / 10, t = o - ch * 10;
+        float a = 0.f;
+        if (t == 9) {
+            for (int i = 0; i < NH; ++i) a += sh[ch * NH + i];
+            dh[144 + ch] = a;
+        } else {
+            const int dy = t / 3, dx = t - dy * 3;
+            for (int i = 0; i < NH; ++i) {
+                const int hy = i / HB_WH, hx = i - hy * HB_WH;
+                a = fmaf(sh[ch * NH + i], sx[(hy + dy) * XP + hx + dx], a);
+            }
+            dh[ch * 9 + t] = a;
+        }
+    }
+    // dx[j] = sum_ch sum_t w1[ch][t] dhid_pre[ch][j - t]   (x cell j = (jr, jc); hidden cell = (jr - dy, jc - dx))
+    float* dm = dmaps + (size_t)b * HW;
+    for (int i = lane; i < HB_WX * HB_WX; i += WAVE) {
+        const int jr = i / HB_WX, jc = i - jr * HB_WX;
+        const int r = kr - (HB_RD + 2) + jr, c = kc - (HB_RD + 2) + jc;
+        if (r < 0 || r >= ph || c < 0 || c >= pw) continue;
+        float a = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int hy = jr - dy, hx = jc - dx;
+                if (hy < 0 || hy >= HB_WH || hx < 0 || hx >= HB_WH) continue;
+#pragma unroll
+                for (int ch = 0; ch < DTK_HEAD_HIDDEN; ++ch) a = fmaf(w1[ch * 9 + dy * 3 + dx], sh[ch * NH + hy * HB_WH + hx], a);
+            }
+        dm[r * pw + c] = a;
+    }
+}
+
+}  // namespace
+
+extern "C" int dtk_head_forward_train(const dtk_geom* g, const float* head, const float* maps, float* out_xy, float* stats, int B,
+                                      int normalized, void* stream) {
+    DTK_REQUIRE(g && head && maps && out_xy && stats && B >= 0, "dtk_head_forward_train: null pointer");
+    DTK_REQUIRE(g->ph > 0 && g->pw > 0 && g->stride > 0 && g->patch > 0, "dtk_head_forward_train: bad geometry");
+    if (B == 0) return DTK_OK;
+    const size_t lds = exact_head_lds(g);
+    DTK_REQUIRE(lds <= 160 * 1024, "dtk_head_forward_train: token grid %dx%d needs %zu B of LDS (> 160 KiB)", g->ph, g->pw, lds);
+    DTK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(head_exact_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DTK_LAUNCH("train_head_fwd", head_exact_kernel, dim3(B), dim3(256), lds, dtk_stream(stream), *g, head, maps, g->ph * g->pw,
+               (const int32_t*)nullptr, out_xy, 0, B, B, (const int32_t*)nullptr, normalized, stats);
+    return DTK_OK;
+}
+
+extern "C" int dtk_head_backward(const dtk_geom* g, const float* head, const float* maps, const float* stats, const float* grad_out,
+                                 float* dmaps, float* dhead_partial, int B, int normalized, void* stream) {
+    DTK_REQUIRE(g && head && maps && stats && grad_out && dmaps && dhead_partial && B >= 0, "dtk_head_backward: null pointer");
+    DTK_REQUIRE(g->stride > 0 && g->radius / (float)g->stride <= (float)HB_RD,
+                "dtk_head_backward: disk radius %g px exceeds %d cells of stride %d", (double)g->radius, HB_RD, g->stride);
+    if (B == 0) return DTK_OK;
+    DTK_LAUNCH("train_head_bwd", head_backward_kernel, dim3(dtk_cdiv(B, 4)), dim3(256), 0, dtk_stream(stream), *g, head, maps,
+               stats, grad_out, dmaps, dhead_partial, B, normalized);
     return DTK_OK;
 }
 

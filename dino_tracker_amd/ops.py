@@ -329,3 +329,24 @@ def resample2d_backward(ddst: torch.Tensor, dsrc: torch.Tensor, yranges, ywhi, x
     check(lib().dtk_resample2d_backward(_p(ddst, torch.float32), _p(dsrc, torch.float32), n * c, hs, ws, hd, wd,
                                         _p(yranges, torch.int32), _p(ywhi, torch.float32), _p(xranges, torch.int32),
                                         _p(xwhi, torch.float32), _stream()))
+
+
+def head_forward_train(g: Geom, packed_head: torch.Tensor, maps: torch.Tensor, normalized: bool = True):
+    """dtk_head_forward_train: maps [B, ph*pw] (>= 0) -> (xy [B, 2], stats [B, 4])."""
+    B = maps.shape[0]
+    out = torch.empty((B, 2), dtype=torch.float32, device=maps.device)
+    stats = torch.empty((B, 4), dtype=torch.float32, device=maps.device)
+    check(lib().dtk_head_forward_train(g, _p(packed_head, torch.float32), _p(maps, torch.float32), _p(out), _p(stats), B,
+                                       int(normalized), _stream()))
+    return out, stats
+
+
+def head_backward(g: Geom, packed_head: torch.Tensor, maps: torch.Tensor, stats: torch.Tensor, grad_out: torch.Tensor,
+                  normalized: bool = True):
+    """dtk_head_backward: (dmaps [B, ph*pw], dhead [305]) -- see include/dtk.h for the no-fallback condition."""
+    B = maps.shape[0]
+    dmaps = torch.zeros_like(maps)
+    part = torch.empty((B, 305), dtype=torch.float32, device=maps.device)
+    check(lib().dtk_head_backward(g, _p(packed_head, torch.float32), _p(maps, torch.float32), _p(stats, torch.float32),
+                                  _p(grad_out, torch.float32), _p(dmaps), _p(part), B, int(normalized), _stream()))
+    return dmaps, part.sum(dim=0)

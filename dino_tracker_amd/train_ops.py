@@ -523,9 +523,62 @@ def soft_argmax(p: torch.Tensor, peak: torch.Tensor, patch: int, stride: int, ra
     return torch.stack([px, py], dim=1)
 
 
+class _HeadFused(torch.autograd.Function):
+    """TrackerHead.forward on head_exact_kernel and its LOCAL backward (csrc/track_exact.hip, dtk_head_forward_train /
+    dtk_head_backward): the autograd-traced form below is ~60 kernels forward and ~120 backward over [B, 16, h, w] tensors;
+    this is one launch each way.  `packed` = w1n[16, 9] | b1[16] | w2n[16, 9] | b2 built by torch from the NORMALISED weights,
+    so the normalisation W / sum W (conv_norm.py:34-44) and its gradient stay with autograd."""
+
+    @staticmethod
+    def forward(ctx, maps, packed, geom):
+        from . import ops
+        maps = maps.contiguous()
+        packed = packed.contiguous()
+        out, stats = ops.head_forward_train(geom, packed, maps, normalized=True)
+        ctx.save_for_backward(maps, packed, stats)
+        ctx.geom = geom
+        ctx.mark_non_differentiable(stats)
+        return out, stats
+
+    @staticmethod
+    def backward(ctx, gout, _gstats):
+        from . import ops
+        maps, packed, stats = ctx.saved_tensors
+        dmaps, dpacked = ops.head_backward(ctx.geom, packed, maps, stats, gout.contiguous(), normalized=True)
+        return dmaps, dpacked, None
+
+
+USE_FUSED_HEAD = True  # device tensors: the head of the training step on the hand-written forward / backward kernels
+
+
+def _head_forward_fused(head, cost: torch.Tensor):
+    """The fused route of head_forward, or None when it does not apply (zero-mass fallback in the batch, geometry)."""
+    from ._lib import make_geom
+    b, _, h, w = cost.shape
+    c0, c2 = head.cnn_refiner[0], head.cnn_refiner[2]
+    if c0.out_channels != 16 or c2.in_channels != 16 or float(head.argmax_radius) / float(head.step_h) > 5.0:
+        return None
+    geom = make_geom(1, 32, head.video_h, head.video_w, head.patch_size, head.step_h, float(head.argmax_radius))
+    if (geom.ph, geom.pw) != (h, w):
+        return None
+    b1 = c0.bias if c0.bias is not None else cost.new_zeros(16)
+    b2 = c2.bias if c2.bias is not None else cost.new_zeros(1)
+    packed = torch.cat([normalized_weight(c0.weight).reshape(-1), b1.reshape(-1), normalized_weight(c2.weight).reshape(-1),
+                        b2.reshape(-1)])
+    out, stats = _HeadFused.apply(cost.reshape(b, h * w), packed, geom)
+    # a zero-mass fallback (tracker_head.py:86-94) makes the gradient dense: rare; one host read decides the route
+    if bool((stats[:, 3] < EPS).any()):
+        return None
+    return out
+
+
 def head_forward(head, cost: torch.Tensor) -> torch.Tensor:
     """TrackerHead.forward (tracker_head.py:107-121): cost [B, 1, h, w] >= 0 -> [B, 2] in [-1, 1]."""
     b, _, h, w = cost.shape
+    if USE_FUSED_HEAD and cost.is_cuda and cost.dtype == torch.float32 and b > 0:
+        out = _head_forward_fused(head, cost)
+        if out is not None:
+            return out
     peak = cost[:, 0].reshape(b, h * w).argmax(dim=1)
     p = torch.softmax(head_logits(head, cost).reshape(b, h * w), dim=1).reshape(b, h, w)
     xy = soft_argmax(p, peak, head.patch_size, head.step_h, float(head.argmax_radius))

@@ -175,6 +175,19 @@ int dtk_head_prepare(const float* w1, const float* b1, const float* w2, const fl
 int dtk_head_forward(const dtk_geom* g, const float* head, const float* maps, float* out_xy, int B, int normalized,
                      void* stream);
 
+/* TrackerHead.forward / backward of the TRAINING step (tracker_head.py:68-121 under autograd).  `head` = the packed parameters of
+ * dtk_head_prepare (305 floats: w1[16][9] | b1[16] | w2[16][9] | b2, weights already normalised W / sum W).
+ * dtk_head_forward_train = dtk_head_forward + stats[b][4] = (arg-max cell as int bits, softmax maximum, partition sum, disk
+ * mass before the zero-mass fallback).  dtk_head_backward: grad_out[b][2] -> dmaps[b][ph*pw] (gradient with respect to the
+ * input maps; the caller ZEROES it: only the 15 x 15 window around each arg-max is written) and dhead_partial[b][305] (per-map
+ * parameter gradients, same packing; the caller sums over b).  Exact when no map's fallback fired (stats[b][3] >= 1e-8): then
+ * the output does not depend on logits outside the disk and the backward is local to the window; the caller must take another
+ * route for a batch in which a fallback fired.  Needs radius / stride <= 5. */
+int dtk_head_forward_train(const dtk_geom* g, const float* head, const float* maps, float* out_xy, float* stats, int B,
+                           int normalized, void* stream);
+int dtk_head_backward(const dtk_geom* g, const float* head, const float* maps, const float* stats, const float* grad_out,
+                      float* dmaps, float* dhead_partial, int B, int normalized, void* stream);
+
 /* NormalizedConv2d.forward as a stand-alone layer (models/networks/conv_norm.py:34-46): x[B][Cin][H][W],
  * w[Cout][Cin][k][k] (RAW weights: the per-kernel W / sum(W) is applied inside), bias[Cout] or NULL -> y[B][Cout][H][W];
  * stride 1, zero padding k/2, k odd.  (The tracker path runs these layers fused inside dtk_track / dtk_head_forward.) */

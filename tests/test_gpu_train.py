@@ -325,3 +325,103 @@ def test_conv_mfma_forward_and_gradients_match_float64(case):
     y2 = train_ops._ConvGemm.apply(xd2, wd2, pad, dil, mode)
     y2.backward(dy.cuda())
     assert rel(y2.detach(), y64.detach()) < 1e-5
+
+
+@pytest.mark.parametrize("hw,stride", [((476, 854), 7), ((224, 308), 7), ((126, 140), 14)])
+def test_fused_head_forward_and_backward_match_float64(hw, stride):
+    """csrc/track_exact.hip head_exact_kernel + head_backward_kernel (one launch each way) vs the autograd-traced statement of
+    TrackerHead.forward in float64 on the host: positions, gradient with respect to the cost maps (incl. maps whose arg-max
+    sits in a corner / on a border, where the 15 x 15 window is clipped) and with respect to the four parameter tensors
+    (through the W / sum W normalisation, which stays with autograd)."""
+    import copy
+    from dino_tracker_amd import train_ops
+    from dino_tracker_amd.networks import TrackerHead
+    H, W = hw
+    g = torch.Generator().manual_seed(11)
+    head = TrackerHead(patch_size=14, step_h=stride, step_w=stride, video_h=H, video_w=W).train()
+    with torch.no_grad():
+        for p in head.parameters():
+            p.copy_(torch.rand(p.shape, generator=g) * 0.8 + 0.1)  # benign: sum W well away from 0
+    ph, pw = (H - 14) // stride + 1, (W - 14) // stride + 1
+    B = 37
+    cost = torch.rand(B, 1, ph, pw, generator=g) * 0.3
+    peaks = [(0, 0), (0, pw - 1), (ph - 1, 0), (ph - 1, pw - 1), (ph // 2, 0), (1, pw // 2), (ph - 2, pw - 3)]
+    peaks += [(int(torch.randint(0, ph, (1,), generator=g)), int(torch.randint(0, pw, (1,), generator=g))) for _ in range(B - len(peaks))]
+    yy, xx = torch.meshgrid(torch.arange(ph), torch.arange(pw), indexing="ij")
+    for b, (r, c) in enumerate(peaks):
+        cost[b, 0] += 0.7 * torch.exp(-((yy - r) ** 2 + (xx - c) ** 2) / 6.0)
+    cost[5, 0] = cost[5, 0] * (torch.rand(ph, pw, generator=g) > 0.5)  # zeros as relu leaves them
+    gout = torch.randn(B, 2, generator=g)
+
+    head_d = copy.deepcopy(head).cuda()
+    cost_d = cost.cuda().requires_grad_(True)
+    assert train_ops.USE_FUSED_HEAD
+    out_d = train_ops.head_forward(head_d, cost_d)
+    assert out_d.grad_fn is not None and "HeadFused" in type(out_d.grad_fn).__name__, "the fused route was not taken"
+    out_d.backward(gout.cuda())
+
+    head_64 = copy.deepcopy(head).double()
+    cost_64 = cost.double().requires_grad_(True)
+    out_64 = train_ops.head_forward(head_64, cost_64)
+    out_64.backward(gout.double())
+
+    def rel(a, b):
+        return float((a.double().cpu() - b).abs().max() / b.abs().max())
+
+    e_out = float((out_d.detach().double().cpu() - out_64.detach()).abs().max())
+    e_dx = rel(cost_d.grad, cost_64.grad)
+    # weight gradients: relative to their own maximum.  Bias gradients: sums that cancel (a bias of the first conv moves every
+    # logit almost alike, the last conv's bias exactly alike: its true gradient is 0 by softmax invariance), so their error is
+    # measured against the scale of the same layer's weight gradient.
+    g64 = dict((n, p.grad) for n, p in head_64.named_parameters())
+    errs = {}
+    for n, pd in head_d.named_parameters():
+        scale = g64[n.replace("bias", "weight")].abs().max()
+        errs[n] = float((pd.grad.double().cpu() - g64[n]).abs().max() / scale)
+    print(f"{hw} stride {stride}: |d out| {e_out:.2e}  rel dcost {e_dx:.2e}  rel dparams {errs}")
+    assert e_out < 2e-6 and e_dx < 2e-5 and all(v < 2e-5 for v in errs.values()), (e_out, e_dx, errs)
+    # nothing outside the windows
+    far = cost_64.grad == 0
+    assert bool((cost_d.grad.cpu()[far] == 0).all())
+
+    # the un-fused device route (what round 2 ran) agrees too
+    train_ops.USE_FUSED_HEAD = False
+    try:
+        head_u = copy.deepcopy(head).cuda()
+        cost_u = cost.cuda().requires_grad_(True)
+        train_ops.head_forward(head_u, cost_u).backward(gout.cuda())
+    finally:
+        train_ops.USE_FUSED_HEAD = True
+    assert rel(cost_u.grad, cost_64.grad) < 2e-4
+
+
+def test_fused_head_zero_mass_fallback_takes_the_traced_route():
+    """A map whose disk mass is below 1e-8 (tracker_head.py:86-94) has a dense gradient: head_forward must notice it from the
+    forward kernel's statistics and hand the whole batch to the traced route; the numbers still equal the float64 chain."""
+    import copy
+    from dino_tracker_amd import train_ops
+    from dino_tracker_amd.networks import TrackerHead
+    H, W = 224, 308
+    g = torch.Generator().manual_seed(5)
+    head = TrackerHead(patch_size=14, step_h=7, step_w=7, video_h=H, video_w=W).train()
+    with torch.no_grad():
+        for p in head.parameters():
+            p.copy_(torch.rand(p.shape, generator=g) * 0.8 + 0.1)
+        head.cnn_refiner[2].bias.fill_(0.0)
+    ph, pw = (H - 14) // 7 + 1, (W - 14) // 7 + 1
+    cost = torch.rand(4, 1, ph, pw, generator=g) * 0.1
+    # map 1: a single arg-max cell in one corner, a huge plateau in the other -> the disk around the arg-max holds no mass
+    cost[1, 0] = 0.0
+    cost[1, 0, 0, 0] = 60.0
+    cost[1, 0, ph // 2:, pw // 2:] = 59.9
+    head_d = copy.deepcopy(head).cuda()
+    cost_d = cost.cuda().requires_grad_(True)
+    out_d = train_ops.head_forward(head_d, cost_d)
+    head_64 = copy.deepcopy(head).double()
+    cost_64 = cost.double().requires_grad_(True)
+    out_64 = train_ops.head_forward(head_64, cost_64)
+    p64 = torch.softmax(train_ops.head_logits(head_64, cost_64).reshape(4, -1), dim=1).reshape(4, ph, pw)
+    if float(p64[1, :6, :6].sum()) >= 1e-8:
+        pytest.skip("the constructed map did not trigger the fallback with these weights")
+    assert "HeadFused" not in type(out_d.grad_fn).__name__
+    assert (out_d.detach().double().cpu() - out_64.detach()).abs().max() < 1e-4
