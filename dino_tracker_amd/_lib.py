@@ -96,6 +96,8 @@ SIGNATURES = {
     "dtk_head_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dtk_head_forward": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dtk_head_forward_train": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "dtk_corr_window_backward": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_int, c_void_p]),
     "dtk_head_backward": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                   c_void_p]),
     "dtk_track_workspace_bytes": (c_size_t, [ctypes.POINTER(Geom), c_int, ctypes.POINTER(TrackOpts)]),

@@ -412,8 +412,11 @@ extern "C" int dtk_head_forward(const dtk_geom* g, const float* head, const floa
 // disk do not move the output.  So dz lives on the disk (<= 81 cells), the hidden gradient on its 13 x 13 neighbourhood, the
 // input gradient on 15 x 15 -- the windows of the inference kernel refine_head.  One wave per map, windows in LDS:
 // recompute hidden and logits of the window, then the two transposed 3 x 3 convolutions and the four parameter gradients
-// (per-map partials, summed by the caller: deterministic).  Maps whose fallback fired (disk mass < 1e-8: dz is dense) are
-// not handled here: the caller checks `stats` and takes the autograd path for such a batch.
+// (per-map partials, summed by the caller: deterministic).  A map whose fallback fired (disk mass s < 1e-8) has q = p + 1/|D|
+// on the disk and the mean no longer vanishes: its WHOLE gradient is of size p_k |dq| <= 1e-8 |dq| (eight orders below an
+// ordinary map's), split into the disk part, which this kernel returns, and -p_j cbar on every other cell of the map
+// (sum over j <= 1e-8 max |dq|), which it drops.  Callers that want that remainder too read `stats` and send such batches
+// through the traced path (train_ops.HEAD_FALLBACK_EXACT).
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 
@@ -511,6 +514,17 @@ __global__ __launch_bounds__(256) void head_backward_kernel(dtk_geom g, const fl
         sq += p_[sl]; sqx += p_[sl] * cx[sl]; sqy += p_[sl] * cy[sl];
     }
     sq = wave_sum(sq); sqx = wave_sum(sqx); sqy = wave_sum(sqy);
+    // zero-mass fallback (tracker_head.py:86-94; the forward's own statistic decides): q = (p + 1 / |D|) on the disk
+    const bool fallback = st[3] < 1e-8f;
+    if (fallback) {
+        float cnt = wave_sum((ok[0] ? 1.f : 0.f) + (ok[1] ? 1.f : 0.f));
+        const float u = 1.f / cnt;
+        float s1 = 0.f, sx1 = 0.f, sy1 = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+            if (ok[sl]) { s1 += u; sx1 += u * cx[sl]; sy1 += u * cy[sl]; }
+        sq += wave_sum(s1); sqx += wave_sum(sx1); sqy += wave_sum(sy1);
+    }
     const float xh = sqx / sq, yh = sqy / sq;
     float gx = gout[2 * (size_t)b], gy = gout[2 * (size_t)b + 1];
     if (normalized) { gx *= 2.f / (float)(g.video_w - 1); gy *= 2.f / (float)(g.video_h - 1); }
@@ -520,7 +534,7 @@ __global__ __launch_bounds__(256) void head_backward_kernel(dtk_geom g, const fl
         dq[sl] = ok[sl] ? (gx * (cx[sl] - xh) + gy * (cy[sl] - yh)) / sq : 0.f;
         cbar += p_[sl] * dq[sl];
     }
-    cbar = wave_sum(cbar);  // zero up to rounding (no fallback here)
+    cbar = wave_sum(cbar);  // zero up to rounding unless the fallback fired (then |cbar| <= 1e-8 max |dq|)
     float db2 = 0.f;
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
@@ -601,6 +615,93 @@ __global__ __launch_bounds__(256) void head_backward_kernel(dtk_geom g, const fl
 }
 
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the cosine maps of the TRAINING step (models/tracker.py:158-173 under autograd) behind the local head backward:
+// the map gradient of a source is non-zero only on the 15 x 15 window around its arg-max (head_backward_kernel), so
+//     rho = <s, f> / max(|s| |f|, 1e-8),   relu'(rho) d_rho  ->  ds += g (f / den - rho s / |s|^2),  df = g (s / den - rho f / |f|^2)
+// (ds += g f / 1e-8, df = g s / 1e-8 where the clamp is active) is evaluated for those <= 225 cells only -- autograd's form is
+// two dense products over every cell of every frame of the batch with a gradient that is 99.7 % zeros.  One wave per source;
+// df goes to the token-major gradient volume with atomic adds (several sources share cells).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void corr_window_backward_kernel(dtk_geom g, const float* __restrict__ feat,
+                                                                   const float* __restrict__ norms, const float* __restrict__ emb,
+                                                                   const int32_t* __restrict__ tgt, const float* __restrict__ maps,
+                                                                   const float* __restrict__ dmaps, const float* __restrict__ stats,
+                                                                   float* __restrict__ demb, float* __restrict__ dfeat, int B) {
+    constexpr int MAXJ = 16;  // C <= 1024
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int C = g.C, pw = g.pw, ph = g.ph, HW = ph * pw;
+    const int nj = (C + WAVE - 1) / WAVE;
+    const int f = min(max(tgt[b], 0), g.T - 1);
+    const int kstar = __float_as_int(stats[4 * (size_t)b]);
+    const int kr = kstar / pw, kc = kstar % pw;
+    float s[MAXJ], ds[MAXJ];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const int c = j * WAVE + lane;
+        s[j] = (j < nj && c < C) ? emb[(size_t)b * C + c] : 0.f;
+        ds[j] = 0.f;
+        ss += s[j] * s[j];
+    }
+    ss = wave_sum(ss);
+    const float sn = sqrtf(ss);
+    const float inv_ss = ss > 0.f ? 1.f / ss : 0.f;
+    const float* fbase = feat + (size_t)f * HW * C;
+    float* dbase = dfeat + (size_t)f * HW * C;
+    const float* mp = maps + (size_t)b * HW;
+    const float* dm = dmaps + (size_t)b * HW;
+    const int r0 = max(kr - (HB_RD + 2), 0), r1 = min(kr + (HB_RD + 2), ph - 1);
+    const int c0 = max(kc - (HB_RD + 2), 0), c1 = min(kc + (HB_RD + 2), pw - 1);
+    for (int r = r0; r <= r1; ++r)
+        for (int c = c0; c <= c1; ++c) {
+            const int cell = r * pw + c;
+            const float gk = dm[cell], rho = mp[cell];
+            if (gk == 0.f || !(rho > 0.f)) continue;  // wave-uniform
+            const float fn = norms[(size_t)f * HW + cell];
+            const float den = sn * fn;
+            const bool clamped = !(den > 1e-8f);
+            const float inv_den = clamped ? 1e8f : 1.f / den;
+            const float a_s = clamped ? 0.f : rho * inv_ss;
+            const float a_f = clamped ? 0.f : rho / (fn * fn);
+            const float* fp = fbase + (size_t)cell * C;
+            float* dp = dbase + (size_t)cell * C;
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                const int ch = j * WAVE + lane;
+                if (j < nj && ch < C) {
+                    const float fv = fp[ch];
+                    ds[j] += gk * (fv * inv_den - a_s * s[j]);
+                    atomicAdd(dp + ch, gk * (s[j] * inv_den - a_f * fv));
+                }
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const int c = j * WAVE + lane;
+        if (j < nj && c < C) demb[(size_t)b * C + c] = ds[j];
+    }
+}
+
+}  // namespace
+
+extern "C" int dtk_corr_window_backward(const dtk_geom* g, const float* feat, const float* norms, const float* emb,
+                                        const int32_t* tgt, const float* maps, const float* dmaps, const float* stats,
+                                        float* demb, float* dfeat, int B, void* stream) {
+    DTK_REQUIRE(g && feat && norms && emb && tgt && maps && dmaps && stats && demb && dfeat && B >= 0,
+                "dtk_corr_window_backward: null pointer");
+    DTK_REQUIRE(g->C > 0 && g->C <= 1024, "dtk_corr_window_backward: C=%d outside 1..1024", g->C);
+    DTK_REQUIRE(g->radius / (float)g->stride <= (float)HB_RD, "dtk_corr_window_backward: radius / stride > %d", HB_RD);
+    if (B == 0) return DTK_OK;
+    DTK_LAUNCH("train_corr_bwd", corr_window_backward_kernel, dim3(dtk_cdiv(B, 4)), dim3(256), 0, dtk_stream(stream), *g, feat,
+               norms, emb, tgt, maps, dmaps, stats, demb, dfeat, B);
+    return DTK_OK;
+}
 
 extern "C" int dtk_head_forward_train(const dtk_geom* g, const float* head, const float* maps, float* out_xy, float* stats, int B,
                                       int normalized, void* stream) {

@@ -22,6 +22,41 @@ class RangeNormalizer(torch.nn.Module):
         return x
 
 
+_PINNED = {}
+
+
+def stage_to_device(host: torch.Tensor, device) -> torch.Tensor:
+    """A small host tensor -> device without stalling the host: through a ring of pinned buffers and an asynchronous copy (a
+    pageable source makes the copy wait for the stream's queued work first: the training loop's index tensors were 250 such
+    waits per iteration).  On a CPU `device` this is the identity."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return host.to(device)
+    key = (host.dtype, device.index)
+    ring = _PINNED.setdefault(key, {"bufs": [], "events": [], "next": 0})
+    n = host.numel()
+    if not ring["bufs"]:
+        for _ in range(64):
+            ring["bufs"].append(torch.empty(4096, dtype=host.dtype).pin_memory())
+            ring["events"].append(None)
+    if n > 4096:
+        return host.to(device)
+    i = ring["next"]
+    ring["next"] = (i + 1) % len(ring["bufs"])
+    if ring["events"][i] is not None:
+        ring["events"][i].synchronize()     # 64 copies ago: long done
+    buf = ring["bufs"][i][:n].view(host.shape) if host.is_contiguous() else None
+    if buf is None:
+        host = host.contiguous()
+        buf = ring["bufs"][i][:n].view(host.shape)
+    buf.copy_(host)
+    out = buf.to(device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    ring["events"][i] = ev
+    return out
+
+
 class LongRangeSampler(torch.nn.Module):
     """Training-pair sampler of the reference (data/dataset.py:56-208): from optical-flow trajectories [N, T, 2] (NaN where
     a point is not tracked) draw `batch_size` pairs (point at t1, same point at t2), both times inside one random set of
@@ -85,6 +120,27 @@ class LongRangeSampler(torch.nn.Module):
     def get_fg_batch_size(self):
         return int(self.batch_size * self.fg_traj_ratio)
 
+    # ---- device-side sampling (no host read of device data) -------------------------------------------------------------
+    def sample_rows_on_device(self, valid_trajectories, can_sample, frame_indices, batch_size):
+        """The same distribution as get_point_correspondences_for_num_frames for a GIVEN frame set, without leaving the
+        device: one uniform key per trajectory, the `batch_size` largest keys among the rows that are tracked in two of
+        the frames (= a uniformly random subset without replacement, what `rows[randperm(len)[:k]]` is), then two distinct
+        tracked frames per row (multinomial over the row's validity, as in the reference).  Fewer eligible rows than
+        `batch_size` give rows flagged invalid (weight 0 in the losses) instead of a shorter batch -- shapes stay static.
+        Returns (t1 [B, 3], t2 [B, 3], local1 [B], local2 [B] (positions in `frame_indices`), ok [B])."""
+        dev = valid_trajectories.device
+        can_f = can_sample[:, frame_indices]                                    # [N, F]
+        eligible = can_f.sum(dim=1) >= 2
+        keys = torch.where(eligible, torch.rand(can_f.shape[0], device=dev), torch.full((), -1.0, device=dev))
+        k = min(batch_size, can_f.shape[0])
+        top = torch.topk(keys, k)
+        rows, ok = top.indices, top.values >= 0
+        allowed = torch.where(ok[:, None], can_f[rows], torch.ones((), dtype=torch.bool, device=dev)).float()
+        l1, l2 = allowed.multinomial(2, replacement=False).unbind(dim=1)
+        t1f, t2f = frame_indices[l1], frame_indices[l2]
+        pick = lambda tt: torch.cat([torch.nan_to_num(valid_trajectories[rows, tt]), tt[:, None].to(valid_trajectories.dtype)], dim=-1)
+        return pick(t1f), pick(t2f), l1, l2, ok
+
     def forward(self):
         assert self.num_frames is not None, "num_frames must be specified"
         n_fg = self.get_fg_batch_size()
@@ -103,6 +159,47 @@ class DinoTrackerSampler(LongRangeSampler):
         super().__init__(batch_size, fg_trajectories=fg_trajectories, bg_trajectories=bg_trajectories,
                          fg_traj_ratio=fg_traj_ratio, num_frames=num_frames, keep_in_cpu=keep_in_cpu)
         self.range_normalizer, self.dst_range = range_normalizer, dst_range
+
+    def forward_device(self, generator=None):
+        """The batch of `forward` with the frame sets drawn on the HOST (torch's CPU generator) and everything that touches
+        the trajectories on the device: no device -> host read, static shapes.  Differences from `forward`, both by
+        construction: (1) `frames_set_t` is the sorted union of the two DRAWN frame sets (foreground and background
+        trajectories draw theirs independently, dataset.py:173), whether or not every frame ends up used by a sampled pair
+        -- `forward` returns the frames the sampled pairs actually use, a subset with the same union in all but rare
+        batches; (2) a frame set with fewer than two eligible trajectories is not redrawn (dataset.py:175-179): its rows
+        come back with ok = False.  Extra keys: "valid" [B] bool and "frames_set_t_host" (list of int)."""
+        assert self.num_frames is not None, "num_frames must be specified"
+        dev = self.fg_valid_trajectories.device
+        n_fg = self.get_fg_batch_size()
+        t = self.vid_len
+        sets = [torch.randperm(t, generator=generator)[:self.num_frames] for _ in range(2)]      # host draws
+        s0, s1 = sets[0].tolist(), sets[1].tolist()
+        union = sorted(set(s0) | set(s1))
+        pos = {f: i for i, f in enumerate(union)}
+        host = torch.tensor([s0, s1, [pos[f] for f in s0], [pos[f] for f in s1]], dtype=torch.long)
+        staged = stage_to_device(host, dev)                                                        # one small async copy
+        frames_set_t = stage_to_device(torch.tensor(union, dtype=torch.int32), dev)
+        parts = []
+        for j, (name, bs) in enumerate((("fg", n_fg), ("bg", self.batch_size - n_fg))):
+            p1, p2, l1, l2, ok = self.sample_rows_on_device(getattr(self, f"{name}_valid_trajectories"),
+                                                            getattr(self, f"{name}_can_sample"), staged[j], bs)
+            parts.append((p1, p2, staged[2 + j][l1], staged[2 + j][l2], ok))
+        t1_points, t2_points, src_idx, tgt_idx, ok = (torch.cat(x) for x in zip(*parts))
+        t1n = self.range_normalizer(t1_points, dst=self.dst_range)
+        t2n = self.range_normalizer(t2_points, dst=self.dst_range)
+        target_times = t2_points[:, 2].clone()
+        t1_points[:, 2] = t1n[:, 2]
+        return {
+            "frames_set_t": frames_set_t,
+            "frames_set_t_host": union,
+            "source_frame_indices": src_idx,
+            "target_frame_indices": tgt_idx,
+            "t1_points_normalized": t1n,
+            "t2_points_normalized": t2n,
+            "t1_points": t1_points,
+            "target_times": target_times,
+            "valid": ok,
+        }
 
     def forward(self):
         t1_points, t2_points = super().forward()

@@ -350,3 +350,14 @@ def head_backward(g: Geom, packed_head: torch.Tensor, maps: torch.Tensor, stats:
     check(lib().dtk_head_backward(g, _p(packed_head, torch.float32), _p(maps, torch.float32), _p(stats, torch.float32),
                                   _p(grad_out, torch.float32), _p(dmaps), _p(part), B, int(normalized), _stream()))
     return dmaps, part.sum(dim=0)
+
+
+def corr_window_backward(g: Geom, feat: torch.Tensor, norms: torch.Tensor, emb: torch.Tensor, tgt: torch.Tensor,
+                         maps: torch.Tensor, dmaps: torch.Tensor, stats: torch.Tensor, dfeat: torch.Tensor) -> torch.Tensor:
+    """dtk_corr_window_backward: returns demb [B, C]; accumulates into dfeat [T, ph*pw, C] (token-major)."""
+    B = emb.shape[0]
+    demb = torch.empty_like(emb)
+    check(lib().dtk_corr_window_backward(g, _p(feat, torch.float32), _p(norms, torch.float32), _p(emb, torch.float32),
+                                         _p(tgt, torch.int32), _p(maps, torch.float32), _p(dmaps, torch.float32),
+                                         _p(stats, torch.float32), _p(demb), _p(dfeat, torch.float32), B, _stream()))
+    return demb

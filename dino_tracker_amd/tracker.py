@@ -153,9 +153,13 @@ class Tracker(nn.Module):
         half = self.dino_patch_size / 2
         last_h = ((h - self.dino_patch_size) // self.stride) * self.stride + half
         last_w = ((w - self.dino_patch_size) // self.stride) * self.stride + half
-        a = torch.tensor([[2 / (last_w - half), 2 / (last_h - half), 1]], device=points.device, dtype=points.dtype)
-        b = torch.tensor([[1 - last_w * 2 / (last_w - half), 1 - last_h * 2 / (last_h - half), 0]],
-                         device=points.device, dtype=points.dtype)
+        key = (str(points.device), points.dtype)
+        if getattr(self, "_norm_ab", None) is None or self._norm_ab[0] != key:  # two constants: built once, not per call
+            a = torch.tensor([[2 / (last_w - half), 2 / (last_h - half), 1]], device=points.device, dtype=points.dtype)
+            b = torch.tensor([[1 - last_w * 2 / (last_w - half), 1 - last_h * 2 / (last_h - half), 0]],
+                             device=points.device, dtype=points.dtype)
+            self._norm_ab = (key, a, b)
+        _, a, b = self._norm_ab
         return a * points + b
 
     def sample_embeddings(self, embeddings, source_points):
@@ -305,9 +309,8 @@ class Tracker(nn.Module):
     def get_point_predictions_from_embeddings(self, source_embeddings, frame_embeddings_set, target_frame_indices):
         if self._differentiable():
             from . import train_ops
-            corr_maps = train_ops.cosine_maps(source_embeddings, frame_embeddings_set,
-                                              target_frame_indices.to(frame_embeddings_set.device))[:, None]
-            return train_ops.head_forward(self.tracker_head, self.cmap_relu(corr_maps))
+            return train_ops.track_points(self.tracker_head, source_embeddings, frame_embeddings_set,
+                                          target_frame_indices.to(frame_embeddings_set.device))
         corr_maps = self.get_corr_maps_for_frame_set(source_embeddings, frame_embeddings_set, target_frame_indices)
         return self.tracker_head(self.cmap_relu(corr_maps))
 
@@ -367,21 +370,9 @@ class Tracker(nn.Module):
         n_fg = int(self.cyc_batch_size_per_frame * self.cyc_fg_points_ratio)
         n_bg = self.cyc_batch_size_per_frame - n_fg
         if self.cyc_sampling == "device":
-            k = self.cyc_n_frames
-            src_t = frames_set_t[source_selector].long()                                  # [k] frame numbers
-            fg = (fg_masks[src_t.to(fg_masks.device)] > 0).reshape(k, h * w).to(dev)
-            keys = torch.rand(k, h * w, device=dev)
-            neg = torch.full_like(keys, -1.0)
-            pick_fg = torch.topk(torch.where(fg, keys, neg), min(n_fg, h * w), dim=1)
-            pick_bg = torch.topk(torch.where(fg, neg, keys), min(n_bg, h * w), dim=1)
-            cells = torch.cat([pick_fg.indices, pick_bg.indices], dim=1)                  # [k, n_fg + n_bg]
-            valid = torch.cat([pick_fg.values, pick_bg.values], dim=1) >= 0               # fewer pixels than asked for: dropped
-            t_col = src_t[:, None].expand_as(cells)
-            pts = torch.stack([(cells % w).float(), torch.div(cells, w, rounding_mode="floor").float(), t_col.float()], dim=2)
-            src_idx = source_selector[:, None].expand_as(cells)
-            tgt_idx = target_selector[:, None].expand_as(cells)
-            keep = valid.reshape(-1).nonzero()[:, 0]                                      # the one host read of this function
-            return pts.reshape(-1, 3)[keep], src_idx.reshape(-1)[keep].long(), tgt_idx.reshape(-1)[keep].long()
+            pts, src_idx, tgt_idx, valid = self._cycle_point_sets_static(frames_set_t, fg_masks, source_selector, target_selector)
+            keep = valid.nonzero()[:, 0]                                                  # the one host read of this function
+            return pts[keep], src_idx[keep], tgt_idx[keep]
         pts, src_idx, tgt_idx = [], [], []
         for s_i, t_i in zip(source_selector.tolist(), target_selector.tolist()):
             source_t = int(frames_set_t[s_i])
@@ -397,6 +388,57 @@ class Tracker(nn.Module):
             src_idx.append(torch.full((xy.shape[0],), s_i, device=dev, dtype=torch.long))
             tgt_idx.append(torch.full((xy.shape[0],), t_i, device=dev, dtype=torch.long))
         return torch.cat(pts), torch.cat(src_idx), torch.cat(tgt_idx)
+
+    def _cycle_point_sets_static(self, frames_set_t, fg_masks, source_selector=None, target_selector=None):
+        """The "device" sampling of _cycle_point_sets with static shapes: cyc_n_frames x cyc_batch_size_per_frame points and
+        a flag per point (False where a frame has fewer foreground / background pixels than asked for)."""
+        n = frames_set_t.shape[0]
+        dev = frames_set_t.device
+        k = self.cyc_n_frames
+        if source_selector is None:
+            source_selector = torch.randint(n, (k,), device=dev)
+            target_selector = torch.randint(n, (k,), device=dev)
+        h, w = fg_masks.shape[-2:]
+        n_fg = int(self.cyc_batch_size_per_frame * self.cyc_fg_points_ratio)
+        n_bg = self.cyc_batch_size_per_frame - n_fg
+        src_t = frames_set_t[source_selector].long()                                  # [k] frame numbers
+        fg = (fg_masks[src_t.to(fg_masks.device)] > 0).reshape(k, h * w).to(dev)
+        keys = torch.rand(k, h * w, device=dev)
+        neg = torch.full_like(keys, -1.0)
+        pick_fg = torch.topk(torch.where(fg, keys, neg), min(n_fg, h * w), dim=1)
+        pick_bg = torch.topk(torch.where(fg, neg, keys), min(n_bg, h * w), dim=1)
+        cells = torch.cat([pick_fg.indices, pick_bg.indices], dim=1)                  # [k, n_fg + n_bg]
+        valid = torch.cat([pick_fg.values, pick_bg.values], dim=1) >= 0
+        t_col = src_t[:, None].expand_as(cells)
+        pts = torch.stack([(cells % w).float(), torch.div(cells, w, rounding_mode="floor").float(), t_col.float()], dim=2)
+        src_idx = source_selector[:, None].expand_as(cells)
+        tgt_idx = target_selector[:, None].expand_as(cells)
+        return pts.reshape(-1, 3), src_idx.reshape(-1).long(), tgt_idx.reshape(-1).long(), valid.reshape(-1)
+
+    def get_cycle_consistency_terms(self, frames_set_t, fg_masks):
+        """get_cycle_consistent_preds (tracker.py:182-301) with static shapes and no host read: EVERY sampled point is tracked
+        source -> target with gradients (its detached result is the target point), back without, and target -> source with
+        gradients; `keep` [M] flags the points that are valid and return within cyc_thresh px -- the rows the reference would
+        have kept.  The caller weights by `keep` (a batch without any consistent point gives zero loss instead of the
+        reference's re-draw)."""
+        pts, src_idx, tgt_idx, valid = self._cycle_point_sets_static(frames_set_t, fg_masks)
+        unnorm = lambda c: self.range_normalizer.unnormalize(c, src=(-1, 1), dims=[0, 1])
+        t_of = frames_set_t.to(pts.device).float()
+        src_tgt = self.get_point_predictions((pts, src_idx, tgt_idx, frames_set_t), self.frame_embeddings)
+        with torch.no_grad():
+            tgt_pts = torch.cat([unnorm(src_tgt.detach()), t_of[tgt_idx][:, None]], dim=1)
+            back_xy = unnorm(self.get_point_predictions((tgt_pts, tgt_idx, src_idx, frames_set_t), self.frame_embeddings.detach()))
+            dist = torch.norm(pts[:, :2] - back_xy[:, :2], dim=1)
+            keep = valid & (dist <= self.cyc_thresh)
+        tgt_src = self.get_point_predictions((tgt_pts, tgt_idx, src_idx, frames_set_t), self.frame_embeddings)
+        return {
+            "source_coords": self.range_normalizer(pts, dst=[-1, 1]),
+            "target_coords": self.range_normalizer(tgt_pts, dst=[-1, 1]),
+            "source_target_coords": src_tgt[:, :2],
+            "target_source_coords": tgt_src[:, :2],
+            "cycle_consistency_dists": dist,
+            "keep": keep,
+        }
 
     @torch.no_grad()
     def get_cycle_consistent_coords(self, frames_set_t, fg_masks):

@@ -22,6 +22,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -548,28 +550,107 @@ class _HeadFused(torch.autograd.Function):
         return dmaps, dpacked, None
 
 
+HEAD_FALLBACK_EXACT = bool(os.environ.get("DTK_HEAD_FALLBACK_EXACT"))
 USE_FUSED_HEAD = True  # device tensors: the head of the training step on the hand-written forward / backward kernels
 
 
 def _head_forward_fused(head, cost: torch.Tensor):
-    """The fused route of head_forward, or None when it does not apply (zero-mass fallback in the batch, geometry)."""
-    from ._lib import make_geom
+    """The fused route of head_forward, or None when it does not apply (geometry; a fallback under HEAD_FALLBACK_EXACT)."""
     b, _, h, w = cost.shape
+    packed_geom = _head_packed(head, 1, 32, h, w, cost)
+    if packed_geom is None:
+        return None
+    packed, geom = packed_geom
+    out, stats = _HeadFused.apply(cost.reshape(b, h * w), packed, geom)
+    # A map whose zero-mass fallback fired (tracker_head.py:86-94) has a dense gradient of total size <= 1e-8 |dq|; the
+    # kernel returns its part on the disk and drops the rest (csrc/track_exact.hip).  HEAD_FALLBACK_EXACT reads the
+    # statistics on the host (a device synchronisation per call) and sends such a batch through the traced route.
+    if HEAD_FALLBACK_EXACT and bool((stats[:, 3] < EPS).any()):
+        return None
+    return out
+
+
+_PACKED = {}
+
+
+def _packed_frames(frames: torch.Tensor):
+    """Token-major copy + norms of the batch's frame embeddings (dtk_pack_features), shared by the calls of one iteration
+    (the prediction, the cycle-consistency passes) while the tensor is the same object at the same version."""
+    import weakref
+    from . import ops
+    ref = _PACKED.get("ref")
+    if ref is None or ref() is not frames or _PACKED["version"] != frames._version:  # identity, not address: the allocator
+        feat, norms = ops.pack_features(frames.detach().contiguous())                # reuses addresses across iterations
+        _PACKED.update(ref=weakref.ref(frames), version=frames._version, feat=feat, norms=norms)
+    return _PACKED["feat"], _PACKED["norms"]
+
+
+class _TrackFused(torch.autograd.Function):
+    """Tracker.get_point_predictions_from_embeddings (tracker.py:158-180) of the training step as kernels both ways:
+        forward   dtk_corr_maps (relu'd cosine map of every source against ITS target frame, sources ordered by target frame)
+                  -> dtk_head_forward_train
+        backward  dtk_head_backward (local: the map gradient lives on the 15 x 15 window around the arg-max)
+                  -> dtk_corr_window_backward (the cosine gradient on those <= 225 cells only) -> dtk_unpack_features.
+    The traced form multiplies every source with every frame of the batch and keeps one map (tracker.py:159-160), and its
+    backward is two dense products with a gradient that is 99.7 % zeros: 3.5 ms of GEMM + ~6 ms of [B, 8 h w] element-wise
+    kernels per iteration."""
+
+    @staticmethod
+    def forward(ctx, src, frames, tgt, packed, geom):
+        from . import ops
+        feat, norms = _packed_frames(frames)
+        order = torch.argsort(tgt, stable=True)          # corr_exact tiles 64 sources: one or two target frames per tile
+        emb = src.detach().index_select(0, order).contiguous()
+        tgt_s = tgt.index_select(0, order).to(torch.int32).contiguous()
+        maps = ops.corr_maps(geom, feat, norms, emb, tgt_s, relu=True).reshape(emb.shape[0], -1)
+        packed = packed.contiguous()
+        out_s, stats = ops.head_forward_train(geom, packed, maps, normalized=True)
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(order.shape[0], device=order.device)
+        ctx.save_for_backward(emb, tgt_s, maps, stats, packed, feat, norms, order, inv)
+        ctx.geom, ctx.frames_shape = geom, frames.shape
+        return out_s.index_select(0, inv)
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import ops
+        emb, tgt_s, maps, stats, packed, feat, norms, order, inv = ctx.saved_tensors
+        g = ctx.geom
+        dmaps, dpacked = ops.head_backward(g, packed, maps, stats, gout.index_select(0, order).contiguous(), normalized=True)
+        dfeat = torch.zeros_like(feat)
+        demb = ops.corr_window_backward(g, feat, norms, emb, tgt_s, maps, dmaps, stats, dfeat)
+        n, c, h, w = ctx.frames_shape
+        return demb.index_select(0, inv), ops.unpack_features(dfeat, h, w), None, dpacked, None
+
+
+USE_FUSED_TRACK = True  # device tensors: correlation + head of the training step on _TrackFused
+
+
+def track_points(head, src: torch.Tensor, frames: torch.Tensor, tgt: torch.Tensor):
+    """tracker.py:171-180 for the training step: source embeddings [B, C], the batch's frame embeddings [n, C, h, w], target
+    indices [B] -> [B, 2] normalised positions.  Device tensors take _TrackFused; host tensors (the CPU parity tests) and
+    geometries the kernels do not cover take the traced statement."""
+    if USE_FUSED_TRACK and not HEAD_FALLBACK_EXACT and src.is_cuda and src.dtype == torch.float32 and src.shape[0] > 0:
+        packed_geom = _head_packed(head, frames.shape[0], frames.shape[1], frames.shape[2], frames.shape[3], src)
+        if packed_geom is not None and frames.shape[1] <= 1024 and frames.shape[1] % 16 == 0:
+            return _TrackFused.apply(src, frames, tgt, *packed_geom)
+    return head_forward(head, torch.relu(cosine_maps(src, frames, tgt))[:, None])
+
+
+def _head_packed(head, n, c, h, w, like):
+    """(packed normalised head parameters with autograd into the weights, geometry) or None if the kernels do not apply."""
+    from ._lib import make_geom
     c0, c2 = head.cnn_refiner[0], head.cnn_refiner[2]
     if c0.out_channels != 16 or c2.in_channels != 16 or float(head.argmax_radius) / float(head.step_h) > 5.0:
         return None
-    geom = make_geom(1, 32, head.video_h, head.video_w, head.patch_size, head.step_h, float(head.argmax_radius))
+    geom = make_geom(n, c, head.video_h, head.video_w, head.patch_size, head.step_h, float(head.argmax_radius))
     if (geom.ph, geom.pw) != (h, w):
         return None
-    b1 = c0.bias if c0.bias is not None else cost.new_zeros(16)
-    b2 = c2.bias if c2.bias is not None else cost.new_zeros(1)
+    b1 = c0.bias if c0.bias is not None else like.new_zeros(16)
+    b2 = c2.bias if c2.bias is not None else like.new_zeros(1)
     packed = torch.cat([normalized_weight(c0.weight).reshape(-1), b1.reshape(-1), normalized_weight(c2.weight).reshape(-1),
                         b2.reshape(-1)])
-    out, stats = _HeadFused.apply(cost.reshape(b, h * w), packed, geom)
-    # a zero-mass fallback (tracker_head.py:86-94) makes the gradient dense: rare; one host read decides the route
-    if bool((stats[:, 3] < EPS).any()):
-        return None
-    return out
+    return packed, geom
 
 
 def head_forward(head, cost: torch.Tensor) -> torch.Tensor:

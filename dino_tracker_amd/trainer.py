@@ -1,0 +1,347 @@
+"""Test-time training: the iteration of the reference's trainer (dino_tracker.py:392-448) and its loss terms
+(dino_tracker.py:128-352) restated for the device -- static shapes, every (source, target) frame pair of a loss in one
+batch, no device -> host read inside the iteration.
+
+The reference's loop is host-bound by construction: per iteration ~300 `.item()` reads (`torch.tensor([idx] * n)` with a
+device scalar `idx`, dino_tracker.py:194-201; `f'{source_frame}_{target_frame}'` keys, :181), ~250 small pageable
+host -> device copies, data-dependent shapes (boolean-mask indexing before every `randperm(len)`), a `while .any()` re-draw and
+`torch.cuda.empty_cache()` (:404).  Run un-modified on this implementation's models that was 4 300 launches and ~540 blocking
+copies per iteration (profiles/r03_train_host_profile.txt) around 45 ms of convolution kernels.  Here:
+
+  * random subsets of data-dependent sets (foreground best buddies of a frame pair, mutual nearest neighbours of the refined
+    features, pixels of a mask) are drawn as "the k largest of one uniform key per element, keys of non-members at -1": a
+    uniformly random k-subset without replacement -- the distribution of `x[randperm(len(x))[:k]]` -- with a flag per slot
+    instead of a shorter tensor; flagged-off slots carry weight 0 in the sums, and every loss of the reference is a SUM
+    divided by a constant (or a mean, restated as sum / count);
+  * the frame-pair selectors stay on the device (`key = s * T + t` indexes tables packed once from the best-buddies file);
+  * losses are accumulated as device scalars and read when `log_losses` formats them (every 100th iteration).
+
+`make_trainer(base)` derives the class from the reference's own `DINOTracker` (loaded from the checkout at run time by
+overlay/dino_tracker.py): configuration, paths, model / optimizer / scheduler set-up, checkpoints and logging stay the
+reference's code; `train`, the loss terms and the batch sampler are this file's.  DTK_TRAINER=reference runs the inherited
+loop instead (bit-identical random draws to the reference for equal seeds: the parity tests of tests/test_gpu_train.py).
+
+The loss terms are pure functions of explicit selections (`*_terms`), so the CPU tests can feed them the selections the
+reference's un-modified methods drew and compare the values (tests/test_trainer_vs_reference.py)."""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+EPS = 1e-8
+
+
+# ---- loss arithmetic (pure functions) -----------------------------------------------------------------------------------
+def contrastive_terms(a: torch.Tensor, b: torch.Tensor, fa: torch.Tensor, fb: torch.Tensor, temp: float):
+    """dino_tracker.py:327-343 for P frame pairs at once.  a, b [P, B, C]: embeddings of B best-buddy pairs (a in the source
+    frame, b in the target frame); fa, fb [P, n, C]: every cell of the source / target frame.  Returns the per-pair InfoNCE
+    terms (source -> target, target -> source), each [P, B]: -log( exp(cos(a, b) / temp) / sum_n exp(cos(a, fb_n) / temp) )."""
+    na, nb = a.norm(dim=2), b.norm(dim=2)
+    nfa, nfb = fa.norm(dim=2), fb.norm(dim=2)
+    bb = (a * b).sum(dim=2) / torch.clamp(na * nb, min=EPS)
+    st = torch.bmm(a, fb.transpose(1, 2)) / torch.clamp(na[:, :, None] * nfb[:, None, :], min=EPS)
+    ts = torch.bmm(b, fa.transpose(1, 2)) / torch.clamp(nb[:, :, None] * nfa[:, None, :], min=EPS)
+    l_st = -torch.log(torch.exp(bb / temp) / torch.exp(st / temp).sum(dim=2))
+    l_ts = -torch.log(torch.exp(bb / temp) / torch.exp(ts / temp).sum(dim=2))
+    return l_st, l_ts
+
+
+def frame_cells(frame_embeddings: torch.Tensor, sel: torch.Tensor) -> torch.Tensor:
+    """[F, C, h, w], sel [P] -> [P, n, C]: rearrange(frame_embeddings[sel_p], 'c h w -> (h w) c') for every p."""
+    return frame_embeddings.flatten(2).index_select(0, sel).transpose(1, 2)
+
+
+def emb_regularization_terms(refined: torch.Tensor, raw: torch.Tensor):
+    """dino_tracker.py:128-139: (mean | |refined| / |raw| - 1 |, mean | cos(refined, raw) - 1 |) over frames and cells."""
+    nr, nd = refined.norm(dim=1), raw.norm(dim=1)
+    cos = (refined * raw).sum(dim=1) / (nr * nd)
+    return (nr / nd - 1).abs().mean(), (cos - 1).abs().mean()
+
+
+def huber(x: torch.Tensor, y: torch.Tensor, delta: float = 1 / 32) -> torch.Tensor:
+    """torch.nn.HuberLoss(delta, reduction='none') (dino_tracker.py:30)."""
+    return F.huber_loss(x, y, reduction="none", delta=delta)
+
+
+def weighted_mean(values: torch.Tensor, keep: torch.Tensor) -> torch.Tensor:
+    """values [M, K], keep [M] bool: the mean over the kept rows' elements (0 when none is kept)."""
+    w = keep.to(values.dtype)
+    return (values * w[:, None]).sum() / (w.sum().clamp(min=1) * values.shape[1])
+
+
+def foreground_at(mask: torch.Tensor, coords: torch.Tensor, resw: int, resh: int) -> torch.Tensor:
+    """models/utils.py:53-58 (filter_bb_foreground_pairs): is pixel position `coords` [N, 2] foreground in `mask` [H, W] --
+    bilinear `grid_sample` of the mask at 2 (x / resw, y / resh) - 1 (torch's default align_corners=False, zero padding) > 0."""
+    if coords.shape[0] == 0:
+        return torch.zeros(0, dtype=torch.bool, device=coords.device)
+    scale = torch.tensor([resw, resh], dtype=coords.dtype, device=coords.device)
+    grid = 2 * (coords[None, None] / scale) - 1
+    return F.grid_sample(mask[None, None].float(), grid, align_corners=False)[0, 0, 0] > 0
+
+
+def pick_subsets(member_sets, counts, generator=None):
+    """member_sets: list of bool [P, L] masks over the same L slots; counts: how many to draw from each.  One uniform key per
+    slot; per set the `count` largest keys among its members.  Returns (slot indices [P, sum(counts)], ok [P, sum(counts)])."""
+    P, L = member_sets[0].shape
+    dev = member_sets[0].device
+    keys = torch.rand(P, L, device=dev, generator=generator)
+    neg = torch.full((), -1.0, device=dev)
+    idx, ok = [], []
+    for members, k in zip(member_sets, counts):
+        top = torch.topk(torch.where(members, keys, neg), min(k, L), dim=1)
+        idx.append(top.indices)
+        ok.append(top.values >= 0)
+    return torch.cat(idx, dim=1), torch.cat(ok, dim=1)
+
+
+# ---- best buddies of the DINO features, packed once ---------------------------------------------------------------------
+class BestBuddyTable:
+    """The dict of preprocessing_dino_bb (`{"s_t": {"source_coords", "target_coords", "cos_sims", "r"}}`, loaded by
+    dino_tracker.py:72-73) as flat device arrays: slot[s * T + t] -> (offset, count) into coords / r / cos / foreground flag
+    (the flag is filter_bb_foreground_pairs of dino_tracker.py:185-189, evaluated once per pair instead of every time the
+    pair is drawn)."""
+
+    def __init__(self, pairs: Dict[str, Dict[str, Optional[torch.Tensor]]], fg_masks: torch.Tensor, n_frames: int, resw: int,
+                 resh: int, device):
+        self.T = n_frames
+        off, cnt, slot = [0], [], torch.full((n_frames * n_frames,), -1, dtype=torch.long)
+        src, tgt, r, cos, fg = [], [], [], [], []
+        by_source = {}
+        for name, bb in pairs.items():
+            s, t = (int(x) for x in name.split("_"))
+            sc = bb.get("source_coords")
+            if sc is None or sc.shape[0] == 0 or s >= n_frames or t >= n_frames:
+                continue
+            by_source.setdefault(s, []).append((t, bb))
+        for s in sorted(by_source):
+            entries = sorted(by_source[s], key=lambda e: e[0])
+            coords_s = torch.cat([bb["source_coords"].to(device, torch.float32) for _, bb in entries])
+            fg.append(foreground_at(fg_masks[s].to(device), coords_s, resw, resh))   # one evaluation per source frame
+            for t, bb in entries:
+                n = bb["source_coords"].shape[0]
+                slot[s * n_frames + t] = len(cnt)
+                cnt.append(n)
+                off.append(off[-1] + n)
+                src.append(bb["source_coords"].to(device, torch.float32))
+                tgt.append(bb["target_coords"].to(device, torch.float32))
+                r.append(bb["r"].to(device, torch.float32).reshape(-1))
+                cos.append(bb["cos_sims"].to(device, torch.float32).reshape(-1))
+        cat = lambda xs, shape: torch.cat(xs) if xs else torch.zeros(shape, device=device)
+        # one trailing dummy entry so that empty slots index something finite
+        self.src = torch.cat([cat(src, (0, 2)), torch.zeros(1, 2, device=device)])
+        self.tgt = torch.cat([cat(tgt, (0, 2)), torch.zeros(1, 2, device=device)])
+        self.r = torch.cat([cat(r, (0,)), torch.ones(1, device=device)])
+        self.cos = torch.cat([cat(cos, (0,)), torch.zeros(1, device=device)])
+        self.fg = torch.cat([cat(fg, (0,)).bool(), torch.zeros(1, dtype=torch.bool, device=device)])
+        self.total = off[-1]
+        self.max_count = max(cnt) if cnt else 1
+        self.slot = slot.to(device)
+        self.off = torch.tensor(off[:-1] + [self.total], dtype=torch.long, device=device)   # [slots + 1]; last = dummy
+        self.cnt = torch.tensor(cnt + [0], dtype=torch.long, device=device)
+        self.n_slots = len(cnt)
+
+    def window(self, s_frames: torch.Tensor, t_frames: torch.Tensor):
+        """Frame numbers [P] (device) -> (flat indices [P, max_count], in-range flag [P, max_count])."""
+        slot = self.slot[s_frames.long() * self.T + t_frames.long()]
+        slot = torch.where(slot < 0, torch.full_like(slot, self.n_slots), slot)
+        ar = torch.arange(self.max_count, device=slot.device)
+        inside = ar[None, :] < self.cnt[slot][:, None]
+        pos = torch.where(inside, self.off[slot][:, None] + ar[None, :], torch.full_like(ar, self.total)[None, :])
+        return pos, inside
+
+
+# ---- mutual nearest neighbours of the refined features ------------------------------------------------------------------
+@torch.no_grad()
+def mutual_argmax(frame_embeddings: torch.Tensor, s_sel: torch.Tensor, t_sel: torch.Tensor, geom=None):
+    """dino_tracker.py:262-283: for P frame pairs (indices into frame_embeddings [F, C, h, w]) the arg-max over the TARGET
+    cells of every source cell's cosine, and over the SOURCE cells of every target cell's -> (nn_st [P, n], nn_ts [P, n]).
+    On the device: dtk_argmax_cells (fp16 MFMA candidate search + exact fp32 decision, the N4 kernel path; first maximum on
+    ties) -- the n x n affinity matrix is never written.  On a host tensor: the affinity matrix and two arg-maxes."""
+    Fn, C, h, w = frame_embeddings.shape
+    n = h * w
+    P = s_sel.shape[0]
+    if frame_embeddings.is_cuda:
+        from . import ops
+        feat, norms = ops.pack_features(frame_embeddings.contiguous())
+        method = ops.TRACK_MFMA if C % 32 == 0 else ops.TRACK_EXACT
+        f16 = ops.make_feat_f16(geom, feat, norms) if method == ops.TRACK_MFMA else None
+        ar = torch.arange(n, device=feat.device)
+        rows = torch.cat([s_sel[:, None] * n + ar[None, :], t_sel[:, None] * n + ar[None, :]]).reshape(-1).to(torch.int32)
+        tgt = torch.cat([t_sel[:, None].expand(P, n), s_sel[:, None].expand(P, n)]).reshape(-1).to(torch.int32)
+        cell, _ = ops.argmax_cells(geom, feat, norms, f16, feat.reshape(Fn * n, C), rows.contiguous(), tgt.contiguous(), method)
+        cell = cell.long().view(2, P, n)
+        return cell[0], cell[1]
+    ff = frame_embeddings.flatten(2).transpose(1, 2)
+    sf, tf = ff[s_sel], ff[t_sel]
+    aff = torch.bmm(sf, tf.transpose(1, 2)) / torch.clamp(sf.norm(dim=2)[:, :, None] * tf.norm(dim=2)[:, None, :], min=EPS)
+    return aff.argmax(dim=2), aff.argmax(dim=1)
+
+
+# ---- the trainer ----------------------------------------------------------------------------------------------------------
+def make_trainer(base):
+    """`base`: the reference's DINOTracker class.  Returns the subclass with the device-side iteration."""
+
+    class DINOTracker(base):
+        LOSS_NAMES = ("total", "of", "cl_dino_bb", "cl_refiner", "emb_norm_reg", "angle_reg", "cyc")
+
+        # -- set-up ------------------------------------------------------------------------------------------------------
+        def prepare_tables(self, model):
+            dev = model.video.device
+            t, _, h, w = model.video.shape
+            self._bb_table = BestBuddyTable(self.dino_bb_pairs, self.fg_masks, t, w, h, dev)
+            grid = self.feature_grid(model, dev)
+            masks = self.fg_masks.to(dev)
+            self._cell_fg = torch.stack([foreground_at(masks[f], grid, w, h) for f in range(t)])      # [T, n]
+
+        @staticmethod
+        def feature_grid(model, dev):
+            """models/utils.py:87-95: pixel centres (x, y) of the token grid, row-major."""
+            _, _, h, w = model.video.shape
+            half = model.dino_patch_size // 2
+            x = torch.arange(half, w - half + 1, step=model.stride, device=dev).float()
+            y = torch.arange(half, h - half + 1, step=model.stride, device=dev).float()
+            yy, xx = torch.meshgrid(y, x, indexing="ij")
+            return torch.stack([xx.reshape(-1), yy.reshape(-1)], dim=-1)
+
+        # -- batch -------------------------------------------------------------------------------------------------------
+        def get_inputs_and_labels_device(self, sampler):
+            sample = sampler.forward_device()
+            labels = sample["t2_points_normalized"][:, :-1]
+            inputs = (sample["t1_points"], sample["source_frame_indices"], sample["target_frame_indices"], sample["frames_set_t"])
+            return inputs, labels, sample["valid"]
+
+        # -- loss terms --------------------------------------------------------------------------------------------------
+        def split_counts(self, per_pair, fg_ratio):
+            n_fg = int(per_pair * fg_ratio)
+            return n_fg, per_pair - n_fg
+
+        def dino_bb_selection(self, frames_set_t):
+            """Random part of dino_tracker.py:159-212: cl_n_frames (source != target) index pairs into the batch's frame set
+            and, per pair, up to cl_points_per_pair of the pair's DINO best buddies, cl_fg_points_ratio of them foreground."""
+            n = frames_set_t.shape[0]
+            dev = frames_set_t.device
+            P = self.config["cl_n_frames"]
+            s_sel = torch.randint(n, (P,), device=dev)
+            t_sel = (s_sel + 1 + torch.randint(max(n - 1, 1), (P,), device=dev)) % n      # uniform over t != s (:163-164)
+            pos, inside = self._bb_table.window(frames_set_t[s_sel], frames_set_t[t_sel])
+            fg = self._bb_table.fg[pos] & inside
+            n_fg, n_bg = self.split_counts(self.config["cl_points_per_pair"], self.config["cl_fg_points_ratio"])
+            col, ok = pick_subsets([fg, inside & ~fg], [n_fg, n_bg])
+            return s_sel, t_sel, pos.gather(1, col), ok
+
+        def dino_bb_terms(self, model, s_sel, t_sel, picks, ok):
+            """Deterministic part of dino_tracker.py:159-240 for explicit selections: s_sel / t_sel [P] index the batch's
+            frame set, picks [P, B] index the flat best-buddy table, ok [P, B] switches slots off."""
+            tb = self._bb_table
+            fe = model.frame_embeddings
+            P, B = picks.shape
+            col = lambda sel: sel[:, None].expand(P, B).to(torch.float32)[:, :, None]
+            src_pts = torch.cat([tb.src[picks], col(s_sel)], dim=2).reshape(P * B, 3)
+            tgt_pts = torch.cat([tb.tgt[picks], col(t_sel)], dim=2).reshape(P * B, 3)
+            a = model.sample_embeddings(fe, model.normalize_points_for_sampling(src_pts)).reshape(P, B, -1)
+            b = model.sample_embeddings(fe, model.normalize_points_for_sampling(tgt_pts)).reshape(P, B, -1)
+            l_st, l_ts = contrastive_terms(a, b, frame_cells(fe, s_sel), frame_cells(fe, t_sel), self.config["cl_temp"])
+            w_amb = torch.sigmoid(self.config["bb_amb_sig_a"] * (1 - tb.r[picks]) + self.config["bb_amb_sig_b"])
+            w_cos = torch.clamp(2 * tb.cos[picks] ** 3, 0)
+            w = w_amb * w_cos * ok.to(w_amb.dtype)
+            div = self.config["cl_div_dino_bb"]
+            return ((l_st * w / div).sum() + (l_ts * w / div).sum()) / 2
+
+        def refined_bb_selection(self, model, frames_set_t):
+            """Random part of dino_tracker.py:245-305: cl_n_frames index pairs (source == target allowed, as there), the
+            mutual nearest neighbours of the current refined features, and up to cl_points_per_pair of them per pair split
+            foreground / background by the source frame's mask at the cell centres."""
+            fe = model.frame_embeddings
+            n = frames_set_t.shape[0]
+            dev = fe.device
+            P = self.config["cl_n_frames"]
+            s_sel = torch.randint(n, (P,), device=dev)
+            t_sel = torch.randint(n, (P,), device=dev)
+            geom = model.tracker_head.geom(fe.shape[0], fe.shape[1]) if fe.is_cuda else None
+            nn_st, nn_ts = mutual_argmax(fe.detach(), s_sel, t_sel, geom)
+            cells = torch.arange(nn_st.shape[1], device=dev)
+            mutual = nn_ts.gather(1, nn_st) == cells[None, :]
+            fg = self._cell_fg[frames_set_t[s_sel].long()]
+            n_fg, n_bg = self.split_counts(self.config["cl_points_per_pair"], self.config["cl_fg_points_ratio"])
+            src_cells, ok = pick_subsets([mutual & fg, mutual & ~fg], [n_fg, n_bg])
+            return s_sel, t_sel, src_cells, nn_st.gather(1, src_cells), ok
+
+        def refined_bb_terms(self, model, s_sel, t_sel, src_cells, tgt_cells, ok):
+            """Deterministic part of dino_tracker.py:245-325 for explicit selections (cells of the token grid)."""
+            fe = model.frame_embeddings
+            sf, tf = frame_cells(fe, s_sel), frame_cells(fe, t_sel)
+            C = sf.shape[2]
+            a = sf.gather(1, src_cells[:, :, None].expand(-1, -1, C))
+            b = tf.gather(1, tgt_cells[:, :, None].expand(-1, -1, C))
+            l_st, l_ts = contrastive_terms(a, b, sf, tf, self.config["cl_temp"])
+            with torch.no_grad():
+                aff = (a * b).sum(dim=2) / torch.clamp(a.norm(dim=2) * b.norm(dim=2), min=EPS)
+                w = torch.clamp(2 * aff ** 3, 0) * ok.to(aff.dtype)
+            return ((l_st * w).sum() + (l_ts * w).sum()) / (2 * self.config["cl_div_ref_bb"])
+
+        def cycle_terms(self, model, frames_set_t):
+            """dino_tracker.py:345-352 over the static-shape cycle batch (Tracker.get_cycle_consistency_terms)."""
+            c = model.get_cycle_consistency_terms(frames_set_t, self.fg_masks)
+            wgt = self.config["cyc_gamma"] ** c["cycle_consistency_dists"]
+            st = wgt[:, None] * huber(c["source_target_coords"], c["target_coords"][:, :2])
+            ts = wgt[:, None] * huber(c["target_source_coords"], c["source_coords"][:, :2])
+            return (weighted_mean(st, c["keep"]) + weighted_mean(ts, c["keep"])) / 2
+
+        def iteration_losses(self, model, inputs, labels, valid, i):
+            """The seven loss values of one iteration as a device vector in LOSS_NAMES order (dino_tracker.py:407-426)."""
+            cfg = self.config
+            frames_set_t = inputs[-1]
+            coords = model(inputs)
+            zero = coords.new_zeros(())
+            tracking = weighted_mean(huber(coords, labels), valid)
+            loss = tracking
+            cyc = cl_ref = zero
+            if i >= cfg.get("apply_cyc_after", 0):
+                cyc = self.cycle_terms(model, frames_set_t)
+                loss = loss + cfg["lambda_cyc"] * cyc
+            if i >= cfg.get("apply_cl_ref_after", 0):
+                cl_ref = self.refined_bb_terms(model, *self.refined_bb_selection(model, frames_set_t))
+                loss = loss + cfg["lambda_cl_ref_bb"] * cl_ref
+            cl_bb = self.dino_bb_terms(model, *self.dino_bb_selection(frames_set_t))
+            norm_reg, angle_reg = emb_regularization_terms(model.frame_embeddings, model.raw_embeddings)
+            loss = loss + cfg["lambda_cl_dino_bb"] * cl_bb + cfg["lambda_emb_norm"] * norm_reg + cfg["lambda_angle"] * angle_reg
+            return loss, torch.stack([loss.detach(), tracking.detach(), cl_bb.detach(), cl_ref.detach(), norm_reg.detach(),
+                                      angle_reg.detach(), cyc.detach()])
+
+        # -- the loop (dino_tracker.py:392-448) ---------------------------------------------------------------------------
+        def train(self):
+            if os.environ.get("DTK_TRAINER", "device") == "reference":
+                return super().train()
+            from tqdm import tqdm
+            self.load_fg_masks()
+            total_iterations = self.config["total_iterations"]
+            checkpoint_interval = self.config["checkpoint_interval"]
+            sampler_batch_iterations = self.config.get("sampler_batch_iterations", 100_000)
+            self.load_dino_best_buddies()
+            train_sampler = self.get_sampler()
+            model, optimizer, scheduler = self.train_setup()
+            self.set_model_train(model)
+            self.init_losses()
+            self.prepare_tables(model)
+            for i in tqdm(range(self.init_iter, total_iterations)):
+                optimizer.zero_grad(set_to_none=True)
+                inputs, labels, valid = self.get_inputs_and_labels_device(train_sampler)
+                loss, values = self.iteration_losses(model, inputs, labels, valid, i)
+                loss.backward()
+                optimizer.step()
+                scheduler.step()
+                self.update_losses(*values.unbind())          # device scalars: read when log_losses formats them
+                if i % 100 == 0:
+                    self.log_losses(i, log_interval=100)
+                if i == total_iterations - 1 or i % checkpoint_interval == 0:
+                    model.save_weights(i)
+                if i % sampler_batch_iterations == 0 and i > 0:
+                    print("Loading next batch", flush=True)
+                    train_sampler.load_next_batch()
+            model.save_weights(total_iterations)
+
+    DINOTracker.__qualname__ = "DINOTracker"
+    return DINOTracker

@@ -188,6 +188,14 @@ int dtk_head_forward_train(const dtk_geom* g, const float* head, const float* ma
 int dtk_head_backward(const dtk_geom* g, const float* head, const float* maps, const float* stats, const float* grad_out,
                       float* dmaps, float* dhead_partial, int B, int normalized, void* stream);
 
+/* Backward of the cosine maps (models/tracker.py:158-173 under autograd) behind dtk_head_backward: maps[b] = relu'd cosine map
+ * of emb[b] against frame tgt[b] (dtk_corr_maps with relu = 1), dmaps[b] its gradient (non-zero only on the 15 x 15 window around
+ * the arg-max cell stats[b][0], as dtk_head_backward leaves it).  demb[b][C] is written; dfeat[T][ph*pw][C] (token-major, ZEROED
+ * by the caller) receives atomic adds.  C <= 1024. */
+int dtk_corr_window_backward(const dtk_geom* g, const float* feat, const float* norms, const float* emb, const int32_t* tgt,
+                             const float* maps, const float* dmaps, const float* stats, float* demb, float* dfeat, int B,
+                             void* stream);
+
 /* NormalizedConv2d.forward as a stand-alone layer (models/networks/conv_norm.py:34-46): x[B][Cin][H][W],
  * w[Cout][Cin][k][k] (RAW weights: the per-kernel W / sum(W) is applied inside), bias[Cout] or NULL -> y[B][Cout][H][W];
  * stride 1, zero padding k/2, k odd.  (The tracker path runs these layers fused inside dtk_track / dtk_head_forward.) */

@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--profile-dir", default="")
     ap.add_argument("--rng-shim", action="store_true", help="keep train_driver's host-side random draws (parity runs; slow)")
+    ap.add_argument("--trainer", choices=["device", "reference"], default="device",
+                    help="hip side: dino_tracker_amd/trainer.py's iteration (default) or the reference's own loop on this implementation's models")
     ap.add_argument("--data-dir", default="", help="reuse / create the synthetic inputs here (shared between the two sides)")
     a = ap.parse_args()
     ref = os.environ.get("DTK_REFERENCE_ROOT", "/root/reference")
@@ -65,6 +67,9 @@ def main():
     if a.side == "hip":
         cmd = [sys.executable, "-m", "dino_tracker_amd.run", "--path", shims, "--path", ref, drv] + tail
         env["PYTHONPATH"] = ROOT
+        env["DTK_TRAINER"] = a.trainer
+        if a.trainer == "device":
+            env["DTK_TRAIN_ASYNC_LOG"] = "1"
     else:
         cmd = [sys.executable, drv] + tail
         env["PYTHONPATH"] = os.pathsep.join([shims, ref, ROOT])
@@ -83,9 +88,16 @@ def main():
     st = rec["seconds"]
     per = [b - a_ for a_, b in zip(st[:-1], st[1:])]
     steady = per[1:] if len(per) > 2 else per
+    median = statistics.median(steady)
+    timing = "median of per-iteration wall clock (every iteration ends with host reads of its losses)"
+    if len(rec.get("synced", [])) == 2:  # device-side trainer: no host read per iteration; synchronised clock at both ends
+        (n0, t0s), (n1, t1s) = rec["synced"]
+        median = (t1s - t0s) / (n1 - n0)
+        timing = f"(synchronised clock after iteration {n1} - after iteration {n0}) / {n1 - n0}; no host read in between"
     import torch
     print(json.dumps({"config": f"train.py un-modified, 854x476x{a.frames}, C={a.width}, config/train.yaml batch sizes, all losses on",
-                      "side": a.side, "iterations": len(st), "s_per_iteration_median": statistics.median(steady),
+                      "side": a.side, "trainer": a.trainer if a.side == "hip" else "reference", "timing": timing,
+                      "iterations": len(st), "s_per_iteration_median": median,
                       "s_per_iteration_all": [round(p, 4) for p in per], "wall_s": round(wall, 1),
                       "data_build_s": round(t_build, 1), "host_threads": torch.get_num_threads(),
                       "final_losses": dict(zip(rec["names"], rec["losses"][-1]))}))

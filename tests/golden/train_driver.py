@@ -47,14 +47,17 @@ if not torch.cuda.is_available():
 
 LOSSES = []
 STAMPS = []  # wall clock at the end of every iteration (after its .item() reads: the device is idle)
+SYNCED = []  # (iteration count, wall clock behind a device synchronisation) -- $DTK_TRAIN_ASYNC_LOG runs
+ASYNC = bool(os.environ.get("DTK_TRAIN_ASYNC_LOG"))
 
 
 def _dump():
     path = os.environ.get("DTK_TRAIN_LOG")
     if path:
         with open(path, "w") as fh:
+            losses = [v.tolist() if isinstance(v, torch.Tensor) else v for v in LOSSES]
             json.dump({"names": ["total", "of", "cl_dino_bb", "cl_refiner", "emb_norm_reg", "angle_reg", "cyc"],
-                       "losses": LOSSES, "seconds": STAMPS}, fh)
+                       "losses": losses, "seconds": STAMPS, "synced": SYNCED}, fh)
 
 
 atexit.register(_dump)
@@ -68,7 +71,7 @@ if __name__ == "__main__":
             data.dataset.RangeNormalizer.__init__.__defaults__ = ("cpu",)
         import models.utils  # get_vit_feature_coords_from_mask(..., device="cuda") (models/utils.py:87)
         models.utils.get_vit_feature_coords_from_mask.__defaults__ = (7, 14, "cpu")
-    import dino_tracker  # the reference's control plane (never overlaid)
+    import dino_tracker  # the reference's trainer, or overlay/dino_tracker.py (its subclass with the device-side iteration)
 
     _update = dino_tracker.DINOTracker.update_losses
 
@@ -76,7 +79,16 @@ if __name__ == "__main__":
     PROF = {}
 
     def update_losses(self, *vals):
-        LOSSES.append([float(v) for v in vals])
+        if ASYNC and isinstance(vals[0], torch.Tensor) and vals[0].is_cuda:
+            # timing runs of the device-side trainer: its loss values stay device scalars (no read per iteration); the clock is
+            # read behind a device synchronisation after iteration 2 and after the last one only
+            LOSSES.append(torch.stack([torch.as_tensor(v, dtype=torch.float32, device=vals[0].device).detach() for v in vals]))
+            n_total = self.config["total_iterations"] - getattr(self, "init_iter", 0)
+            if len(LOSSES) in (2, n_total):
+                torch.cuda.synchronize()
+                SYNCED.append((len(LOSSES), time.time()))
+        else:
+            LOSSES.append([float(v) for v in vals])
         STAMPS.append(time.time())
         if tprof_path:  # per-operator host / device time of iterations 3 .. 6 only (set-up and warm-up excluded)
             if len(LOSSES) == 2:
@@ -89,6 +101,13 @@ if __name__ == "__main__":
                 with open(tprof_path, "w") as fh:
                     fh.write("iterations 3..6 (4 iterations)\n")
                     fh.write(PROF["p"].key_averages().table(sort_by="self_cpu_time_total", row_limit=70, max_name_column_width=70))
+                    if torch.cuda.is_available():
+                        fh.write("\n\nsorted by device time\n")
+                        fh.write(PROF["p"].key_averages().table(sort_by="self_cuda_time_total", row_limit=50, max_name_column_width=70))
+                    if os.environ.get("DTK_TRAIN_TORCHPROF_STACK"):
+                        fh.write("\n\nby source location, sorted by device time (group_by_stack_n = 6)\n")
+                        fh.write(PROF["p"].key_averages(group_by_stack_n=6).table(sort_by="self_cuda_time_total", row_limit=50,
+                                                                                  max_name_column_width=50, max_src_column_width=110))
                     if os.environ.get("DTK_TRAIN_TORCHPROF_STACK"):
                         fh.write("\n\nby source location (group_by_stack_n = 6)\n")
                         fh.write(PROF["p"].key_averages(group_by_stack_n=6).table(sort_by="self_cpu_time_total", row_limit=60,
