@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 3) void conv5x5_split_kernel(const half_t* __r
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             half_t* __restrict__ out_hi, half_t* __restrict__ out_lo,
                                                             float* __restrict__ out_f32, int H, int W, int Cin, int Cout,
-                                                            int relu, int tiles_x) {
+                                                            int relu, int tiles_x, int zero_pad) {
     typedef SplitCfg<DIL> Cfg;
     constexpr int PY = Cfg::PY, PX = Cfg::PX, PXP = Cfg::PXP;
     extern __shared__ __attribute__((aligned(16))) half_t smem_s[];
@@ -202,10 +202,14 @@ __global__ __launch_bounds__(256, 3) void conv5x5_split_kernel(const half_t* __r
         for (int idx = tid; idx < PY * PX * 4; idx += 256) {
             const int plane = idx & 1, piece = (idx >> 1) & 1, p = idx >> 2;
             const int py = p / PX, px = p - py * PX;
-            const int gy = reflect(y0 - 2 * DIL + py, H), gx = reflect(x0 - 2 * DIL + px, W);
+            const int iy = y0 - 2 * DIL + py, ix = x0 - 2 * DIL + px;
+            const int gy = reflect(iy, H), gx = reflect(ix, W);
             const half_t* src = (plane ? fl : fh) + ((size_t)gy * W + gx) * Cin + ck * SK + piece * 8;
-            *reinterpret_cast<uint4*>((plane ? Xl : Xh) + (py * PXP + px) * Cfg::XPT + piece * 8) =
-                *reinterpret_cast<const uint4*>(src);
+            uint4 v = *reinterpret_cast<const uint4*>(src);
+            // zero padding (the training step's data gradients): positions outside the image contribute nothing; rows /
+            // columns past the far edge of a partial tile are never used by a stored output either way
+            if (zero_pad && (iy < 0 || iy >= H || ix < 0 || ix >= W)) v = uint4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<uint4*>((plane ? Xl : Xh) + (py * PXP + px) * Cfg::XPT + piece * 8) = v;
         }
         for (int ky = 0; ky < 5; ++ky) {
             if (ky) __syncthreads();
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(256, 3) void conv5x5_split_kernel(const half_t* __r
     for (int n = 0; n < 2; ++n) {
         const int co = ct * 64 + n * 32 + li;
         if (co >= Cout) continue;
-        const float sc = scale[co], sh = shift[co];
+        const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -461,7 +465,9 @@ __global__ __launch_bounds__(256) void blurpool_to_split_kernel(const float* __r
 }
 
 // [Cout][Cin][5][5] fp32 -> split planes [cout tile][cin chunk][25][64][16] of w * 2^8
-__global__ void pack_split_kernel(const float* __restrict__ w, int Cin, int Cout, half_t* __restrict__ Wh, half_t* __restrict__ Wl) {
+// (flip_transpose: the operator of the data gradient -- w is then [Cin][Cout][5][5] and tap t reads tap 24 - t)
+__global__ void pack_split_kernel(const float* __restrict__ w, int Cin, int Cout, half_t* __restrict__ Wh, half_t* __restrict__ Wl,
+                                  int flip_transpose) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const int nck = Cin / SK, nct = (Cout + 63) / 64;
     const long long total = (long long)nct * nck * 25 * 64 * SK;
@@ -472,7 +478,8 @@ __global__ void pack_split_kernel(const float* __restrict__ w, int Cin, int Cout
     const int ck = (int)((idx / (SK * 64 * 25)) % nck);
     const int ct = (int)(idx / ((long long)SK * 64 * 25 * nck));
     const int co = ct * 64 + co_l, ci = ck * SK + ci_l;
-    const float v = (co < Cout) ? w[((size_t)co * Cin + ci) * 25 + tap] * WSCALE : 0.f;
+    const size_t src = flip_transpose ? ((size_t)ci * Cout + co) * 25 + (24 - tap) : ((size_t)co * Cin + ci) * 25 + tap;
+    const float v = (co < Cout) ? w[src] * WSCALE : 0.f;
     const half_t h = (half_t)v;
     Wh[idx] = h;
     Wl[idx] = (half_t)(v - (float)h);
@@ -651,7 +658,7 @@ extern "C" int dtk_delta_dino_pack(int layer, int C, const float* w, const float
         half_t* Wh = reinterpret_cast<half_t*>(packed + f32_packed_floats(cinp, coutp));
         const size_t nh = split_plane_halves(cin, cout);
         DTK_LAUNCH("dd_pack", pack_split_kernel, dim3(dtk_cdiv((long long)nh, 256)), dim3(256), 0, dtk_stream(stream), w, cin,
-                   cout, Wh, Wh + nh);
+                   cout, Wh, Wh + nh, 0);
     }
     return DTK_OK;
 }
@@ -733,11 +740,11 @@ extern "C" int dtk_delta_dino_refine(const dtk_geom* g, const float* video, cons
                 dim3 grid(tiles_x * tiles_y, (cout + 63) / 64, nf);
                 if (l < 3) {
                     DTK_LAUNCH("dd_conv23", (conv5x5_split_kernel<1, true>), grid, dim3(256), SplitCfg<1>::LDS_BYTES, st, ih,
-                               ih + in_n, Wh, Wl, scale, shift, oh, oh + out_n, (float*)nullptr, H, W, cin, cout, 1, tiles_x);
+                               ih + in_n, Wh, Wl, scale, shift, oh, oh + out_n, (float*)nullptr, H, W, cin, cout, 1, tiles_x, 0);
                 } else {
                     DTK_LAUNCH("dd_conv4", (conv5x5_split_kernel<2, false>), grid, dim3(256), SplitCfg<2>::LDS_BYTES, st, ih,
                                ih + in_n, Wh, Wl, scale, shift, (half_t*)nullptr, (half_t*)nullptr, act, H, W, cin, cout, 0,
-                               tiles_x);
+                               tiles_x, 0);
                 }
             }
             cur = act;
@@ -769,5 +776,174 @@ extern "C" int dtk_delta_dino_refine(const dtk_geom* g, const float* video, cons
                    dino + (size_t)f0 * HW * g->C, out + (size_t)f0 * HW * g->C, norms ? norms + (size_t)f0 * HW : nullptr,
                    p.H[3], p.W[3], g->ph, g->pw, g->C, g->patch, g->stride, 8, nf);
     }
+    return DTK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The split-fp16 implicit-GEMM convolution as a stand-alone operator for the TRAINING step (delta_dino.py:29-44 under
+// autograd; dino_tracker_amd/train_ops.py _ConvMfma): forward and data gradient of the 5 x 5 layers run on
+// conv5x5_split_kernel -- no unfolded operand in memory (round 3's first form wrote and re-read 10 GB of im2col columns per
+// iteration) -- between two layout kernels, because the training pipeline around it (batch-statistics BatchNorm, blur-pool,
+// autograd) is NCHW fp32:
+//   nchw_to_split_kernel   x [N][C][H][W] fp32 (times a power-of-two device scalar)  ->  hi / lo fp16 planes [N][H+2b][W+2b][C],
+//                          a ring of b zero pixels around the image (the data gradient of a reflect-padded convolution is a
+//                          zero-padded convolution of dY over the PADDED domain);
+//   nhwc_to_nchw_kernel    y [N][H+2b][W+2b][C] fp32  ->  [N][C][H][W], optionally folding the ring back with the adjoint of the
+//                          reflect padding (a pixel within b of the border also collects what its mirror images received)
+//                          and dividing by the scalar.
+// Both move 64 pixels x 64 channels through an LDS tile so that global reads and writes are contiguous on both sides.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int LT = 64;  // tile: 64 pixels x 64 channels
+
+__global__ __launch_bounds__(256) void nchw_to_split_kernel(const float* __restrict__ x, half_t* __restrict__ hi,
+                                                            half_t* __restrict__ lo, int C, int H, int W, int b,
+                                                            const float* __restrict__ scale) {
+    __shared__ float tile[LT][LT + 1];  // [channel][pixel]
+    const int He = H + 2 * b, We = W + 2 * b;
+    const long long Le = (long long)He * We;
+    const int n = blockIdx.z, c0 = blockIdx.y * LT;
+    const long long p0 = (long long)blockIdx.x * LT;
+    const int tid = threadIdx.x;
+    const float sc = scale ? *scale : 1.f;
+    {   // read: lanes along pixels (contiguous in a row of the source plane)
+        const int px = tid & 63;
+        const long long pe = p0 + px;
+        const int ye = (int)(pe / We), xe = (int)(pe - (long long)ye * We);
+        const int y = ye - b, xx = xe - b;
+        const bool in = pe < Le && y >= 0 && y < H && xx >= 0 && xx < W;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int ch = i * 4 + (tid >> 6);
+            const int c = c0 + ch;
+            tile[ch][px] = (in && c < C) ? x[(((size_t)n * C + c) * H + y) * W + xx] * sc : 0.f;
+        }
+    }
+    __syncthreads();
+    // write: 8 lanes cover the 64 channels of one pixel (128 contiguous bytes per plane)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int px = i * 32 + (tid >> 3), cg = (tid & 7) * 8;
+        const long long pe = p0 + px;
+        if (pe >= Le || c0 + cg >= C) continue;
+        h8 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = tile[cg + e][px];
+            vh[e] = (half_t)v;
+            vl[e] = (half_t)(v - (float)vh[e]);
+        }
+        const size_t o = ((size_t)n * Le + pe) * C + c0 + cg;
+        *reinterpret_cast<h8*>(hi + o) = vh;
+        *reinterpret_cast<h8*>(lo + o) = vl;
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ y, float* __restrict__ out, int C, int H,
+                                                           int W, int b, int fold, const float* __restrict__ scale) {
+    __shared__ float tile[LT][LT + 1];  // [channel][pixel]
+    const int He = H + 2 * b, We = W + 2 * b;
+    const long long L = (long long)H * W;
+    const int n = blockIdx.z, c0 = blockIdx.y * LT;
+    const long long p0 = (long long)blockIdx.x * LT;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float inv = scale ? 1.f / *scale : 1.f;
+    const float* yn = y + (size_t)n * He * We * C;
+    // read: lanes along channels; each wave gathers 16 pixels (+ their mirror images in the ring)
+    for (int i = 0; i < 16; ++i) {
+        const int px = w * 16 + i;
+        const long long p = p0 + px;
+        float a = 0.f;
+        if (p < L && c0 + lane < C) {
+            const int yy = (int)(p / W), xx = (int)(p - (long long)yy * W);
+            int qy[2], qx[2], ny = 1, nx = 1;
+            qy[0] = yy + b;
+            qx[0] = xx + b;
+            if (fold) {
+                if (yy >= 1 && yy <= b) qy[ny++] = b - yy;
+                else if (yy <= H - 2 && yy >= H - 1 - b) qy[ny++] = b + 2 * (H - 1) - yy;
+                if (xx >= 1 && xx <= b) qx[nx++] = b - xx;
+                else if (xx <= W - 2 && xx >= W - 1 - b) qx[nx++] = b + 2 * (W - 1) - xx;
+            }
+            for (int iy = 0; iy < ny; ++iy)
+                for (int ix = 0; ix < nx; ++ix) a += yn[((size_t)qy[iy] * We + qx[ix]) * C + c0 + lane];
+        }
+        tile[lane][px] = a * inv;
+    }
+    __syncthreads();
+    // write: lanes along pixels of one channel plane
+    const long long p = p0 + lane;
+    if (p < L) {
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int ch = i * 4 + w;
+            if (c0 + ch < C) out[((size_t)n * C + c0 + ch) * L + p] = tile[ch][lane];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t dtk_conv_split_weight_halves(int Cin, int Cout) { return split_plane_halves(Cin, Cout); }
+
+extern "C" int dtk_conv_split_pack(const float* w, int Cin, int Cout, int flip_transpose, void* Wh, void* Wl, void* stream) {
+    DTK_REQUIRE(w && Wh && Wl, "dtk_conv_split_pack: null pointer");
+    DTK_REQUIRE(Cin > 0 && Cin % SK == 0 && Cout > 0, "dtk_conv_split_pack: Cin=%d must be a positive multiple of %d", Cin, SK);
+    const size_t nh = split_plane_halves(Cin, Cout);
+    DTK_LAUNCH("train_conv_pack", pack_split_kernel, dim3(dtk_cdiv((long long)nh, 256)), dim3(256), 0, dtk_stream(stream), w, Cin,
+               Cout, reinterpret_cast<half_t*>(Wh), reinterpret_cast<half_t*>(Wl), flip_transpose);
+    return DTK_OK;
+}
+
+extern "C" int dtk_conv_split_input(const float* x, int N, int C, int H, int W, int border, const float* scale, void* hi,
+                                    void* lo, void* stream) {
+    DTK_REQUIRE(x && hi && lo, "dtk_conv_split_input: null pointer");
+    DTK_REQUIRE(N > 0 && N <= 65535 && C > 0 && C % 8 == 0 && H > 0 && W > 0 && border >= 0, "dtk_conv_split_input: bad shape");
+    const long long Le = (long long)(H + 2 * border) * (W + 2 * border);
+    DTK_LAUNCH("train_conv_in", nchw_to_split_kernel, dim3(dtk_cdiv(Le, LT), dtk_cdiv(C, LT), N), dim3(256), 0,
+               dtk_stream(stream), x, reinterpret_cast<half_t*>(hi), reinterpret_cast<half_t*>(lo), C, H, W, border, scale);
+    return DTK_OK;
+}
+
+extern "C" int dtk_conv_split_run(const void* in_hi, const void* in_lo, const void* Wh, const void* Wl, float* out_nhwc, int N,
+                                  int H, int W, int Cin, int Cout, int dilation, int zero_pad, void* stream) {
+    DTK_REQUIRE(in_hi && in_lo && Wh && Wl && out_nhwc, "dtk_conv_split_run: null pointer");
+    DTK_REQUIRE(N > 0 && N <= 65535 && H > 4 * dilation && W > 4 * dilation, "dtk_conv_split_run: bad shape");
+    DTK_REQUIRE(Cin % SK == 0 && Cout > 0, "dtk_conv_split_run: Cin=%d must be a multiple of %d", Cin, SK);
+    DTK_REQUIRE(dilation == 1 || dilation == 2, "dtk_conv_split_run: dilation %d (1 or 2)", dilation);
+    static const bool lds_ok = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5x5_split_kernel<1, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitCfg<1>::LDS_BYTES) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5x5_split_kernel<2, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitCfg<2>::LDS_BYTES) == hipSuccess;
+    }();
+    DTK_REQUIRE(lds_ok, "dtk_conv_split_run: cannot reserve LDS for the split-fp16 convolution");
+    const int tiles_x = dtk_cdiv(W, STX), tiles_y = dtk_cdiv(H, STY);
+    dim3 grid(tiles_x * tiles_y, (Cout + 63) / 64, N);
+    const half_t* ih = reinterpret_cast<const half_t*>(in_hi);
+    const half_t* il = reinterpret_cast<const half_t*>(in_lo);
+    const half_t* wh = reinterpret_cast<const half_t*>(Wh);
+    const half_t* wl = reinterpret_cast<const half_t*>(Wl);
+    if (dilation == 1) {
+        DTK_LAUNCH("train_conv", (conv5x5_split_kernel<1, false>), grid, dim3(256), SplitCfg<1>::LDS_BYTES, dtk_stream(stream), ih,
+                   il, wh, wl, (const float*)nullptr, (const float*)nullptr, (half_t*)nullptr, (half_t*)nullptr, out_nhwc, H, W,
+                   Cin, Cout, 0, tiles_x, zero_pad);
+    } else {
+        DTK_LAUNCH("train_conv_d2", (conv5x5_split_kernel<2, false>), grid, dim3(256), SplitCfg<2>::LDS_BYTES, dtk_stream(stream),
+                   ih, il, wh, wl, (const float*)nullptr, (const float*)nullptr, (half_t*)nullptr, (half_t*)nullptr, out_nhwc, H,
+                   W, Cin, Cout, 0, tiles_x, zero_pad);
+    }
+    return DTK_OK;
+}
+
+extern "C" int dtk_conv_split_output(const float* y_nhwc, int N, int C, int H, int W, int border, int reflect_fold,
+                                     const float* scale, float* out_nchw, void* stream) {
+    DTK_REQUIRE(y_nhwc && out_nchw, "dtk_conv_split_output: null pointer");
+    DTK_REQUIRE(N > 0 && N <= 65535 && C > 0 && H > 0 && W > 0 && border >= 0, "dtk_conv_split_output: bad shape");
+    DTK_REQUIRE(!reflect_fold || (H > 2 * border + 1 && W > 2 * border + 1), "dtk_conv_split_output: image smaller than the fold");
+    const long long L = (long long)H * W;
+    DTK_LAUNCH("train_conv_out", nhwc_to_nchw_kernel, dim3(dtk_cdiv(L, LT), dtk_cdiv(C, LT), N), dim3(256), 0,
+               dtk_stream(stream), y_nhwc, out_nchw, C, H, W, border, reflect_fold, scale);
     return DTK_OK;
 }

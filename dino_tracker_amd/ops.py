@@ -361,3 +361,35 @@ def corr_window_backward(g: Geom, feat: torch.Tensor, norms: torch.Tensor, emb: 
                                          _p(tgt, torch.int32), _p(maps, torch.float32), _p(dmaps, torch.float32),
                                          _p(stats, torch.float32), _p(demb), _p(dfeat, torch.float32), B, _stream()))
     return demb
+
+
+def conv_split_pack(weight: torch.Tensor, flip_transpose: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """dtk_conv_split_pack: weight [Cout, Cin, 5, 5] -> (Wh, Wl) fp16 planes.  flip_transpose packs the operator of the data
+    gradient (its Cin is the forward's Cout)."""
+    w = weight.detach().to(torch.float32).contiguous()
+    cout, cin = w.shape[:2]
+    k_in, k_out = (cout, cin) if flip_transpose else (cin, cout)
+    nh = int(lib().dtk_conv_split_weight_halves(k_in, k_out))
+    wh = torch.empty(nh, dtype=torch.float16, device=w.device)
+    wl = torch.empty(nh, dtype=torch.float16, device=w.device)
+    check(lib().dtk_conv_split_pack(_p(w), k_in, k_out, int(flip_transpose), _p(wh), _p(wl), _stream()))
+    return wh, wl
+
+
+def conv_split_input(x: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor, border: int = 0,
+                     scale: Optional[torch.Tensor] = None) -> None:
+    n, c, h, w = x.shape
+    check(lib().dtk_conv_split_input(_p(x, torch.float32), n, c, h, w, border, _p(scale, torch.float32), _p(hi), _p(lo), _stream()))
+
+
+def conv_split_run(hi: torch.Tensor, lo: torch.Tensor, wh: torch.Tensor, wl: torch.Tensor, out_nhwc: torch.Tensor, n: int, h: int,
+                   w: int, cin: int, cout: int, dilation: int, zero_pad: bool) -> None:
+    check(lib().dtk_conv_split_run(_p(hi), _p(lo), _p(wh), _p(wl), _p(out_nhwc, torch.float32), n, h, w, cin, cout, dilation,
+                                   int(zero_pad), _stream()))
+
+
+def conv_split_output(y_nhwc: torch.Tensor, out: torch.Tensor, border: int = 0, reflect_fold: bool = False,
+                      scale: Optional[torch.Tensor] = None) -> None:
+    n, c, h, w = out.shape
+    check(lib().dtk_conv_split_output(_p(y_nhwc, torch.float32), n, c, h, w, border, int(reflect_fold), _p(scale, torch.float32),
+                                      _p(out, torch.float32), _stream()))

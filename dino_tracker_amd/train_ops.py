@@ -147,6 +147,28 @@ def _pow2_scale(t: torch.Tensor) -> torch.Tensor:
     return torch.exp2(torch.floor(10.0 - torch.log2(amax))).reshape(1)
 
 
+USE_IMPLICIT_CONVS = True  # 5 x 5 layers with Cin % 16 == 0: forward / data gradient on the implicit-GEMM kernel (no im2col)
+
+
+def _implicit_conv(x, weight, dilation, zero_pad, flip_transpose, border, fold, scale):
+    """conv5x5_split_kernel between the two layout kernels (csrc/delta_dino.hip, dtk_conv_split_*): x [n, c, h, w] fp32 ->
+    [n, c_out, h, w] fp32.  `border` / `fold` / `scale`: the data-gradient form (see _ConvMfma.backward)."""
+    from . import ops
+    n, cin, h, w = x.shape
+    cout = weight.shape[1] if flip_transpose else weight.shape[0]
+    he, we = h + 2 * border, w + 2 * border
+    wh, wl = ops.conv_split_pack(weight, flip_transpose)
+    planes = _workspace("conv_in_planes", n * he * we * cin, x)      # fp32-sized slot: hi plane | lo plane (2 bytes each)
+    hi = planes.view(torch.float16)[:n * he * we * cin]
+    lo = planes.view(torch.float16)[n * he * we * cin:2 * n * he * we * cin]
+    ops.conv_split_input(x, hi, lo, border, scale)
+    y_nhwc = _workspace("conv_out_nhwc", n * he * we * cout, x)
+    ops.conv_split_run(hi, lo, wh, wl, y_nhwc, n, he, we, cin, cout, dilation, zero_pad)
+    out = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
+    ops.conv_split_output(y_nhwc, out, border, fold, scale)
+    return out
+
+
 class _ConvMfma(torch.autograd.Function):
     """Stride-1 'same' convolution (k x k, reflect or zero padding, dilation) on the hand-written kernels of csrc/train.hip
     (round 3): im2col -> split-fp16 MFMA GEMM, forward, weight gradient and data gradient; fp32-grade (2^-22 relative per
@@ -165,6 +187,13 @@ class _ConvMfma(torch.autograd.Function):
         kp = (k + 31) // 32 * 32
         L = h * w
         x = x.contiguous()
+        ctx.implicit = (USE_IMPLICIT_CONVS and kh == 5 and cin % 16 == 0 and cout % 16 == 0 and dilation in (1, 2)
+                        and min(h, w) > 4 * dilation + 1)
+        if ctx.implicit:
+            y = _implicit_conv(x, weight, dilation, padding_mode == "zeros", False, 0, False, None)
+            ctx.save_for_backward(x, weight)
+            ctx.conf = (padding, dilation, padding_mode, kp)
+            return y
         cols = _workspace("cols", n * L * kp, x)
         ops.im2col(x, cols, kh, padding, dilation, padding_mode == "reflect", 0, kp)
         wp = torch.zeros(cout, kp, dtype=torch.float32, device=x.device)
@@ -204,7 +233,14 @@ class _ConvMfma(torch.autograd.Function):
             ops.gemm_nt(dyp, colst, dwp, cout, kp, lp, lp, lp, kp, batch=n, stride_a=cout * lp, stride_b=kp * lp, stride_c=0,
                         split_k=split, accumulate=2, scale_a=s_dy)
             dw = dwp[:, :k].reshape(weight.shape)
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.implicit:
+            # dX = zero-padded convolution of dY with the flipped, transposed kernel; under reflect padding over the PADDED
+            # domain (dY inside a ring of 2 d zeros), folded back onto the image by the adjoint of the padding
+            if padding_mode == "reflect":
+                dx = _implicit_conv(dy, weight, dilation, True, True, padding, True, s_dy)
+            else:
+                dx = _implicit_conv(dy, weight, dilation, True, True, 0, False, s_dy)
+        elif ctx.needs_input_grad[0]:
             wt = torch.zeros(kp, cout, dtype=torch.float32, device=dev)
             wt[:k] = weight.detach().reshape(cout, k).t()
             dyt = _workspace("dyt", n * L * cout, x)

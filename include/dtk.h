@@ -188,6 +188,27 @@ int dtk_head_forward_train(const dtk_geom* g, const float* head, const float* ma
 int dtk_head_backward(const dtk_geom* g, const float* head, const float* maps, const float* stats, const float* grad_out,
                       float* dmaps, float* dhead_partial, int B, int normalized, void* stream);
 
+/* The split-fp16 implicit-GEMM 5 x 5 convolution as a stand-alone operator: forward and data gradient of the Delta-DINO layers
+ * in the TRAINING step (models/networks/delta_dino.py:29-44 under autograd), fp32-grade (operands as hi + lo fp16 planes, three
+ * matrix-core products per term), stride 1, "same" size, dilation 1 or 2, reflect or zero padding.  Cin a multiple of 16.
+ *   dtk_conv_split_pack     w [Cout][Cin][5][5] -> the kernel's weight planes (dtk_conv_split_weight_halves(Cin, Cout) fp16 values
+ *                           each).  flip_transpose: w is [Cin][Cout][5][5] and taps are read reversed -- the operator of the data
+ *                           gradient with respect to the forward's input.
+ *   dtk_conv_split_input    x [N][C][H][W] fp32 times *scale (device scalar or NULL) -> hi / lo planes [N][H+2b][W+2b][C] with a
+ *                           ring of b zero pixels.  C a multiple of 8.
+ *   dtk_conv_split_run      planes [N][H][W][Cin] -> out [N][H][W][Cout] fp32.
+ *   dtk_conv_split_output   y [N][H+2b][W+2b][C] -> [N][C][H][W] divided by *scale; reflect_fold adds the ring back onto the image
+ *                           with the adjoint of the reflect padding (b = 2 * dilation: the data gradient of a reflect-padded
+ *                           convolution is the zero-padded convolution of dY over the padded domain, folded). */
+size_t dtk_conv_split_weight_halves(int Cin, int Cout);
+int dtk_conv_split_pack(const float* w, int Cin, int Cout, int flip_transpose, void* Wh, void* Wl, void* stream);
+int dtk_conv_split_input(const float* x, int N, int C, int H, int W, int border, const float* scale, void* hi, void* lo,
+                         void* stream);
+int dtk_conv_split_run(const void* in_hi, const void* in_lo, const void* Wh, const void* Wl, float* out_nhwc, int N, int H, int W,
+                       int Cin, int Cout, int dilation, int zero_pad, void* stream);
+int dtk_conv_split_output(const float* y_nhwc, int N, int C, int H, int W, int border, int reflect_fold, const float* scale,
+                          float* out_nchw, void* stream);
+
 /* Backward of the cosine maps (models/tracker.py:158-173 under autograd) behind dtk_head_backward: maps[b] = relu'd cosine map
  * of emb[b] against frame tgt[b] (dtk_corr_maps with relu = 1), dmaps[b] its gradient (non-zero only on the 15 x 15 window around
  * the arg-max cell stats[b][0], as dtk_head_backward leaves it).  demb[b][C] is written; dfeat[T][ph*pw][C] (token-major, ZEROED
