@@ -308,6 +308,56 @@ __global__ __launch_bounds__(256) void blurpool_bwd_kernel(const float* __restri
     dx[idx] = acc;
 }
 
+// The same operator with one thread per 2 x 2 block of inputs (positions 2m, 2m + 1 per axis): away from the borders
+//     dx[2m] = (3 dy[m] + dy[m - 1]) / 8,   dx[2m + 1] = (dy[m + 1] + 3 dy[m]) / 8     per axis,
+// i.e. nine loads and four stores without the tap lists and the 64-bit index divisions of the per-element form (which made the
+// kernel 4-7x slower than its traffic: 1.8 ms for the 832 MB of the first layer's gradient); blocks that touch index 1 or the
+// last three indices of an axis take the per-element path.
+__global__ __launch_bounds__(256) void blurpool_bwd2_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W,
+                                                            int Ho, int Wo, int vec) {
+    const int mx = blockIdx.x * 64 + (threadIdx.x & 63), my = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (2 * mx >= W || 2 * my >= H) return;
+    const float* gp = dy + (long long)blockIdx.z * Ho * Wo;
+    float* dp = dx + (long long)blockIdx.z * H * W;
+    const bool inx = mx >= 1 && 2 * mx + 1 <= W - 4, iny = my >= 1 && 2 * my + 1 <= H - 4;
+    if (inx && iny) {
+        float re[3], ro[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float* row = gp + (long long)(my - 1 + a) * Wo + mx - 1;
+            const float g0 = row[0], g1 = row[1], g2 = row[2];
+            re[a] = fmaf(0.375f, g1, 0.125f * g0);
+            ro[a] = fmaf(0.125f, g2, 0.375f * g1);
+        }
+        const float e0 = fmaf(0.375f, re[1], 0.125f * re[0]), o0 = fmaf(0.375f, ro[1], 0.125f * ro[0]);
+        const float e1 = fmaf(0.125f, re[2], 0.375f * re[1]), o1 = fmaf(0.125f, ro[2], 0.375f * ro[1]);
+        float* r0 = dp + (long long)(2 * my) * W + 2 * mx;
+        if (vec) {
+            *reinterpret_cast<float2*>(r0) = float2{e0, o0};
+            *reinterpret_cast<float2*>(r0 + W) = float2{e1, o1};
+        } else {
+            r0[0] = e0; r0[1] = o0;
+            r0[W] = e1; r0[W + 1] = o1;
+        }
+        return;
+    }
+    for (int sy = 0; sy < 2; ++sy)
+        for (int sx = 0; sx < 2; ++sx) {
+            const int py = 2 * my + sy, px = 2 * mx + sx;
+            if (py >= H || px >= W) continue;
+            int oy[6], ox[6];
+            float wy[6], wx[6];
+            const int ny = blur_adjoint(py, H, Ho, oy, wy), nx = blur_adjoint(px, W, Wo, ox, wx);
+            float acc = 0.f;
+            for (int a = 0; a < ny; ++a) {
+                float r = 0.f;
+                for (int b = 0; b < nx; ++b) r = fmaf(wx[b], gp[(long long)oy[a] * Wo + ox[b]], r);
+                acc = fmaf(wy[a], r, acc);
+            }
+            dp[(long long)py * W + px] = acc;
+        }
+}
+
 int slices(int N, int C, int HW) {
     const long long L = (long long)N * HW;
     long long S = 4096 / (C > 0 ? C : 1);  // ~16 workgroups per CU over all channels
@@ -371,6 +421,12 @@ extern "C" int dtk_blurpool_backward(const float* dy, float* dx, int64_t planes,
     DTK_REQUIRE(dy && dx, "dtk_blurpool_backward: null pointer");
     DTK_REQUIRE(planes > 0 && H >= 4 && W >= 4, "dtk_blurpool_backward: bad shape %lld x %d x %d", (long long)planes, H, W);
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    if (planes <= 65535) {
+        const int vec = (((long long)H * W) % 2 == 0 && W % 2 == 0) ? 1 : 0;  // every row pair starts 8-byte aligned
+        DTK_LAUNCH("blurpool_bwd", blurpool_bwd2_kernel, dim3(dtk_cdiv((W + 1) / 2, 64), dtk_cdiv((H + 1) / 2, 4), (unsigned)planes),
+                   dim3(256), 0, dtk_stream(stream), dy, dx, H, W, Ho, Wo, vec);
+        return DTK_OK;
+    }
     const long long total = (long long)planes * H * W;
     DTK_LAUNCH("blurpool_bwd", blurpool_bwd_kernel, dim3(dtk_cdiv(total, 256)), dim3(256), 0, dtk_stream(stream), dy, dx,
                (long long)planes, H, W, Ho, Wo);
@@ -779,5 +835,189 @@ extern "C" int dtk_resample2d_backward(const float* ddst, float* dsrc, int64_t p
     DTK_REQUIRE(planes > 0 && planes <= 65535 && hs > 0 && ws > 0 && hd > 0 && wd > 0, "dtk_resample2d_backward: bad sizes");
     DTK_LAUNCH("train_align_bwd", resample_bwd_kernel, dim3(dtk_cdiv((long long)hs * ws, 256), (unsigned)planes), dim3(256), 0,
                dtk_stream(stream), ddst, dsrc, hs, ws, hd, wd, yranges, ywhi, xranges, xwhi);
+    return DTK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a 5 x 5 convolution WITHOUT the unfolded operand (round 3, second form):
+//     dW[co][ci][ky][kx] = sum_{frames, y, x} dY[co][y][x] Xpad[ci][y + ky d][x + kx d]
+// as 25 small matrix products per workgroup whose reduction index is the PIXEL: both operands are read where autograd leaves
+// them (NCHW fp32: pixels contiguous), split hi + lo into fp16 while they are staged into LDS as [channel][row][x], and the
+// MFMA 16x16x32 fragments are 8 consecutive pixels of one channel -- a 16-byte LDS read.  The x shift of a tap (kx d pixels)
+// is applied IN REGISTERS: a lane reads the two aligned 8-pixel groups that cover its shifted window and selects / funnel-
+// shifts (v_alignbit) the 16-bit elements, so that no tap needs an unaligned LDS access or its own copy of the tile.
+// A workgroup (4 waves) owns a 32 x 32 block of (cout, cin) for all 25 taps -- 25 accumulator tiles of 16 x 16 per wave -- and
+// walks its share of 4-row x 32-pixel tiles of all frames; the partial sums go to dW with atomic adds (S-way split over the
+// pixels).  The im2col form wrote and re-read 10 GB of columns per iteration for the same products.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int WG_R = 4, WG_TW = 32, WG_XP = 40;  // tile rows, tile width, LDS row pitch of X in halves (width + 8)
+
+template <int DIL>
+struct WgradCfg {
+    static constexpr int XR = WG_R + 4 * DIL;               // X rows incl. halo
+    static constexpr int XC = XR * WG_XP + 8;               // halves per cin plane (+16 B: conflict-free across channels)
+    static constexpr int YC = WG_R * WG_TW + 8;             // halves per cout plane
+    static constexpr int X_HALVES = 32 * XC, Y_HALVES = 32 * YC;
+    static constexpr size_t LDS_BYTES = (size_t)(2 * X_HALVES + 2 * Y_HALVES) * sizeof(half_t);
+};
+
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+
+// halves [S .. S + 7] of the 16 halves (a, b)
+template <int S>
+__device__ __forceinline__ h8 shift_window(const u4v a, const u4v b) {
+    const unsigned int u[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    u4v r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (S % 2 == 0) r[j] = u[S / 2 + j];
+        else r[j] = __builtin_amdgcn_alignbit(u[(S - 1) / 2 + j + 1], u[(S - 1) / 2 + j], 16);
+    }
+    return __builtin_bit_cast(h8, r);
+}
+
+template <int DIL>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                   float* __restrict__ dw, int N, int Cin, int Cout, int H, int W,
+                                                                   int reflect_pad, const float* __restrict__ scale_dy,
+                                                                   int tiles_x, int tiles_y, int splits) {
+    typedef WgradCfg<DIL> Cfg;
+    extern __shared__ __attribute__((aligned(16))) half_t wg_smem[];
+    half_t* Xh = wg_smem;
+    half_t* Xl = Xh + Cfg::X_HALVES;
+    half_t* Yh = Xl + Cfg::X_HALVES;
+    half_t* Yl = Yh + Cfg::Y_HALVES;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fj = lane & 15, fg = lane >> 4;
+    const int cot = w & 1, cit = w >> 1;
+    const int nci = (Cin + 31) / 32;
+    const int co0 = (blockIdx.y / nci) * 32, ci0 = (blockIdx.y % nci) * 32;
+    const float sdy = scale_dy ? *scale_dy : 1.f;
+    f4 acc[25];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+    const long long tiles = (long long)N * tiles_y * tiles_x;
+    const size_t plane = (size_t)H * W;
+    for (long long tile = blockIdx.x; tile < tiles; tile += splits) {
+        const int n = (int)(tile / (tiles_y * tiles_x));
+        const int rem = (int)(tile - (long long)n * tiles_y * tiles_x);
+        const int y0 = (rem / tiles_x) * WG_R, x0 = (rem % tiles_x) * WG_TW;
+        __syncthreads();  // the previous tile's fragment reads are done
+        // X: 32 cin x XR rows x 5 groups of 8 pixels, starting 2 DIL left of / above the tile
+        for (int it = tid; it < 32 * Cfg::XR * (WG_XP / 8); it += 256) {
+            const int xg = it % (WG_XP / 8), rr = (it / (WG_XP / 8)) % Cfg::XR, c = it / ((WG_XP / 8) * Cfg::XR);
+            const int ci = ci0 + c;
+            const int iy = y0 - 2 * DIL + rr;
+            float v[8];
+            const bool row_in = reflect_pad || (iy >= 0 && iy < H);
+            int gy = iy < 0 ? -iy : (iy >= H ? 2 * (H - 1) - iy : iy);
+            gy = min(max(gy, 0), H - 1);
+            const float* src = x + ((size_t)n * Cin + min(ci, Cin - 1)) * plane + (size_t)gy * W;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ix = x0 - 2 * DIL + xg * 8 + e;
+                int gx = ix < 0 ? -ix : (ix >= W ? 2 * (W - 1) - ix : ix);
+                gx = min(max(gx, 0), W - 1);
+                const bool in = ci < Cin && row_in && (reflect_pad || (ix >= 0 && ix < W));
+                v[e] = in ? src[gx] : 0.f;
+            }
+            h8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                hi[e] = (half_t)v[e];
+                lo[e] = (half_t)(v[e] - (float)hi[e]);
+            }
+            const int o = c * Cfg::XC + rr * WG_XP + xg * 8;
+            *reinterpret_cast<h8*>(Xh + o) = hi;
+            *reinterpret_cast<h8*>(Xl + o) = lo;
+        }
+        // dY: 32 cout x 4 rows x 4 groups of 8 pixels (zero outside the image: partial tiles contribute nothing)
+        for (int it = tid; it < 32 * WG_R * (WG_TW / 8); it += 256) {
+            const int xg = it % (WG_TW / 8), rr = (it / (WG_TW / 8)) % WG_R, c = it / ((WG_TW / 8) * WG_R);
+            const int co = co0 + c, iy = y0 + rr;
+            const float* src = dy + ((size_t)n * Cout + min(co, Cout - 1)) * plane + (size_t)min(iy, H - 1) * W;
+            h8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ix = x0 + xg * 8 + e;
+                const float v = (co < Cout && iy < H && ix < W) ? src[ix] * sdy : 0.f;
+                hi[e] = (half_t)v;
+                lo[e] = (half_t)(v - (float)hi[e]);
+            }
+            const int o = c * Cfg::YC + rr * WG_TW + xg * 8;
+            *reinterpret_cast<h8*>(Yh + o) = hi;
+            *reinterpret_cast<h8*>(Yl + o) = lo;
+        }
+        __syncthreads();
+        const half_t* ybase_h = Yh + (cot * 16 + fj) * Cfg::YC + fg * 8;
+        const half_t* ybase_l = Yl + (cot * 16 + fj) * Cfg::YC + fg * 8;
+        const half_t* xbase_h = Xh + (cit * 16 + fj) * Cfg::XC + fg * 8;
+        const half_t* xbase_l = Xl + (cit * 16 + fj) * Cfg::XC + fg * 8;
+#pragma unroll 1
+        for (int r = 0; r < WG_R; ++r) {
+            const h8 ah = *reinterpret_cast<const h8*>(ybase_h + r * WG_TW);
+            const h8 al = *reinterpret_cast<const h8*>(ybase_l + r * WG_TW);
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const int ro = (r + ky * DIL) * WG_XP;
+                const u4v h0 = *reinterpret_cast<const u4v*>(xbase_h + ro), h1 = *reinterpret_cast<const u4v*>(xbase_h + ro + 8);
+                const u4v l0 = *reinterpret_cast<const u4v*>(xbase_l + ro), l1 = *reinterpret_cast<const u4v*>(xbase_l + ro + 8);
+#define WG_TAP(KX)                                                                                              \
+    {                                                                                                           \
+        const h8 bh = shift_window<(KX) * DIL>(h0, h1), bl = shift_window<(KX) * DIL>(l0, l1);                  \
+        f4& a_ = acc[ky * 5 + (KX)];                                                                            \
+        a_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, a_, 0, 0, 0);                                       \
+        a_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, a_, 0, 0, 0);                                       \
+        a_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, a_, 0, 0, 0);                                       \
+    }
+                WG_TAP(0) WG_TAP(1) WG_TAP(2) WG_TAP(3) WG_TAP(4)
+#undef WG_TAP
+            }
+        }
+    }
+    // D fragment: rows 4 fg + r (cout) of column fj (cin)
+    const float inv = 1.f / sdy;
+    const int ci = ci0 + cit * 16 + fj;
+    if (ci < Cin) {
+#pragma unroll
+        for (int t = 0; t < 25; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + cot * 16 + 4 * fg + r;
+                if (co < Cout) atomicAdd(dw + ((size_t)co * Cin + ci) * 25 + t, acc[t][r] * inv);
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int dtk_conv_wgrad_split(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W,
+                                    int dilation, int reflect_pad, const float* scale_dy, void* stream) {
+    DTK_REQUIRE(x && dy && dw, "dtk_conv_wgrad_split: null pointer");
+    DTK_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 4 * dilation && W > 4 * dilation, "dtk_conv_wgrad_split: bad shape");
+    DTK_REQUIRE(dilation == 1 || dilation == 2, "dtk_conv_wgrad_split: dilation %d (1 or 2)", dilation);
+    static const bool lds_ok = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel<1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgradCfg<1>::LDS_BYTES) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel<2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgradCfg<2>::LDS_BYTES) == hipSuccess;
+    }();
+    DTK_REQUIRE(lds_ok, "dtk_conv_wgrad_split: cannot reserve LDS");
+    const int tiles_x = dtk_cdiv(W, WG_TW), tiles_y = dtk_cdiv(H, WG_R);
+    const int blocks = dtk_cdiv(Cout, 32) * dtk_cdiv(Cin, 32);
+    const long long tiles = (long long)N * tiles_x * tiles_y;
+    long long splits = dtk_cdiv(1024, blocks);  // ~4 workgroups per CU over all weight blocks
+    if (splits > tiles) splits = tiles;
+    if (splits < 1) splits = 1;
+    dim3 grid((unsigned)splits, blocks);
+    if (dilation == 1) {
+        DTK_LAUNCH("train_conv_wgrad", conv_wgrad_split_kernel<1>, grid, dim3(256), WgradCfg<1>::LDS_BYTES, dtk_stream(stream), x, dy,
+                   dw, N, Cin, Cout, H, W, reflect_pad, scale_dy, tiles_x, tiles_y, (int)splits);
+    } else {
+        DTK_LAUNCH("train_conv_wgrad_d2", conv_wgrad_split_kernel<2>, grid, dim3(256), WgradCfg<2>::LDS_BYTES, dtk_stream(stream), x,
+                   dy, dw, N, Cin, Cout, H, W, reflect_pad, scale_dy, tiles_x, tiles_y, (int)splits);
+    }
     return DTK_OK;
 }

@@ -393,3 +393,12 @@ def conv_split_output(y_nhwc: torch.Tensor, out: torch.Tensor, border: int = 0, 
     n, c, h, w = out.shape
     check(lib().dtk_conv_split_output(_p(y_nhwc, torch.float32), n, c, h, w, border, int(reflect_fold), _p(scale, torch.float32),
                                       _p(out, torch.float32), _stream()))
+
+
+def conv_wgrad_split(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, dilation: int, reflect: bool,
+                     scale_dy: Optional[torch.Tensor] = None) -> None:
+    """dtk_conv_wgrad_split: dw [Cout, Cin, 5, 5] (zeroed by the caller) += the weight gradient of the 5 x 5 'same' convolution."""
+    n, cin, h, w = x.shape
+    cout = dy.shape[1]
+    check(lib().dtk_conv_wgrad_split(_p(x, torch.float32), _p(dy, torch.float32), _p(dw, torch.float32), n, cin, cout, h, w, dilation,
+                                     int(reflect), _p(scale_dy, torch.float32), _stream()))

@@ -218,7 +218,10 @@ class _ConvMfma(torch.autograd.Function):
         dy = dy.contiguous()
         s_dy = _pow2_scale(dy)
         dw = dx = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and ctx.implicit:
+            dw = torch.zeros(weight.shape, dtype=torch.float32, device=dev)
+            ops.conv_wgrad_split(x, dy, dw, dilation, padding_mode == "reflect", s_dy)
+        elif ctx.needs_input_grad[1]:
             lp = (L + 31) // 32 * 32
             colst = _workspace("cols", n * kp * lp, x)
             ops.im2col(x, colst, kh, padding, dilation, padding_mode == "reflect", 1, kp, lp)

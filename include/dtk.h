@@ -209,6 +209,12 @@ int dtk_conv_split_run(const void* in_hi, const void* in_lo, const void* Wh, con
 int dtk_conv_split_output(const float* y_nhwc, int N, int C, int H, int W, int border, int reflect_fold, const float* scale,
                           float* out_nchw, void* stream);
 
+/* Weight gradient of the same convolution without an unfolded operand: dw [Cout][Cin][5][5] (ZEROED by the caller; atomic adds)
+ * += sum over frames and pixels of dy [N][Cout][H][W] (times *scale_dy, a power of two, undone on output) and the padded
+ * x [N][Cin][H][W]; both operands fp32 NCHW as autograd holds them, split into fp16 halves while staged (fp32-grade). */
+int dtk_conv_wgrad_split(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W, int dilation,
+                         int reflect_pad, const float* scale_dy, void* stream);
+
 /* Backward of the cosine maps (models/tracker.py:158-173 under autograd) behind dtk_head_backward: maps[b] = relu'd cosine map
  * of emb[b] against frame tgt[b] (dtk_corr_maps with relu = 1), dmaps[b] its gradient (non-zero only on the 15 x 15 window around
  * the arg-max cell stats[b][0], as dtk_head_backward leaves it).  demb[b][C] is written; dfeat[T][ph*pw][C] (token-major, ZEROED

@@ -26,8 +26,11 @@ for m in (models.tracker, models.model_inference, data.dataset, utils):
 if REF:
     import models.utils, data.tapvid
     assert REF in models.utils.__file__ and REF in data.tapvid.__file__
-    import dino_tracker                       # the reference's orchestrator imports cleanly on top of the overlay
-    assert dino_tracker.Tracker is T.Tracker
+    import dino_tracker                       # overlay/dino_tracker.py: the reference's trainer class, loaded from the
+    assert dino_tracker.reference.Tracker is T.Tracker                  # checkout on top of the overlay's models, ...
+    assert issubclass(dino_tracker.DINOTracker, dino_tracker.reference.DINOTracker)   # ... with the device-side iteration
+    assert dino_tracker.DINOTracker.train is not dino_tracker.reference.DINOTracker.train
+    assert REF in dino_tracker.reference.__file__
 print("overlay ok")
 '''
 
