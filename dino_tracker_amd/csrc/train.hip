@@ -14,6 +14,7 @@
 //
 // Layout: x, y, dy, dx are [N][C][HW] float32 (NCHW, contiguous).  Grid (S, C): workgroup (s, c) owns slice s of channel
 // c's N * HW values; S is chosen so that S * C fills the chip, and is at most 64 (one partial per lane in the merge).
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -853,6 +854,7 @@ extern "C" int dtk_resample2d_backward(const float* ddst, float* dsrc, int64_t p
 namespace {
 
 constexpr int WG_R = 4, WG_TW = 32, WG_XP = 40;  // tile rows, tile width, LDS row pitch of X in halves (width + 8)
+constexpr int WG_PART = 4 * 25 * 4 * 64;          // floats of one workgroup's partial block: 32 cout x 32 cin x 25 taps
 
 template <int DIL>
 struct WgradCfg {
@@ -880,8 +882,8 @@ __device__ __forceinline__ h8 shift_window(const u4v a, const u4v b) {
 
 template <int DIL>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                   float* __restrict__ dw, int N, int Cin, int Cout, int H, int W,
-                                                                   int reflect_pad, const float* __restrict__ scale_dy,
+                                                                   float* __restrict__ partial, int N, int Cin, int Cout, int H,
+                                                                   int W, int reflect_pad, const float* __restrict__ scale_dy,
                                                                    int tiles_x, int tiles_y, int splits) {
     typedef WgradCfg<DIL> Cfg;
     extern __shared__ __attribute__((aligned(16))) half_t wg_smem[];
@@ -900,49 +902,89 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const float* _
     for (int t = 0; t < 25; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
     const long long tiles = (long long)N * tiles_y * tiles_x;
     const size_t plane = (size_t)H * W;
-    for (long long tile = blockIdx.x; tile < tiles; tile += splits) {
+    // Operand tiles travel through REGISTERS one tile ahead (requested before the MFMA loop of the current tile, converted and
+    // written to LDS after it): X = 32 cin x XR rows x 5 groups of 8 pixels, dY = 32 cout x 4 rows x 4 groups.
+    constexpr int XITEMS = 32 * Cfg::XR * (WG_XP / 8), XPER = (XITEMS + 255) / 256;
+    constexpr int YITEMS = 32 * WG_R * (WG_TW / 8), YPER = YITEMS / 256;
+    static_assert(YITEMS % 256 == 0, "dY items per thread");
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // rows of an NCHW plane are only 4-byte aligned
+    f4 xr[XPER][2], yr[YPER][2];
+    auto load_tile = [&](long long tile) {
         const int n = (int)(tile / (tiles_y * tiles_x));
         const int rem = (int)(tile - (long long)n * tiles_y * tiles_x);
         const int y0 = (rem / tiles_x) * WG_R, x0 = (rem % tiles_x) * WG_TW;
-        __syncthreads();  // the previous tile's fragment reads are done
-        // X: 32 cin x XR rows x 5 groups of 8 pixels, starting 2 DIL left of / above the tile
-        for (int it = tid; it < 32 * Cfg::XR * (WG_XP / 8); it += 256) {
+        // every X position of the tile inside the image (then so is every dY position): no reflection, no bounds
+        const bool interior = y0 - 2 * DIL >= 0 && y0 + WG_R - 1 + 2 * DIL < H && x0 - 2 * DIL >= 0 && x0 - 2 * DIL + WG_XP - 1 < W;
+#pragma unroll
+        for (int i = 0; i < XPER; ++i) {
+            const int it = tid + 256 * i;
             const int xg = it % (WG_XP / 8), rr = (it / (WG_XP / 8)) % Cfg::XR, c = it / ((WG_XP / 8) * Cfg::XR);
             const int ci = ci0 + c;
-            const int iy = y0 - 2 * DIL + rr;
-            float v[8];
-            const bool row_in = reflect_pad || (iy >= 0 && iy < H);
-            int gy = iy < 0 ? -iy : (iy >= H ? 2 * (H - 1) - iy : iy);
-            gy = min(max(gy, 0), H - 1);
-            const float* src = x + ((size_t)n * Cin + min(ci, Cin - 1)) * plane + (size_t)gy * W;
+            const bool live = it < XITEMS && ci < Cin;
+            const int iy = y0 - 2 * DIL + rr, ix0 = x0 - 2 * DIL + xg * 8;
+            const float* pl = x + ((size_t)n * Cin + min(ci, Cin - 1)) * plane;
+            if (interior) {
+                const float* src = pl + (size_t)iy * W + ix0;
+                xr[i][0] = live ? (f4)*reinterpret_cast<const f4u*>(src) : f4{0.f, 0.f, 0.f, 0.f};
+                xr[i][1] = live ? (f4)*reinterpret_cast<const f4u*>(src + 4) : f4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                const bool row_in = reflect_pad || (iy >= 0 && iy < H);
+                int gy = iy < 0 ? -iy : (iy >= H ? 2 * (H - 1) - iy : iy);
+                gy = min(max(gy, 0), H - 1);
+                const float* src = pl + (size_t)gy * W;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int ix = x0 - 2 * DIL + xg * 8 + e;
-                int gx = ix < 0 ? -ix : (ix >= W ? 2 * (W - 1) - ix : ix);
-                gx = min(max(gx, 0), W - 1);
-                const bool in = ci < Cin && row_in && (reflect_pad || (ix >= 0 && ix < W));
-                v[e] = in ? src[gx] : 0.f;
+                for (int e = 0; e < 8; ++e) {
+                    const int ix = ix0 + e;
+                    int gx = ix < 0 ? -ix : (ix >= W ? 2 * (W - 1) - ix : ix);
+                    gx = min(max(gx, 0), W - 1);
+                    const bool in = live && row_in && (reflect_pad || (ix >= 0 && ix < W));
+                    xr[i][e >> 2][e & 3] = in ? src[gx] : 0.f;
+                }
             }
+        }
+#pragma unroll
+        for (int i = 0; i < YPER; ++i) {
+            const int it = tid + 256 * i;
+            const int xg = it % (WG_TW / 8), rr = (it / (WG_TW / 8)) % WG_R, c = it / ((WG_TW / 8) * WG_R);
+            const int co = co0 + c, iy = y0 + rr, ix0 = x0 + xg * 8;
+            const float* src = dy + ((size_t)n * Cout + min(co, Cout - 1)) * plane + (size_t)min(iy, H - 1) * W;
+            if (interior) {
+                yr[i][0] = co < Cout ? (f4)*reinterpret_cast<const f4u*>(src + ix0) : f4{0.f, 0.f, 0.f, 0.f};
+                yr[i][1] = co < Cout ? (f4)*reinterpret_cast<const f4u*>(src + ix0 + 4) : f4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ix = ix0 + e;
+                    yr[i][e >> 2][e & 3] = (co < Cout && iy < H && ix < W) ? src[ix] : 0.f;  // zero outside: no contribution
+                }
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < XPER; ++i) {
+            const int it = tid + 256 * i;
+            if (it >= XITEMS) continue;
+            const int xg = it % (WG_XP / 8), rr = (it / (WG_XP / 8)) % Cfg::XR, c = it / ((WG_XP / 8) * Cfg::XR);
             h8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                hi[e] = (half_t)v[e];
-                lo[e] = (half_t)(v[e] - (float)hi[e]);
+                const float v = xr[i][e >> 2][e & 3];
+                hi[e] = (half_t)v;
+                lo[e] = (half_t)(v - (float)hi[e]);
             }
             const int o = c * Cfg::XC + rr * WG_XP + xg * 8;
             *reinterpret_cast<h8*>(Xh + o) = hi;
             *reinterpret_cast<h8*>(Xl + o) = lo;
         }
-        // dY: 32 cout x 4 rows x 4 groups of 8 pixels (zero outside the image: partial tiles contribute nothing)
-        for (int it = tid; it < 32 * WG_R * (WG_TW / 8); it += 256) {
+#pragma unroll
+        for (int i = 0; i < YPER; ++i) {
+            const int it = tid + 256 * i;
             const int xg = it % (WG_TW / 8), rr = (it / (WG_TW / 8)) % WG_R, c = it / ((WG_TW / 8) * WG_R);
-            const int co = co0 + c, iy = y0 + rr;
-            const float* src = dy + ((size_t)n * Cout + min(co, Cout - 1)) * plane + (size_t)min(iy, H - 1) * W;
             h8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int ix = x0 + xg * 8 + e;
-                const float v = (co < Cout && iy < H && ix < W) ? src[ix] * sdy : 0.f;
+                const float v = yr[i][e >> 2][e & 3] * sdy;
                 hi[e] = (half_t)v;
                 lo[e] = (half_t)(v - (float)hi[e]);
             }
@@ -950,7 +992,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const float* _
             *reinterpret_cast<h8*>(Yh + o) = hi;
             *reinterpret_cast<h8*>(Yl + o) = lo;
         }
+    };
+    if ((long long)blockIdx.x < tiles) load_tile(blockIdx.x);
+    for (long long tile = blockIdx.x; tile < tiles; tile += splits) {
+        __syncthreads();  // the previous tile's fragment reads are done
+        store_tile();
         __syncthreads();
+        if (tile + splits < tiles) load_tile(tile + splits);  // in flight under this tile's MFMAs
         const half_t* ybase_h = Yh + (cot * 16 + fj) * Cfg::YC + fg * 8;
         const half_t* ybase_l = Yl + (cot * 16 + fj) * Cfg::YC + fg * 8;
         const half_t* xbase_h = Xh + (cit * 16 + fj) * Cfg::XC + fg * 8;
@@ -977,27 +1025,65 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const float* _
             }
         }
     }
-    // D fragment: rows 4 fg + r (cout) of column fj (cin)
-    const float inv = 1.f / sdy;
-    const int ci = ci0 + cit * 16 + fj;
-    if (ci < Cin) {
+    // Partial sums of this workgroup, in FRAGMENT order (wave, tap, r, lane): every store instruction writes 64 consecutive
+    // floats.  (Atomic adds straight into dW serialise: 1024 workgroups x 25 600 adds on the same 2e5 addresses took as long
+    // as the products.)  conv_wgrad_reduce_kernel sums over the pixel splits and un-permutes.
+    float* part = partial + ((size_t)blockIdx.y * splits + blockIdx.x) * WG_PART + (size_t)w * 25 * 4 * 64 + lane;
 #pragma unroll
-        for (int t = 0; t < 25; ++t)
+    for (int t = 0; t < 25; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + cot * 16 + 4 * fg + r;
-                if (co < Cout) atomicAdd(dw + ((size_t)co * Cin + ci) * 25 + t, acc[t][r] * inv);
-            }
-    }
+        for (int r = 0; r < 4; ++r) part[(t * 4 + r) * 64] = acc[t][r];
+}
+
+// dw[co][ci][t] = (1 / scale) sum_s partial[block(co, ci)][s][fragment index of (co, ci, t)]
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int Cin,
+                                                                int Cout, int splits, const float* __restrict__ scale_dy) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;  // position inside one workgroup's partial block
+    if (idx >= WG_PART) return;
+    const int lane = idx & 63, r = (idx >> 6) & 3, t = (idx >> 8) % 25, w = idx / (25 * 4 * 64);
+    const int fj = lane & 15, fg = lane >> 4, cot = w & 1, cit = w >> 1;
+    const int nci = (Cin + 31) / 32;
+    const int co = (blockIdx.y / nci) * 32 + cot * 16 + 4 * fg + r, ci = (blockIdx.y % nci) * 32 + cit * 16 + fj;
+    if (co >= Cout || ci >= Cin) return;
+    const float* p = partial + (size_t)blockIdx.y * splits * WG_PART + idx;
+    float a = 0.f;
+    for (int sp = 0; sp < splits; ++sp) a += p[(size_t)sp * WG_PART];
+    dw[((size_t)co * Cin + ci) * 25 + t] = a / (scale_dy ? *scale_dy : 1.f);
 }
 
 }  // namespace
 
+static long long wgrad_splits(int N, int Cin, int Cout, int H, int W, int dilation) {
+    const int blocks = dtk_cdiv(Cout, 32) * dtk_cdiv(Cin, 32);
+    const long long tiles = (long long)N * dtk_cdiv(W, WG_TW) * dtk_cdiv(H, WG_R);
+    // measured (scripts/wgrad_bench.py, 8 frames): two resident workgroups per CU are best at dilation 1 (512: 1.14 / 1.12 ms for
+    // layers 2 / 3, 1024: 1.25 / 1.22); the dilated layer's kernel holds one workgroup per CU and wants shorter ones (2048: 1.44 ms,
+    // 512: 1.79)
+    long long splits = dtk_cdiv(dilation == 1 ? 512 : 2048, blocks);
+#ifdef DTK_DEV
+    if (const char* e = getenv("DTK_WGRAD_WORKGROUPS")) splits = dtk_cdiv(atoi(e) > 0 ? atoi(e) : 1024, blocks);
+#endif
+    if (splits > tiles) splits = tiles;
+    if (splits < 1) splits = 1;
+    return splits;
+}
+
+extern "C" size_t dtk_conv_wgrad_split_workspace_bytes(int N, int Cin, int Cout, int H, int W, int dilation) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)dtk_cdiv(Cout, 32) * dtk_cdiv(Cin, 32) * wgrad_splits(N, Cin, Cout, H, W, dilation) * WG_PART * sizeof(float);
+}
+
 extern "C" int dtk_conv_wgrad_split(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W,
-                                    int dilation, int reflect_pad, const float* scale_dy, void* stream) {
-    DTK_REQUIRE(x && dy && dw, "dtk_conv_wgrad_split: null pointer");
+                                    int dilation, int reflect_pad, const float* scale_dy, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    DTK_REQUIRE(x && dy && dw && workspace, "dtk_conv_wgrad_split: null pointer");
     DTK_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 4 * dilation && W > 4 * dilation, "dtk_conv_wgrad_split: bad shape");
     DTK_REQUIRE(dilation == 1 || dilation == 2, "dtk_conv_wgrad_split: dilation %d (1 or 2)", dilation);
+    if (workspace_bytes < dtk_conv_wgrad_split_workspace_bytes(N, Cin, Cout, H, W, dilation)) {
+        dtk_set_error("dtk_conv_wgrad_split: workspace %zu B < required %zu B", workspace_bytes,
+                      dtk_conv_wgrad_split_workspace_bytes(N, Cin, Cout, H, W, dilation));
+        return DTK_E_WORKSPACE;
+    }
     static const bool lds_ok = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel<1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgradCfg<1>::LDS_BYTES) == hipSuccess &&
@@ -1007,17 +1093,17 @@ extern "C" int dtk_conv_wgrad_split(const float* x, const float* dy, float* dw, 
     DTK_REQUIRE(lds_ok, "dtk_conv_wgrad_split: cannot reserve LDS");
     const int tiles_x = dtk_cdiv(W, WG_TW), tiles_y = dtk_cdiv(H, WG_R);
     const int blocks = dtk_cdiv(Cout, 32) * dtk_cdiv(Cin, 32);
-    const long long tiles = (long long)N * tiles_x * tiles_y;
-    long long splits = dtk_cdiv(1024, blocks);  // ~4 workgroups per CU over all weight blocks
-    if (splits > tiles) splits = tiles;
-    if (splits < 1) splits = 1;
+    const long long splits = wgrad_splits(N, Cin, Cout, H, W, dilation);
+    float* partial = static_cast<float*>(workspace);
     dim3 grid((unsigned)splits, blocks);
     if (dilation == 1) {
         DTK_LAUNCH("train_conv_wgrad", conv_wgrad_split_kernel<1>, grid, dim3(256), WgradCfg<1>::LDS_BYTES, dtk_stream(stream), x, dy,
-                   dw, N, Cin, Cout, H, W, reflect_pad, scale_dy, tiles_x, tiles_y, (int)splits);
+                   partial, N, Cin, Cout, H, W, reflect_pad, scale_dy, tiles_x, tiles_y, (int)splits);
     } else {
         DTK_LAUNCH("train_conv_wgrad_d2", conv_wgrad_split_kernel<2>, grid, dim3(256), WgradCfg<2>::LDS_BYTES, dtk_stream(stream), x,
-                   dy, dw, N, Cin, Cout, H, W, reflect_pad, scale_dy, tiles_x, tiles_y, (int)splits);
+                   dy, partial, N, Cin, Cout, H, W, reflect_pad, scale_dy, tiles_x, tiles_y, (int)splits);
     }
+    DTK_LAUNCH("train_conv_wgrad_reduce", conv_wgrad_reduce_kernel, dim3(dtk_cdiv(WG_PART, 256), blocks), dim3(256), 0,
+               dtk_stream(stream), partial, dw, Cin, Cout, (int)splits, scale_dy);
     return DTK_OK;
 }

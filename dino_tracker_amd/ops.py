@@ -397,8 +397,10 @@ def conv_split_output(y_nhwc: torch.Tensor, out: torch.Tensor, border: int = 0, 
 
 def conv_wgrad_split(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, dilation: int, reflect: bool,
                      scale_dy: Optional[torch.Tensor] = None) -> None:
-    """dtk_conv_wgrad_split: dw [Cout, Cin, 5, 5] (zeroed by the caller) += the weight gradient of the 5 x 5 'same' convolution."""
+    """dtk_conv_wgrad_split: dw [Cout, Cin, 5, 5] = the weight gradient of the 5 x 5 'same' convolution (overwritten)."""
     n, cin, h, w = x.shape
     cout = dy.shape[1]
+    nb = int(lib().dtk_conv_wgrad_split_workspace_bytes(n, cin, cout, h, w, dilation))
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
     check(lib().dtk_conv_wgrad_split(_p(x, torch.float32), _p(dy, torch.float32), _p(dw, torch.float32), n, cin, cout, h, w, dilation,
-                                     int(reflect), _p(scale_dy, torch.float32), _stream()))
+                                     int(reflect), _p(scale_dy, torch.float32), _p(ws), nb, _stream()))

@@ -219,7 +219,7 @@ class _ConvMfma(torch.autograd.Function):
         s_dy = _pow2_scale(dy)
         dw = dx = None
         if ctx.needs_input_grad[1] and ctx.implicit:
-            dw = torch.zeros(weight.shape, dtype=torch.float32, device=dev)
+            dw = torch.empty(weight.shape, dtype=torch.float32, device=dev)
             ops.conv_wgrad_split(x, dy, dw, dilation, padding_mode == "reflect", s_dy)
         elif ctx.needs_input_grad[1]:
             lp = (L + 31) // 32 * 32

@@ -209,11 +209,13 @@ int dtk_conv_split_run(const void* in_hi, const void* in_lo, const void* Wh, con
 int dtk_conv_split_output(const float* y_nhwc, int N, int C, int H, int W, int border, int reflect_fold, const float* scale,
                           float* out_nchw, void* stream);
 
-/* Weight gradient of the same convolution without an unfolded operand: dw [Cout][Cin][5][5] (ZEROED by the caller; atomic adds)
- * += sum over frames and pixels of dy [N][Cout][H][W] (times *scale_dy, a power of two, undone on output) and the padded
- * x [N][Cin][H][W]; both operands fp32 NCHW as autograd holds them, split into fp16 halves while staged (fp32-grade). */
+/* Weight gradient of the same convolution without an unfolded operand: dw [Cout][Cin][5][5] (overwritten) = sum over frames and
+ * pixels of dy [N][Cout][H][W] (times *scale_dy, a power of two, undone on output) and the padded x [N][Cin][H][W]; both operands
+ * fp32 NCHW as autograd holds them, split into fp16 halves while staged (fp32-grade).  workspace: the per-workgroup partial sums
+ * (dtk_conv_wgrad_split_workspace_bytes), reduced by a second kernel -- no atomics, deterministic. */
+size_t dtk_conv_wgrad_split_workspace_bytes(int N, int Cin, int Cout, int H, int W, int dilation);
 int dtk_conv_wgrad_split(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W, int dilation,
-                         int reflect_pad, const float* scale_dy, void* stream);
+                         int reflect_pad, const float* scale_dy, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of the cosine maps (models/tracker.py:158-173 under autograd) behind dtk_head_backward: maps[b] = relu'd cosine map
  * of emb[b] against frame tgt[b] (dtk_corr_maps with relu = 1), dmaps[b] its gradient (non-zero only on the 15 x 15 window around
