@@ -1107,3 +1107,90 @@ extern "C" int dtk_conv_wgrad_split(const float* x, const float* dy, float* dw, 
                dtk_stream(stream), partial, dw, Cin, Cout, (int)splits, scale_dy);
     return DTK_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The two embedding regularisers of the training loss (dino_tracker.py:128-139) in one pass each way:
+//     norm term  = mean over frames and cells of | |x| / |raw| - 1 |,     angle term = mean of | <x, raw> / (|x| |raw|) - 1 |
+// with x, raw [F][C][n] (NCHW: a cell's channels are n floats apart, adjacent cells adjacent -- one thread per cell reads
+// coalesced).  Forward leaves the per-cell sums (|x|^2, |raw|^2, <x, raw>) for the backward, which is closed form per element:
+//     dx = gn sgn(|x|/|raw| - 1) x / (|x| |raw|)  +  ga sgn(cos - 1) (raw / (|x| |raw|) - <x, raw> x / (|x|^3 |raw|)).
+// The traced form is ~25 element-wise / reduce kernels over 100 MB tensors.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void emb_reg_forward_kernel(const float* __restrict__ x, const float* __restrict__ raw,
+                                                              float* __restrict__ cell_sums, float* __restrict__ out, int C,
+                                                              long long n, long long cells) {
+    __shared__ float red[2][4];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float tn = 0.f, ta = 0.f;
+    if (i < cells) {
+        const long long f = i / n, c0 = i - f * n;
+        const float* xp = x + f * C * n + c0;
+        const float* rp = raw + f * C * n + c0;
+        float r = 0.f, d = 0.f, dot = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float a = xp[(long long)c * n], b = rp[(long long)c * n];
+            r = fmaf(a, a, r);
+            d = fmaf(b, b, d);
+            dot = fmaf(a, b, dot);
+        }
+        cell_sums[i] = r;
+        cell_sums[cells + i] = d;
+        cell_sums[2 * cells + i] = dot;
+        const float nr = sqrtf(r), nd = sqrtf(d);
+        tn = fabsf(nr / nd - 1.f);
+        ta = fabsf(dot / (nr * nd) - 1.f);
+    }
+    tn = wave_sum(tn);
+    ta = wave_sum(ta);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = tn; red[1][w] = ta; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float inv = 1.f / (float)cells;
+        atomicAdd(out, (red[0][0] + red[0][1] + red[0][2] + red[0][3]) * inv);
+        atomicAdd(out + 1, (red[1][0] + red[1][1] + red[1][2] + red[1][3]) * inv);
+    }
+}
+
+__global__ __launch_bounds__(256) void emb_reg_backward_kernel(const float* __restrict__ x, const float* __restrict__ raw,
+                                                               const float* __restrict__ cell_sums, const float* __restrict__ gout,
+                                                               float* __restrict__ dx, int C, long long n, long long cells) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= cells) return;
+    const long long f = i / n, c0 = i - f * n;
+    const float r = cell_sums[i], d = cell_sums[cells + i], dot = cell_sums[2 * cells + i];
+    const float nr = sqrtf(r), nd = sqrtf(d);
+    const float inv = 1.f / (float)cells;
+    auto sgn = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
+    const float gn = gout[0] * inv * sgn(nr / nd - 1.f), ga = gout[1] * inv * sgn(dot / (nr * nd) - 1.f);
+    const float kx = gn / (nr * nd) - ga * dot / (nr * nr * nr * nd);   // coefficient of x
+    const float kr = ga / (nr * nd);                                    // coefficient of raw
+    const float* xp = x + f * C * n + c0;
+    const float* rp = raw + f * C * n + c0;
+    float* dp = dx + f * C * n + c0;
+    for (int c = 0; c < C; ++c) dp[(long long)c * n] = fmaf(kx, xp[(long long)c * n], kr * rp[(long long)c * n]);
+}
+
+}  // namespace
+
+extern "C" int dtk_emb_reg_forward(const float* x, const float* raw, int F, int C, int n, float* cell_sums, float* out2,
+                                   void* stream) {
+    DTK_REQUIRE(x && raw && cell_sums && out2 && F > 0 && C > 0 && n > 0, "dtk_emb_reg_forward: bad arguments");
+    const long long cells = (long long)F * n;
+    hipStream_t st = dtk_stream(stream);
+    DTK_HIP(hipMemsetAsync(out2, 0, 2 * sizeof(float), st));
+    DTK_LAUNCH("train_emb_reg", emb_reg_forward_kernel, dim3(dtk_cdiv(cells, 256)), dim3(256), 0, st, x, raw, cell_sums, out2, C,
+               (long long)n, cells);
+    return DTK_OK;
+}
+
+extern "C" int dtk_emb_reg_backward(const float* x, const float* raw, const float* cell_sums, const float* grad_out2, int F, int C,
+                                    int n, float* dx, void* stream) {
+    DTK_REQUIRE(x && raw && cell_sums && grad_out2 && dx && F > 0 && C > 0 && n > 0, "dtk_emb_reg_backward: bad arguments");
+    const long long cells = (long long)F * n;
+    DTK_LAUNCH("train_emb_reg_bwd", emb_reg_backward_kernel, dim3(dtk_cdiv(cells, 256)), dim3(256), 0, dtk_stream(stream), x, raw,
+               cell_sums, grad_out2, dx, C, (long long)n, cells);
+    return DTK_OK;
+}

@@ -404,3 +404,20 @@ def conv_wgrad_split(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, dilati
     ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
     check(lib().dtk_conv_wgrad_split(_p(x, torch.float32), _p(dy, torch.float32), _p(dw, torch.float32), n, cin, cout, h, w, dilation,
                                      int(reflect), _p(scale_dy, torch.float32), _p(ws), nb, _stream()))
+
+
+def emb_reg_forward(x: torch.Tensor, raw: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """dtk_emb_reg_forward: x, raw [F, C, h, w] -> (out [2], per-cell sums [3, F * h * w])."""
+    f, c, h, w = x.shape
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    sums = torch.empty(3, f * h * w, dtype=torch.float32, device=x.device)
+    check(lib().dtk_emb_reg_forward(_p(x, torch.float32), _p(raw, torch.float32), f, c, h * w, _p(sums), _p(out), _stream()))
+    return out, sums
+
+
+def emb_reg_backward(x: torch.Tensor, raw: torch.Tensor, sums: torch.Tensor, gout: torch.Tensor) -> torch.Tensor:
+    f, c, h, w = x.shape
+    dx = torch.empty_like(x)
+    check(lib().dtk_emb_reg_backward(_p(x, torch.float32), _p(raw, torch.float32), _p(sums, torch.float32), _p(gout, torch.float32),
+                                     f, c, h * w, _p(dx), _stream()))
+    return dx

@@ -54,8 +54,29 @@ def frame_cells(frame_embeddings: torch.Tensor, sel: torch.Tensor) -> torch.Tens
     return frame_embeddings.flatten(2).index_select(0, sel).transpose(1, 2)
 
 
+class _EmbReg(torch.autograd.Function):
+    """Both regularisers in one kernel each way (csrc/train.hip: dtk_emb_reg_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, refined, raw):
+        from . import ops
+        refined, raw = refined.contiguous(), raw.detach().contiguous()
+        out, sums = ops.emb_reg_forward(refined, raw)
+        ctx.save_for_backward(refined, raw, sums)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import ops
+        refined, raw, sums = ctx.saved_tensors
+        return ops.emb_reg_backward(refined, raw, sums, gout.contiguous()), None
+
+
 def emb_regularization_terms(refined: torch.Tensor, raw: torch.Tensor):
     """dino_tracker.py:128-139: (mean | |refined| / |raw| - 1 |, mean | cos(refined, raw) - 1 |) over frames and cells."""
+    if refined.is_cuda and refined.dtype == torch.float32:
+        out = _EmbReg.apply(refined, raw)
+        return out[0], out[1]
     nr, nd = refined.norm(dim=1), raw.norm(dim=1)
     cos = (refined * raw).sum(dim=1) / (nr * nd)
     return (nr / nd - 1).abs().mean(), (cos - 1).abs().mean()

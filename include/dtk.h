@@ -217,6 +217,13 @@ size_t dtk_conv_wgrad_split_workspace_bytes(int N, int Cin, int Cout, int H, int
 int dtk_conv_wgrad_split(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W, int dilation,
                          int reflect_pad, const float* scale_dy, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The embedding regularisers of the training loss (dino_tracker.py:128-139): out2 = (mean | |x| / |raw| - 1 |, mean | cos(x, raw) - 1 |)
+ * over the F * n cells of x, raw [F][C][n]; cell_sums [3][F * n] keeps the per-cell sums for dtk_emb_reg_backward, which writes
+ * dx [F][C][n] for the upstream gradients grad_out2 (device, two floats). */
+int dtk_emb_reg_forward(const float* x, const float* raw, int F, int C, int n, float* cell_sums, float* out2, void* stream);
+int dtk_emb_reg_backward(const float* x, const float* raw, const float* cell_sums, const float* grad_out2, int F, int C, int n,
+                         float* dx, void* stream);
+
 /* Backward of the cosine maps (models/tracker.py:158-173 under autograd) behind dtk_head_backward: maps[b] = relu'd cosine map
  * of emb[b] against frame tgt[b] (dtk_corr_maps with relu = 1), dmaps[b] its gradient (non-zero only on the 15 x 15 window around
  * the arg-max cell stats[b][0], as dtk_head_backward leaves it).  demb[b][C] is written; dfeat[T][ph*pw][C] (token-major, ZEROED

@@ -5,7 +5,7 @@ R=$PWD
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 export DTK_REFERENCE_ROOT=$PWD/.ref_scratch/reference
-timeout 900 python -m pytest tests/test_gpu_train.py -m gpu -q -rA -s -k "conv_mfma or fused or trainer_terms or training_step or blurpool" > gpurun_out/pytest_r3p.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_train.py -m gpu -q -rA -s -k "conv_mfma or fused or trainer or training_step or blurpool or regularisers" > gpurun_out/pytest_r3p.log 2>&1
 grep -E "passed|failed|rel err" gpurun_out/pytest_r3p.log | tail -14 | cut -c1-300
 grep -E "^(FAILED|ERROR)|^E  +" gpurun_out/pytest_r3p.log | head -30 | cut -c1-300
 D=/tmp/dtk_train_data_384

@@ -186,6 +186,31 @@ def test_trainer_terms_on_device_match_host():
         assert rel_v < 2e-5 and rel_g < 5e-5, (name, rel_v, rel_g)
 
 
+def test_embedding_regularisers_kernel_matches_float64():
+    """trainer.emb_regularization_terms on the device (dtk_emb_reg_forward / _backward: both terms and their gradient in one pass
+    each way) vs the traced statement in float64 on the host, incl. cells where the refined embedding is shorter / longer than the
+    raw one and on either side of cos = 1 (the sign branches of the two absolute values)."""
+    from dino_tracker_amd import trainer as T
+    g = torch.Generator().manual_seed(3)
+    F_, C, h, w = 3, 48, 13, 17
+    raw = torch.randn(F_, C, h, w, generator=g) + 0.5
+    x = raw * (0.7 + 0.6 * torch.rand(F_, 1, h, w, generator=g)) + 0.2 * torch.randn(F_, C, h, w, generator=g)
+    x[0, :, 0, 0] = 2.0 * raw[0, :, 0, 0]                      # cos = 1 exactly up to rounding: sign(0)-ish branch
+    gout = torch.tensor([0.7, -1.3])
+    xd = x.cuda().requires_grad_(True)
+    n_d, a_d = T.emb_regularization_terms(xd, raw.cuda())
+    (gout[0] * n_d + gout[1] * a_d).backward()
+    x64 = x.double().requires_grad_(True)
+    n_h, a_h = T.emb_regularization_terms(x64, raw.double())
+    (gout[0] * n_h + gout[1] * a_h).backward()
+    assert abs(float(n_d) - float(n_h)) < 1e-6 * abs(float(n_h)) + 1e-9 and abs(float(a_d) - float(a_h)) < 2e-5 * abs(float(a_h)) + 1e-9
+    mask = torch.ones(F_, 1, h, w, dtype=torch.bool)
+    mask[0, 0, 0, 0] = False                                   # the constructed cos = 1 cell: the sign there is rounding
+    err = ((xd.grad.double().cpu() - x64.grad) * mask).abs().max() / x64.grad.abs().max()
+    print(f"norm {float(n_d):.6g} / {float(n_h):.6g}, angle {float(a_d):.6g} / {float(a_h):.6g}, gradient rel err {float(err):.1e}")
+    assert float(err) < 2e-5
+
+
 def test_training_step_on_device_matches_host():
     """Without the reference: one training step of Tracker.forward (train mode) on the device -- Delta-DINO with
     batch-statistics BatchNorm, sampling, correlation, head -- against the same arithmetic on the host (train_ops on CPU
