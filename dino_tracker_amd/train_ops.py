@@ -143,7 +143,7 @@ W_SCALE = 256.0  # weights carry 2^8 into the fp16 split (their lo halves stay n
 def _pow2_scale(t: torch.Tensor) -> torch.Tensor:
     """Device scalar 2^e with max |t| * 2^e in [2^9, 2^10]: the operand scale of a gradient tensor for the fp16 split (its
     entries down to 2^-24 of the largest keep normal halves).  No host synchronisation."""
-    amax = t.abs().amax().clamp_min(1e-30)
+    amax = torch.linalg.vector_norm(t, ord=float("inf")).clamp_min(1e-30)  # one reduction pass, no |t| temporary
     return torch.exp2(torch.floor(10.0 - torch.log2(amax))).reshape(1)
 
 
