@@ -78,6 +78,7 @@ def _workspace(name: str, numel: int, like: torch.Tensor) -> torch.Tensor:
 def release_scratch() -> None:
     """Drop the persistent scratch (Tracker.eval() calls this: inference needs none of it)."""
     _WORKSPACE.clear()
+    _PACKED.clear()
 
 
 class _ConvGemm(torch.autograd.Function):
