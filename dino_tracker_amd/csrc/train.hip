@@ -895,7 +895,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const float* _
     const int fj = lane & 15, fg = lane >> 4;
     const int cot = w & 1, cit = w >> 1;
     const int nci = (Cin + 31) / 32;
-    const int co0 = (blockIdx.y / nci) * 32, ci0 = (blockIdx.y % nci) * 32;
+    // XCD-aware 1-D grid: workgroup ids go round-robin over the 8 XCDs; within one XCD consecutive workgroups take the weight
+    // blocks of ONE pixel split, so the X / dY tiles they all read come from HBM once and from that XCD's L2 afterwards
+    // (plain (split, block) grid: 2.9 GB fetched per launch, 8x the operands)
+    const int nblocks = nci * ((Cout + 31) / 32);
+    const long long lin = blockIdx.x, jj = lin >> 3;
+    const int wblock = (int)(jj % nblocks);
+    const int split = (int)((jj / nblocks) * 8 + (lin & 7));
+    if (split >= splits) return;
+    const int co0 = (wblock / nci) * 32, ci0 = (wblock % nci) * 32;
     const float sdy = scale_dy ? *scale_dy : 1.f;
     f4 acc[25];
 #pragma unroll
@@ -993,8 +1001,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const float* _
             *reinterpret_cast<h8*>(Yl + o) = lo;
         }
     };
-    if ((long long)blockIdx.x < tiles) load_tile(blockIdx.x);
-    for (long long tile = blockIdx.x; tile < tiles; tile += splits) {
+    if ((long long)split < tiles) load_tile(split);
+    for (long long tile = split; tile < tiles; tile += splits) {
         __syncthreads();  // the previous tile's fragment reads are done
         store_tile();
         __syncthreads();
@@ -1028,7 +1036,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const float* _
     // Partial sums of this workgroup, in FRAGMENT order (wave, tap, r, lane): every store instruction writes 64 consecutive
     // floats.  (Atomic adds straight into dW serialise: 1024 workgroups x 25 600 adds on the same 2e5 addresses took as long
     // as the products.)  conv_wgrad_reduce_kernel sums over the pixel splits and un-permutes.
-    float* part = partial + ((size_t)blockIdx.y * splits + blockIdx.x) * WG_PART + (size_t)w * 25 * 4 * 64 + lane;
+    float* part = partial + ((size_t)wblock * splits + split) * WG_PART + (size_t)w * 25 * 4 * 64 + lane;
 #pragma unroll
     for (int t = 0; t < 25; ++t)
 #pragma unroll
@@ -1095,7 +1103,7 @@ extern "C" int dtk_conv_wgrad_split(const float* x, const float* dy, float* dw, 
     const int blocks = dtk_cdiv(Cout, 32) * dtk_cdiv(Cin, 32);
     const long long splits = wgrad_splits(N, Cin, Cout, H, W, dilation);
     float* partial = static_cast<float*>(workspace);
-    dim3 grid((unsigned)splits, blocks);
+    dim3 grid((unsigned)(((splits + 7) / 8) * 8 * blocks));
     if (dilation == 1) {
         DTK_LAUNCH("train_conv_wgrad", conv_wgrad_split_kernel<1>, grid, dim3(256), WgradCfg<1>::LDS_BYTES, dtk_stream(stream), x, dy,
                    partial, N, Cin, Cout, H, W, reflect_pad, scale_dy, tiles_x, tiles_y, (int)splits);

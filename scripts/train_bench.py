@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--rng-shim", action="store_true", help="keep train_driver's host-side random draws (parity runs; slow)")
     ap.add_argument("--trainer", choices=["device", "reference"], default="device",
                     help="hip side: dino_tracker_amd/trainer.py's iteration (default) or the reference's own loop on this implementation's models")
+    ap.add_argument("--keep-losses", default="", help="copy the per-iteration loss log (JSON) here")
     ap.add_argument("--data-dir", default="", help="reuse / create the synthetic inputs here (shared between the two sides)")
     a = ap.parse_args()
     ref = os.environ.get("DTK_REFERENCE_ROOT", "/root/reference")
@@ -85,6 +86,9 @@ def main():
         raise SystemExit(r.returncode)
     with open(log) as fh:
         rec = json.load(fh)
+    if a.keep_losses:
+        with open(a.keep_losses, "w") as fh:
+            json.dump(rec, fh)
     st = rec["seconds"]
     per = [b - a_ for a_, b in zip(st[:-1], st[1:])]
     steady = per[1:] if len(per) > 2 else per
