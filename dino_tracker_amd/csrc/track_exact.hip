@@ -621,8 +621,8 @@ __global__ __launch_bounds__(256) void head_backward_kernel(dtk_geom g, const fl
 // the map gradient of a source is non-zero only on the 15 x 15 window around its arg-max (head_backward_kernel), so
 //     rho = <s, f> / max(|s| |f|, 1e-8),   relu'(rho) d_rho  ->  ds += g (f / den - rho s / |s|^2),  df = g (s / den - rho f / |f|^2)
 // (ds += g f / 1e-8, df = g s / 1e-8 where the clamp is active) is evaluated for those <= 225 cells only -- autograd's form is
-// two dense products over every cell of every frame of the batch with a gradient that is 99.7 % zeros.  One wave per source;
-// df goes to the token-major gradient volume with atomic adds (several sources share cells).
+// two dense products over every cell of every frame of the batch with a gradient that is 99.7 % zeros.  One workgroup per
+// source; df goes to the token-major gradient volume with atomic adds (several sources share cells).
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 
@@ -631,10 +631,12 @@ __global__ __launch_bounds__(256) void corr_window_backward_kernel(dtk_geom g, c
                                                                    const int32_t* __restrict__ tgt, const float* __restrict__ maps,
                                                                    const float* __restrict__ dmaps, const float* __restrict__ stats,
                                                                    float* __restrict__ demb, float* __restrict__ dfeat, int B) {
+    // one workgroup per source: its four waves take the window's rows round-robin (a single wave walking all 225 cells is a
+    // chain of dependent global loads: 0.41 ms per call), their partial ds are summed through LDS
     constexpr int MAXJ = 16;  // C <= 1024
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
+    __shared__ float s_ds[4][MAXJ * WAVE];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.x;
     const int C = g.C, pw = g.pw, ph = g.ph, HW = ph * pw;
     const int nj = (C + WAVE - 1) / WAVE;
     const int f = min(max(tgt[b], 0), g.T - 1);
@@ -658,7 +660,7 @@ __global__ __launch_bounds__(256) void corr_window_backward_kernel(dtk_geom g, c
     const float* dm = dmaps + (size_t)b * HW;
     const int r0 = max(kr - (HB_RD + 2), 0), r1 = min(kr + (HB_RD + 2), ph - 1);
     const int c0 = max(kc - (HB_RD + 2), 0), c1 = min(kc + (HB_RD + 2), pw - 1);
-    for (int r = r0; r <= r1; ++r)
+    for (int r = r0 + w; r <= r1; r += 4)
         for (int c = c0; c <= c1; ++c) {
             const int cell = r * pw + c;
             const float gk = dm[cell], rho = mp[cell];
@@ -682,10 +684,9 @@ __global__ __launch_bounds__(256) void corr_window_backward_kernel(dtk_geom g, c
             }
         }
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-        const int c = j * WAVE + lane;
-        if (j < nj && c < C) demb[(size_t)b * C + c] = ds[j];
-    }
+    for (int j = 0; j < MAXJ; ++j) s_ds[w][j * WAVE + lane] = ds[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) demb[(size_t)b * C + c] = (s_ds[0][c] + s_ds[1][c]) + (s_ds[2][c] + s_ds[3][c]);
 }
 
 }  // namespace
@@ -698,7 +699,7 @@ extern "C" int dtk_corr_window_backward(const dtk_geom* g, const float* feat, co
     DTK_REQUIRE(g->C > 0 && g->C <= 1024, "dtk_corr_window_backward: C=%d outside 1..1024", g->C);
     DTK_REQUIRE(g->radius / (float)g->stride <= (float)HB_RD, "dtk_corr_window_backward: radius / stride > %d", HB_RD);
     if (B == 0) return DTK_OK;
-    DTK_LAUNCH("train_corr_bwd", corr_window_backward_kernel, dim3(dtk_cdiv(B, 4)), dim3(256), 0, dtk_stream(stream), *g, feat,
+    DTK_LAUNCH("train_corr_bwd", corr_window_backward_kernel, dim3(B), dim3(256), 0, dtk_stream(stream), *g, feat,
                norms, emb, tgt, maps, dmaps, stats, demb, dfeat, B);
     return DTK_OK;
 }
