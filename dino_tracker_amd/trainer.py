@@ -253,21 +253,25 @@ def make_trainer(base):
             col, ok = pick_subsets([fg, inside & ~fg], [n_fg, n_bg])
             return s_sel, t_sel, pos.gather(1, col), ok
 
-        def dino_bb_terms(self, model, s_sel, t_sel, picks, ok):
-            """Deterministic part of dino_tracker.py:159-240 for explicit selections: s_sel / t_sel [P] index the batch's
-            frame set, picks [P, B] index the flat best-buddy table, ok [P, B] switches slots off."""
+        def dino_bb_operands(self, model, s_sel, t_sel, picks, ok):
+            """Embeddings of the selected DINO best buddies in their source / target frames (one bilinear-sampling call for
+            both: one gradient edge into the frame embeddings) and their weights (dino_tracker.py:220-231) -> a, b [P, B, C], w."""
             tb = self._bb_table
             fe = model.frame_embeddings
             P, B = picks.shape
             col = lambda sel: sel[:, None].expand(P, B).to(torch.float32)[:, :, None]
-            src_pts = torch.cat([tb.src[picks], col(s_sel)], dim=2).reshape(P * B, 3)
-            tgt_pts = torch.cat([tb.tgt[picks], col(t_sel)], dim=2).reshape(P * B, 3)
-            a = model.sample_embeddings(fe, model.normalize_points_for_sampling(src_pts)).reshape(P, B, -1)
-            b = model.sample_embeddings(fe, model.normalize_points_for_sampling(tgt_pts)).reshape(P, B, -1)
-            l_st, l_ts = contrastive_terms(a, b, frame_cells(fe, s_sel), frame_cells(fe, t_sel), self.config["cl_temp"])
+            pts = torch.cat([torch.cat([tb.src[picks], col(s_sel)], dim=2), torch.cat([tb.tgt[picks], col(t_sel)], dim=2)])
+            emb = model.sample_embeddings(fe, model.normalize_points_for_sampling(pts.reshape(2 * P * B, 3))).reshape(2, P, B, -1)
             w_amb = torch.sigmoid(self.config["bb_amb_sig_a"] * (1 - tb.r[picks]) + self.config["bb_amb_sig_b"])
             w_cos = torch.clamp(2 * tb.cos[picks] ** 3, 0)
-            w = w_amb * w_cos * ok.to(w_amb.dtype)
+            return emb[0], emb[1], w_amb * w_cos * ok.to(w_amb.dtype)
+
+        def dino_bb_terms(self, model, s_sel, t_sel, picks, ok):
+            """Deterministic part of dino_tracker.py:159-240 for explicit selections: s_sel / t_sel [P] index the batch's
+            frame set, picks [P, B] index the flat best-buddy table, ok [P, B] switches slots off."""
+            fe = model.frame_embeddings
+            a, b, w = self.dino_bb_operands(model, s_sel, t_sel, picks, ok)
+            l_st, l_ts = contrastive_terms(a, b, frame_cells(fe, s_sel), frame_cells(fe, t_sel), self.config["cl_temp"])
             div = self.config["cl_div_dino_bb"]
             return ((l_st * w / div).sum() + (l_ts * w / div).sum()) / 2
 
@@ -303,6 +307,45 @@ def make_trainer(base):
                 w = torch.clamp(2 * aff ** 3, 0) * ok.to(aff.dtype)
             return ((l_st * w).sum() + (l_ts * w).sum()) / (2 * self.config["cl_div_ref_bb"])
 
+        def contrastive_losses(self, model, bb_sel, ref_sel):
+            """Both contrastive losses in ONE evaluation: the cl_n_frames pairs of the DINO best-buddy loss and those of the
+            refined best-buddy loss are the same arithmetic (dino_tracker.py:327-343) with different operands and weights, so
+            they run as one batch of 2 cl_n_frames pairs -- half the launches, and the frame embeddings receive one gathered
+            gradient (plus the sampling's) instead of four full-size ones.  Returns (cl_dino_bb, cl_refiner); equal to
+            dino_bb_terms / refined_bb_terms up to summation order."""
+            fe = model.frame_embeddings
+            s1, t1, picks, ok1 = bb_sel
+            s2, t2, src_cells, tgt_cells, ok2 = ref_sel
+            P = s1.shape[0]
+            cells = frame_cells(fe, torch.cat([s1, s2, t1, t2]))          # [4 P, n, C]: one gather of the frames' cells
+            sf, tf = cells[:2 * P], cells[2 * P:]
+            C = sf.shape[2]
+            a1, b1, w1 = self.dino_bb_operands(model, s1, t1, picks, ok1)
+            a2 = sf[P:].gather(1, src_cells[:, :, None].expand(-1, -1, C))
+            b2 = tf[P:].gather(1, tgt_cells[:, :, None].expand(-1, -1, C))
+            # the two selections may differ in width (a pair has fewer DINO best buddies than cl_points_per_pair): the narrower
+            # one is padded with copies of its first slot at weight 0
+            B = max(a1.shape[1], a2.shape[1])
+
+            def pad(x, value_from_first=True):
+                extra = B - x.shape[1]
+                if extra == 0:
+                    return x
+                fill = x[:, :1].expand(-1, extra, *x.shape[2:]) if value_from_first else x.new_zeros(x.shape[0], extra, *x.shape[2:])
+                return torch.cat([x, fill], dim=1)
+
+            a1, b1, a2, b2 = pad(a1), pad(b1), pad(a2), pad(b2)
+            w1 = pad(w1, value_from_first=False)
+            ok2 = pad(ok2, value_from_first=False)
+            l_st, l_ts = contrastive_terms(torch.cat([a1, a2]), torch.cat([b1, b2]), sf, tf, self.config["cl_temp"])
+            with torch.no_grad():
+                aff = (a2 * b2).sum(dim=2) / torch.clamp(a2.norm(dim=2) * b2.norm(dim=2), min=EPS)
+                w2 = torch.clamp(2 * aff ** 3, 0) * ok2.to(aff.dtype)
+            div = self.config["cl_div_dino_bb"]
+            cl_bb = ((l_st[:P] * w1 / div).sum() + (l_ts[:P] * w1 / div).sum()) / 2
+            cl_ref = ((l_st[P:] * w2).sum() + (l_ts[P:] * w2).sum()) / (2 * self.config["cl_div_ref_bb"])
+            return cl_bb, cl_ref
+
         def cycle_terms(self, model, frames_set_t):
             """dino_tracker.py:345-352 over the static-shape cycle batch (Tracker.get_cycle_consistency_terms)."""
             c = model.get_cycle_consistency_terms(frames_set_t, self.fg_masks)
@@ -324,9 +367,11 @@ def make_trainer(base):
                 cyc = self.cycle_terms(model, frames_set_t)
                 loss = loss + cfg["lambda_cyc"] * cyc
             if i >= cfg.get("apply_cl_ref_after", 0):
-                cl_ref = self.refined_bb_terms(model, *self.refined_bb_selection(model, frames_set_t))
+                cl_bb, cl_ref = self.contrastive_losses(model, self.dino_bb_selection(frames_set_t),
+                                                        self.refined_bb_selection(model, frames_set_t))
                 loss = loss + cfg["lambda_cl_ref_bb"] * cl_ref
-            cl_bb = self.dino_bb_terms(model, *self.dino_bb_selection(frames_set_t))
+            else:
+                cl_bb = self.dino_bb_terms(model, *self.dino_bb_selection(frames_set_t))
             norm_reg, angle_reg = emb_regularization_terms(model.frame_embeddings, model.raw_embeddings)
             loss = loss + cfg["lambda_cl_dino_bb"] * cl_bb + cfg["lambda_emb_norm"] * norm_reg + cfg["lambda_angle"] * angle_reg
             return loss, torch.stack([loss.detach(), tracking.detach(), cl_bb.detach(), cl_ref.detach(), norm_reg.detach(),

@@ -205,6 +205,34 @@ def test_random_selections_are_members_and_feed_the_terms(world):
         assert torch.isfinite(wd.ours.refined_bb_terms(wd.m_ours, *sel))
 
 
+def test_joint_contrastive_evaluation_equals_the_separate_terms(world):
+    """trainer.contrastive_losses (both losses as one batch of pairs) against dino_bb_terms + refined_bb_terms on the same
+    selections: values and the gradient with respect to the frame embeddings."""
+    wd = world
+    torch.manual_seed(11)
+    bb_sel = wd.ours.dino_bb_selection(wd.frames_set_t)
+    ref_sel = wd.ours.refined_bb_selection(wd.m_ours, wd.frames_set_t)
+    fe = wd.m_ours.frame_embeddings
+    sep_bb, sep_ref = wd.ours.dino_bb_terms(wd.m_ours, *bb_sel), wd.ours.refined_bb_terms(wd.m_ours, *ref_sel)
+    (sep_bb + 3 * sep_ref).backward()
+    g_sep, fe.grad = fe.grad.clone(), None
+    j_bb, j_ref = wd.ours.contrastive_losses(wd.m_ours, bb_sel, ref_sel)
+    (j_bb + 3 * j_ref).backward()
+    _close(j_bb, sep_bb, 1e-6)
+    _close(j_ref, sep_ref, 1e-6)
+    assert (fe.grad - g_sep).abs().max() <= 1e-5 * g_sep.abs().max()
+    # selections of different widths (fewer best buddies per pair than cl_points_per_pair)
+    narrow = (bb_sel[0], bb_sel[1], bb_sel[2][:, :17], bb_sel[3][:, :17])
+    sep_n = wd.ours.dino_bb_terms(wd.m_ours, *narrow)
+    j_n, j_ref2 = wd.ours.contrastive_losses(wd.m_ours, narrow, ref_sel)
+    _close(j_n, sep_n, 1e-6)
+    _close(j_ref2, sep_ref, 1e-6)
+    wide_ref = tuple(x[:, :9] if x.dim() == 2 else x for x in ref_sel)
+    j_bb3, j_ref3 = wd.ours.contrastive_losses(wd.m_ours, bb_sel, wide_ref)
+    _close(j_bb3, sep_bb, 1e-6)
+    _close(j_ref3, wd.ours.refined_bb_terms(wd.m_ours, *wide_ref), 1e-6)
+
+
 def test_regularisation_tracking_and_cycle_terms_match_reference(world):
     wd = world
     want_n = wd.theirs.get_emb_norm_regularization_loss(wd.m_theirs)
