@@ -346,6 +346,9 @@ class Tracker(nn.Module):
             frame_embeddings, residual_embeddings, raw_embeddings = self.get_refined_embeddings(
                 frames_set_t, return_raw_embeddings=True)
             self.residual_embeddings = residual_embeddings
+        if torch.is_grad_enabled() and frame_embeddings.requires_grad:
+            from . import train_ops
+            frame_embeddings = train_ops.attach_grad_sink(frame_embeddings)  # one gradient buffer for the point / window reads
         self.frame_embeddings = frame_embeddings
         self.raw_embeddings = raw_embeddings
         return self.get_point_predictions(inp, frame_embeddings)

@@ -443,6 +443,56 @@ def delta_dino_residual(delta_dino, frames: torch.Tensor, h: int, w: int, vit_pa
 
 
 # ---- sampling -------------------------------------------------------------------------------------------------------------
+# ---- one gradient buffer for the point / window consumers of the frame embeddings ---------------------------------------
+class _SinkBuffer:
+    """Token-major [F h w, C] gradient buffer shared by the consumers whose gradient touches a few cells per source."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, n, h, w, c, like):
+        if self.buf is None:
+            self.buf = torch.zeros(n * h * w, c, dtype=like.dtype, device=like.device)
+        return self.buf
+
+
+class _GradSink(torch.autograd.Function):
+    """Identity on the batch's frame embeddings.  The bilinear point reads and the fused tracker passes of an iteration each
+    have a gradient that touches a few hundred cells per source, but autograd would have every one of them return a
+    zero-filled full-size tensor (266 MB at C = 1024) and add them pairwise: seven fills and additions per iteration.  Those
+    consumers instead ACCUMULATE into the buffer attached to this node's output (`_dtk_sink`) and return no gradient for it;
+    this node runs after all of them (they are its dependents in the graph) and adds the buffer to the dense gradients that
+    arrived the ordinary way."""
+
+    @staticmethod
+    def forward(ctx, emb, sink):
+        ctx.sink = sink
+        ctx.shape = emb.shape
+        ctx.set_materialize_grads(False)   # no dense gradient arrived: `g` is None, not a zero-filled tensor
+        return emb.view_as(emb)
+
+    @staticmethod
+    def backward(ctx, g):
+        buf, ctx.sink.buf = ctx.sink.buf, None
+        if buf is None:
+            return g, None
+        n, c, h, w = ctx.shape
+        if buf.is_cuda:
+            from . import ops
+            d = ops.unpack_features(buf.view(n, h * w, c), h, w)
+        else:
+            d = buf.view(n, h, w, c).permute(0, 3, 1, 2)
+        return (d if g is None else g + d), None
+
+
+def attach_grad_sink(emb: torch.Tensor) -> torch.Tensor:
+    """`emb` [n, C, h, w] (requires grad) -> the same values as a tensor whose point / window consumers share one gradient buffer."""
+    sink = _SinkBuffer()
+    out = _GradSink.apply(emb, sink)
+    out._dtk_sink = sink
+    return out
+
+
 def _bilinear_corners(emb_shape, pts: torch.Tensor):
     """Frame index, the four corner cells (y, x) and their weights of Tracker.sample_embeddings' bilinear read."""
     n, c, h, w = emb_shape
@@ -481,6 +531,7 @@ class _SampleBilinear(torch.autograd.Function):
         t, corners, weights = _bilinear_corners(emb.shape, pts)
         ctx.save_for_backward(t, *[i for yx in corners for i in yx], *weights)
         ctx.shape = emb.shape
+        ctx.sink = getattr(emb, "_dtk_sink", None)
         return _bilinear_read(emb, t, corners, weights)
 
     @staticmethod
@@ -488,9 +539,11 @@ class _SampleBilinear(torch.autograd.Function):
         sv = ctx.saved_tensors
         t, yx, weights = sv[0], sv[1:9], sv[9:]
         n, c, h, w = ctx.shape
-        d = torch.zeros(n * h * w, c, dtype=g.dtype, device=g.device)
+        d = ctx.sink.get(n, h, w, c, g) if ctx.sink is not None else torch.zeros(n * h * w, c, dtype=g.dtype, device=g.device)
         for i in range(4):
             d.index_add_(0, (t * h + yx[2 * i]) * w + yx[2 * i + 1], g * weights[i])
+        if ctx.sink is not None:
+            return None, None    # left in the shared buffer (_GradSink adds it)
         return d.view(n, h, w, c).permute(0, 3, 1, 2), None
 
 
@@ -687,6 +740,7 @@ class _TrackFused(torch.autograd.Function):
         inv[order] = torch.arange(order.shape[0], device=order.device)
         ctx.save_for_backward(emb, tgt_s, maps, stats, packed, feat, norms, order, inv)
         ctx.geom, ctx.frames_shape = geom, frames.shape
+        ctx.sink = getattr(frames, "_dtk_sink", None)
         return out_s.index_select(0, inv)
 
     @staticmethod
@@ -695,9 +749,12 @@ class _TrackFused(torch.autograd.Function):
         emb, tgt_s, maps, stats, packed, feat, norms, order, inv = ctx.saved_tensors
         g = ctx.geom
         dmaps, dpacked = ops.head_backward(g, packed, maps, stats, gout.index_select(0, order).contiguous(), normalized=True)
+        n, c, h, w = ctx.frames_shape
+        if ctx.sink is not None:   # accumulate into the iteration's shared buffer (same token-major layout as `feat`)
+            demb = ops.corr_window_backward(g, feat, norms, emb, tgt_s, maps, dmaps, stats, ctx.sink.get(n, h, w, c, feat))
+            return demb.index_select(0, inv), None, None, dpacked, None
         dfeat = torch.zeros_like(feat)
         demb = ops.corr_window_backward(g, feat, norms, emb, tgt_s, maps, dmaps, stats, dfeat)
-        n, c, h, w = ctx.frames_shape
         return demb.index_select(0, inv), ops.unpack_features(dfeat, h, w), None, dpacked, None
 
 

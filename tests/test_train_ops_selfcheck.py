@@ -88,3 +88,24 @@ def test_head_forward_equals_convs_softmax_softargmax_and_gradcheck():
     # the last bias shifts every logit alike: exactly zero gradient
     (g_b2,) = torch.autograd.grad(train_ops.head_forward(head, cost).sum(), [c2.bias])
     assert g_b2.abs().max() < 1e-12
+
+
+def test_gradient_sink_equals_ordinary_accumulation():
+    """train_ops.attach_grad_sink: consumers that accumulate into the shared buffer (here two bilinear point reads) plus a dense
+    consumer give the gradient autograd's ordinary accumulation gives; also with sparse consumers only, and twice in a row (the
+    buffer is handed over and reset by the sink node)."""
+    torch.manual_seed(0)
+    emb = torch.randn(3, 5, 6, 7, dtype=torch.double, requires_grad=True)
+    pts = torch.rand(11, 3, dtype=torch.double) * 2 - 1
+    pts[:, 2] = torch.randint(0, 3, (11,)).double()
+    w = torch.randn(11, 5, dtype=torch.double)
+    plain = lambda e: (train_ops.sample_bilinear(e, pts) * w).sum() + (train_ops.sample_bilinear(e, pts.flip(0)) * w).sum()
+    (want,) = torch.autograd.grad(plain(emb) + (emb ** 2).sum(), emb)
+    (want_sparse,) = torch.autograd.grad(plain(emb), emb)
+    for _ in range(2):
+        es = train_ops.attach_grad_sink(emb)
+        (got,) = torch.autograd.grad(plain(es) + (es ** 2).sum(), emb)
+        assert (got - want).abs().max() < 1e-12
+        es = train_ops.attach_grad_sink(emb)
+        (got,) = torch.autograd.grad(plain(es), emb)
+        assert (got - want_sparse).abs().max() < 1e-12
