@@ -50,7 +50,14 @@ def contrastive_terms(a: torch.Tensor, b: torch.Tensor, fa: torch.Tensor, fb: to
 
 
 def frame_cells(frame_embeddings: torch.Tensor, sel: torch.Tensor) -> torch.Tensor:
-    """[F, C, h, w], sel [P] -> [P, n, C]: rearrange(frame_embeddings[sel_p], 'c h w -> (h w) c') for every p."""
+    """[F, C, h, w], sel [P] -> [P, n, C]: rearrange(frame_embeddings[sel_p], 'c h w -> (h w) c') for every p.
+    On the device the selection is a product with the one-hot matrix of `sel` (exact: every output is one input times 1 plus
+    zeros): its backward is the transposed product, where index_select's is a scatter kernel that serialises over the few
+    distinct frames (1.7 ms per iteration at C = 1024)."""
+    f, c = frame_embeddings.shape[:2]
+    if frame_embeddings.is_cuda:
+        onehot = torch.nn.functional.one_hot(sel, f).to(frame_embeddings.dtype)
+        return (onehot @ frame_embeddings.flatten(1)).view(sel.shape[0], c, -1).transpose(1, 2)
     return frame_embeddings.flatten(2).index_select(0, sel).transpose(1, 2)
 
 
