@@ -135,7 +135,7 @@ class LongRangeSampler(torch.nn.Module):
         """The same distribution as get_point_correspondences_for_num_frames for a GIVEN frame set, without leaving the
         device: one uniform key per trajectory, the `batch_size` largest keys among the rows that are tracked in two of
         the frames (= a uniformly random subset without replacement, what `rows[randperm(len)[:k]]` is), then two distinct
-        tracked frames per row (multinomial over the row's validity, as in the reference).  Fewer eligible rows than
+        tracked frames per row (uniformly among the row's tracked frames, as the reference's multinomial over the row's validity).  Fewer eligible rows than
         `batch_size` give rows flagged invalid (weight 0 in the losses) instead of a shorter batch -- shapes stay static.
         Returns (t1 [B, 3], t2 [B, 3], local1 [B], local2 [B] (positions in `frame_indices`), ok [B])."""
         dev = valid_trajectories.device
@@ -145,8 +145,12 @@ class LongRangeSampler(torch.nn.Module):
         k = min(batch_size, can_f.shape[0])
         top = torch.topk(keys, k)
         rows, ok = top.indices, top.values >= 0
-        allowed = torch.where(ok[:, None], can_f[rows], torch.ones((), dtype=torch.bool, device=dev)).float()
-        l1, l2 = allowed.multinomial(2, replacement=False).unbind(dim=1)
+        # two distinct tracked frames per row, uniformly (what multinomial(2, replacement=False) over the 0 / 1 validity row
+        # draws) -- as the two largest of one uniform key per tracked frame: torch.multinomial validates its input with two host
+        # reads per call
+        allowed = torch.where(ok[:, None], can_f[rows], torch.ones((), dtype=torch.bool, device=dev))
+        fkeys = torch.where(allowed, torch.rand(allowed.shape, device=dev), torch.full((), -1.0, device=dev))
+        l1, l2 = torch.topk(fkeys, 2, dim=1).indices.unbind(dim=1)
         t1f, t2f = frame_indices[l1], frame_indices[l2]
         pick = lambda tt: torch.cat([torch.nan_to_num(valid_trajectories[rows, tt]), tt[:, None].to(valid_trajectories.dtype)], dim=-1)
         return pick(t1f), pick(t2f), l1, l2, ok

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--rng-shim", action="store_true", help="keep train_driver's host-side random draws (parity runs; slow)")
     ap.add_argument("--trainer", choices=["device", "reference"], default="device",
                     help="hip side: dino_tracker_amd/trainer.py's iteration (default) or the reference's own loop on this implementation's models")
+    ap.add_argument("--keep-stderr", default="", help="write the training process's stderr here")
     ap.add_argument("--keep-losses", default="", help="copy the per-iteration loss log (JSON) here")
     ap.add_argument("--data-dir", default="", help="reuse / create the synthetic inputs here (shared between the two sides)")
     a = ap.parse_args()
@@ -81,6 +82,9 @@ def main():
     t0 = time.time()
     r = subprocess.run(cmd, env=env, cwd=ref, capture_output=True, text=True)
     wall = time.time() - t0
+    if a.keep_stderr:
+        with open(a.keep_stderr, "w") as fh:
+            fh.write(r.stderr)
     if r.returncode != 0:
         sys.stderr.write(r.stderr[-4000:])
         raise SystemExit(r.returncode)

@@ -79,6 +79,10 @@ if __name__ == "__main__":
     PROF = {}
 
     def update_losses(self, *vals):
+        if os.environ.get("DTK_TRAIN_SYNC_DEBUG") and torch.cuda.is_available() and len(LOSSES) == 3:
+            import warnings
+            warnings.simplefilter("always")
+            torch.cuda.set_sync_debug_mode("warn")  # every synchronising call of the following iterations, with its location
         if ASYNC and isinstance(vals[0], torch.Tensor) and vals[0].is_cuda:
             # timing runs of the device-side trainer: its loss values stay device scalars (no read per iteration); the clock is
             # read behind a device synchronisation after iteration 2 and after the last one only
