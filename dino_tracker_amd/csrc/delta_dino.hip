@@ -141,7 +141,8 @@ struct SplitCfg {
     static_assert(PX <= PXP, "patch wider than the padded LDS row");
 };
 
-template <int DIL, bool OUT_SPLIT>
+// (SINGLE: the hi halves only -- plain fp16 operands, one product per term instead of three: the "fp16" training mode.)
+template <int DIL, bool OUT_SPLIT, bool SINGLE = false>
 __global__ __launch_bounds__(256, 3) void conv5x5_split_kernel(const half_t* __restrict__ in_hi, const half_t* __restrict__ in_lo,
                                                             const half_t* __restrict__ Wh, const half_t* __restrict__ Wl,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
@@ -246,8 +247,10 @@ __global__ __launch_bounds__(256, 3) void conv5x5_split_kernel(const half_t* __r
                     const h8 wl = *reinterpret_cast<const h8*>(Wsl + wr);
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[m], wh, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[m], wl, acc[m][n], 0, 0, 0);
+                        if (!SINGLE) {
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[m], wh, acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[m], wl, acc[m][n], 0, 0, 0);
+                        }
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[m], wh, acc[m][n], 0, 0, 0);
                     }
                 }
@@ -920,16 +923,22 @@ extern "C" int dtk_conv_split_input(const float* x, int N, int C, int H, int W, 
 }
 
 extern "C" int dtk_conv_split_run(const void* in_hi, const void* in_lo, const void* Wh, const void* Wl, float* out_nhwc, int N,
-                                  int H, int W, int Cin, int Cout, int dilation, int zero_pad, void* stream) {
+                                  int H, int W, int Cin, int Cout, int dilation, int zero_pad, int fp16_only, void* stream) {
     DTK_REQUIRE(in_hi && in_lo && Wh && Wl && out_nhwc, "dtk_conv_split_run: null pointer");
     DTK_REQUIRE(N > 0 && N <= 65535 && H > 4 * dilation && W > 4 * dilation, "dtk_conv_split_run: bad shape");
     DTK_REQUIRE(Cin % SK == 0 && Cout > 0, "dtk_conv_split_run: Cin=%d must be a multiple of %d", Cin, SK);
     DTK_REQUIRE(dilation == 1 || dilation == 2, "dtk_conv_split_run: dilation %d (1 or 2)", dilation);
     static const bool lds_ok = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5x5_split_kernel<1, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitCfg<1>::LDS_BYTES) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5x5_split_kernel<2, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitCfg<2>::LDS_BYTES) == hipSuccess;
+        bool ok = true;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5x5_split_kernel<1, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitCfg<1>::LDS_BYTES) == hipSuccess;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5x5_split_kernel<2, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitCfg<2>::LDS_BYTES) == hipSuccess;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5x5_split_kernel<1, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitCfg<1>::LDS_BYTES) == hipSuccess;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5x5_split_kernel<2, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitCfg<2>::LDS_BYTES) == hipSuccess;
+        return ok;
     }();
     DTK_REQUIRE(lds_ok, "dtk_conv_split_run: cannot reserve LDS for the split-fp16 convolution");
     const int tiles_x = dtk_cdiv(W, STX), tiles_y = dtk_cdiv(H, STY);
@@ -941,15 +950,15 @@ extern "C" int dtk_conv_split_run(const void* in_hi, const void* in_lo, const vo
     const half_t* il = reinterpret_cast<const half_t*>(in_lo);
     const half_t* wh = reinterpret_cast<const half_t*>(Wh);
     const half_t* wl = reinterpret_cast<const half_t*>(Wl);
-    if (dilation == 1) {
-        DTK_LAUNCH("train_conv", (conv5x5_split_kernel<1, false>), grid, dim3(256), SplitCfg<1>::LDS_BYTES, dtk_stream(stream), ih,
-                   il, wh, wl, (const float*)nullptr, (const float*)nullptr, (half_t*)nullptr, (half_t*)nullptr, out_nhwc, H, W,
-                   Cin, Cout, 0, tiles_x, zero_pad, xcd_tiles);
-    } else {
-        DTK_LAUNCH("train_conv_d2", (conv5x5_split_kernel<2, false>), grid, dim3(256), SplitCfg<2>::LDS_BYTES, dtk_stream(stream),
-                   ih, il, wh, wl, (const float*)nullptr, (const float*)nullptr, (half_t*)nullptr, (half_t*)nullptr, out_nhwc, H,
-                   W, Cin, Cout, 0, tiles_x, zero_pad, xcd_tiles);
-    }
+#define DTK_CONV_RUN(NAME, DILV, SINGLEV)                                                                                      \
+    DTK_LAUNCH(NAME, (conv5x5_split_kernel<DILV, false, SINGLEV>), grid, dim3(256), SplitCfg<DILV>::LDS_BYTES, dtk_stream(stream), \
+               ih, il, wh, wl, (const float*)nullptr, (const float*)nullptr, (half_t*)nullptr, (half_t*)nullptr, out_nhwc, H, W, \
+               Cin, Cout, 0, tiles_x, zero_pad, xcd_tiles)
+    if (dilation == 1 && !fp16_only) { DTK_CONV_RUN("train_conv", 1, false); }
+    else if (dilation == 1) { DTK_CONV_RUN("train_conv_h", 1, true); }
+    else if (!fp16_only) { DTK_CONV_RUN("train_conv_d2", 2, false); }
+    else { DTK_CONV_RUN("train_conv_d2_h", 2, true); }
+#undef DTK_CONV_RUN
     return DTK_OK;
 }
 

@@ -880,7 +880,7 @@ __device__ __forceinline__ h8 shift_window(const u4v a, const u4v b) {
     return __builtin_bit_cast(h8, r);
 }
 
-template <int DIL>
+template <int DIL, bool SINGLE>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                    float* __restrict__ partial, int N, int Cin, int Cout, int H,
                                                                    int W, int reflect_pad, const float* __restrict__ scale_dy,
@@ -1022,10 +1022,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(const float* _
                 const u4v l0 = *reinterpret_cast<const u4v*>(xbase_l + ro), l1 = *reinterpret_cast<const u4v*>(xbase_l + ro + 8);
 #define WG_TAP(KX)                                                                                              \
     {                                                                                                           \
-        const h8 bh = shift_window<(KX) * DIL>(h0, h1), bl = shift_window<(KX) * DIL>(l0, l1);                  \
+        const h8 bh = shift_window<(KX) * DIL>(h0, h1);                                                         \
         f4& a_ = acc[ky * 5 + (KX)];                                                                            \
-        a_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, a_, 0, 0, 0);                                       \
-        a_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, a_, 0, 0, 0);                                       \
+        if (!SINGLE) {                                                                                          \
+            const h8 bl = shift_window<(KX) * DIL>(l0, l1);                                                     \
+            a_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, a_, 0, 0, 0);                                   \
+            a_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, a_, 0, 0, 0);                                   \
+        }                                                                                                       \
         a_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, a_, 0, 0, 0);                                       \
     }
                 WG_TAP(0) WG_TAP(1) WG_TAP(2) WG_TAP(3) WG_TAP(4)
@@ -1082,8 +1085,8 @@ extern "C" size_t dtk_conv_wgrad_split_workspace_bytes(int N, int Cin, int Cout,
 }
 
 extern "C" int dtk_conv_wgrad_split(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W,
-                                    int dilation, int reflect_pad, const float* scale_dy, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
+                                    int dilation, int reflect_pad, const float* scale_dy, int fp16_only,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
     DTK_REQUIRE(x && dy && dw && workspace, "dtk_conv_wgrad_split: null pointer");
     DTK_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 4 * dilation && W > 4 * dilation, "dtk_conv_wgrad_split: bad shape");
     DTK_REQUIRE(dilation == 1 || dilation == 2, "dtk_conv_wgrad_split: dilation %d (1 or 2)", dilation);
@@ -1093,10 +1096,16 @@ extern "C" int dtk_conv_wgrad_split(const float* x, const float* dy, float* dw, 
         return DTK_E_WORKSPACE;
     }
     static const bool lds_ok = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel<1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgradCfg<1>::LDS_BYTES) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel<2>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgradCfg<2>::LDS_BYTES) == hipSuccess;
+        bool ok = true;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel<1, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgradCfg<1>::LDS_BYTES) == hipSuccess;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel<2, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgradCfg<2>::LDS_BYTES) == hipSuccess;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel<1, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgradCfg<1>::LDS_BYTES) == hipSuccess;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_split_kernel<2, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgradCfg<2>::LDS_BYTES) == hipSuccess;
+        return ok;
     }();
     DTK_REQUIRE(lds_ok, "dtk_conv_wgrad_split: cannot reserve LDS");
     const int tiles_x = dtk_cdiv(W, WG_TW), tiles_y = dtk_cdiv(H, WG_R);
@@ -1104,13 +1113,14 @@ extern "C" int dtk_conv_wgrad_split(const float* x, const float* dy, float* dw, 
     const long long splits = wgrad_splits(N, Cin, Cout, H, W, dilation);
     float* partial = static_cast<float*>(workspace);
     dim3 grid((unsigned)(((splits + 7) / 8) * 8 * blocks));
-    if (dilation == 1) {
-        DTK_LAUNCH("train_conv_wgrad", conv_wgrad_split_kernel<1>, grid, dim3(256), WgradCfg<1>::LDS_BYTES, dtk_stream(stream), x, dy,
-                   partial, N, Cin, Cout, H, W, reflect_pad, scale_dy, tiles_x, tiles_y, (int)splits);
-    } else {
-        DTK_LAUNCH("train_conv_wgrad_d2", conv_wgrad_split_kernel<2>, grid, dim3(256), WgradCfg<2>::LDS_BYTES, dtk_stream(stream), x,
-                   dy, partial, N, Cin, Cout, H, W, reflect_pad, scale_dy, tiles_x, tiles_y, (int)splits);
-    }
+#define DTK_WGRAD_RUN(NAME, DILV, SINGLEV)                                                                                        \
+    DTK_LAUNCH(NAME, (conv_wgrad_split_kernel<DILV, SINGLEV>), grid, dim3(256), WgradCfg<DILV>::LDS_BYTES, dtk_stream(stream), x, dy, \
+               partial, N, Cin, Cout, H, W, reflect_pad, scale_dy, tiles_x, tiles_y, (int)splits)
+    if (dilation == 1 && !fp16_only) { DTK_WGRAD_RUN("train_conv_wgrad", 1, false); }
+    else if (dilation == 1) { DTK_WGRAD_RUN("train_conv_wgrad_h", 1, true); }
+    else if (!fp16_only) { DTK_WGRAD_RUN("train_conv_wgrad_d2", 2, false); }
+    else { DTK_WGRAD_RUN("train_conv_wgrad_d2_h", 2, true); }
+#undef DTK_WGRAD_RUN
     DTK_LAUNCH("train_conv_wgrad_reduce", conv_wgrad_reduce_kernel, dim3(dtk_cdiv(WG_PART, 256), blocks), dim3(256), 0,
                dtk_stream(stream), partial, dw, Cin, Cout, (int)splits, scale_dy);
     return DTK_OK;

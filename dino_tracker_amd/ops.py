@@ -383,9 +383,9 @@ def conv_split_input(x: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor, border
 
 
 def conv_split_run(hi: torch.Tensor, lo: torch.Tensor, wh: torch.Tensor, wl: torch.Tensor, out_nhwc: torch.Tensor, n: int, h: int,
-                   w: int, cin: int, cout: int, dilation: int, zero_pad: bool) -> None:
+                   w: int, cin: int, cout: int, dilation: int, zero_pad: bool, fp16_only: bool = False) -> None:
     check(lib().dtk_conv_split_run(_p(hi), _p(lo), _p(wh), _p(wl), _p(out_nhwc, torch.float32), n, h, w, cin, cout, dilation,
-                                   int(zero_pad), _stream()))
+                                   int(zero_pad), int(fp16_only), _stream()))
 
 
 def conv_split_output(y_nhwc: torch.Tensor, out: torch.Tensor, border: int = 0, reflect_fold: bool = False,
@@ -396,14 +396,14 @@ def conv_split_output(y_nhwc: torch.Tensor, out: torch.Tensor, border: int = 0, 
 
 
 def conv_wgrad_split(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, dilation: int, reflect: bool,
-                     scale_dy: Optional[torch.Tensor] = None) -> None:
+                     scale_dy: Optional[torch.Tensor] = None, fp16_only: bool = False) -> None:
     """dtk_conv_wgrad_split: dw [Cout, Cin, 5, 5] = the weight gradient of the 5 x 5 'same' convolution (overwritten)."""
     n, cin, h, w = x.shape
     cout = dy.shape[1]
     nb = int(lib().dtk_conv_wgrad_split_workspace_bytes(n, cin, cout, h, w, dilation))
     ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
     check(lib().dtk_conv_wgrad_split(_p(x, torch.float32), _p(dy, torch.float32), _p(dw, torch.float32), n, cin, cout, h, w, dilation,
-                                     int(reflect), _p(scale_dy, torch.float32), _p(ws), nb, _stream()))
+                                     int(reflect), _p(scale_dy, torch.float32), int(fp16_only), _p(ws), nb, _stream()))
 
 
 def emb_reg_forward(x: torch.Tensor, raw: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -148,6 +148,10 @@ def _pow2_scale(t: torch.Tensor) -> torch.Tensor:
     return torch.exp2(torch.floor(10.0 - torch.log2(amax))).reshape(1)
 
 
+# "fp16": the implicit-GEMM convolutions of the training step use plain fp16 operands (the hi halves only: one matrix-core
+# product per term instead of three; 2^-11 relative operand rounding, accumulation in fp32) -- BASELINE.json's config 5 names
+# fp16.  Default "split": fp32-grade (hi + lo), what the parity tests against the reference's float32 run use.
+CONV_OPERANDS = os.environ.get("DTK_TRAIN_CONV_OPERANDS", "split")
 USE_IMPLICIT_CONVS = True  # 5 x 5 layers with Cin % 16 == 0: forward / data gradient on the implicit-GEMM kernel (no im2col)
 
 
@@ -164,7 +168,7 @@ def _implicit_conv(x, weight, dilation, zero_pad, flip_transpose, border, fold, 
     lo = planes.view(torch.float16)[n * he * we * cin:2 * n * he * we * cin]
     ops.conv_split_input(x, hi, lo, border, scale)
     y_nhwc = _workspace("conv_out_nhwc", n * he * we * cout, x)
-    ops.conv_split_run(hi, lo, wh, wl, y_nhwc, n, he, we, cin, cout, dilation, zero_pad)
+    ops.conv_split_run(hi, lo, wh, wl, y_nhwc, n, he, we, cin, cout, dilation, zero_pad, CONV_OPERANDS == "fp16")
     out = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
     ops.conv_split_output(y_nhwc, out, border, fold, scale)
     return out
@@ -221,7 +225,7 @@ class _ConvMfma(torch.autograd.Function):
         dw = dx = None
         if ctx.needs_input_grad[1] and ctx.implicit:
             dw = torch.empty(weight.shape, dtype=torch.float32, device=dev)
-            ops.conv_wgrad_split(x, dy, dw, dilation, padding_mode == "reflect", s_dy)
+            ops.conv_wgrad_split(x, dy, dw, dilation, padding_mode == "reflect", s_dy, CONV_OPERANDS == "fp16")
         elif ctx.needs_input_grad[1]:
             lp = (L + 31) // 32 * 32
             colst = _workspace("cols", n * kp * lp, x)

@@ -196,7 +196,9 @@ int dtk_head_backward(const dtk_geom* g, const float* head, const float* maps, c
  *                           gradient with respect to the forward's input.
  *   dtk_conv_split_input    x [N][C][H][W] fp32 times *scale (device scalar or NULL) -> hi / lo planes [N][H+2b][W+2b][C] with a
  *                           ring of b zero pixels.  C a multiple of 8.
- *   dtk_conv_split_run      planes [N][H][W][Cin] -> out [N][H][W][Cout] fp32.
+ *   dtk_conv_split_run      planes [N][H][W][Cin] -> out [N][H][W][Cout] fp32.  fp16_only: use the hi halves only (plain fp16
+ *                           operands, 2^-11 relative per operand, a third of the matrix-core work) -- the "fp16" training mode; the
+ *                           same switch exists on dtk_conv_wgrad_split.
  *   dtk_conv_split_output   y [N][H+2b][W+2b][C] -> [N][C][H][W] divided by *scale; reflect_fold adds the ring back onto the image
  *                           with the adjoint of the reflect padding (b = 2 * dilation: the data gradient of a reflect-padded
  *                           convolution is the zero-padded convolution of dY over the padded domain, folded). */
@@ -205,7 +207,7 @@ int dtk_conv_split_pack(const float* w, int Cin, int Cout, int flip_transpose, v
 int dtk_conv_split_input(const float* x, int N, int C, int H, int W, int border, const float* scale, void* hi, void* lo,
                          void* stream);
 int dtk_conv_split_run(const void* in_hi, const void* in_lo, const void* Wh, const void* Wl, float* out_nhwc, int N, int H, int W,
-                       int Cin, int Cout, int dilation, int zero_pad, void* stream);
+                       int Cin, int Cout, int dilation, int zero_pad, int fp16_only, void* stream);
 int dtk_conv_split_output(const float* y_nhwc, int N, int C, int H, int W, int border, int reflect_fold, const float* scale,
                           float* out_nchw, void* stream);
 
@@ -215,7 +217,8 @@ int dtk_conv_split_output(const float* y_nhwc, int N, int C, int H, int W, int b
  * (dtk_conv_wgrad_split_workspace_bytes), reduced by a second kernel -- no atomics, deterministic. */
 size_t dtk_conv_wgrad_split_workspace_bytes(int N, int Cin, int Cout, int H, int W, int dilation);
 int dtk_conv_wgrad_split(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W, int dilation,
-                         int reflect_pad, const float* scale_dy, void* workspace, size_t workspace_bytes, void* stream);
+                         int reflect_pad, const float* scale_dy, int fp16_only, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 /* The embedding regularisers of the training loss (dino_tracker.py:128-139): out2 = (mean | |x| / |raw| - 1 |, mean | cos(x, raw) - 1 |)
  * over the F * n cells of x, raw [F][C][n]; cell_sums [3][F * n] keeps the per-cell sums for dtk_emb_reg_backward, which writes

@@ -39,11 +39,12 @@ def main():
         dw = torch.zeros_like(w)
         t_f = timed(lambda: train_ops._implicit_conv(x, w, L["dil"], False, False, 0, False, None))
         t_d = timed(lambda: train_ops._implicit_conv(dy, w, L["dil"], True, True, 2 * L["dil"], True, s))
-        t_w = timed(lambda: ops.conv_wgrad_split(x, dy, dw, L["dil"], True, s))
+        t_w = timed(lambda: ops.conv_wgrad_split(x, dy, dw, L["dil"], True, s, train_ops.CONV_OPERANDS == "fp16"))
         key = f"{L['cin']}->{L['cout']} {L['h']}x{L['w']} d{L['dil']}"
         out[key] = {"gflop": flop / 1e9, "forward_ms": t_f, "dgrad_ms": t_d, "wgrad_ms": t_w,
                     "forward_tflops": flop / t_f / 1e9, "dgrad_tflops": flop / t_d / 1e9, "wgrad_tflops": flop / t_w / 1e9}
-    print(json.dumps({"wgrad_workgroups": os.environ.get("DTK_WGRAD_WORKGROUPS", "default"), "layers": out}))
+    print(json.dumps({"operands": train_ops.CONV_OPERANDS, "wgrad_workgroups": os.environ.get("DTK_WGRAD_WORKGROUPS", "default"),
+                      "layers": out}))
 
 
 if __name__ == "__main__":

@@ -186,6 +186,36 @@ def test_trainer_terms_on_device_match_host():
         assert rel_v < 2e-5 and rel_g < 5e-5, (name, rel_v, rel_g)
 
 
+def test_conv_fp16_operand_mode():
+    """DTK_TRAIN_CONV_OPERANDS=fp16 (train_ops.CONV_OPERANDS): the implicit-GEMM kernels with the hi halves only -- plain fp16
+    operands, fp32 accumulation.  Output, data gradient and weight gradient within fp16 operand rounding of a float64 convolution
+    (2^-11 per operand; measured ~3e-4 of the largest entry), and measurably different from the default split mode."""
+    from dino_tracker_amd import train_ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    n, cin, cout, h, w, dil = 2, 64, 128, 60, 107, 1
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 5, 5, generator=g) * 0.05
+    dy = torch.randn(n, cout, h, w, generator=g) * 1e-6
+    x64, w64 = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    y64 = F.conv2d(F.pad(x64, (2,) * 4, mode="reflect"), w64)
+    y64.backward(dy.double())
+    rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max())
+    errs = {}
+    for mode in ("fp16", "split"):
+        train_ops.CONV_OPERANDS = mode
+        try:
+            xd, wd = x.cuda().requires_grad_(True), wt.cuda().requires_grad_(True)
+            y = train_ops._ConvMfma.apply(xd, wd, 2, dil, "reflect")
+            y.backward(dy.cuda())
+        finally:
+            train_ops.CONV_OPERANDS = "split"
+        errs[mode] = (rel(y.detach(), y64.detach()), rel(xd.grad, x64.grad), rel(wd.grad, w64.grad))
+    print("rel err (y, dx, dw):", errs)
+    assert all(e < 3e-3 for e in errs["fp16"]) and all(e > 2e-5 for e in errs["fp16"]), errs
+    assert all(e < 3e-6 for e in errs["split"]), errs
+
+
 def test_embedding_regularisers_kernel_matches_float64():
     """trainer.emb_regularization_terms on the device (dtk_emb_reg_forward / _backward: both terms and their gradient in one pass
     each way) vs the traced statement in float64 on the host, incl. cells where the refined embedding is shorter / longer than the
