@@ -327,6 +327,11 @@ __global__ __launch_bounds__(512, QT == 1 ? 4 : 2) void attention2_kernel(const 
         // with sched_barrier): left alone, hipcc under the 128-VGPR cap issues ds_read -> s_waitcnt lgkmcnt(0) -> MFMA one
         // fragment at a time and every MFMA eats a full LDS latency (measured: -21 % when the reads are taken away).
         auto ldk = [&](int f) {  // K fragment f: d step ks = f >> 1 of key block b = f & 1 (accumulators alternate)
+            // experiment (ABL & 32 / 64, micro-benchmark only): the fragments of key block 1 (32) or of both blocks' odd d steps
+            // (64) come straight from global memory through the texture path instead of LDS -- a quarter of the fragment reads
+            // of the scores, an eighth of all: is the LDS read rate the wall?
+            if (((ABL & 32) && (f & 1)) || ((ABL & 64) && ((f >> 1) & 1)))
+                return *reinterpret_cast<const op8*>(Kb + (size_t)min(t * 64 + (f & 1) * 32 + krow, Sp - 1) * 64 + (f >> 1) * 16 + hi * 8);
             return *reinterpret_cast<const op8*>((ABL & 4) ? tb + lane * 16 : tb + (koff[f & 1] ^ ((f >> 1) << 5)));
         };
         auto ldv = [&](int g) {  // V^T fragment g: key group bj = g >> 1 (b = bj >> 1, j = bj & 1) of d-block db = g & 1

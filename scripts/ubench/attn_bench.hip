@@ -143,18 +143,32 @@ struct Run {
         if constexpr (F16) {
             timeit("v2 QT1 max", [&] { v2(att2_f16::attention2_kernel<1, 0, 0, true>, 1); });
             timeit("v2 QT1 opt (library)", [&] { v2(att2_f16::attention2_kernel<1, 0, 1, true>, 1); });
-            timeit("v3 8 waves, ring 5", [&] { v3(att2_f16::attention3_kernel<8, 5>, 8); });
-            timeit("v3 8 waves, ring 4", [&] { v3(att2_f16::attention3_kernel<8, 4>, 8); });
-            timeit("v3 4 waves, ring 4", [&] { v3(att2_f16::attention3_kernel<4, 4>, 4); });
+            timeit("v2 K block 1 from global (ABL 32)", [&] { v2(att2_f16::attention2_kernel<1, 32, 1, true>, 1); });
+            timeit("v2 K odd d steps from global (ABL 64)", [&] { v2(att2_f16::attention2_kernel<1, 64, 1, true>, 1); });
+            timeit("v2 QT1 opt (library), again", [&] { v2(att2_f16::attention2_kernel<1, 0, 1, true>, 1); });
+            // (-DATTN_NO_V3: without the v3 instantiations.  The out-of-line safe pass is ONE function per translation unit: next
+            // to attention3 (<= 256 registers) it is compiled with 178 and drags every attention2 variant here to 2 waves per
+            // SIMD, while the library's (attention2 only) has 128 registers / 4 waves -- 3.5 ms here against 3.0 ms there.)
+#ifndef ATTN_NO_V3
+            if (abl > 1) {
+                timeit("v3 8 waves, ring 5", [&] { v3(att2_f16::attention3_kernel<8, 5>, 8); });
+                timeit("v3 8 waves, ring 4", [&] { v3(att2_f16::attention3_kernel<8, 4>, 8); });
+                timeit("v3 4 waves, ring 4", [&] { v3(att2_f16::attention3_kernel<4, 4>, 4); });
+            }
+#endif
             if (abl) {
                 timeit("v2 abl: no exp", [&] { v2(att2_f16::attention2_kernel<1, 1, 1, true>, 1); });
                 timeit("v2 abl: MFMA + cvt only", [&] { v2(att2_f16::attention2_kernel<1, 1 | 2 | 4 | 8 | 16, 1, true>, 1); });
+#ifndef ATTN_NO_V3
                 timeit("v3 abl: no exp", [&] { v3(att2_f16::attention3_kernel<8, 5, 1>, 8); });
                 timeit("v3 abl: no barrier", [&] { v3(att2_f16::attention3_kernel<8, 5, 16>, 8); });
+#endif
             }
         } else {
             timeit("v2 QT1 opt (library)", [&] { v2(att2_bf16::attention2_kernel<1, 0, 1, true>, 1); });
-            timeit("v3 8 waves, ring 5", [&] { v3(att2_bf16::attention3_kernel<8, 5>, 8); });
+#ifndef ATTN_NO_V3
+            if (abl > 1) timeit("v3 8 waves, ring 5", [&] { v3(att2_bf16::attention3_kernel<8, 5>, 8); });
+#endif
         }
         CK(hipFree(q)); CK(hipFree(k)); CK(hipFree(vt)); CK(hipFree(o2));
     }
