@@ -333,12 +333,14 @@ def main():
                                     "note": "video -> HIP ViT/Delta-DINO/infer vs video -> oracle ViT/refine/infer"}
 
     if rank == 0:
+        from dino_tracker_amd import delta_dino as _dd
+        p2_mode = {0: "split-f16 conv operands (fp32-grade)", 1: "f16 conv operands"}[_dd.conv_operand_mode(None)]
         out = {
             "metric": "query-points*frames/s", "value": round(videos_per_step * N * T * args.steps / dt, 1),
             "unit": "query-points*frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if (qpar or args.videos > 0) else "weak",
-            "vs_baseline": None, "dtype": (f"mixed: {args.operands} ViT operands, split-f16 convs (fp32-grade), " + ("f32 tracker" if method == ops.TRACK_EXACT
+            "vs_baseline": None, "dtype": (f"mixed: {args.operands} ViT operands, {p2_mode} in Delta-DINO, " + ("f32 tracker" if method == ops.TRACK_EXACT
                                                                        else "f16 candidates + f32 deciders in the tracker")
                       + "; f32 accumulate"),
             "data": "synthetic",

@@ -87,6 +87,8 @@ SIGNATURES = {
     "dtk_delta_dino_workspace_bytes": (c_size_t, [ctypes.POINTER(Geom)]),
     "dtk_delta_dino_refine": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_void_p,
                                       c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "dtk_delta_dino_refine_mode": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_void_p,
+                                           c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "dtk_sample_points": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "dtk_sample_grid": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "dtk_normalized_conv2d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -690,6 +690,15 @@ extern "C" size_t dtk_delta_dino_workspace_bytes(const dtk_geom* g) {
 extern "C" int dtk_delta_dino_refine(const dtk_geom* g, const float* video, const float* dino, const float* const* packed,
                                      float* out, float* norms, int t0, int nframes, void* workspace,
                                      size_t workspace_bytes, void* stream) {
+    return dtk_delta_dino_refine_mode(g, video, dino, packed, out, norms, t0, nframes, DTK_DD_SPLIT, workspace, workspace_bytes,
+                                      stream);
+}
+
+extern "C" int dtk_delta_dino_refine_mode(const dtk_geom* g, const float* video, const float* dino,
+                                          const float* const* packed, float* out, float* norms, int t0, int nframes,
+                                          int operands, void* workspace, size_t workspace_bytes, void* stream) {
+    DTK_REQUIRE(operands == DTK_DD_SPLIT || operands == DTK_DD_FP16, "dtk_delta_dino_refine_mode: unknown operand mode");
+    const bool single = operands == DTK_DD_FP16;
     DTK_REQUIRE(g && video && dino && packed && out && workspace, "dtk_delta_dino_refine: null pointer");
     DTK_REQUIRE(g->C % 4 == 0, "dtk_delta_dino_refine: C must be a multiple of 4");
     DTK_REQUIRE(t0 >= 0 && nframes >= 0 && t0 + nframes <= g->T, "dtk_delta_dino_refine: frame range out of bounds");
@@ -708,6 +717,10 @@ extern "C" int dtk_delta_dino_refine(const dtk_geom* g, const float* video, cons
         return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5x5_split_kernel<1, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitCfg<1>::LDS_BYTES) == hipSuccess &&
                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5x5_split_kernel<2, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitCfg<2>::LDS_BYTES) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5x5_split_kernel<1, true, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitCfg<1>::LDS_BYTES) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5x5_split_kernel<2, false, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitCfg<2>::LDS_BYTES) == hipSuccess;
     }();
     DTK_REQUIRE(lds_ok, "dtk_delta_dino_refine: cannot reserve LDS for the split-fp16 convolution");
@@ -754,7 +767,14 @@ extern "C" int dtk_delta_dino_refine(const dtk_geom* g, const float* video, cons
                 half_t* oh = reinterpret_cast<half_t*>(act);
                 const int tiles_x = dtk_cdiv(W, STX), tiles_y = dtk_cdiv(H, STY);
                 dim3 grid(tiles_x * tiles_y, (cout + 63) / 64, nf);
-                if (l < 3) {
+                if (l < 3 && single) {
+                    DTK_LAUNCH("dd_conv23", (conv5x5_split_kernel<1, true, true>), grid, dim3(256), SplitCfg<1>::LDS_BYTES, st, ih,
+                               ih + in_n, Wh, Wl, scale, shift, oh, oh + out_n, (float*)nullptr, H, W, cin, cout, 1, tiles_x, 0, 0);
+                } else if (single) {
+                    DTK_LAUNCH("dd_conv4", (conv5x5_split_kernel<2, false, true>), grid, dim3(256), SplitCfg<2>::LDS_BYTES, st, ih,
+                               ih + in_n, Wh, Wl, scale, shift, (half_t*)nullptr, (half_t*)nullptr, act, H, W, cin, cout, 0,
+                               tiles_x, 0, 0);
+                } else if (l < 3) {
                     DTK_LAUNCH("dd_conv23", (conv5x5_split_kernel<1, true>), grid, dim3(256), SplitCfg<1>::LDS_BYTES, st, ih,
                                ih + in_n, Wh, Wl, scale, shift, oh, oh + out_n, (float*)nullptr, H, W, cin, cout, 1, tiles_x, 0, 0);
                 } else {

@@ -152,6 +152,14 @@ size_t dtk_delta_dino_workspace_bytes(const dtk_geom* g);
 int dtk_delta_dino_refine(const dtk_geom* g, const float* video, const float* dino, const float* const* packed,
                           float* out, float* norms, int t0, int nframes, void* workspace, size_t workspace_bytes,
                           void* stream);
+/* The same with the operand precision of the 5x5 convolutions of layers 2-4 chosen by the caller:
+ *   DTK_DD_SPLIT  every fp32 operand as hi + lo fp16 halves, three MFMA products per term (fp32-grade: 3e-5 of the reference)
+ *   DTK_DD_FP16   the hi halves only: plain fp16 operands, fp32 accumulation, one product per term */
+#define DTK_DD_SPLIT 0
+#define DTK_DD_FP16 1
+int dtk_delta_dino_refine_mode(const dtk_geom* g, const float* video, const float* dino, const float* const* packed,
+                               float* out, float* norms, int t0, int nframes, int operands, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* ---- K8: bilinear point sampling -------------------------------------------------------------------------
  * Tracker.sample_embeddings (models/tracker.py:96-111 -> utils.py:75-101) for integral frame indices:

@@ -112,11 +112,14 @@ def head_refiner(x: torch.Tensor, head: Dict[str, torch.Tensor]) -> torch.Tensor
 
 
 def tracker_head(x: torch.Tensor, head: Dict[str, torch.Tensor], video_h: int, video_w: int, patch: int = 14,
-                 stride: int = 7, radius: float = 35.0, return_aux: bool = False):
+                 stride: int = 7, radius: float = 35.0, return_aux: bool = False,
+                 force_argmax: Optional[torch.Tensor] = None):
     """TrackerHead.forward (models/networks/tracker_head.py:107-121) on the ReLU'd cost volume x [B,h,w] (>=0).
-    Returns normalised (x,y) in [-1,1] ([B,2]); with return_aux also (argmax_flat, z, fallback_mask)."""
+    Returns normalised (x,y) in [-1,1] ([B,2]); with return_aux also (argmax_flat, z, fallback_mask).
+    force_argmax [B] (test helper, not in the reference): the flat cell to take instead of the arg-max -- what the head
+    returns when a near-tie of the map is decided the other way (tie_arbiter below)."""
     b, h, w = x.shape
-    k = x.reshape(b, -1).argmax(dim=1)  # :115  (first maximum)
+    k = x.reshape(b, -1).argmax(dim=1) if force_argmax is None else force_argmax.long()  # :115  (first maximum)
     row, col = k // w, k % w
     z = head_refiner(x[:, None], head)[:, 0]
     p = torch.softmax(z.reshape(b, -1), dim=1).reshape(b, h, w)  # :100-105
@@ -166,6 +169,35 @@ def track(src: torch.Tensor, feats: torch.Tensor, tgt: torch.Tensor, head: Dict[
             o = tracker_head(F.relu(x).reshape(-1, h, w), head, video_h, video_w, patch, stride)
             out[ii] = torch.stack([(o[:, 0] + 1) / 2 * (video_w - 1), (o[:, 1] + 1) / 2 * (video_h - 1)], dim=1)
     return out
+
+
+def tie_arbiter(feats: torch.Tensor, q_xy_t: torch.Tensor, t: int, got_xy: torch.Tensor, head: Dict[str, torch.Tensor],
+                video_h: int, video_w: int, delta: float, patch: int = 14, stride: int = 7, tol_px: float = 1e-3,
+                max_cells: int = 256) -> Dict[str, float]:
+    """Test helper (not in the reference): decides whether a position `got_xy` that differs from this oracle's for the
+    query q_xy_t = (x, y, t_q) in frame t is the reference's answer for a map whose near-tie went the other way.
+    The cosine map is evaluated in FLOAT64 from the fp32 features; every cell whose float64 cosine is within `delta` of the
+    float64 maximum is admissible (the caller derives delta from a bound on what can move a cosine: fp32 rounding of the
+    dot products, C * 2^-24, plus the measured deviation of the features a device path computed), and for each admissible
+    cell the head (models/networks/tracker_head.py:68-121, fp32 as the reference runs it) is evaluated with its arg-max
+    forced there.  Returns the float64 gap of the best-matching admissible cell, its distance to got_xy, and the counts."""
+    tq = q_xy_t[2:3].long()
+    q = sample_bilinear(feats.double(), q_xy_t[None, :2].double(), tq, video_h, video_w, patch, stride)[0]
+    _, c, h, w = feats.shape
+    fr = feats[t].double().reshape(c, h * w)
+    m64 = F.relu((q @ fr) / (q.norm() * fr.norm(dim=0)).clamp(min=EPS))
+    top = m64.max()
+    cells = torch.nonzero(m64 >= top - delta)[:, 0]
+    if cells.numel() > max_cells:
+        cells = cells[torch.argsort(m64[cells], descending=True)[:max_cells]]
+    q32 = sample_bilinear(feats, q_xy_t[None, :2], tq, video_h, video_w, patch, stride)
+    x32 = F.relu(cosine_maps(q32, feats[t][None]))  # the map the reference's head sees
+    o = tracker_head(x32.expand(cells.numel(), -1, -1), head, video_h, video_w, patch, stride, force_argmax=cells)
+    xy = torch.stack([(o[:, 0] + 1) / 2 * (video_w - 1), (o[:, 1] + 1) / 2 * (video_h - 1)], dim=1)
+    d = (xy - got_xy[None]).norm(dim=1)
+    i = int(d.argmin())
+    return {"admissible_cells": int(cells.numel()), "gap64": float(top - m64[cells[i]]), "dist_px": float(d[i]),
+            "cell": int(cells[i]), "ok": bool(d[i] <= tol_px), "delta": float(delta)}
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -1,6 +1,6 @@
 // attn_bench.hip -- stand-alone timing + correctness harness for the ViT attention kernels (d_head = 64).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -I dino_tracker_amd/csrc \
-//         scripts/ubench/attn_bench.hip -o /tmp/attn_bench && /tmp/attn_bench [frames] [S] [abl]
+//         -I scripts/ubench scripts/ubench/attn_bench.hip -o /tmp/attn_bench && /tmp/attn_bench [frames] [S] [abl]
 // Shapes of the benchmark: 30 frames x 6 heads, S = 8108 tokens.  Random Q / K / V^T in the operand type (fp16 and bf16
 // are both run), Q pre-scaled like the QKV epilogue does.  Every variant is checked against a host fp64 softmax(QK^T)V on a
 // sample of (frame, head, query) rows.  v2 = attention2_kernel (rounds 2-3), v3 = attention3_kernel (pipelined across
@@ -19,6 +19,10 @@
 #define ATT2_F16 1
 #define ATT2_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
 #include "vit_attention2.h"
+#ifndef ATTN_NO_V3
+#include "attention3.h"
+#endif
+#include "vit_attention4.h"
 #undef ATT2_NS
 #undef ATT2_T
 #undef ATT2_F16
@@ -28,6 +32,10 @@
 #define ATT2_F16 0
 #define ATT2_MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
 #include "vit_attention2.h"
+#ifndef ATTN_NO_V3
+#include "attention3.h"
+#endif
+#include "vit_attention4.h"
 #undef ATT2_NS
 #undef ATT2_T
 #undef ATT2_F16
@@ -140,7 +148,18 @@ struct Run {
             hipLaunchKernelGGL(kern, dim3(g), dim3(512), 0, 0, (const T*)q, (const T*)k, (const T*)vt, o2, S, Sp, heads, D, FH, QB); };
         auto v3 = [&](auto kern, int NW) { const int QB = (S + 32 * NW - 1) / (32 * NW); const unsigned g = (unsigned)(((FH + 7) / 8) * 8 * QB);
             hipLaunchKernelGGL(kern, dim3(g), dim3(64 * NW), 0, 0, (const T*)q, (const T*)k, (const T*)vt, o2, S, Sp, heads, D, FH, QB); };
+        auto v4 = [&](auto kern) { int QB; const unsigned g = att2_f16::attention4_grid(FH, S, &QB);
+            hipLaunchKernelGGL(kern, dim3(g), dim3(256), 0, 0, (const T*)q, (const T*)k, (const T*)vt, o2, S, Sp, heads, D, FH, QB); };
         if constexpr (F16) {
+            timeit("v4 (1 wave/SIMD, 64 q/wave)", [&] { v4(att2_f16::attention4_kernel<0, false>); });
+            timeit("v4 packed row-sum adds", [&] { v4(att2_f16::attention4_kernel<0, true>); });
+            if (abl) {
+                timeit("v4 abl: no exp", [&] { v4(att2_f16::attention4_kernel<1, false>); });
+                timeit("v4 abl: no barrier", [&] { v4(att2_f16::attention4_kernel<16, false>); });
+                timeit("v4 abl: no DMA", [&] { v4(att2_f16::attention4_kernel<2, false>); });
+                timeit("v4 abl: no LDS reads", [&] { v4(att2_f16::attention4_kernel<128, false>); });
+                timeit("v4 abl: MFMA + cvt only", [&] { v4(att2_f16::attention4_kernel<1 | 2 | 8 | 16 | 128, false>); });
+            }
             timeit("v2 QT1 max", [&] { v2(att2_f16::attention2_kernel<1, 0, 0, true>, 1); });
             timeit("v2 QT1 opt (library)", [&] { v2(att2_f16::attention2_kernel<1, 0, 1, true>, 1); });
             timeit("v2 K block 1 from global (ABL 32)", [&] { v2(att2_f16::attention2_kernel<1, 32, 1, true>, 1); });
@@ -166,6 +185,7 @@ struct Run {
             }
         } else {
             timeit("v2 QT1 opt (library)", [&] { v2(att2_bf16::attention2_kernel<1, 0, 1, true>, 1); });
+            timeit("v4 (1 wave/SIMD, 64 q/wave)", [&] { v4(att2_bf16::attention4_kernel<0, false>); });
 #ifndef ATTN_NO_V3
             if (abl > 1) timeit("v3 8 waves, ring 5", [&] { v3(att2_bf16::attention3_kernel<8, 5>, 8); });
 #endif

@@ -199,16 +199,18 @@ def summarise_training(ckpt_dir, start_iter, end_iter):
     return out
 
 
-def run_reference_training():
+def run_reference_training(synthetic=False):
     """train.py of the reference (BASELINE.json config 5 at reduced size), un-modified, on CPU: three iterations from the
     seeded start checkpoint with every loss term active, through tests/golden/train_driver.py (host-side random draws,
-    per-iteration loss capture)."""
+    per-iteration loss capture).  synthetic: on train_data's generated video + masks (a data directory that can be rebuilt
+    WITHOUT the reference checkout -- the fixture of the reference-free twin, tests/golden/train_twin.py) instead of the
+    reference's horsejump frames."""
     import json
     import subprocess
     import train_data as TD
     ref = ref_harness.REFERENCE_ROOT
     tmp = tempfile.mkdtemp()
-    d, cfg = TD.build(os.path.join(tmp, "train"), ref)
+    d, cfg = TD.build(os.path.join(tmp, "train"), ref, synthetic_video=synthetic)
     log = os.path.join(tmp, "losses.json")
     env = dict(os.environ, DTK_TRAIN_LOG=log,
                PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "oracle", "shims"), ref, ROOT]))
@@ -231,6 +233,14 @@ if __name__ == "__main__":
         path = os.path.join(OUT, "ref_train.npz")
         np.savez_compressed(path, **res)
         print("ref_train", res["losses"], os.path.getsize(path) // 1024, "KiB")
+        if not names:
+            sys.exit(0)
+    if "ref_train_synth" in names:
+        names.remove("ref_train_synth")
+        res = run_reference_training(synthetic=True)
+        path = os.path.join(OUT, "ref_train_synth.npz")
+        np.savez_compressed(path, **res)
+        print("ref_train_synth", res["losses"], os.path.getsize(path) // 1024, "KiB")
         if not names:
             sys.exit(0)
     if "ref_scripts" in names or "ref_scripts_cfg3" in names:  # (not "ref_scripts_synth": handled below)

@@ -12,7 +12,9 @@ from dino_tracker_amd.tracker import Tracker
 DEV = "cuda:0"
 
 
-def make_tracker(video, dino, head, delta=None, method=ops.TRACK_EXACT, cache=True):
+def make_tracker(video, dino, head, delta=None, method=ops.TRACK_EXACT, cache=True, p2_operands="split"):
+    """p2_operands: Delta-DINO convolution operands -- "split" (fp32-grade; what the 3e-5 feature comparisons need) or "fp16"
+    (the library default) or None (whatever the default / $DTK_P2_OPERANDS says)."""
     tmp = tempfile.mkdtemp()
     path = os.path.join(tmp, "dino_embed_video.pt")
     torch.save(dino, path)
@@ -23,6 +25,8 @@ def make_tracker(video, dino, head, delta=None, method=ops.TRACK_EXACT, cache=Tr
     if delta is not None:
         trk.delta_dino.load_state_dict(delta)
         trk.delta_dino.to(DEV)
+        if p2_operands is not None:
+            trk.delta_dino.conv_operands = p2_operands
     elif cache:
         trk.refined_features = dino.to(DEV)  # zero-initialised Delta-DINO == identity (delta_dino.py:33-35)
     return trk

@@ -38,6 +38,33 @@ def test_refine_matches_reference_golden_and_tracks():
 
 
 @pytest.mark.parametrize("C,H,W", [(384, 476, 854), (32, 98, 126)])
+def test_refine_fp16_operands_vs_oracle(C, H, W):
+    """The library default since round 4: plain fp16 operands in the 5x5 convolutions of layers 2-4 (DTK_DD_FP16), fp32
+    accumulation.  Four stages of 2^-11 operand rounding: the residual is within 2e-3 of its own size of the fp32 oracle's
+    (measured 3-6e-4), and measurably different from the split mode (so the switch is live)."""
+    from gpu_util import make_tracker
+    T = 2
+    ph, pw = A.feature_grid(H, W)
+    video = synth.synth_video(T, H, W, seed=61)
+    dino = synth.synth_features(T, C, ph, pw, seed=62)
+    delta = synth.synth_delta_dino_weights(C, seed=63)
+    ref = A.refine_features(video, dino, delta)
+    res_scale = float((ref - dino).abs().max())
+    got = {}
+    for mode in ("fp16", "split", None):
+        trk = make_tracker(video, dino, synth.synth_head_weights(3), delta=delta, p2_operands=mode)
+        trk.eval()
+        trk.cache_refined_embeddings()
+        got[mode] = trk.refined_features.cpu()
+    err16, err_split = float((got["fp16"] - ref).abs().max()), float((got["split"] - ref).abs().max())
+    print(f"C={C}: residual scale {res_scale:.3g}, fp16-operand error {err16:.3g} ({err16 / res_scale:.2g} of the residual), split {err_split:.3g}")
+    assert err16 < 2e-3 * res_scale
+    assert err_split < FEAT_TOL and err16 > 2 * err_split
+    if not os.environ.get("DTK_P2_OPERANDS"):
+        assert torch.equal(got[None], got["fp16"]), "fp16 operands are the default"
+
+
+@pytest.mark.parametrize("C,H,W", [(384, 476, 854), (32, 98, 126)])
 def test_refine_vs_oracle(C, H, W):
     from gpu_util import make_tracker
     T = 2
