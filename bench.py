@@ -150,10 +150,15 @@ def main():
 
     def one_video(video):
         if "extract" in stages:
-            trk.set_video(video, ex.encode(video))        # P1: ViT-S/14 block-11 tokens, stride 7
+            # P1: ViT-S/14 block-11 tokens, stride 7.  The fp16 overflow word of the encoder is read once per video, behind
+            # the tracker's own synchronisations, instead of draining the stream between P1 and P2
+            trk.set_video(video, ex.encode(video, defer_check=True))
         if "refine" in stages or "extract" in stages:
             trk.cache_refined_embeddings()                # P2: dino + Delta-DINO(video)
-        return mi.infer(queries) if "track" in stages else (None, None)   # P3
+        res = mi.infer(queries) if "track" in stages else (None, None)   # P3
+        if "extract" in stages:
+            ex.check_overflow()
+        return res
 
     def step():
         if qpar:

@@ -8,9 +8,12 @@
 //   gemm_tiled_kernel   C = A W^T on MFMA 16x16x32 (fp32 accumulate), 128x128 tiles, LDS double-buffered, with
 //                       fused epilogues: QKV split (Q pre-scaled by log2(e)/sqrt(d), V written transposed), GELU,
 //                       LayerScale + residual add into the fp32 stream
-//   attention2_kernel   (vit_attention2.h) flash attention, d_head = 64: S^T = K Q^T and O^T = V^T P^T on MFMA 32x32x16 so
-//                       that every per-query quantity is lane-local; K / V^T tiles by LDS-DMA into XOR-swizzled images,
-//                       16 waves per CU, exp2-domain softmax with optimistic exponentials (guarded), XCD-aware grid
+//   attention4_kernel   (vit_attention4.h; round 4) flash attention, d_head = 64: S^T = K Q^T and O^T = V^T P^T on MFMA 32x32x16
+//                       so that every per-query quantity is lane-local; K / V^T tiles by LDS-DMA into XOR-swizzled images;
+//                       ONE wave per SIMD with 64 queries, its two query tiles half a key tile out of phase (the softmax of
+//                       one runs under the MFMAs of the other), fragments held in registers for both; exp2-domain softmax
+//                       with optimistic exponentials (guarded); XCD-aware grid.  attention2_kernel (vit_attention2.h: 16
+//                       waves per CU, 32 queries each; rounds 2-3) stays selectable (DTK_VIT_ATTENTION_V2) as the cross-check.
 // Residual stream fp32.  Matrix operands (LN output, Q / K / V^T / P, attention output, MLP hidden, the pending residual
 // update, the weights) are a template parameter T: _Float16 by default since round 3 -- the same MFMA rate as bf16 with
 // 8x less operand rounding (fp16 range: activations saturate at +-65504, FP16_OVFL mode, and set the model's overflow
@@ -24,6 +27,7 @@
 #define ATT2_F16 1
 #define ATT2_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
 #include "vit_attention2.h"
+#include "vit_attention4.h"
 #undef ATT2_NS
 #undef ATT2_T
 #undef ATT2_F16
@@ -33,6 +37,7 @@
 #define ATT2_F16 0
 #define ATT2_MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
 #include "vit_attention2.h"
+#include "vit_attention4.h"
 #undef ATT2_NS
 #undef ATT2_T
 #undef ATT2_F16
@@ -994,21 +999,33 @@ VitPlan vit_plan(const dtk_vit_model* m, int ph, int pw, int frames) {
 template <typename T> struct Att;
 template <> struct Att<_Float16> {
     static int launch(const _Float16* q, const _Float16* k, const _Float16* vt, _Float16* o, int S, int Sp, int heads, int D,
-                      int FH, hipStream_t st) {
+                      int FH, bool v2, hipStream_t st) {
         int QB;
-        const unsigned grid = att2c::attention2_grid(FH, S, 1, &QB);
-        DTK_LAUNCH("vit_attention", (att2_f16::attention2_kernel<1>), dim3(grid), dim3(512), 0, st, q, k, vt, o, S, Sp, heads,
-                   D, FH, QB);
+        if (v2) {
+            const unsigned grid = att2c::attention2_grid(FH, S, 1, &QB);
+            DTK_LAUNCH("vit_attention", (att2_f16::attention2_kernel<1>), dim3(grid), dim3(512), 0, st, q, k, vt, o, S, Sp,
+                       heads, D, FH, QB);
+        } else {
+            const unsigned grid = att2_f16::attention4_grid(FH, S, &QB);
+            DTK_LAUNCH("vit_attention", (att2_f16::attention4_kernel<0>), dim3(grid), dim3(256), 0, st, q, k, vt, o, S, Sp, heads,
+                       D, FH, QB);
+        }
         return DTK_OK;
     }
 };
 template <> struct Att<__bf16> {
     static int launch(const __bf16* q, const __bf16* k, const __bf16* vt, __bf16* o, int S, int Sp, int heads, int D, int FH,
-                      hipStream_t st) {
+                      bool v2, hipStream_t st) {
         int QB;
-        const unsigned grid = att2c::attention2_grid(FH, S, 1, &QB);
-        DTK_LAUNCH("vit_attention", (att2_bf16::attention2_kernel<1>), dim3(grid), dim3(512), 0, st, q, k, vt, o, S, Sp, heads,
-                   D, FH, QB);
+        if (v2) {
+            const unsigned grid = att2c::attention2_grid(FH, S, 1, &QB);
+            DTK_LAUNCH("vit_attention", (att2_bf16::attention2_kernel<1>), dim3(grid), dim3(512), 0, st, q, k, vt, o, S, Sp,
+                       heads, D, FH, QB);
+        } else {
+            const unsigned grid = att2_bf16::attention4_grid(FH, S, &QB);
+            DTK_LAUNCH("vit_attention", (att2_bf16::attention4_kernel<0>), dim3(grid), dim3(256), 0, st, q, k, vt, o, S, Sp,
+                       heads, D, FH, QB);
+        }
         return DTK_OK;
     }
 };
@@ -1039,7 +1056,11 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
     T* hid = reinterpret_cast<T*>(ws + p.hid);
     T* delta = reinterpret_cast<T*>(ws + p.delta);
     int* ovf = m->overflow;
-    const bool scan = ovf && (m->flags & DTK_VIT_CHECK_RANGE);
+    // Saturation of Q / K / V^T and of the MLP hidden (overflow bits 2 / 4): with DTK_VIT_CHECK_RANGE every frame of every
+    // block is scanned (a pass over 1.3 GB per block and 30 frames); without it the FIRST frame of the call is, every block
+    // (four small launches per block): the out-of-range activations of a trained ViT are systematic -- the same few
+    // channels / tokens in every image -- so a model that does not fit fp16 is reported on any video, at ~0.1 % of the step.
+    const bool scan_all = ovf && (m->flags & DTK_VIT_CHECK_RANGE);
     const int S = p.S, Sp = p.Sp;
     // Q/K/V^T padding rows (s >= S) must be finite zeros: they are read by the last KV tile
     {
@@ -1050,9 +1071,12 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
         const int nf = (nframes - f0) < p.FB ? (nframes - f0) : p.FB;
         const long long rows = (long long)nf * S;
         auto scan_range = [&](const T* t, long long n, int bit) -> int {
-            if (scan) DTK_LAUNCH("vit_range_scan", range_scan_kernel<T>, dim3(1024), dim3(256), 0, st, t, n / 8, ovf, bit);
+            const int blocks = (int)(dtk_cdiv(n / 8, 256) < 1024 ? dtk_cdiv(n / 8, 256) : 1024);
+            DTK_LAUNCH("vit_range_scan", range_scan_kernel<T>, dim3(blocks), dim3(256), 0, st, t, n / 8, ovf, bit);
             return DTK_OK;
         };
+        const bool scan_first = ovf && !scan_all && f0 == 0;
+        const long long frame_qkv = (long long)m->heads * Sp * 64;   // one frame's part of Q, of K and of V^T
         const bool pe_fits = (size_t)nf * video_h * video_w * 16 <= p.delta - p.hid &&
                              (size_t)D * PE_K * 4 <= p.total - p.delta;
         if (m->patch == PE_P && m->stride == PE_S && pe_fits) {
@@ -1118,8 +1142,10 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                 DTK_LAUNCH("vit_gemm_qkv", (gemm_tiled_kernel<T, EPI_QKV>), dim3(gemm_grid(3 * D, rows)), dim3(256), 0, st, xn,
                            qkv_w, rows, 3 * D, D, e);
             }
-            if (scan_range(q, (long long)(p.ao - p.q) / 2, 2)) return DTK_E_HIP;
-            if (Att<T>::launch(q, k, vt, ao, S, Sp, m->heads, D, nf * m->heads, st)) return DTK_E_HIP;
+            if (scan_all && scan_range(q, (long long)(p.ao - p.q) / 2, 2)) return DTK_E_HIP;
+            if (scan_first && (scan_range(q, frame_qkv, 2) || scan_range(k, frame_qkv, 2) || scan_range(vt, frame_qkv, 2)))
+                return DTK_E_HIP;
+            if (Att<T>::launch(q, k, vt, ao, S, Sp, m->heads, D, nf * m->heads, (m->flags & DTK_VIT_ATTENTION_V2) != 0, st)) return DTK_E_HIP;
             e = GemmEpi<T>{};
             e.bias = L.proj_b; e.delta = delta; e.gamma = L.ls1; e.no_store = dbg_ns;
             if (ws_ok) {
@@ -1148,7 +1174,8 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                 DTK_LAUNCH("vit_gemm_fc1", (gemm_tiled_kernel<T, EPI_GELU>), dim3(gemm_grid(4 * D, rows)), dim3(256), 0, st, xn,
                            fc1_w, rows, 4 * D, D, e);
             }
-            if (scan_range(hid, rows * 4 * D, 4)) return DTK_E_HIP;
+            if (scan_all && scan_range(hid, rows * 4 * D, 4)) return DTK_E_HIP;
+            if (scan_first && scan_range(hid, (long long)S * 4 * D, 4)) return DTK_E_HIP;
             e = GemmEpi<T>{};
             e.bias = L.fc2_b; e.delta = delta; e.gamma = L.ls2;
             if (ws_ok && D == WD_N) {  // (ws_ok: the fast-path GEMMs are on, dtk_vit_model.flags)
@@ -1213,12 +1240,14 @@ extern "C" int dtk_vit_attention(const void* q, const void* k, const void* vt, v
                                  int Sp, int operand_type, void* stream) {
     DTK_REQUIRE(q && k && vt && out, "dtk_vit_attention: null pointer");
     DTK_REQUIRE(frames > 0 && heads > 0 && S > 0 && Sp >= S && Sp % 64 == 0, "dtk_vit_attention: bad sizes (Sp %% 64 == 0, Sp >= S)");
+    const bool v2 = (operand_type & DTK_OPERAND_ATTENTION_V2) != 0;
+    operand_type &= ~DTK_OPERAND_ATTENTION_V2;
     DTK_REQUIRE(operand_type == DTK_OPERAND_F16 || operand_type == DTK_OPERAND_BF16, "dtk_vit_attention: operand_type");
     if (operand_type == DTK_OPERAND_BF16)
         return Att<__bf16>::launch(reinterpret_cast<const __bf16*>(q), reinterpret_cast<const __bf16*>(k),
                                    reinterpret_cast<const __bf16*>(vt), reinterpret_cast<__bf16*>(out), S, Sp, heads,
-                                   heads * 64, frames * heads, dtk_stream(stream));
+                                   heads * 64, frames * heads, v2, dtk_stream(stream));
     return Att<_Float16>::launch(reinterpret_cast<const _Float16*>(q), reinterpret_cast<const _Float16*>(k),
                                  reinterpret_cast<const _Float16*>(vt), reinterpret_cast<_Float16*>(out), S, Sp, heads,
-                                 heads * 64, frames * heads, dtk_stream(stream));
+                                 heads * 64, frames * heads, v2, dtk_stream(stream));
 }

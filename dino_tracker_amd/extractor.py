@@ -29,7 +29,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from ._lib import VIT_BF16, VIT_CHECK_RANGE, VIT_TILED_GEMMS, VitLayer, VitModel, check, lib
+from ._lib import VIT_ATTENTION_V2, VIT_BF16, VIT_CHECK_RANGE, VIT_TILED_GEMMS, VitLayer, VitModel, check, lib
 from .synth import VIT_CONFIGS, make_vit_weights
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
@@ -46,7 +46,11 @@ class VitExtractor(nn.Module):
         if operand_dtype not in ("fp16", "bf16"):
             raise ValueError(f"operand_dtype {operand_dtype!r}: 'fp16' or 'bf16'")
         self.operand_dtype = operand_dtype
-        self.check_range = check_range  # also scan Q / K / V and the MLP hidden of every block for saturation (slower)
+        # What is checked for fp16 saturation (include/dtk.h: dtk_vit_model.overflow): every residual update of every token
+        # (always); Q / K / V and the MLP hidden of the FIRST frame of each encode() call, every block (always); with
+        # check_range=True those tensors for every frame (one extra pass per block).
+        self.check_range = check_range
+        self.attention_v2 = False       # the round-2/3 attention kernel instead of the one-wave-per-SIMD one (cross-check)
         self.frame_batch = 0            # frames per pass of the encoder; 0 = the library's default
         if model_name not in VIT_CONFIGS:
             raise NotImplementedError(f"{model_name}: the HIP encoder covers dinov2_vit{{s,b,l}}14 (d_head 64)")
@@ -121,9 +125,13 @@ class VitExtractor(nn.Module):
 
     # ---- forward ------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def encode(self, frames: torch.Tensor, layer: Optional[int] = None, normalize: bool = True, want: str = "feat"):
+    def encode(self, frames: torch.Tensor, layer: Optional[int] = None, normalize: bool = True, want: str = "feat",
+               defer_check: bool = False):
         """frames [n,3,H,W] fp32 -> `feat`: token-major [n, ph*pw, D] (CLS dropped) or `tokens`: [n, 1+ph*pw, D].
-        normalize=True applies the ImageNet mean/std inside the patch-embedding kernel (utils.py:46,55)."""
+        normalize=True applies the ImageNet mean/std inside the patch-embedding kernel (utils.py:46,55).
+        A saturated fp16 activation (see __init__) raises RuntimeError -- here, behind one stream synchronisation, or, with
+        defer_check=True, in the caller's next `check_overflow()`: the call then returns with the kernels still in flight (what
+        it hands to them stays alive in this object) and the overflow word keeps accumulating until it is read."""
         frames = frames.to(self.device, torch.float32).contiguous()
         n, _, H, W = frames.shape
         layer = self.n_layers - 1 if layer is None else layer
@@ -132,12 +140,14 @@ class VitExtractor(nn.Module):
         patch = self.get_patch_size()
         ph, pw = 1 + (H - patch) // self.stride, 1 + (W - patch) // self.stride
         pos, cls_pos = self._pos_embed(ph, pw)
-        ms = torch.tensor((IMAGENET_MEAN + IMAGENET_STD) if normalize else (0.0, 0.0, 0.0, 1.0, 1.0, 1.0),
-                          dtype=torch.float32, device=self.device)
+        if not hasattr(self, "_ms"):
+            self._ms = {flag: torch.tensor((IMAGENET_MEAN + IMAGENET_STD) if flag else (0.0, 0.0, 0.0, 1.0, 1.0, 1.0),
+                                           dtype=torch.float32, device=self.device) for flag in (True, False)}
+            self._overflow = torch.zeros(1, dtype=torch.int32, device=self.device)
+        ms, overflow = self._ms[bool(normalize)], self._overflow
         D = self.cfg["dim"]
         flags = (VIT_TILED_GEMMS if self.tiled_gemms else 0) | (VIT_BF16 if self.operand_dtype == "bf16" else 0) | \
-            (VIT_CHECK_RANGE if self.check_range else 0)
-        overflow = torch.zeros(1, dtype=torch.int32, device=self.device)
+            (VIT_CHECK_RANGE if self.check_range else 0) | (VIT_ATTENTION_V2 if self.attention_v2 else 0)
         m = VitModel(D, self.cfg["heads"], layer + 1, patch, self.stride, 1e-6, flags,
                      self._sd["patch_embed.proj.weight"].data_ptr(),
                      self._sd["patch_embed.proj.bias"].data_ptr(), cls_pos.data_ptr(), pos.data_ptr(), ms.data_ptr(),
@@ -146,7 +156,7 @@ class VitExtractor(nn.Module):
         # the workspace (2.6 GB for 30 frames of 854 x 476) is kept between calls: handing it back to the caching allocator
         # and asking again costs a device allocation (~25 ms) whenever the block has been split or released in between
         ws = getattr(self, "_ws", None)
-        if ws is None or ws.numel() < ws_bytes or ws.device != torch.device(self.device):
+        if ws is None or ws.numel() < ws_bytes or ws.device != frames.device:   # (frames.device carries the resolved index)
             self._ws = ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
         S = ph * pw + 1
         if want not in ("tokens", "feat", "qkv"):
@@ -156,13 +166,26 @@ class VitExtractor(nn.Module):
         qkv = torch.empty((n, S, 3 * D), dtype=torch.float32, device=self.device) if want == "qkv" else None
         check(lib().dtk_vit_forward(m, ops._p(frames), n, H, W, ops._p(tokens), ops._p(feat), ops._p(qkv), ops._p(ws),
                                     ws_bytes, ops._stream()))
-        torch.cuda.current_stream().synchronize()  # `ms`, `ws` must outlive the launches
-        self.last_overflow = int(overflow.item())
+        # (`ms`, `ws`, the position encoding and the overflow word are members: they outlive the launches)
+        if not defer_check:
+            self.check_overflow()
+        return {"tokens": tokens, "feat": feat, "qkv": qkv}[want]
+
+    def check_overflow(self):
+        """Reads (one stream synchronisation) and clears the overflow word of the encode() calls since the last check."""
+        if not hasattr(self, "_overflow"):
+            return
+        self.last_overflow = int(self._overflow.item())
         if self.last_overflow:
+            self._overflow.zero_()
             what = [n for b, n in ((1, "a residual update"), (2, "Q / K / V"), (4, "the MLP hidden")) if self.last_overflow & b]
             raise RuntimeError(f"dtk_vit_forward: {' and '.join(what)} left the fp16 range (saturated at 65504); "
                                "construct the extractor with operand_dtype='bf16'")
-        return {"tokens": tokens, "feat": feat, "qkv": qkv}[want]
+
+    def release_workspace(self):
+        """Frees the encoder's activation workspace (2.6 GB for 30 frames of 854 x 476): preprocessing is done."""
+        torch.cuda.current_stream().synchronize()
+        self._ws = None
 
     def get_feature_from_input(self, input_img, layers: List[int]):  # models/extractor.py:137-150
         """input_img [B,3,H,W] ALREADY ImageNet-normalised (as the reference's caller does) -> mean over `layers` of

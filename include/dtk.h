@@ -101,8 +101,10 @@ typedef struct dtk_vit_model {
     const dtk_vit_layer* layers;  /* HOST array of `depth` entries */
     int32_t frame_batch;          /* frames per pass of the encoder (workspace grows with it); 0 = the library's default (30) */
     int32_t* overflow;            /* DEVICE word or NULL; OR-ed with 1 when a residual update (projection / MLP output) reached
-                                   * the fp16 limit 65504 or is not finite, with 2 / 4 when Q, K, V / the MLP hidden did
-                                   * (the latter two only with DTK_VIT_CHECK_RANGE).  The caller zeroes it.  fp16 activations
+                                   * the fp16 limit 65504 or is not finite (every token of every frame: the LayerNorm that
+                                   * applies the update checks it), with 2 / 4 when Q, K, V / the MLP hidden did: those are
+                                   * scanned for the FIRST frame of the call in every block, and for every frame with
+                                   * DTK_VIT_CHECK_RANGE.  The caller zeroes it.  fp16 activations
                                    * SATURATE (FP16_OVFL mode) instead of becoming inf; a non-zero word means the features
                                    * are not trustworthy and the model should be run with DTK_VIT_BF16. */
 } dtk_vit_model;
@@ -110,8 +112,11 @@ typedef struct dtk_vit_model {
 #define DTK_VIT_TILED_GEMMS 1   /* run the K = 384 GEMMs on the tiled kernel too (cross-check in the tests) */
 #define DTK_VIT_BF16 2          /* operand type bf16 instead of fp16 (weights must then be bf16) */
 #define DTK_VIT_CHECK_RANGE 4   /* scan Q / K / V^T and the MLP hidden of every block for saturated values (costs a pass) */
+#define DTK_VIT_ATTENTION_V2 8  /* attention on the round-2/3 kernel (16 waves per CU x 32 queries) instead of the one-wave-per-SIMD
+                                 * kernel of round 4: the cross-check path of the tests */
 #define DTK_OPERAND_F16 0
 #define DTK_OPERAND_BF16 1
+#define DTK_OPERAND_ATTENTION_V2 0x100  /* OR-ed into dtk_vit_attention's operand_type: the same selection for the stand-alone stage */
 
 /* frames [n][3][video_h][video_w] fp32 in [0,1] -> block output of layer depth-1 (before the final norm):
  * tokens_out [n][1 + ph*pw][D] (CLS first; what get_feature_from_input returns) and/or

@@ -15,6 +15,9 @@ for WHAT in "$@"; do
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -DATTN_NO_V3 -I dino_tracker_amd/csrc \
           -I scripts/ubench scripts/ubench/attn_bench.hip -o /tmp/attn_bench 2> gpurun_out/attn_build.log || { cat gpurun_out/attn_build.log; continue; }
       timeout 600 /tmp/attn_bench 30 8108 1 > gpurun_out/attn_bench.log 2>&1; cat gpurun_out/attn_bench.log ;;
+    slot_rate)
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 scripts/ubench/slot_rate.hip -o /tmp/slot_rate 2> gpurun_out/slot_build.log || { cat gpurun_out/slot_build.log; continue; }
+      timeout 300 /tmp/slot_rate > gpurun_out/slot_rate.log 2>&1; cat gpurun_out/slot_rate.log ;;
     e2e_p2)
       timeout 1500 python scripts/e2e_error.py 476 854 8 8 fp16 split,fp16 > gpurun_out/e2e_p2.log 2>&1
       python - <<'PY'

@@ -151,14 +151,29 @@ struct Run {
         auto v4 = [&](auto kern) { int QB; const unsigned g = att2_f16::attention4_grid(FH, S, &QB);
             hipLaunchKernelGGL(kern, dim3(g), dim3(256), 0, 0, (const T*)q, (const T*)k, (const T*)vt, o2, S, Sp, heads, D, FH, QB); };
         if constexpr (F16) {
-            timeit("v4 (1 wave/SIMD, 64 q/wave)", [&] { v4(att2_f16::attention4_kernel<0, false>); });
-            timeit("v4 packed row-sum adds", [&] { v4(att2_f16::attention4_kernel<0, true>); });
+            timeit("v4 (1 wave/SIMD, 64 q/wave)", [&] { v4(att2_f16::attention4_kernel<0>); });
+            timeit("v4 row sums on the matrix pipe", [&] { v4(att2_f16::attention4_kernel<0, true>); });
             if (abl) {
-                timeit("v4 abl: no exp", [&] { v4(att2_f16::attention4_kernel<1, false>); });
-                timeit("v4 abl: no barrier", [&] { v4(att2_f16::attention4_kernel<16, false>); });
-                timeit("v4 abl: no DMA", [&] { v4(att2_f16::attention4_kernel<2, false>); });
-                timeit("v4 abl: no LDS reads", [&] { v4(att2_f16::attention4_kernel<128, false>); });
-                timeit("v4 abl: MFMA + cvt only", [&] { v4(att2_f16::attention4_kernel<1 | 2 | 8 | 16 | 128, false>); });
+                timeit("v4 abl: no exp", [&] { v4(att2_f16::attention4_kernel<1>); });
+                timeit("v4 abl: no barrier", [&] { v4(att2_f16::attention4_kernel<16>); });
+                timeit("v4 abl: no DMA", [&] { v4(att2_f16::attention4_kernel<2>); });
+                timeit("v4 abl: no LDS reads", [&] { v4(att2_f16::attention4_kernel<128>); });
+                timeit("v4 abl: MFMA + cvt only", [&] { v4(att2_f16::attention4_kernel<1 | 2 | 8 | 16 | 128>); });
+                auto clocked = [&](const char* name, auto kern) {
+                    // shader-clock cycles of workgroup 0 (s_memtime) against the launch's wall time: the effective clock
+                    // = cycles per workgroup x workgroup rounds / wall time (5760 workgroups over 256 CUs = 22.5 rounds)
+                    CK(hipDeviceSynchronize());
+                    CK(hipEventRecord(a)); v4(kern); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+                    float ms; CK(hipEventElapsedTime(&ms, a, b));
+                    unsigned w2[2]; CK(hipMemcpy(w2, o2, 8, hipMemcpyDeviceToHost));
+                    const double cyc = (double)(((unsigned long long)w2[1] << 32) | w2[0]);
+                    int QB; const unsigned g = att2_f16::attention4_grid(FH, S, &QB);
+                    const double rounds = g / 256.0, ntiles = (S + 63) / 64;
+                    printf("%-26s workgroup 0: %.0f cycles = %.1f per MFMA slot; %.3f ms -> %.2f GHz if every round took as long (%.1f rounds)\n",
+                           name, cyc, cyc / (ntiles * 32), ms, cyc * rounds / (ms * 1e6), rounds);
+                };
+                clocked("v4 clock", att2_f16::attention4_kernel<256>);
+                clocked("v4 clock, MFMA + cvt only", att2_f16::attention4_kernel<256 | 1 | 2 | 8 | 16 | 128>);
             }
             timeit("v2 QT1 max", [&] { v2(att2_f16::attention2_kernel<1, 0, 0, true>, 1); });
             timeit("v2 QT1 opt (library)", [&] { v2(att2_f16::attention2_kernel<1, 0, 1, true>, 1); });
@@ -185,7 +200,8 @@ struct Run {
             }
         } else {
             timeit("v2 QT1 opt (library)", [&] { v2(att2_bf16::attention2_kernel<1, 0, 1, true>, 1); });
-            timeit("v4 (1 wave/SIMD, 64 q/wave)", [&] { v4(att2_bf16::attention4_kernel<0, false>); });
+            timeit("v4 (1 wave/SIMD, 64 q/wave)", [&] { v4(att2_bf16::attention4_kernel<0>); });
+            timeit("v4 row sums on the matrix pipe", [&] { v4(att2_bf16::attention4_kernel<0, true>); });
 #ifndef ATTN_NO_V3
             if (abl > 1) timeit("v3 8 waves, ring 5", [&] { v3(att2_bf16::attention3_kernel<8, 5>, 8); });
 #endif

@@ -135,7 +135,7 @@ def test_feature_handoff_and_set_video(full384):
     video = synth.synth_video(T, H, W, seed=90)
     queries = synth.grid_queries(3, 2, H, W, 1)
     from gpu_util import make_tracker
-    a = make_tracker(video, feats, head, delta=delta, method=ops.TRACK_MFMA)
+    a = make_tracker(video, feats, head, delta=delta, method=ops.TRACK_MFMA, p2_operands=None)  # the library default, as `b`
     ta, oa = make_inference(a, H, W, T).infer(queries.cuda())
     thwc = feats.permute(0, 2, 3, 1).reshape(T, 67 * 121, C).contiguous().cuda()
     b = Tracker(video=video.cuda(), dino_features=thwc, dino_patch_size=14, stride=7, device="cuda:0",
