@@ -53,6 +53,7 @@ def parse():
                     help="vit: features come from the (random-weight) ViT on the synthetic video; synthetic: the "
                          "feature-level generator with dense anchors (worst case for the tracker stage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=8, help="host threads of the oracle's infer leg (fixed: comparable across rounds)")
     ap.add_argument("--cpu-queries", type=int, default=4, help="queries of the TIMED CPU sample (SURVEY 8d: K = 4, full T)")
     ap.add_argument("--parity-queries", type=int, default=16,
                     help="queries of parity_sample (>= --cpu-queries; the extra ones go through the oracle untimed)")
@@ -74,6 +75,20 @@ def self_launch(args) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+def literal_over_port(C):
+    """How much slower the reference's LITERAL per-call path is than the oracle port on the same host threads (measured in the
+    build container, where the un-modified reference runs: scripts/cpu_reference_literal.py) -- from the committed file."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_cpu_reference_literal.json")) as fh:
+            d = json.load(fh)
+        for row in d["runs"]:
+            if f"C={int(C)}," in row["config"]:
+                return round(row["literal_over_port"], 1)
+    except Exception:
+        pass
+    return None
 
 
 def main():
@@ -262,20 +277,20 @@ def main():
         q_cpu = queries.cpu()[sel]
         one_video(videos[0])                                 # the state the sample is compared against
         refined_cpu = trk.refined_features.cpu()
-        # torch's CPU kernels on maps of 67 x 121 lose time to thread fan-out on a many-core host: time a slice of the
-        # first pass at a few thread counts and run the oracle at the fastest (reported as `cores`)
+        # torch's CPU kernels on maps of 67 x 121 lose time to thread fan-out on a many-core host (round 3: 3 x slower on 128
+        # threads than on 8).  The infer leg runs on a FIXED thread count (--cpu-threads, default 8) so that the baseline is
+        # comparable from round to round; the sweep over thread counts of a slice of the first pass is reported beside it.
         ncore = torch.get_num_threads()
-        best_thr, best_t = ncore, None
+        best_thr = max(1, min(args.cpu_threads, ncore))
         probe_src = refined_cpu[0].reshape(C, -1).t()[:128].contiguous()
+        sweep = {}
         for thr in sorted({ncore, 64, 32, 16, 8}):
             if thr > ncore:
                 continue
             torch.set_num_threads(thr)
             c0 = time.perf_counter()
             A.track(probe_src, refined_cpu, torch.zeros(128, dtype=torch.long), head, H, W)
-            el = time.perf_counter() - c0
-            if best_t is None or el < best_t:
-                best_thr, best_t = thr, el
+            sweep[str(thr)] = round(time.perf_counter() - c0, 3)
         torch.set_num_threads(best_thr)
         c0 = time.perf_counter()
         rt_t, ro_t, cs_t, _ = A.infer(refined_cpu, q_cpu[timed], head, H, W, return_aux=True)
@@ -306,11 +321,12 @@ def main():
                "sample": f"oracle (fp32 torch restatement of the reference; the un-modified reference is not on this box, its "
                          f"literal per-call path is ~T x more expensive: profiles/r03_cpu_reference_literal.json): "
                          f"infer on {nq} of the {N} queries at full T={T} with all their anchors ({a_bar:.1f} per query) "
-                         f"{t_query:.2f} s/query on {best_thr} threads (fastest of 8..{ncore}); ViT {t_vit:.2f} s/frame and "
+                         f"{t_query:.2f} s/query on {best_thr} threads (fixed; sweep of a 128-map slice in thread_sweep_s); ViT {t_vit:.2f} s/frame and "
                          f"Delta-DINO {t_delta:.2f} s/frame on {nf} frame(s), {ncore} threads; "
                          f"N T / (T t_vit + T t_delta + N t_query), SURVEY 8d",
                "t_query_s": round(t_query, 3), "t_vit_s": round(t_vit, 3), "t_delta_s": round(t_delta, 3),
-               "anchors_per_query": round(a_bar, 2), "host_threads": ncore}
+               "anchors_per_query": round(a_bar, 2), "host_threads": ncore, "thread_sweep_s": sweep,
+               "literal_over_port": literal_over_port(C)}
         tg, og = mi.infer(queries[sel.to(dev)])
         parity = {"queries": npar, "frames": T, "correlation_maps": int(npar * T + float((cs_all >= 0.7).sum()) * T),
                   "max_dxy_px": round(float((tg.cpu() - rt).abs().max()), 6),
@@ -355,6 +371,8 @@ def main():
                        "track_method": "exact" if method == ops.TRACK_EXACT else "mfma",
                        "anchor_pairs": pairs, "correlation_maps_per_video": maps, "anchor_track_tiers": tiers,
                        "rccl_ranks": rccl_ranks,
+                       "vit_frames_per_rank": ([sharding.split_range(T, r, world)[1] - sharding.split_range(T, r, world)[0]
+                                                for r in range(world)] if qpar else [T] * world),
                        "parallelism": (f"query-parallel x{world} (frames split for P1/P2, queries for P3)" if qpar
                                        else f"video-parallel x{world}")},
             "roofline": roofline, "cpu_baseline": cpu, "parity_sample": parity,

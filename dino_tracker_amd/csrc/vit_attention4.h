@@ -384,12 +384,14 @@ __global__ __launch_bounds__(256, 1) void attention4_kernel(const op_t* __restri
         pend1 = __builtin_amdgcn_readfirstlane(__any(!(lsum1 < RESC_T)));
         if (trip0) guard_tripped(0, ls_e);
     };
+    const unsigned long long clk1 = (ABL & 256) ? __builtin_amdgcn_s_memtime() : 0ull;
     for (int t = 0; t < ntiles; t += A4_NB) {
         key_tile(std::integral_constant<int, 0>{}, t);
         if (t + 1 < ntiles) key_tile(std::integral_constant<int, 1>{}, t + 1);
         if (t + 2 < ntiles) key_tile(std::integral_constant<int, 2>{}, t + 2);
         if (t + 3 < ntiles) key_tile(std::integral_constant<int, 3>{}, t + 3);
     }
+    const unsigned long long clk2 = (ABL & 256) ? __builtin_amdgcn_s_memtime() : 0ull;
     // epilogue: PV(1, last) (and, RSM, its row sum)
     {
         f4v lacc = {0.f, 0.f, 0.f, 0.f};
@@ -436,10 +438,12 @@ __global__ __launch_bounds__(256, 1) void attention4_kernel(const op_t* __restri
                 }
         }
     }
-    if ((ABL & 256) && blockIdx.x == 0 && tid == 0) {   // cycles this workgroup took, into the first output words
-        const unsigned long long dt = __builtin_amdgcn_s_memtime() - clk0;
-        reinterpret_cast<unsigned*>(O)[0] = (unsigned)dt;
-        reinterpret_cast<unsigned*>(O)[1] = (unsigned)(dt >> 32);
+    if ((ABL & 256) && blockIdx.x == gridDim.x - 8 && tid == 0) {   // cycles of one LATE workgroup (prologue | key loop | epilogue)
+        const unsigned long long now = __builtin_amdgcn_s_memtime();   // into output words whose owner (workgroup 0) finished long ago
+        unsigned* dst = reinterpret_cast<unsigned*>(O);
+        dst[0] = (unsigned)(clk1 - clk0);
+        dst[1] = (unsigned)(clk2 - clk1);
+        dst[2] = (unsigned)(now - clk2);
     }
 }
 

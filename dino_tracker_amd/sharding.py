@@ -5,6 +5,11 @@ Level 2 (one video on several GPUs, for the single-video scaling curve): `query_
 ranks for P1 / P2 (each rank encodes and refines T / world frames), all-gathers the refined volume once (T*HW*C fp32 =
 1.1 GB at T = 90, C = 384: ~140 MB per rank over xGMI), splits the QUERIES over the ranks for P3 (every rank needs all
 frames: a query is correlated against every frame) and gathers the [N/world, T, 3] results on rank 0.
+The volume travels as fp32, not as the 16-bit unit-norm copy SURVEY 8e budgets (0.56 GB): everything that DECIDES a result
+(bilinear sampling, the fp32 re-scoring of the arg-max candidates, the window correlations) reads the fp32 master, so a 16-bit
+gather would make an 8-GPU run differ from a 1-GPU run; at xGMI rates the extra 0.5 GB is a few milliseconds of a step that
+takes every rank > 100 ms.  At 8 ranks a rank encodes 12 / 12 / ... / 6 frames of a 90-frame video (`split_range`): the ViT
+runs one pass per rank at that batch (bench.py prints it as config.vit_frames_per_rank).
 `torch.distributed` backend "nccl" is RCCL on ROCm; the same code runs on "gloo" for the CPU tests.
 """
 from __future__ import annotations

@@ -160,17 +160,17 @@ struct Run {
                 timeit("v4 abl: no LDS reads", [&] { v4(att2_f16::attention4_kernel<128>); });
                 timeit("v4 abl: MFMA + cvt only", [&] { v4(att2_f16::attention4_kernel<1 | 2 | 8 | 16 | 128>); });
                 auto clocked = [&](const char* name, auto kern) {
-                    // shader-clock cycles of workgroup 0 (s_memtime) against the launch's wall time: the effective clock
-                    // = cycles per workgroup x workgroup rounds / wall time (5760 workgroups over 256 CUs = 22.5 rounds)
+                    // shader-clock cycles (s_memtime) of one workgroup's three phases; the effective clock follows from the key
+                    // loop's slot count and the wall time.  The stamps land in the first words of the output, which workgroup
+                    // 0 (a different one) also writes: read them from a second launch into a scratch copy of O.
                     CK(hipDeviceSynchronize());
                     CK(hipEventRecord(a)); v4(kern); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
                     float ms; CK(hipEventElapsedTime(&ms, a, b));
-                    unsigned w2[2]; CK(hipMemcpy(w2, o2, 8, hipMemcpyDeviceToHost));
-                    const double cyc = (double)(((unsigned long long)w2[1] << 32) | w2[0]);
+                    unsigned w3[3]; CK(hipMemcpy(w3, o2, 12, hipMemcpyDeviceToHost));
                     int QB; const unsigned g = att2_f16::attention4_grid(FH, S, &QB);
-                    const double rounds = g / 256.0, ntiles = (S + 63) / 64;
-                    printf("%-26s workgroup 0: %.0f cycles = %.1f per MFMA slot; %.3f ms -> %.2f GHz if every round took as long (%.1f rounds)\n",
-                           name, cyc, cyc / (ntiles * 32), ms, cyc * rounds / (ms * 1e6), rounds);
+                    const double rounds = g / 256.0, ntiles = (S + 63) / 64, tot = (double)w3[0] + w3[1] + w3[2];
+                    printf("%-26s prologue %u, key loop %u (%.1f per MFMA slot), epilogue %u cycles; %.3f ms -> %.2f GHz if every round took as long (%.1f rounds)\n",
+                           name, w3[0], w3[1], w3[1] / (ntiles * 32), w3[2], ms, tot * rounds / (ms * 1e6), rounds);
                 };
                 clocked("v4 clock", att2_f16::attention4_kernel<256>);
                 clocked("v4 clock, MFMA + cvt only", att2_f16::attention4_kernel<256 | 1 | 2 | 8 | 16 | 128>);

@@ -423,3 +423,40 @@ def test_bb_nms_kernel_edge_rows():
     assert (peak.cpu() - top2).abs().max() < 1e-6, (peak.cpu(), top2)
     assert torch.allclose(r.cpu(), rr, atol=1e-6, equal_nan=True), (r.cpu(), rr)
     assert float(rr[0]) == 0.0 and abs(float(rr[1]) - 0.5) < 1e-6 and float(rr[2]) == 0.0 and abs(float(rr[3]) - 0.9) < 1e-6
+
+
+def test_config2_t50_256_queries_from_the_video():
+    """BASELINE.json config 2 as a test (round 3 kept it as a bench line under profiles/ only): 854 x 480 x 50 synthetic video
+    (global translation of 4.2, 2.1 px per frame), 256 grid queries at t = 0, DINOv2 ViT-S/14 (seeded weights, block
+    11) -> Delta-DINO -> ModelInference.infer on one GPU, everything through the library's default kernels.  Parity sample:
+    16 of the queries at full T with all their anchors through the oracle on the step's own refined volume (the form of
+    bench.py's parity_sample): positions within 1e-3 px, occlusion flags identical."""
+    from dino_tracker_amd.dataset import RangeNormalizer
+    from dino_tracker_amd.extractor import VitExtractor
+    from dino_tracker_amd.model_inference import ModelInference
+    from dino_tracker_amd.tracker import Tracker
+    T, N = 50, 256
+    dev = "cuda:0"
+    video = synth.synth_video(T, H, W, seed=1)
+    queries = synth.grid_queries(16, 16, H, W, 0, margin=60.0)
+    assert queries.shape == (N, 3) and float(queries[:, 0].min()) == 60.0 and float(queries[:, 0].max()) == W - 1 - 60.0
+    head = synth.synth_head_weights(3)
+    delta = synth.synth_delta_dino_weights(384, seed=4)
+    ex = VitExtractor("dinov2_vits14", stride=7, device=dev, state_dict=synth.make_vit_weights("dinov2_vits14", seed=2, layerscale=0.1))
+    trk = Tracker(video=video.to(dev), dino_features=ex.encode(video, defer_check=True), dino_patch_size=14, stride=7, device=dev,
+                  track_method=ops.TRACK_MFMA)
+    trk.tracker_head.load_state_dict(head)
+    trk.delta_dino.load_state_dict(delta)
+    trk.to(dev).eval()
+    mi = ModelInference(trk, RangeNormalizer((W, H, T), device=dev), 0.7, 0.6)
+    traj, occ = mi.infer(queries.to(dev))
+    ex.check_overflow()
+    assert traj.shape == (N, T, 2) and occ.shape == (N, T) and occ.dtype == torch.bool and torch.isfinite(traj).all()
+    sel = torch.linspace(0, N - 1, 16).long()
+    refined = trk.refined_features.cpu()
+    rt, ro, cs, _ = A.infer(refined, queries[sel], head, H, W, return_aux=True)
+    err = (traj.cpu()[sel] - rt).norm(dim=-1)
+    print(f"config 2: {N} queries x {T} frames; parity sample 16 queries, {int((cs >= 0.7).sum())} anchor pairs: "
+          f"max |dxy| {float(err.max()):.2e} px, {int((occ.cpu()[sel] != ro).sum())} of {ro.numel()} flags differ; tiers {trk.last_track_stats}")
+    assert err.max() < PX_TOL
+    assert torch.equal(occ.cpu()[sel], ro)

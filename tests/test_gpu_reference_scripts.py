@@ -164,27 +164,38 @@ def test_device_metrics_random_tracks_first_and_strided():
 
 
 def test_end_to_end_from_the_video():
-    """north_star's bar on identical VIDEOS: video -> HIP ViT (fp16 operands) -> HIP Delta-DINO -> HIP infer vs the fp32
-    oracle on the same video (oracle ViT -> oracle refine -> oracle infer), benchmark weights, 854 x 476, T = 8, 64 grid
-    queries: every predicted position within 1e-3 px, every occlusion flag identical.  (Round 2, bf16 operands: p99
-    1.4e-3 px, 22 % of the points beyond 1e-3.)  scripts/e2e_error.py is the measurement; profiles/r03_e2e_error_*.json."""
+    """north_star's bar on identical VIDEOS: video -> HIP ViT (fp16 operands) -> HIP Delta-DINO (fp16 conv operands, the
+    default) -> HIP infer vs the fp32 oracle on the same video (oracle ViT -> oracle refine -> oracle infer), benchmark
+    weights, 854 x 476, T = 16, 256 grid queries = 4096 positions: every predicted position within 1e-3 px, every occlusion
+    flag identical.  (Round 2, bf16 operands: p99 1.4e-3 px, 22 % of the points beyond 1e-3.)
+
+    A position may differ by more only where the reference's own answer hangs on a near-tie of the cosine map -- the untrained
+    ViT's maps are flat: far-apart cells within a few fp32 ulps of each other -- and then it is ARBITRATED, not waved through
+    (round 3 allowed 1 % of the points to be arbitrarily wrong): oracle.ref_algo.tie_arbiter evaluates the map in float64 from
+    the oracle's fp32 features; the device's position must be what the reference's head returns around a cell whose float64
+    cosine is within delta of the float64 maximum, delta = C 2^-24 (fp32 rounding of the oracle's own dot products) + twice the
+    measured relative deviation of the device's refined features (query embedding + worst cell of the frame).  Occlusion flags
+    of a query with an arbitrated point follow that point and are compared for the other queries.
+    scripts/e2e_error.py is the measurement; profiles/r04_e2e_error_*.json."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import e2e_error
-    r = e2e_error.run(476, 854, 8, 8)
+    r = e2e_error.run(476, 854, 16, 16)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "e2e_error_test_476x854x8.json"), "w") as fh:
+    with open(os.path.join(ROOT, "gpurun_out", "e2e_error_test_476x854x16.json"), "w") as fh:
         json.dump(r, fh, indent=1)
-    px, dec, am = r["px_err_vs_oracle_on_same_video"], r["px_err_decidable_points"], r["argmax_margin"]
-    print("end to end from the video:", json.dumps(dec), json.dumps(am), "P1 feature rel err", r["feature_rel_err_P1"])
-    assert r["feature_rel_err_P1"] < 3e-4
-    # every point whose ORACLE arg-max is decided by more than 5e-6 (cosine) is within 1e-3 px (measured: 3.6e-4); the others
-    # -- the untrained ViT's maps have far-apart cells within two fp32 ulps of each other: one such point on this video,
-    # 717 px apart, for bf16, fp16 and any re-ordered fp32 sum alike -- are counted, not bounded (e2e_error.argmax_margins)
-    assert dec["max"] <= 1e-3, (dec, am)
-    assert am["ties"] <= 0.01 * am["points"], am
+    px, am, arb = r["px_err_vs_oracle_on_same_video"], r["argmax_margin"], r["arbitrated"]
+    print("end to end from the video:", json.dumps(px), "beyond 1e-3 px:", r["points_beyond_1e-3px"], json.dumps(arb),
+          "P1 feature rel err", r["feature_rel_err_P1"], "refined", r["feature_rel_err_refined"])
+    assert r["feature_rel_err_P1"] < 3e-4 and r["feature_rel_err_refined"] < 3e-4
+    assert am["points"] == 4096
+    # every point: within 1e-3 px, or the reference's answer for a near-tie decided the other way (float64 arbiter)
+    assert r["arbitration_failures"] == 0, arb
+    assert all(a["gap64"] <= a["delta"] and a["dist_px"] <= 1e-3 for a in arb), arb
+    assert len(arb) <= 8, arb                       # (near-ties are rare: 1 of 512 at T = 8, margin 1.2e-7)
     assert px["p99"] <= 1e-3, px
-    assert r["occ_mismatch_same_video"] == 0
-    assert r["px_err_vs_oracle_on_same_features"]["max"] < 1e-3
+    assert r["occ_mismatch_same_video_queries_without_a_tie"] == 0
+    # P3 on IDENTICAL features (the device's refined volume through the oracle): no exemption of any kind
+    assert r["px_err_vs_oracle_on_same_features"]["max"] < 1e-3 and r["occ_mismatch_same_features"] == 0
 
 
 def test_bf16_embedding_file(tmp_path):

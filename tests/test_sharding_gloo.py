@@ -103,3 +103,25 @@ def test_split_range():
     assert [sharding.split_range(90, r, 8)[:2] for r in range(8)] == [(0, 12), (12, 24), (24, 36), (36, 48), (48, 60),
                                                                         (60, 72), (72, 84), (84, 90)]
     assert sharding.split_range(3, 3, 4) == (3, 3, 1) and sharding.split_range(5, 1, 2) == (3, 5, 3)
+
+
+def test_query_parallel_world4_ragged():
+    """World size 4 with T not divisible by the world size (T = 10: frames 3 / 3 / 3 / 1) and fewer queries than would fill the
+    last rank (N = 9: 3 / 3 / 3 / 0 -- rank 3 has NO query and still takes part in both collectives)."""
+    world, t, hw, c, n = 4, 10, 3, 4, 9
+    assert [sharding.split_range(t, r, world)[:2] for r in range(world)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert sharding.split_range(n, 3, world)[:2] == (9, 9)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 1000)
+    mp.spawn(_qp_worker, args=(world, port, t, hw, c, n, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_video_parallel_gather_world4():
+    world, n_videos, n, t = 4, 6, 5, 3  # 6 videos over 4 ranks: the second round has two idle ranks
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 32500 + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(world, port, n_videos, n, t, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
