@@ -174,19 +174,35 @@ class DinoTrackerSampler(LongRangeSampler):
                          fg_traj_ratio=fg_traj_ratio, num_frames=num_frames, keep_in_cpu=keep_in_cpu)
         self.range_normalizer, self.dst_range = range_normalizer, dst_range
 
+    def _draw_frame_set(self, name, t, generator=None, max_tries=64):
+        """A random set of num_frames frames in which at least two trajectories of the `name` set have two tracked frames (the
+        reference's `while True` re-draw, dataset.py:173-179), decided on a host copy of the validity table."""
+        can = getattr(self, f"{name}_can_sample")
+        cached = getattr(self, "_can_host", {}).get(name)
+        if cached is None or cached[0] is not can:          # (the device table changes when load_next_batch rotates the chunk)
+            self._can_host = dict(getattr(self, "_can_host", {}))
+            self._can_host[name] = cached = (can, can.cpu())
+        can_h = cached[1]
+        for _ in range(max_tries):
+            frames = torch.randperm(t, generator=generator)[:self.num_frames]
+            if int((can_h[:, frames].sum(dim=1) >= 2).sum()) >= 2:
+                break
+        return frames
+
     def forward_device(self, generator=None):
         """The batch of `forward` with the frame sets drawn on the HOST (torch's CPU generator) and everything that touches
         the trajectories on the device: no device -> host read, static shapes.  Differences from `forward`, both by
         construction: (1) `frames_set_t` is the sorted union of the two DRAWN frame sets (foreground and background
         trajectories draw theirs independently, dataset.py:173), whether or not every frame ends up used by a sampled pair
         -- `forward` returns the frames the sampled pairs actually use, a subset with the same union in all but rare
-        batches; (2) a frame set with fewer than two eligible trajectories is not redrawn (dataset.py:175-179): its rows
-        come back with ok = False.  Extra keys: "valid" [B] bool and "frames_set_t_host" (list of int)."""
+        batches.  A frame set with fewer than two eligible trajectories is redrawn, as in the reference (dataset.py:175-179) --
+        on the HOST, against a host copy of the (static) per-frame validity of the trajectories, so the redraw costs no
+        device read.  Extra keys: "valid" [B] bool and "frames_set_t_host" (list of int)."""
         assert self.num_frames is not None, "num_frames must be specified"
         dev = self.fg_valid_trajectories.device
         n_fg = self.get_fg_batch_size()
         t = self.vid_len
-        sets = [torch.randperm(t, generator=generator)[:self.num_frames] for _ in range(2)]      # host draws
+        sets = [self._draw_frame_set(name, t, generator) for name in ("fg", "bg")]               # host draws
         s0, s1 = sets[0].tolist(), sets[1].tolist()
         union = sorted(set(s0) | set(s1))
         pos = {f: i for i, f in enumerate(union)}

@@ -420,20 +420,22 @@ class Tracker(nn.Module):
 
     def get_cycle_consistency_terms(self, frames_set_t, fg_masks):
         """get_cycle_consistent_preds (tracker.py:182-301) with static shapes and no host read: EVERY sampled point is tracked
-        source -> target with gradients (its detached result is the target point), back without, and target -> source with
-        gradients; `keep` [M] flags the points that are valid and return within cyc_thresh px -- the rows the reference would
-        have kept.  The caller weights by `keep` (a batch without any consistent point gives zero loss instead of the
-        reference's re-draw)."""
+        source -> target with gradients (its detached result is the target point) and target -> source with gradients -- the
+        detached result of that second pass IS the return point of the reference's no-grad filter pass (the same embeddings,
+        the same inputs), so two tracker passes serve where the reference runs four (round 3 ran three); `keep` [M]
+        flags the points that are valid and return within cyc_thresh px -- the rows the reference would have kept.  The caller
+        weights by `keep` (a batch without any consistent point gives zero loss instead of the reference's re-draw)."""
         pts, src_idx, tgt_idx, valid = self._cycle_point_sets_static(frames_set_t, fg_masks)
         unnorm = lambda c: self.range_normalizer.unnormalize(c, src=(-1, 1), dims=[0, 1])
         t_of = frames_set_t.to(pts.device).float()
         src_tgt = self.get_point_predictions((pts, src_idx, tgt_idx, frames_set_t), self.frame_embeddings)
         with torch.no_grad():
             tgt_pts = torch.cat([unnorm(src_tgt.detach()), t_of[tgt_idx][:, None]], dim=1)
-            back_xy = unnorm(self.get_point_predictions((tgt_pts, tgt_idx, src_idx, frames_set_t), self.frame_embeddings.detach()))
+        tgt_src = self.get_point_predictions((tgt_pts, tgt_idx, src_idx, frames_set_t), self.frame_embeddings)
+        with torch.no_grad():
+            back_xy = unnorm(tgt_src.detach())
             dist = torch.norm(pts[:, :2] - back_xy[:, :2], dim=1)
             keep = valid & (dist <= self.cyc_thresh)
-        tgt_src = self.get_point_predictions((tgt_pts, tgt_idx, src_idx, frames_set_t), self.frame_embeddings)
         return {
             "source_coords": self.range_normalizer(pts, dst=[-1, 1]),
             "target_coords": self.range_normalizer(tgt_pts, dst=[-1, 1]),

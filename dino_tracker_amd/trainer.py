@@ -19,7 +19,8 @@ copies per iteration (profiles/r03_train_host_profile.txt) around 45 ms of convo
 `make_trainer(base)` derives the class from the reference's own `DINOTracker` (loaded from the checkout at run time by
 overlay/dino_tracker.py): configuration, paths, model / optimizer / scheduler set-up, checkpoints and logging stay the
 reference's code; `train`, the loss terms and the batch sampler are this file's.  DTK_TRAINER=reference runs the inherited
-loop instead (bit-identical random draws to the reference for equal seeds: the parity tests of tests/test_gpu_train.py).
+loop instead (bit-identical random draws to the reference for equal seeds, the cycle-consistency point sets included: it
+defaults DTK_CYC_SAMPLING to "reference"; the parity tests of tests/test_gpu_train.py).
 
 The loss terms are pure functions of explicit selections (`*_terms`), so the CPU tests can feed them the selections the
 reference's un-modified methods drew and compare the values (tests/test_trainer_vs_reference.py)."""
@@ -387,6 +388,9 @@ def make_trainer(base):
         # -- the loop (dino_tracker.py:392-448) ---------------------------------------------------------------------------
         def train(self):
             if os.environ.get("DTK_TRAINER", "device") == "reference":
+                # the inherited loop promises the reference's sequence of random draws: that includes the cycle-consistency
+                # point sets, which Tracker draws on the device unless told otherwise
+                os.environ.setdefault("DTK_CYC_SAMPLING", "reference")
                 return super().train()
             from tqdm import tqdm
             self.load_fg_masks()

@@ -35,6 +35,8 @@ PY
       DTK_P2_OPERANDS=fp16 timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_p2fp16.json 2> gpurun_out/bench_p2fp16.err; cat gpurun_out/bench_p2fp16.json; tail -3 gpurun_out/bench_p2fp16.err ;;
     bench_full)
       timeout 1200 python bench.py > gpurun_out/bench_full.json 2> gpurun_out/bench_full.err; cat gpurun_out/bench_full.json; tail -3 gpurun_out/bench_full.err ;;
+    twin)
+      timeout 2400 python -m pytest tests/test_gpu_train.py -m gpu -q -s -k "twin or reference_order" 2>&1 | tail -40 > gpurun_out/pytest_twin.log; tail -30 gpurun_out/pytest_twin.log ;;
     tests)
       timeout 2400 python -m pytest tests -m gpu -q -x --durations=8 2>&1 | tail -40 > gpurun_out/pytest_gpu.log; tail -25 gpurun_out/pytest_gpu.log ;;
     tests:*)

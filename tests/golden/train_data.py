@@ -22,6 +22,17 @@ import yaml
 
 from dino_tracker_amd import synth
 
+# config/train.yaml of the reference (lines 1-64), restated so that the data directory can be built WITHOUT the checkout
+# (tests/test_train_vs_reference.py::test_restated_train_yaml_matches_reference pins it against the file where it exists)
+TRAIN_YAML = dict(
+    checkpoint_interval=2500, video_resw=854, video_resh=476, fg_traj_ratio=0.5, keep_traj_in_cpu=False, train_batch_size=512,
+    batch_n_frames=4, total_iterations=10000, lr_delta_dino=0.01, lr_cnn_refiner=0.01, apply_scheduler_every=40,
+    scheduler_gamma=0.999, lambda_cyc=0.5, apply_cyc_after=5000, cyc_n_frames=4, cyc_batch_size_per_frame=256,
+    cyc_fg_points_ratio=0.7, cyc_thresh=4, cyc_gamma=0.8, lambda_emb_norm=0.0001, lambda_angle=0.0001,
+    lambda_cl_dino_bb=0.00025, lambda_cl_ref_bb=0.00005, cl_n_frames=4, cl_points_per_pair=256, cl_fg_points_ratio=0.7,
+    cl_temp=0.1, cl_div_dino_bb=700, cl_div_ref_bb=900, apply_cl_ref_after=5000, bb_amb_sig_a=27, bb_amb_sig_b=-5.7, stride=7,
+    dino_patch_size=14, anchor_cosine_similarity_threshold=0.7, cosine_similarity_threshold=0.6)
+
 CFG = dict(T=8, C=1024, H=126, W=854, feat_seed=31, head_seed=3, delta_seed=9, start_iter=1, total_iterations=4,
            n_fg=160, n_bg=240, bb_per_pair=48)
 
@@ -54,7 +65,8 @@ def build(dst, ref_root, cfg=CFG, overrides=None, synthetic_video=False):
     """`overrides`: entries of train.yaml to replace (default: the small-batch settings of the parity fixture);
     `synthetic_video`: generated frames + masks instead of the reference's horsejump clip (any T, any size)."""
     T, C, H, W = cfg["T"], cfg["C"], cfg["H"], cfg["W"]
-    src = os.path.join(ref_root, "dataset", "horsejump")
+    assert ref_root or synthetic_video, "without the reference checkout only the synthetic video can be built"
+    src = os.path.join(ref_root, "dataset", "horsejump") if ref_root else None
     for sub in ("video", "masks"):
         os.makedirs(os.path.join(dst, sub), exist_ok=True)
         if synthetic_video:
@@ -94,8 +106,11 @@ def build(dst, ref_root, cfg=CFG, overrides=None, synthetic_video=False):
             }
     os.makedirs(os.path.join(dst, "dino_best_buddies"), exist_ok=True)
     torch.save(bb, os.path.join(dst, "dino_best_buddies", "dino_best_buddies_filtered.pt"))
-    with open(os.path.join(ref_root, "config", "train.yaml")) as fh:
-        conf = yaml.safe_load(fh.read())
+    if ref_root:
+        with open(os.path.join(ref_root, "config", "train.yaml")) as fh:
+            conf = yaml.safe_load(fh.read())
+    else:
+        conf = dict(TRAIN_YAML)
     conf.update(video_resh=H, video_resw=W, total_iterations=cfg["total_iterations"], checkpoint_interval=100000,
                 apply_cyc_after=0, apply_cl_ref_after=0)
     if overrides is None:

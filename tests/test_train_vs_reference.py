@@ -191,3 +191,38 @@ def test_samplers_draw_what_the_reference_draws():
             assert torch.equal(a[k], b[k]), k
         assert b["frames_set_t"].numel() <= 8 and b["t1_points"].shape == (64, 3)
         assert not torch.isnan(b["t1_points"]).any() and not torch.isnan(b["t2_points_normalized"]).any()
+
+
+def test_restated_train_yaml_matches_reference():
+    """tests/golden/train_data.TRAIN_YAML (what the reference-free data directory is configured from) == config/train.yaml."""
+    import yaml
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import train_data as TD
+    with open(os.path.join(ref_harness.REFERENCE_ROOT, "config", "train.yaml")) as fh:
+        assert yaml.safe_load(fh.read()) == TD.TRAIN_YAML
+
+
+@pytest.mark.skipif(not os.environ.get("DTK_SLOW_CPU_TESTS"), reason="~4 min of reference training on CPU: set DTK_SLOW_CPU_TESTS=1 "
+                    "(measured in round 4: all 21 losses within 2.6e-6 of tests/golden/ref_train_synth.npz)")
+def test_train_twin_pinned_against_reference_on_cpu(tmp_path):
+    """tests/golden/train_twin.py (the reference-free twin of train.py that the driver's GPU box runs) around the REFERENCE's own
+    Tracker on CPU: its control plane, its order of random draws and the loss terms it evaluates reproduce the golden run of the
+    un-modified train.py (ref_train_synth.npz) -- so what the GPU test adds to the comparison is this implementation's models
+    and kernels, nothing else."""
+    import json
+    import subprocess
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
+    import train_data as TD
+    d, cfg = TD.build(str(tmp_path / "train"), None, synthetic_video=True)
+    log = str(tmp_path / "l.json")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "oracle", "shims"), ref_harness.REFERENCE_ROOT, root]),
+               DTK_TWIN_MODEL="reference")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "train_twin.py"), "--config", cfg, "--data-path", d,
+                        "--seed", "2", "--log", log, "--device", "cpu"], capture_output=True, text=True, env=env,
+                       cwd=ref_harness.REFERENCE_ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.array(json.load(open(log))["losses"])
+    gold = np.load(os.path.join(root, "tests", "golden", "ref_train_synth.npz"))["losses"]
+    assert (np.abs(got - gold) / np.maximum(np.abs(gold), 1e-6)).max() < 2e-5
