@@ -94,6 +94,32 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ int wave_sum_i(int v) {
     return wave_allreduce_bits(v, [](int a, int b) { return a + b; });
 }
+// LDS-DMA through a buffer descriptor (round 4): global address = descriptor base + scalar byte offset (the tile: one SALU add
+// per request) + 32-bit per-lane offset (a VGPR that is constant for the whole kernel); LDS destination = wave-uniform scalar +
+// immediate (+ 16 bytes per lane, the hardware's lane-linear image).  Three issue slots per request; the global_load_lds form
+// with a 64-bit per-lane pointer cost a lone wave ~13 (64-bit address arithmetic on the VALU per request, m0 saved and restored)
+// -- 9 % of the attention kernel, and more of corr_peaks.  A kernel that uses it must not use m0 otherwise (no indirect register
+// indexing, no GWS / sendmsg): the compiler reserves m0 but is not told about the write.
+typedef unsigned dtk_u4 __attribute__((ext_vector_type(4)));
+template <int LDS_IMM>
+__device__ __forceinline__ void dtk_buffer_lds16(dtk_u4 srd, unsigned soff, unsigned voff, unsigned lds_dst) {
+    asm volatile(
+        "s_add_u32 m0, %3, %4\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %0, %1, %2 offen lds"
+        :
+        : "v"(voff), "s"(srd), "s"(soff), "s"(lds_dst), "i"(LDS_IMM)
+        : "memory");
+}
+// raw buffer descriptor (stride 0) over `p`; the range check is disabled by a maximal size -- callers clamp their offsets
+__device__ __forceinline__ dtk_u4 dtk_make_srd(const void* p) {
+    const unsigned long long a = (unsigned long long)(size_t)p;
+    dtk_u4 r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = __builtin_amdgcn_readfirstlane(r[k]);
+    return r;
+}
+
 // effective source count: min(M, *dM) when a device-side count is supplied
 __device__ __forceinline__ int dtk_active(int M, const int32_t* dM) {
     if (dM == nullptr) return M;

@@ -17,6 +17,7 @@
 //   are appended to a redo list and re-done by the exact path (track_exact.hip) -- device-side count, no host sync.
 #include <limits.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "head_common.h"
 
@@ -410,8 +411,8 @@ __global__ __launch_bounds__(256) void select_kernel(dtk_geom g, const TileRec* 
 // its neighbours split evenly between the two top-4 lists of a source.  The epilogue of step n-1 is
 // independent of the MFMAs of step n and is interleaved with them by the scheduler (one wave per SIMD: 512 VGPRs).
 constexpr int PK_SRC = 256;               // sources per workgroup
-constexpr int PK_CELLS = 32;              // cells per step
-constexpr int PK_IDX_BITS = 13;           // position tag: step << 4 | accumulator register
+constexpr int PK_CB = 1;                  // 32-cell blocks per step in production (2 = the four-accumulator variant: measured slower)
+constexpr int PK_IDX_BITS = 13;           // position tag: step << 5 | cell block << 4 | accumulator register
 constexpr int PK_VAL_BITS = 17;           // sources carry 2^12 x, cells 2^5 x unit vectors: the accumulator is 2^17 rho
 constexpr float PK_SRC_SCALE = 4096.f;
 constexpr int PK_TOP = 6;                 // list length per lane half
@@ -420,59 +421,91 @@ constexpr int PK_TOP = 6;                 // list length per lane half
 // truncation to PK_VAL_BITS
 constexpr float EPS_PK = 2.1e-3f;
 typedef float f16v __attribute__((ext_vector_type(16)));
+constexpr size_t peaks_lds_bytes(int cb) { return 3 * (size_t)(32 * cb) * 384 * 2 + 64; }   // three tiles + the frame range (dynamic LDS)
 
-// LDS-DMA of 16 bytes per lane: LDS destination = wave-uniform `lds_dst` + 16 * lane, source = the lane's own pointer plus
-// a literal byte offset.  Issued from asm so that the compiler does not serialise it against the ds_reads of the OTHER
-// buffer with a vmcnt(0) of its own; completion is awaited explicitly (glds_wait) before the barrier that publishes
-// the tile.  M0 carries the LDS base and is restored (the compiler reserves it).
-// (No immediate offset: the instruction offset would be added to the LDS address as well as to the global one.)
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
-}
+// (LDS-DMA requests go through dtk_buffer_lds16, common.h; issued from asm so that the compiler does not serialise them against
+// the ds_reads of the OTHER buffer with a vmcnt(0) of its own: completion is awaited explicitly -- glds_wait -- before the
+// barrier that publishes the tile.)
 template <int N>
 __device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
-// sorted top-N insertion on signed integers: one v_med3_i32 per list entry and a v_max_i32 for the head
+// Sorted top-6 insertion of one accumulator value as a program of eight VALU instructions: value -> key (fixed point -- the
+// accumulator already is 2^17 rho; negative values stay negative and never enter a list that starts at zero -- shifted above
+// the 13-bit position tag, which is wave-uniform: an SGPR operand), then one v_med3_i32 per list entry from the tail up and a
+// v_max_i32 for the head.  top_push_op<OP> issues instruction OP of it, so that the caller can spread the 32 x 8 instructions of
+// a tile EVENLY over its 48 MFMA slots (5 or 6 per slot): a lone wave hides about five VALU instructions under a 32x32x16 MFMA
+// and pays ~6 cycles for each further one (profiles/r04_slot_rate_one_wave_per_simd.txt), so eight in two slots and none in the
+// third -- the round-1 arrangement -- cost ~45 cycles per slot where 5.3 in every slot cost ~38.
 __device__ __forceinline__ int med3_i32(int a, int b, int c) {
     int d;
     asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
-template <int N>
-__device__ __forceinline__ void top_push(int (&v)[N], int x) {
-#pragma unroll
-    for (int k = N - 1; k > 0; --k) v[k] = med3_i32(v[k - 1], v[k], x);
-    v[0] = max(v[0], x);
+template <int OP>
+__device__ __forceinline__ void top_push_op(int (&v)[PK_TOP], float x, int tag, int& key) {
+    static_assert(PK_TOP == 6, "the insertion program is written out for six entries");
+    if constexpr (OP == 0) key = (int)x;                                   // v_cvt_i32_f32
+    else if constexpr (OP == 1) {   // v_lshl_or_b32 with the tag in an SGPR (opaque to the compiler, which otherwise spends a second
+        int t2;                     // VALU instruction -- v_lshlrev + v_or3 -- on folding the register index into it)
+        asm("s_mov_b32 %0, %1" : "=s"(t2) : "s"(tag));
+        key = (key << PK_IDX_BITS) | t2;
+    }
+    else if constexpr (OP < 7) v[7 - OP] = med3_i32(v[6 - OP], v[7 - OP], key);   // OP 2..6: entries 5, 4, 3, 2, 1
+    else v[0] = max(v[0], key);
 }
-// value -> key: fixed point (the accumulator already is 2^17 rho; negative values stay negative and never enter a list
-// that starts at zero) shifted above the position tag.  The wave-uniform tag sits in an SGPR.
-__device__ __forceinline__ int make_key(float x, int tag) {
-    int d;
-    const int xi = (int)x;  // v_cvt_i32_f32
-    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(xi), "n"(PK_IDX_BITS), "s"(tag));
-    return d;
+__device__ __forceinline__ void top_push_value(int (&v)[PK_TOP], float x, int tag) {
+    int key;
+    top_push_op<0>(v, x, tag, key); top_push_op<1>(v, x, tag, key); top_push_op<2>(v, x, tag, key); top_push_op<3>(v, x, tag, key);
+    top_push_op<4>(v, x, tag, key); top_push_op<5>(v, x, tag, key); top_push_op<6>(v, x, tag, key); top_push_op<7>(v, x, tag, key);
 }
+
+// acc (+)= A . B with B pinned to the AGPR half of the register file: the 192 source registers of a wave are only ever MFMA
+// operands, and with them in AGPRs everything the VALU touches (accumulators, lists, fragment ring, addresses) fits the 256
+// architectural VGPRs -- left to the register allocator the kernel sat at exactly 256 VGPRs and shuttled ~34 values per tile
+// through v_accvgpr_read.  (The compiler's hazard recognizer does not see through the asm: an accumulator is next read by the
+// list instructions of the FOLLOWING tile, 48 MFMAs later; the one immediate read -- the frame's last tile -- is behind explicit
+// wait states, mfma_settle.)
+__device__ __forceinline__ void mfma_b_agpr(f16v& c, h8 a, h8 b, bool first) {
+    // ("=&v": the destination of an MFMA must not overlap its A / B operands -- an output the compiler may otherwise place on an input)
+    if (first) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void mfma_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
 // VAR: development variants (DTK_DEBUG bits 8192 / 16384 / 32768): 1 = no top-N updates, 2 = no tile requests after the
 // first two, 4 = no LDS reads.  0 in production.  (Measured with them: MFMAs alone 1.63 PF; + LDS reads or + DMA alone
 // unchanged; both 1.22 PF; + list updates 0.90 PF.  Staging the tiles through registers instead of LDS-DMA: 0.39 PF.)
-template <int KS, int VAR>
+template <int I, int N, class F>
+__device__ __forceinline__ void peaks_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        peaks_static_for<I + 1, N>(f);
+    }
+}
+
+// LDS-DMA requests I .. N-1 of a tile: request I covers k-step (w LQ + I / CB), cell block I % CB (see the kernel)
+template <int I, int N, int CB, int C>
+__device__ __forceinline__ void peaks_dma(dtk_u4 srd, unsigned toff, unsigned voff, unsigned dst) {
+    if constexpr (I < N) {
+        dtk_buffer_lds16<I * 1024>(srd, toff + (unsigned)((I / CB) * 32 + (I % CB) * 32 * C * 2), voff, dst);
+        peaks_dma<I + 1, N, CB, C>(srd, toff, voff, dst);
+    }
+}
+
+// CB = 32-cell blocks per step.  CB = 2 (round 4 experiment): a step is 64 cells, so that FOUR accumulators (2 source tiles x 2
+// cell blocks) take turns instead of two and the barriers per cell halve -- measured SLOWER than CB = 1 (816 against 955 TFLOP/s,
+// profiles/r04_corr_peaks_ablations.txt), kept as a development variant.
+template <int KS, int VAR, int CB>
 __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_t* __restrict__ f16,
                                                          const half_t* __restrict__ s16, const int32_t* __restrict__ tgt,
                                                          Rec* __restrict__ rec, int m0, int count, int HWp) {
     constexpr int C = KS * 16;
+    constexpr int PK_CELLS = 32 * CB;            // cells per step: CB 32-cell blocks
+    constexpr int TSH = CB > 1 ? 5 : 4;          // position tag: step << TSH | cell block << 4 | accumulator register
     constexpr int TILE_BYTES = PK_CELLS * C * 2;
-    __shared__ __attribute__((aligned(1024))) unsigned char cells[3][TILE_BYTES];
-    __shared__ int s_fr[8];
+    extern __shared__ __attribute__((aligned(1024))) unsigned char cells_dyn[];   // [3][TILE_BYTES] + s_fr[8]
+    unsigned char* cells = cells_dyn;
+    int* s_fr = reinterpret_cast<int*>(cells_dyn + 3 * TILE_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -494,101 +527,119 @@ __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_
         }
         if (lane == 0) { s_fr[w] = lo; s_fr[4 + w] = hi; }
     }
-    // the sources: B operand, lane (j, h) holds source j, k = 16 ks + 8 h .. + 7
+    // the sources: B operand, lane (j, h) holds source j, k = 16 ks + 8 h .. + 7.  Loaded STRAIGHT INTO AGPRs (the asm below is
+    // what defines them, so the register allocator keeps them there: a value defined in a VGPR and merely used through an "a"
+    // constraint is copied at every use); sources past `count` read the last valid row -- their lists are never written out.
     h8 bs[2][KS];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int i = src0 + t * 32 + j;
         const half_t* sp = s16 + (size_t)min(i, count - 1) * C + h * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            uint4 u = *reinterpret_cast<const uint4*>(sp + ks * 16);
-            if (i >= count) u = make_uint4(0, 0, 0, 0);
-            bs[t][ks] = *reinterpret_cast<const h8*>(&u);
-        }
+        for (int ks = 0; ks < KS; ++ks)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(bs[t][ks]) : "v"(sp + ks * 16) : "memory");
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int fmin = min(min(s_fr[0], s_fr[1]), min(s_fr[2], s_fr[3]));
     const int fmax = max(max(s_fr[4], s_fr[5]), max(s_fr[6], s_fr[7]));
-    // loader: wave w fills k-steps w*KS/4 .. of the tile; lane l' fetches cell c(l' & 31), k-half l' >> 5, where MFMA row
-    // i = 8a + 4p + b carries cell 8a + 2b + p
+    // loader: wave w fills k-steps w*KS/4 .. of the tile; lane l' fetches cell c(l' & 31) of each 32-cell block, k-half l' >> 5,
+    // where MFMA row i = 8a + 4p + b carries cell 8a + 2b + p
     // (on odd map rows the two halves swap: a peak's vertical neighbours split between the lists as well)
     const int lcell = 8 * (j >> 3) + 2 * (j & 3) + ((j >> 2) & 1);
-    const int lcell_odd = lcell ^ 1;
     const int tiles_per_row = pw_pad(g.pw) / PK_CELLS;
     constexpr int LQ = KS / 4;
-    const unsigned lds_base = (unsigned)(size_t)&cells[0][0];
+    const unsigned lds_base = (unsigned)(size_t)cells;
     const int NT = HWp / PK_CELLS;
     const int band = (int)(EPS_PK * (float)(1 << PK_VAL_BITS)) << PK_IDX_BITS;
+    // LDS-DMA through a buffer descriptor over the fp16 volume (common.h): per-lane byte offset of (cell, k-piece) inside a
+    // 32-cell block -- one for even map rows, one for odd ones --, scalar offset = tile + request, LDS destination = scalar +
+    // immediate.  LDS image of a tile: [k-step][cell block][lane (k-half, MFMA row)][16 B]
+    const dtk_u4 srd = dtk_make_srd(f16);
+    const unsigned voff_even = (unsigned)((lcell * C + (w * LQ) * 16 + h * 8) * 2);
+    const unsigned voff_odd = (unsigned)(((lcell ^ 1) * C + (w * LQ) * 16 + h * 8) * 2);
+    const unsigned dma_dst = __builtin_amdgcn_readfirstlane(lds_base + (w * LQ) * CB * 1024);
     for (int f = fmin; f <= fmax; ++f) {
-        const half_t* gl = f16 + ((size_t)f * HWp + lcell) * C + (w * LQ) * 16 + h * 8;
-        const half_t* gl_odd = f16 + ((size_t)f * HWp + lcell_odd) * C + (w * LQ) * 16 + h * 8;
+        // tiles are requested in order (0, 1, 2, ...; past the end the last one again): the scalar offset of the next tile and
+        // the parity of its map row advance incrementally (a division by the runtime tiles-per-row costs ~15 SALU instructions)
+        unsigned next_off = __builtin_amdgcn_readfirstlane((unsigned)f * (unsigned)HWp * (unsigned)(C * 2));   // (volume < 4 GB: host check)
+        int next_n = 0, next_in_row = 0, next_odd = 0;
         auto issue = [&](int n, int buf) {
             if ((VAR & 2) && n > 1) return;
-            const half_t* gp = (((n / tiles_per_row) & 1) ? gl_odd : gl) + (size_t)n * PK_CELLS * C;
-#pragma unroll
-            for (int q = 0; q < LQ; ++q) glds16(gp + q * 16, lds_base + buf * TILE_BYTES + (w * LQ + q) * 1024);
+            const unsigned voff = next_odd ? voff_odd : voff_even;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(dma_dst + (unsigned)buf * (unsigned)TILE_BYTES);
+            peaks_dma<0, LQ * CB, CB, C>(srd, next_off, voff, dst);
+            if (next_n + 1 < NT) {   // (n == next_n except for the clamped repeats of the last tile)
+                ++next_n;
+                next_off += (unsigned)(PK_CELLS * C * 2);
+                if (++next_in_row == tiles_per_row) { next_in_row = 0; next_odd ^= 1; }
+            }
         };
         int v[2][PK_TOP];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int k = 0; k < PK_TOP; ++k) v[t][k] = 0;
-        // one step: the MFMAs of the tile in `buf` into accN, interleaved one-to-one with the top-4 updates of the
-        // previous tile's accP (step index np): a 32-cycle MFMA covers the five VALU instructions of one value
-        auto step = [&](int buf, f16v (&accN)[2], const f16v (&accP)[2], int np) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) accN[t][r] = 0.f;
-            const unsigned char* base = &cells[buf][lane * 16];
-            const int ib = np << 4;
+        // one step: the MFMAs of the tile in `buf` into accN[cell block][source tile], interleaved with the list updates of
+        // the previous tile's accP (step index np)
+        auto step = [&](int buf, f16v (&accN)[CB][2], const f16v (&accP)[CB][2], int np) {
+            const unsigned char* base = cells + (size_t)buf * TILE_BYTES + lane * 16;
+            const int ib = np << TSH;
+            int keys[2] = {0, 0};   // the key of the value whose insertion is in flight (one per source tile at most)
             h8 a[3];
             a[0] = *reinterpret_cast<const h8*>(base);
             a[1] = *reinterpret_cast<const h8*>(base + 1024);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                if (ks + 2 < KS && !(VAR & 4)) a[(ks + 2) % 3] = *reinterpret_cast<const h8*>(base + (ks + 2) * 1024);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    accN[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks % 3], bs[t][ks], accN[t], 0, 0, 0);
-                    // the 32 values of the previous tile are spread evenly over the 2 KS MFMAs
-                    const int q = ks * 2 + t;
-#pragma unroll
-                    for (int e = q * 32 / (2 * KS); e < (q + 1) * 32 / (2 * KS); ++e)
-                        if (!(VAR & 1) || e == 0) top_push(v[e & 1], make_key(accP[e & 1][e >> 1], ib | (e >> 1)));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+            constexpr int NF = KS * CB;          // A fragments of the tile: fragment fr = k-step fr / CB, cell block fr % CB
+            constexpr int NSLOT = 2 * NF, NINS = 32 * CB * 8;   // MFMA slots; list instructions (32 CB values x 8)
+            // (compile-time recursion instead of `#pragma unroll`: at 96 slots the unroller gives up and the accumulators'
+            // indices become run-time -- scratch memory)
+            peaks_static_for<0, NSLOT>([&](auto qc) {
+                constexpr int q = decltype(qc)::value, fr = q / 2, t = q % 2, ks = fr / CB, cb = fr % CB;
+                if (t == 0 && fr + 2 < NF && !(VAR & 4)) a[(fr + 2) % 3] = *reinterpret_cast<const h8*>(base + (fr + 2) * 1024);
+                mfma_b_agpr(accN[cb][t], a[fr % 3], bs[t][ks], ks == 0);
+                // the list instructions of the previous tile, spread evenly over the MFMA slots: slot q issues instructions
+                // [NINS q / NSLOT, NINS (q + 1) / NSLOT) of the stream; value e = index / 8 is accumulator register e / (2 CB) of
+                // (source tile e & 1, cell block (e >> 1) % CB); position tag = step << 5 | cell block << 4 | register
+                peaks_static_for<q * NINS / NSLOT, (q + 1) * NINS / NSLOT>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, e = i >> 3, lt = e & 1, lcb = (e >> 1) % CB, lr = e / (2 * CB);
+                    if (!(VAR & 1) || e == 0) top_push_op<(i & 7)>(v[lt], accP[lcb][lt][lr], ib | (lcb << 4) | lr, keys[lt]);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
         };
-        auto epi = [&](const f16v (&acc)[2], int np) {
+        auto epi = [&](const f16v (&acc)[CB][2], int np) {
+            mfma_settle();
 #pragma unroll
             for (int r = 0; r < 16; ++r)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) top_push(v[t], make_key(acc[t][r], (np << 4) | r));
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) top_push_value(v[t], acc[cb][t][r], (np << TSH) | (cb << 4) | r);
         };
-        f16v accA[2], accB[2];
+        f16v accA[CB][2], accB[CB][2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) accB[t][r] = 0.f;
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accB[cb][t][r] = 0.f;
         // three LDS buffers, tiles requested two steps ahead (an L2 miss takes longer than one step): at the end of step
-        // n the tile of step n+1 must have landed while the LQ requests of step n+2 stay in flight -> vmcnt(LQ).  Tiles past
+        // n the tile of step n+1 must have landed while the requests of step n+2 stay in flight -> vmcnt(LQ CB).  Tiles past
         // the end are clamped to the last one (never read), which keeps that count uniform.
         issue(0, 0);
         issue(min(1, NT - 1), 1);
-        glds_wait<LQ>();
+        glds_wait<LQ * CB>();
         __syncthreads();
         int n = 0, b0 = 0;  // b0 = n % 3
         for (; n + 1 < NT; n += 2) {
             const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
             issue(min(n + 2, NT - 1), b2);
             step(b0, accA, accB, max(n - 1, 0));  // first step: accB = 0, pushes zeros
-            glds_wait<LQ>();
+            glds_wait<LQ * CB>();
             __syncthreads();
             issue(min(n + 3, NT - 1), b0);
             step(b1, accB, accA, n);
-            glds_wait<LQ>();
+            glds_wait<LQ * CB>();
             __syncthreads();
             b0 = b2;
         }
@@ -618,8 +669,8 @@ __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_
                     const int xi = k < PK_TOP ? v[t][k] : o[k - PK_TOP];
                     if (xi >= thr) {
                         const int tag = xi & ((1 << PK_IDX_BITS) - 1);
-                        const int r = tag & 15, st = tag >> 4;
-                        const int pc = st * PK_CELLS + 8 * (r >> 2) + 2 * (r & 3) +
+                        const int r = tag & 15, cb = CB > 1 ? (tag >> 4) & 1 : 0, st = tag >> TSH;
+                        const int pc = st * PK_CELLS + cb * 32 + 8 * (r >> 2) + 2 * (r & 3) +
                                        ((k < PK_TOP ? 0 : 1) ^ ((st / tiles_per_row) & 1));
                         const int row = pc / PWP, col = pc - row * PWP;
                         if (nc < KC) rr->cand[nc] = row * g.pw + min(col, g.pw - 1);
@@ -1541,23 +1592,46 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
     for (long long s0 = 0; s0 < M; s0 += L.super) {
         const int scnt = (int)((M - s0) < L.super ? (M - s0) : L.super);
         // source-stationary fused correlation + selection (C = 384, position tags of 13 bits)
-        const bool peaks = fast && g->C == 384 && L.HWp / PK_CELLS <= (1 << (PK_IDX_BITS - 4)) && !DTK_DBG(dbg, 2048);
+        const int pk_cb = DTK_DBG(dbg, 65536) ? 2 : PK_CB, pk_cells = 32 * pk_cb;
+        const bool peaks = fast && g->C == 384 && L.HWp / pk_cells <= (1 << (PK_IDX_BITS - (pk_cb > 1 ? 5 : 4))) &&
+                           L.HWp % pk_cells == 0 && pw_pad(g->pw) % pk_cells == 0 && !DTK_DBG(dbg, 2048) &&
+                           (long long)g->T * L.HWp * g->C * 2 < (1LL << 32);   // (32-bit tile offsets of the LDS-DMA descriptor)
         if (peaks) {
             DTK_LAUNCH("src16", src16_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, emb, in.src_row, s16, (int)s0, scnt, M,
                        nodm, g->C, PK_SRC_SCALE);
             const dim3 pgrid(dtk_cdiv(scnt, PK_SRC));
-#define DTK_PEAKS(V)                                                                                                   \
-    DTK_LAUNCH("corr_peaks", (corr_peaks_kernel<24, V>), pgrid, dim3(256), 0, st, *g, f16, s16, in.tgt, rec, (int)s0, scnt, L.HWp)
+#define DTK_PEAKS(V, CBV)                                                                                                    \
+    do {                                                                                                                     \
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_peaks_kernel<24, V, CBV>),  \
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize,                      \
+                                                            (int)peaks_lds_bytes(CBV));                                      \
+        DTK_HIP(attr_);                                                                                                      \
+        DTK_LAUNCH("corr_peaks", (corr_peaks_kernel<24, V, CBV>), pgrid, dim3(256), peaks_lds_bytes(CBV), st, *g, f16, s16,  \
+                   in.tgt, rec, (int)s0, scnt, L.HWp);                                                                       \
+    } while (0)
 #ifdef DTK_DEV
-            switch ((dbg >> 13) & 7) {
-                case 0: DTK_PEAKS(0); break;
-                case 1: DTK_PEAKS(1); break;
-                case 2: DTK_PEAKS(2); break;
-                case 4: DTK_PEAKS(4); break;
-                default: DTK_PEAKS(7); break;
+            if (pk_cb == 2) {
+                switch ((dbg >> 13) & 7) {
+                    case 0: DTK_PEAKS(0, 2); break;
+                    case 1: DTK_PEAKS(1, 2); break;
+                    case 2: DTK_PEAKS(2, 2); break;
+                    case 4: DTK_PEAKS(4, 2); break;
+                    default: DTK_PEAKS(7, 2); break;
+                }
+            } else {
+                switch ((dbg >> 13) & 7) {
+                    case 0: DTK_PEAKS(0, PK_CB); break;
+                    case 1: DTK_PEAKS(1, PK_CB); break;
+                    case 2: DTK_PEAKS(2, PK_CB); break;
+                    case 3: DTK_PEAKS(3, PK_CB); break;
+                    case 4: DTK_PEAKS(4, PK_CB); break;
+                    case 5: DTK_PEAKS(5, PK_CB); break;
+                    case 6: DTK_PEAKS(6, PK_CB); break;
+                    default: DTK_PEAKS(7, PK_CB); break;
+                }
             }
 #else
-            DTK_PEAKS(0);
+            DTK_PEAKS(0, PK_CB);
 #endif
 #undef DTK_PEAKS
         }

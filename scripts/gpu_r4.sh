@@ -35,6 +35,10 @@ PY
       DTK_P2_OPERANDS=fp16 timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_p2fp16.json 2> gpurun_out/bench_p2fp16.err; cat gpurun_out/bench_p2fp16.json; tail -3 gpurun_out/bench_p2fp16.err ;;
     bench_full)
       timeout 1200 python bench.py > gpurun_out/bench_full.json 2> gpurun_out/bench_full.err; cat gpurun_out/bench_full.json; tail -3 gpurun_out/bench_full.err ;;
+    peaks_abl)
+      # corr_peaks ablations need the development switches: DEV build on the box (the shipped library has none)
+      make -C dino_tracker_amd/csrc -B DEV=1 -j16 > gpurun_out/make_dev.log 2>&1 || { tail -5 gpurun_out/make_dev.log; continue; }
+      for d in 0 8192 16384 32768 24576 40960 49152 57344; do DTK_DEBUG=$d python scripts/prof_peaks.py 30 2097152 2>&1 | tail -1; done | tee gpurun_out/peaks_abl.log ;;
     twin)
       timeout 2400 python -m pytest tests/test_gpu_train.py -m gpu -q -s -k "twin or reference_order" 2>&1 | tail -40 > gpurun_out/pytest_twin.log; tail -30 gpurun_out/pytest_twin.log ;;
     tests)
