@@ -483,12 +483,12 @@ __device__ __forceinline__ void peaks_static_for(F&& f) {
     }
 }
 
-// LDS-DMA requests I .. N-1 of a tile: request I covers k-step (w LQ + I / CB), cell block I % CB (see the kernel)
-template <int I, int N, int CB, int C>
+// LDS-DMA requests I .. N-1 of a tile for one wave: request I = (cell block I / NL, cache line I % NL of a cell's 768-byte row)
+template <int I, int N, int NL, int C>
 __device__ __forceinline__ void peaks_dma(dtk_u4 srd, unsigned toff, unsigned voff, unsigned dst) {
     if constexpr (I < N) {
-        dtk_buffer_lds16<I * 1024>(srd, toff + (unsigned)((I / CB) * 32 + (I % CB) * 32 * C * 2), voff, dst);
-        peaks_dma<I + 1, N, CB, C>(srd, toff, voff, dst);
+        dtk_buffer_lds16<I * 4096>(srd, toff + (unsigned)((I % NL) * 128 + (I / NL) * 32 * C * 2), voff, dst);
+        peaks_dma<I + 1, N, NL, C>(srd, toff, voff, dst);
     }
 }
 
@@ -543,22 +543,40 @@ __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_
     __syncthreads();
     const int fmin = min(min(s_fr[0], s_fr[1]), min(s_fr[2], s_fr[3]));
     const int fmax = max(max(s_fr[4], s_fr[5]), max(s_fr[6], s_fr[7]));
-    // loader: wave w fills k-steps w*KS/4 .. of the tile; lane l' fetches cell c(l' & 31) of each 32-cell block, k-half l' >> 5,
-    // where MFMA row i = 8a + 4p + b carries cell 8a + 2b + p
-    // (on odd map rows the two halves swap: a peak's vertical neighbours split between the lists as well)
-    const int lcell = 8 * (j >> 3) + 2 * (j & 3) + ((j >> 2) & 1);
+    // The LDS image of a 32-cell block, chosen so that ONE LDS-DMA request touches 8 cache lines instead of 32 (a VMEM
+    // instruction costs the issuing wave one address-unit slot per cache line: DESIGN section 3; round 1-3's image
+    // [k-step][k-half][cell] made every request gather 32 B from each of 32 cells and cost a lone wave ~136 cycles of issue):
+    //   [line L of a cell's row: 64 k-values = 4 k-steps][position pos of the cell][8 pieces of 16 B]      (NL x 32 x 128 B)
+    // a cell's 128-byte line stays contiguous, so the 64 lanes of a request fetch 8 whole lines (lane l: line of position
+    // 8 w + (l >> 3), piece slot l & 7).  For the fragment reads to be conflict-free (ds_read_b128 serves lane groups of 16:
+    // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32; the 16 pieces of a group must fall into 16 distinct 16-byte
+    // bank slots) MFMA row j sits at position pi(j) = (j & 16) | (j & 7) << 1 | (j >> 3) & 1 and its pieces are XOR-swizzled by
+    // j & 7: slot = (piece & 7) ^ (j & 7) -- through the SOURCE address of the DMA, whose LDS side is lane-linear.
+    // MFMA row i = 8a + 4p + b carries cell 8a + 2b + p of the block (on odd map rows the two lane halves swap: a peak's
+    // vertical neighbours split between the lists as well).
+    constexpr int NL = KS / 4;                   // 128-byte lines per cell
     const int tiles_per_row = pw_pad(g.pw) / PK_CELLS;
-    constexpr int LQ = KS / 4;
     const unsigned lds_base = (unsigned)(size_t)cells;
     const int NT = HWp / PK_CELLS;
     const int band = (int)(EPS_PK * (float)(1 << PK_VAL_BITS)) << PK_IDX_BITS;
-    // LDS-DMA through a buffer descriptor over the fp16 volume (common.h): per-lane byte offset of (cell, k-piece) inside a
-    // 32-cell block -- one for even map rows, one for odd ones --, scalar offset = tile + request, LDS destination = scalar +
-    // immediate.  LDS image of a tile: [k-step][cell block][lane (k-half, MFMA row)][16 B]
     const dtk_u4 srd = dtk_make_srd(f16);
-    const unsigned voff_even = (unsigned)((lcell * C + (w * LQ) * 16 + h * 8) * 2);
-    const unsigned voff_odd = (unsigned)(((lcell ^ 1) * C + (w * LQ) * 16 + h * 8) * 2);
-    const unsigned dma_dst = __builtin_amdgcn_readfirstlane(lds_base + (w * LQ) * CB * 1024);
+    unsigned voff_even, voff_odd;
+    {
+        const int pos = 8 * w + (lane >> 3), slot = lane & 7;
+        const int jr = (pos & 16) | ((pos >> 1) & 7) | ((pos & 1) << 3);      // the MFMA row whose cell sits at `pos`
+        const int cell = 8 * (jr >> 3) + 2 * (jr & 3) + ((jr >> 2) & 1);
+        const int piece = slot ^ (jr & 7);                                      // piece (within the line) that lands in `slot`
+        voff_even = (unsigned)(cell * C * 2 + piece * 16);
+        voff_odd = (unsigned)((cell ^ 1) * C * 2 + piece * 16);
+    }
+    const unsigned dma_dst = __builtin_amdgcn_readfirstlane(lds_base + w * 1024);
+    // fragment addresses of lane (j, h): k-step ks -> line ks >> 2 (an immediate), piece 2 (ks & 3) + h inside it
+    unsigned frag_off[4];
+    {
+        const int pi = (j & 16) | ((j & 7) << 1) | ((j >> 3) & 1);
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) frag_off[k4] = (unsigned)(pi * 128 + (((2 * k4 + h) ^ (j & 7)) << 4));
+    }
     for (int f = fmin; f <= fmax; ++f) {
         // tiles are requested in order (0, 1, 2, ...; past the end the last one again): the scalar offset of the next tile and
         // the parity of its map row advance incrementally (a division by the runtime tiles-per-row costs ~15 SALU instructions)
@@ -568,7 +586,7 @@ __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_
             if ((VAR & 2) && n > 1) return;
             const unsigned voff = next_odd ? voff_odd : voff_even;
             const unsigned dst = __builtin_amdgcn_readfirstlane(dma_dst + (unsigned)buf * (unsigned)TILE_BYTES);
-            peaks_dma<0, LQ * CB, CB, C>(srd, next_off, voff, dst);
+            peaks_dma<0, NL * CB, NL, C>(srd, next_off, voff, dst);
             if (next_n + 1 < NT) {   // (n == next_n except for the clamped repeats of the last tile)
                 ++next_n;
                 next_off += (unsigned)(PK_CELLS * C * 2);
@@ -583,19 +601,24 @@ __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_
         // one step: the MFMAs of the tile in `buf` into accN[cell block][source tile], interleaved with the list updates of
         // the previous tile's accP (step index np)
         auto step = [&](int buf, f16v (&accN)[CB][2], const f16v (&accP)[CB][2], int np) {
-            const unsigned char* base = cells + (size_t)buf * TILE_BYTES + lane * 16;
+            const unsigned char* base = cells + (size_t)buf * TILE_BYTES;
+            // fragment fr = (k-step fr / CB, cell block fr % CB)
+            auto frag = [&](int fr) {
+                const int ks = fr / CB, cb = fr % CB;
+                return *reinterpret_cast<const h8*>(base + frag_off[ks & 3] + (cb * NL + (ks >> 2)) * 4096);
+            };
             const int ib = np << TSH;
             int keys[2] = {0, 0};   // the key of the value whose insertion is in flight (one per source tile at most)
             h8 a[3];
-            a[0] = *reinterpret_cast<const h8*>(base);
-            a[1] = *reinterpret_cast<const h8*>(base + 1024);
+            a[0] = frag(0);
+            a[1] = frag(1);
             constexpr int NF = KS * CB;          // A fragments of the tile: fragment fr = k-step fr / CB, cell block fr % CB
             constexpr int NSLOT = 2 * NF, NINS = 32 * CB * 8;   // MFMA slots; list instructions (32 CB values x 8)
             // (compile-time recursion instead of `#pragma unroll`: at 96 slots the unroller gives up and the accumulators'
             // indices become run-time -- scratch memory)
             peaks_static_for<0, NSLOT>([&](auto qc) {
                 constexpr int q = decltype(qc)::value, fr = q / 2, t = q % 2, ks = fr / CB, cb = fr % CB;
-                if (t == 0 && fr + 2 < NF && !(VAR & 4)) a[(fr + 2) % 3] = *reinterpret_cast<const h8*>(base + (fr + 2) * 1024);
+                if (t == 0 && fr + 2 < NF && !(VAR & 4)) a[(fr + 2) % 3] = frag(fr + 2);
                 mfma_b_agpr(accN[cb][t], a[fr % 3], bs[t][ks], ks == 0);
                 // the list instructions of the previous tile, spread evenly over the MFMA slots: slot q issues instructions
                 // [NINS q / NSLOT, NINS (q + 1) / NSLOT) of the stream; value e = index / 8 is accumulator register e / (2 CB) of
@@ -628,18 +651,18 @@ __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_
         // the end are clamped to the last one (never read), which keeps that count uniform.
         issue(0, 0);
         issue(min(1, NT - 1), 1);
-        glds_wait<LQ * CB>();
+        glds_wait<NL * CB>();
         __syncthreads();
         int n = 0, b0 = 0;  // b0 = n % 3
         for (; n + 1 < NT; n += 2) {
             const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
             issue(min(n + 2, NT - 1), b2);
             step(b0, accA, accB, max(n - 1, 0));  // first step: accB = 0, pushes zeros
-            glds_wait<LQ * CB>();
+            glds_wait<NL * CB>();
             __syncthreads();
             issue(min(n + 3, NT - 1), b0);
             step(b1, accB, accA, n);
-            glds_wait<LQ * CB>();
+            glds_wait<NL * CB>();
             __syncthreads();
             b0 = b2;
         }

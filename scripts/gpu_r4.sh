@@ -38,7 +38,7 @@ PY
     peaks_abl)
       # corr_peaks ablations need the development switches: DEV build on the box (the shipped library has none)
       make -C dino_tracker_amd/csrc -B DEV=1 -j16 > gpurun_out/make_dev.log 2>&1 || { tail -5 gpurun_out/make_dev.log; continue; }
-      for d in 0 8192 16384 32768 24576 40960 49152 57344; do DTK_DEBUG=$d python scripts/prof_peaks.py 30 2097152 2>&1 | tail -1; done | tee gpurun_out/peaks_abl.log ;;
+      for d in 0 8192 16384 32768 24576 40960 49152 57344 65536 73728; do DTK_DEBUG=$d python scripts/prof_peaks.py 30 2097152 2>&1 | tail -1; done | tee gpurun_out/peaks_abl.log ;;
     twin)
       timeout 2400 python -m pytest tests/test_gpu_train.py -m gpu -q -s -k "twin or reference_order" 2>&1 | tail -40 > gpurun_out/pytest_twin.log; tail -30 gpurun_out/pytest_twin.log ;;
     tests)
