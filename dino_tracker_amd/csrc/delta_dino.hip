@@ -138,6 +138,7 @@ struct SplitCfg {
     static constexpr int WPT = 16;
     static constexpr int W_HALVES = 5 * 64 * WPT;
     static constexpr size_t LDS_BYTES = (size_t)(2 * X_HALVES + 2 * W_HALVES) * sizeof(half_t);
+    static constexpr size_t LDS_BYTES_SINGLE = (size_t)(X_HALVES + W_HALVES) * sizeof(half_t);   // hi planes only
     static_assert(PX <= PXP, "patch wider than the padded LDS row");
 };
 
@@ -152,9 +153,10 @@ __global__ __launch_bounds__(256, 3) void conv5x5_split_kernel(const half_t* __r
     typedef SplitCfg<DIL> Cfg;
     constexpr int PY = Cfg::PY, PX = Cfg::PX, PXP = Cfg::PXP;
     extern __shared__ __attribute__((aligned(16))) half_t smem_s[];
+    // (SINGLE: the hi planes only -- half the LDS, the lo operands are neither staged nor read; in_lo / Wl / out_lo unused)
     half_t* Xh = smem_s;                       // [PY][PXP][SPT]
     half_t* Xl = Xh + Cfg::X_HALVES;
-    half_t* Wsh = Xl + Cfg::X_HALVES;          // [5 taps][64 cout][SPT]
+    half_t* Wsh = SINGLE ? Xl : Xl + Cfg::X_HALVES;   // [5 taps][64 cout][SPT]
     half_t* Wsl = Wsh + Cfg::W_HALVES;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int tile_id = blockIdx.x, ct = blockIdx.y;  // pixel tile of the frame, 64-cout tile
@@ -189,32 +191,47 @@ __global__ __launch_bounds__(256, 3) void conv5x5_split_kernel(const half_t* __r
     // weights of one tap row (5 taps x 64 cout x 2 pieces, both planes = 5 x 16 bytes per thread) travel through
     // registers one stage ahead, so that their L2 latency hides behind the MFMAs of the current row
     // (macros with named registers: an array captured by a lambda ends up in scratch memory)
+    // SINGLE: 5 taps x 64 cout x 2 pieces of the hi plane = 640 pieces of 16 bytes: three per thread (the third for tid < 128)
     uint4 wr0, wr1, wr2, wr3, wr4;
 #define DD_WSRC(i) (((tid & 1) ? Wl : Wh) + wbase_ + (size_t)((tid + (i) * 256) >> 2) * SK + ((tid >> 1) & 1) * 8)
 #define DD_WDST(i) (((tid & 1) ? Wsl : Wsh) + ((tid + (i) * 256) >> 2) * Cfg::WPT + ((tid >> 1) & 1) * 8)
+#define DD_WSRC1(i) (Wh + wbase_ + (size_t)((tid + (i) * 256) >> 1) * SK + (tid & 1) * 8)
+#define DD_WDST1(i) (Wsh + ((tid + (i) * 256) >> 1) * Cfg::WPT + (tid & 1) * 8)
 #define wload(ck_, ky_)                                                                          \
     do {                                                                                         \
         const size_t wbase_ = ((((size_t)ct * nck + (ck_)) * 25) + (ky_) * 5) * 64 * SK;         \
-        wr0 = *reinterpret_cast<const uint4*>(DD_WSRC(0));                                       \
-        wr1 = *reinterpret_cast<const uint4*>(DD_WSRC(1));                                       \
-        wr2 = *reinterpret_cast<const uint4*>(DD_WSRC(2));                                       \
-        wr3 = *reinterpret_cast<const uint4*>(DD_WSRC(3));                                       \
-        wr4 = *reinterpret_cast<const uint4*>(DD_WSRC(4));                                       \
+        if (SINGLE) {                                                                            \
+            wr0 = *reinterpret_cast<const uint4*>(DD_WSRC1(0));                                  \
+            wr1 = *reinterpret_cast<const uint4*>(DD_WSRC1(1));                                  \
+            if (tid < 128) wr2 = *reinterpret_cast<const uint4*>(DD_WSRC1(2));                   \
+        } else {                                                                                 \
+            wr0 = *reinterpret_cast<const uint4*>(DD_WSRC(0));                                   \
+            wr1 = *reinterpret_cast<const uint4*>(DD_WSRC(1));                                   \
+            wr2 = *reinterpret_cast<const uint4*>(DD_WSRC(2));                                   \
+            wr3 = *reinterpret_cast<const uint4*>(DD_WSRC(3));                                   \
+            wr4 = *reinterpret_cast<const uint4*>(DD_WSRC(4));                                   \
+        }                                                                                        \
     } while (0)
 #define wstore()                                                                                 \
     do {                                                                                         \
-        *reinterpret_cast<uint4*>(DD_WDST(0)) = wr0;                                             \
-        *reinterpret_cast<uint4*>(DD_WDST(1)) = wr1;                                             \
-        *reinterpret_cast<uint4*>(DD_WDST(2)) = wr2;                                             \
-        *reinterpret_cast<uint4*>(DD_WDST(3)) = wr3;                                             \
-        *reinterpret_cast<uint4*>(DD_WDST(4)) = wr4;                                             \
+        if (SINGLE) {                                                                            \
+            *reinterpret_cast<uint4*>(DD_WDST1(0)) = wr0;                                        \
+            *reinterpret_cast<uint4*>(DD_WDST1(1)) = wr1;                                        \
+            if (tid < 128) *reinterpret_cast<uint4*>(DD_WDST1(2)) = wr2;                         \
+        } else {                                                                                 \
+            *reinterpret_cast<uint4*>(DD_WDST(0)) = wr0;                                         \
+            *reinterpret_cast<uint4*>(DD_WDST(1)) = wr1;                                         \
+            *reinterpret_cast<uint4*>(DD_WDST(2)) = wr2;                                         \
+            *reinterpret_cast<uint4*>(DD_WDST(3)) = wr3;                                         \
+            *reinterpret_cast<uint4*>(DD_WDST(4)) = wr4;                                         \
+        }                                                                                        \
     } while (0)
     wload(0, 0);
     for (int ck = 0; ck < nck; ++ck) {
         __syncthreads();
         // input patch, both planes: PY*PX pixels x 2 pieces of 8 cin
-        for (int idx = tid; idx < PY * PX * 4; idx += 256) {
-            const int plane = idx & 1, piece = (idx >> 1) & 1, p = idx >> 2;
+        for (int idx = tid; idx < PY * PX * (SINGLE ? 2 : 4); idx += 256) {
+            const int plane = SINGLE ? 0 : idx & 1, piece = SINGLE ? idx & 1 : (idx >> 1) & 1, p = SINGLE ? idx >> 1 : idx >> 2;
             const int py = p / PX, px = p - py * PX;
             const int iy = y0 - 2 * DIL + py, ix = x0 - 2 * DIL + px;
             const int gy = reflect(iy, H), gx = reflect(ix, W);
@@ -238,13 +255,14 @@ __global__ __launch_bounds__(256, 3) void conv5x5_split_kernel(const half_t* __r
                 for (int m = 0; m < 2; ++m) {
                     const int p = (ly + ky * DIL) * PXP + m * 8 + lx + kx * DIL;
                     xh[m] = *reinterpret_cast<const h8*>(Xh + p * Cfg::XPT + hi * 8);
-                    xl[m] = *reinterpret_cast<const h8*>(Xl + p * Cfg::XPT + hi * 8);
+                    if (!SINGLE) xl[m] = *reinterpret_cast<const h8*>(Xl + p * Cfg::XPT + hi * 8);
                 }
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     const int wr = (kx * 64 + n * 32 + li) * Cfg::WPT + hi * 8;
                     const h8 wh = *reinterpret_cast<const h8*>(Wsh + wr);
-                    const h8 wl = *reinterpret_cast<const h8*>(Wsl + wr);
+                    h8 wl = wh;
+                    if (!SINGLE) wl = *reinterpret_cast<const h8*>(Wsl + wr);
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         if (!SINGLE) {
@@ -261,6 +279,8 @@ __global__ __launch_bounds__(256, 3) void conv5x5_split_kernel(const half_t* __r
 #undef wstore
 #undef DD_WSRC
 #undef DD_WDST
+#undef DD_WSRC1
+#undef DD_WDST1
     // D[i][j]: j = lane&31 (cout), i = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel of the M-tile's 4 x 8 block)
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -280,7 +300,7 @@ __global__ __launch_bounds__(256, 3) void conv5x5_split_kernel(const half_t* __r
                     if (OUT_SPLIT) {
                         const half_t vh = (half_t)v;
                         out_hi[o] = vh;
-                        out_lo[o] = (half_t)(v - (float)vh);
+                        if (!SINGLE) out_lo[o] = (half_t)(v - (float)vh);
                     } else {
                         out_f32[o] = v;
                     }
@@ -333,10 +353,13 @@ __global__ void pack_conv1_split_kernel(const float* __restrict__ w, half_t* __r
     Wl[idx] = (half_t)(v - (float)h);
 }
 
+// (SINGLE: plain fp16 operands -- the hi planes only, one product per term -- and an fp16 NHWC output)
+template <bool SINGLE>
 __global__ __launch_bounds__(256) void conv1_split_kernel(const h4v* __restrict__ in_hi, const h4v* __restrict__ in_lo,
                                                           const half_t* __restrict__ Wh, const half_t* __restrict__ Wl,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
-                                                          float* __restrict__ out, int H, int W, int tiles_x) {
+                                                          float* __restrict__ out, half_t* __restrict__ out16, int H, int W,
+                                                          int tiles_x) {
     constexpr int PY = C1_TY + 4, PX = C1_TX + 4;
     __shared__ h4v Xh[PY * PX], Xl[PY * PX];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -352,7 +375,7 @@ __global__ __launch_bounds__(256) void conv1_split_kernel(const h4v* __restrict_
         for (int ks = 0; ks < C1_KS; ++ks) {
             const size_t o = (size_t)(n * 32 + li) * C1_K + ks * 16 + hh * 8;
             wh[n][ks] = *reinterpret_cast<const h8*>(Wh + o);
-            wl[n][ks] = *reinterpret_cast<const h8*>(Wl + o);
+            if (!SINGLE) wl[n][ks] = *reinterpret_cast<const h8*>(Wl + o);
         }
     const h4v* fh = in_hi + frame * (size_t)H * W;
     const h4v* fl = in_lo + frame * (size_t)H * W;
@@ -360,7 +383,7 @@ __global__ __launch_bounds__(256) void conv1_split_kernel(const h4v* __restrict_
         const int py = idx / PX, px = idx - py * PX;
         const size_t g = (size_t)reflect(y0 - 2 + py, H) * W + reflect(x0 - 2 + px, W);
         Xh[idx] = fh[g];
-        Xl[idx] = fl[g];
+        if (!SINGLE) Xl[idx] = fl[g];
     }
     __syncthreads();
     const int ly = w * 4 + (li >> 3), lx = li & 7;  // this lane's pixel (row of the A operand)
@@ -374,13 +397,19 @@ __global__ __launch_bounds__(256) void conv1_split_kernel(const h4v* __restrict_
         // the 8 k values of this lane: taps t0 = 2 (2 ks + hh) and t0 + 1 (taps >= 25 carry zero weights: any valid pixel)
         const int t0 = min(4 * ks + 2 * hh, 24), t1 = min(4 * ks + 2 * hh + 1, 24);
         const int p0 = (ly + t0 / 5) * PX + lx + t0 % 5, p1 = (ly + t1 / 5) * PX + lx + t1 % 5;
-        const h4v a0 = Xh[p0], a1 = Xh[p1], b0 = Xl[p0], b1 = Xl[p1];
+        const h4v a0 = Xh[p0], a1 = Xh[p1];
         const h8 xh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        const h8 xl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        h8 xl = xh;
+        if (!SINGLE) {
+            const h4v b0 = Xl[p0], b1 = Xl[p1];
+            xl = h8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        }
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh[n][ks], acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl[n][ks], acc[n], 0, 0, 0);
+            if (!SINGLE) {
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh[n][ks], acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl[n][ks], acc[n], 0, 0, 0);
+            }
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh[n][ks], acc[n], 0, 0, 0);
         }
     }
@@ -393,7 +422,12 @@ __global__ __launch_bounds__(256) void conv1_split_kernel(const h4v* __restrict_
         for (int r = 0; r < 16; ++r) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;
             const int oy = y0 + w * 4 + (i >> 3), ox = x0 + (i & 7);
-            if (oy < H && ox < W) out[(frame * (size_t)H * W + (size_t)oy * W + ox) * 64 + co] = fmaxf(acc[n][r] * sc + sh, 0.f);
+            if (oy < H && ox < W) {
+                const size_t o = (frame * (size_t)H * W + (size_t)oy * W + ox) * 64 + co;
+                const float v = fmaxf(acc[n][r] * sc + sh, 0.f);
+                if (SINGLE) out16[o] = (half_t)v;
+                else out[o] = v;
+            }
         }
     }
 }
@@ -438,6 +472,41 @@ __global__ __launch_bounds__(256) void blurpool_split_kernel(const half_t* __res
     const size_t oo = frame * (size_t)Ho * Wo * C + ((size_t)oy * Wo + ox) * C + cq * 8;
     *reinterpret_cast<h8*>(out_hi + oo) = oh;
     *reinterpret_cast<h8*>(out_lo + oo) = ol;
+}
+
+// NHWC blur-pool on one fp16 plane (the fp16 operand mode: every activation is a single fp16 NHWC plane): one thread per
+// (output pixel, 8 channels); fp32 accumulation of the 16 taps
+__global__ __launch_bounds__(256) void blurpool_half_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int H, int W,
+                                                            int Ho, int Wo, int C) {
+    const size_t frame = blockIdx.y;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c8 = C / 8;
+    if (idx >= (long long)Ho * Wo * c8) return;
+    const int cq = (int)(idx % c8);
+    const int p = (int)(idx / c8);
+    const int oy = p / Wo, ox = p - oy * Wo;
+    const half_t* fin = in + frame * (size_t)H * W * C;
+    const float f[4] = {1.f, 3.f, 3.f, 1.f};
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gy = reflect(2 * oy - 1 + i, H);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gx = reflect(2 * ox - 1 + j, W);
+            const float wgt = f[i] * f[j] * (1.f / 64.f);
+            const uint4 u = *reinterpret_cast<const uint4*>(fin + ((size_t)gy * W + gx) * C + cq * 8);
+            const h8 v = *reinterpret_cast<const h8*>(&u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(wgt, (float)v[e], acc[e]);
+        }
+    }
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[e];
+    *reinterpret_cast<h8*>(out + frame * (size_t)Ho * Wo * C + ((size_t)oy * Wo + ox) * C + cq * 8) = o;
 }
 
 // NHWC blur-pool of the fp32 first-layer output, written as split planes: one thread per (output pixel, 4 channels)
@@ -719,15 +788,18 @@ extern "C" int dtk_delta_dino_refine_mode(const dtk_geom* g, const float* video,
                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5x5_split_kernel<2, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitCfg<2>::LDS_BYTES) == hipSuccess &&
                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5x5_split_kernel<1, true, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitCfg<1>::LDS_BYTES) == hipSuccess &&
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitCfg<1>::LDS_BYTES_SINGLE) == hipSuccess &&
                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5x5_split_kernel<2, false, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitCfg<2>::LDS_BYTES) == hipSuccess;
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)SplitCfg<2>::LDS_BYTES_SINGLE) == hipSuccess;
     }();
     DTK_REQUIRE(lds_ok, "dtk_delta_dino_refine: cannot reserve LDS for the split-fp16 convolution");
     for (int f0 = t0; f0 < t0 + nframes; f0 += fb) {
         const int nf = (t0 + nframes - f0) < fb ? (t0 + nframes - f0) : fb;
         const float* cur = video + (size_t)f0 * 3 * g->video_h * g->video_w;
         const bool split = !dd_force_f32();
+        // DTK_DD_FP16 (`single`): every activation is ONE fp16 NHWC plane (the first half of its fp32-sized slot) and every
+        // product one MFMA: the lo halves are neither written, staged nor multiplied.  The last layer's output stays fp32.
+        const bool half_path = single && split;
         for (int l = 0; l < 4; ++l) {
             const int H = p.H[l], W = p.W[l], cin = p.Cin[l], cout = p.Cout[l];
             const int cinp = pad_to(cin, CK), coutp = pad_to(cout, TNC);
@@ -745,8 +817,13 @@ extern "C" int dtk_delta_dino_refine_mode(const dtk_geom* g, const float* video,
                            npix);
                 const half_t* Wh = reinterpret_cast<const half_t*>(Wk + f32_packed_floats(cinp, coutp));
                 const int tiles_x = dtk_cdiv(W, C1_TX), tiles_y = dtk_cdiv(H, C1_TY);
-                DTK_LAUNCH("dd_conv1", conv1_split_kernel, dim3(tiles_x * tiles_y, 1, nf), dim3(256), 0, st, vh, vl, Wh,
-                           Wh + 64 * C1_K, scale, shift, act, H, W, tiles_x);
+                if (half_path) {
+                    DTK_LAUNCH("dd_conv1", conv1_split_kernel<true>, dim3(tiles_x * tiles_y, 1, nf), dim3(256), 0, st, vh, vl, Wh,
+                               Wh + 64 * C1_K, scale, shift, (float*)nullptr, reinterpret_cast<half_t*>(act), H, W, tiles_x);
+                } else {
+                    DTK_LAUNCH("dd_conv1", conv1_split_kernel<false>, dim3(tiles_x * tiles_y, 1, nf), dim3(256), 0, st, vh, vl, Wh,
+                               Wh + 64 * C1_K, scale, shift, act, (half_t*)nullptr, H, W, tiles_x);
+                }
             } else if (l == 0 || !split) {
                 const int tiles_x = dtk_cdiv(W, TP), tiles_y = dtk_cdiv(H, TP);
                 dim3 grid(tiles_x * tiles_y, coutp / TNC, nf);
@@ -768,11 +845,11 @@ extern "C" int dtk_delta_dino_refine_mode(const dtk_geom* g, const float* video,
                 const int tiles_x = dtk_cdiv(W, STX), tiles_y = dtk_cdiv(H, STY);
                 dim3 grid(tiles_x * tiles_y, (cout + 63) / 64, nf);
                 if (l < 3 && single) {
-                    DTK_LAUNCH("dd_conv23", (conv5x5_split_kernel<1, true, true>), grid, dim3(256), SplitCfg<1>::LDS_BYTES, st, ih,
-                               ih + in_n, Wh, Wl, scale, shift, oh, oh + out_n, (float*)nullptr, H, W, cin, cout, 1, tiles_x, 0, 0);
+                    DTK_LAUNCH("dd_conv23", (conv5x5_split_kernel<1, true, true>), grid, dim3(256), SplitCfg<1>::LDS_BYTES_SINGLE,
+                               st, ih, ih, Wh, Wl, scale, shift, oh, oh, (float*)nullptr, H, W, cin, cout, 1, tiles_x, 0, 0);
                 } else if (single) {
-                    DTK_LAUNCH("dd_conv4", (conv5x5_split_kernel<2, false, true>), grid, dim3(256), SplitCfg<2>::LDS_BYTES, st, ih,
-                               ih + in_n, Wh, Wl, scale, shift, (half_t*)nullptr, (half_t*)nullptr, act, H, W, cin, cout, 0,
+                    DTK_LAUNCH("dd_conv4", (conv5x5_split_kernel<2, false, true>), grid, dim3(256), SplitCfg<2>::LDS_BYTES_SINGLE,
+                               st, ih, ih, Wh, Wl, scale, shift, (half_t*)nullptr, (half_t*)nullptr, act, H, W, cin, cout, 0,
                                tiles_x, 0, 0);
                 } else if (l < 3) {
                     DTK_LAUNCH("dd_conv23", (conv5x5_split_kernel<1, true>), grid, dim3(256), SplitCfg<1>::LDS_BYTES, st, ih,
@@ -792,6 +869,10 @@ extern "C" int dtk_delta_dino_refine_mode(const dtk_geom* g, const float* video,
                     const long long n = (long long)Ho * Wo * (cout / 4);
                     DTK_LAUNCH("dd_blurpool", blurpool_kernel, dim3(dtk_cdiv(n, 256), nf), dim3(256), 0, st, act, pl, H, W,
                                Ho, Wo, cout);
+                } else if (half_path) {
+                    const long long n = (long long)Ho * Wo * (cout / 8);
+                    DTK_LAUNCH("dd_blurpool", blurpool_half_kernel, dim3(dtk_cdiv(n, 256), nf), dim3(256), 0, st,
+                               reinterpret_cast<const half_t*>(act), reinterpret_cast<half_t*>(pl), H, W, Ho, Wo, cout);
                 } else if (l == 0) {
                     const long long n = (long long)Ho * Wo * (cout / 4);
                     half_t* ph_ = reinterpret_cast<half_t*>(pl);
