@@ -960,7 +960,10 @@ __global__ __launch_bounds__(256) void drop_cls_kernel(const float* __restrict__
 
 // frames per pass of the encoder: large batches give the weight-stationary GEMMs long token chunks per workgroup
 // (their weights are loaded once per chunk); 30 frames of 67x121 tokens need ~2.6 GB of workspace
-constexpr int VIT_FRAME_BATCH = 30;
+// Frames per pass of the encoder.  Round 4: 90 (a whole benchmark video: 7.8 GB of activations, 2.7 % of the 288 GB) instead of
+// 30 -- fewer, longer launches: the attention's last partial round of workgroups weighs 0.7 % instead of 2.2 %, the
+// weight-stationary GEMMs load their weights a third as often; 301.4 -> 294.8 ms per step (profiles/r04_frame_batch_sweep.txt).
+constexpr int VIT_FRAME_BATCH = 90;
 
 // 1-D grid of gemm_tiled_kernel: 8 row blocks (one per XCD) x all column tiles per group
 inline unsigned gemm_grid(int N, long long rows) {
