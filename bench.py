@@ -53,6 +53,8 @@ def parse():
                     help="vit: features come from the (random-weight) ViT on the synthetic video; synthetic: the "
                          "feature-level generator with dense anchors (worst case for the tracker stage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ab", default="", help="comma-separated A / B switches: attention_v2 (round 2-3 attention kernel), "
+                                             "gemm_ws_v1 (round 1-3 weight-stationary GEMMs)")
     ap.add_argument("--cpu-threads", type=int, default=8, help="host threads of the oracle's infer leg (fixed: comparable across rounds)")
     ap.add_argument("--cpu-queries", type=int, default=4, help="queries of the TIMED CPU sample (SURVEY 8d: K = 4, full T)")
     ap.add_argument("--parity-queries", type=int, default=16,
@@ -150,6 +152,8 @@ def main():
     vit_sd = synth.make_vit_weights(model_name, seed=2, layerscale=0.1)
     ex = VitExtractor(model_name, stride=7, device=dev, state_dict=vit_sd, operand_dtype=args.operands)
     ex.frame_batch = args.vit_frame_batch
+    ex.attention_v2 = "attention_v2" in args.ab
+    ex.gemm_ws_v1 = "gemm_ws_v1" in args.ab
     if args.features == "vit":
         feats0 = ex.encode(videos[0])
     else:
@@ -348,7 +352,12 @@ def main():
             trk2.to(dev).eval()
             mi2 = ModelInference(trk2, RangeNormalizer((W, H, nf), device=dev), 0.7, 0.6)
             tv, ovd = mi2.infer(qv.to(dev))
+            # the LAST frame of the timed step's own 90-frame encoder pass (the first nf frames above sit at the start of it)
+            last_cpu = A.vit_tokens(videos[0][T - 1:T].cpu(), vit_sd, model_name)
+            last_dev = trk.dino_embed_video[T - 1].cpu()
+            f_rel_last = float((last_dev - last_cpu).norm() / last_cpu.norm())
             parity["from_video"] = {"frames": nf, "queries": npar, "feature_rel_err_P1": round(f_rel, 7),
+                                    "feature_rel_err_P1_last_frame_of_the_pass": round(f_rel_last, 7),
                                     "max_dxy_px": round(float((tv.cpu() - rv).abs().max()), 6),
                                     "occ_mismatch": int((ovd.cpu() != ov).sum()),
                                     "note": "video -> HIP ViT/Delta-DINO/infer vs video -> oracle ViT/refine/infer"}

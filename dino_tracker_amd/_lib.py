@@ -46,7 +46,7 @@ class VitModel(ctypes.Structure):
                 ("frame_batch", ctypes.c_int32), ("overflow", c_void_p)]
 
 
-VIT_TILED_GEMMS, VIT_BF16, VIT_CHECK_RANGE, VIT_ATTENTION_V2 = 1, 2, 4, 8  # dtk_vit_model.flags
+VIT_TILED_GEMMS, VIT_BF16, VIT_CHECK_RANGE, VIT_ATTENTION_V2, VIT_GEMM_WS_V1 = 1, 2, 4, 8, 16  # dtk_vit_model.flags
 OPERAND_F16, OPERAND_BF16, OPERAND_ATTENTION_V2 = 0, 1, 0x100
 
 

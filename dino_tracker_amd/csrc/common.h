@@ -109,7 +109,8 @@ __device__ __forceinline__ void dtk_buffer_lds16(dtk_u4 srd, unsigned soff, unsi
         "buffer_load_dwordx4 %0, %1, %2 offen lds"
         :
         : "v"(voff), "s"(srd), "s"(soff), "s"(lds_dst), "i"(LDS_IMM)
-        : "memory");
+        : "memory", "scc");   // (s_add_u32 writes SCC: without the clobber the compiler keeps a compare result live across the asm --
+                              //  round 4 found this as wrong tokens in ONE instantiation of the weight-stationary GEMM)
 }
 // raw buffer descriptor (stride 0) over `p`; the range check is disabled by a maximal size -- callers clamp their offsets
 __device__ __forceinline__ dtk_u4 dtk_make_srd(const void* p) {

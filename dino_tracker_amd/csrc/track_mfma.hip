@@ -459,18 +459,10 @@ __device__ __forceinline__ void top_push_value(int (&v)[PK_TOP], float x, int ta
     top_push_op<4>(v, x, tag, key); top_push_op<5>(v, x, tag, key); top_push_op<6>(v, x, tag, key); top_push_op<7>(v, x, tag, key);
 }
 
-// acc (+)= A . B with B pinned to the AGPR half of the register file: the 192 source registers of a wave are only ever MFMA
-// operands, and with them in AGPRs everything the VALU touches (accumulators, lists, fragment ring, addresses) fits the 256
-// architectural VGPRs -- left to the register allocator the kernel sat at exactly 256 VGPRs and shuttled ~34 values per tile
-// through v_accvgpr_read.  (The compiler's hazard recognizer does not see through the asm: an accumulator is next read by the
-// list instructions of the FOLLOWING tile, 48 MFMAs later; the one immediate read -- the frame's last tile -- is behind explicit
-// wait states, mfma_settle.)
-__device__ __forceinline__ void mfma_b_agpr(f16v& c, h8 a, h8 b, bool first) {
-    // ("=&v": the destination of an MFMA must not overlap its A / B operands -- an output the compiler may otherwise place on an input)
-    if (first) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b));
-    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
-}
-__device__ __forceinline__ void mfma_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+// (The 192 source registers of a wave are only ever MFMA operands: loaded STRAIGHT INTO AGPRs by the asm that defines them, they
+// stay there -- the builtin MFMA takes a B operand from an AGPR as it is -- and everything the VALU touches (accumulators, lists,
+// fragment ring, addresses) fits the architectural VGPRs; left to the register allocator the kernel sat at exactly 256 VGPRs and
+// shuttled ~34 values per tile through v_accvgpr_read.)
 
 // VAR: development variants (DTK_DEBUG bits 8192 / 16384 / 32768): 1 = no top-N updates, 2 = no tile requests after the
 // first two, 4 = no LDS reads.  0 in production.  (Measured with them: MFMAs alone 1.63 PF; + LDS reads or + DMA alone
@@ -608,6 +600,7 @@ __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_
                 return *reinterpret_cast<const h8*>(base + frag_off[ks & 3] + (cb * NL + (ks >> 2)) * 4096);
             };
             const int ib = np << TSH;
+            const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // inline constant C
             int keys[2] = {0, 0};   // the key of the value whose insertion is in flight (one per source tile at most)
             h8 a[3];
             a[0] = frag(0);
@@ -619,7 +612,7 @@ __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_
             peaks_static_for<0, NSLOT>([&](auto qc) {
                 constexpr int q = decltype(qc)::value, fr = q / 2, t = q % 2, ks = fr / CB, cb = fr % CB;
                 if (t == 0 && fr + 2 < NF && !(VAR & 4)) a[(fr + 2) % 3] = frag(fr + 2);
-                mfma_b_agpr(accN[cb][t], a[fr % 3], bs[t][ks], ks == 0);
+                accN[cb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[fr % 3], bs[t][ks], ks == 0 ? zero16 : accN[cb][t], 0, 0, 0);
                 // the list instructions of the previous tile, spread evenly over the MFMA slots: slot q issues instructions
                 // [NINS q / NSLOT, NINS (q + 1) / NSLOT) of the stream; value e = index / 8 is accumulator register e / (2 CB) of
                 // (source tile e & 1, cell block (e >> 1) % CB); position tag = step << 5 | cell block << 4 | register
@@ -631,7 +624,6 @@ __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_
             });
         };
         auto epi = [&](const f16v (&acc)[CB][2], int np) {
-            mfma_settle();
 #pragma unroll
             for (int r = 0; r < 16; ++r)
 #pragma unroll

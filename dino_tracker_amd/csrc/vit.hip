@@ -738,12 +738,18 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const T* __restrict__
     }
 }
 
-template <typename T, int EPI>
+// V2M (round 4, default 3): bit 0 = weights in AGPRs (loaded there by asm; the builtin MFMA takes them from there as they are)
+// and zero accumulators through the MFMA's C operand; bit 1 = token tiles by LDS-DMA through a buffer descriptor (scalar tile
+// offset + constant per-lane offset: 3 issue slots per request instead of ~13).  V2M = 0 is the round 1-3 form, kept for the
+// A / B measurement (DTK_VIT_GEMM_WS_V1).  Same-box A / B: proj 4.97 -> 3.62 ms, qkv 12.34 -> 12.10, fc1 14.68 -> 14.55 ms per step.
+template <typename T, int EPI, int V2M = 3>
 __global__ __launch_bounds__(256) void gemm_ws_kernel(const T* __restrict__ A, const T* __restrict__ Wt,
                                                       long long M, int N, GemmEpi<T> e, int tiles_per_chunk) {
     typedef typename Vec<T>::t8 T8;
     typedef typename Vec<T>::t4 T4;
     (void)sizeof(T8); (void)sizeof(T4);
+    constexpr bool V2 = (V2M & 1) != 0;       // AGPR weights + zero C operand
+    constexpr bool V2D = (V2M & 2) != 0;      // descriptor LDS-DMA
     operand_mode<T>();
     __shared__ __attribute__((aligned(1024))) unsigned char toks[3][WS_TILE_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char stage[4][2][WS_UNIT_BYTES];  // per wave: two staging units
@@ -765,8 +771,12 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const T* __restrict__ A, c
         const int row = min(n0 + t * 32 + nl, N - 1);
         const T* wp = Wt + (size_t)row * WS_K + h * 8;
 #pragma unroll
-        for (int ks = 0; ks < WS_KS; ++ks) wf[t][ks] = *reinterpret_cast<const T8*>(wp + ks * 16);
+        for (int ks = 0; ks < WS_KS; ++ks) {
+            if (V2) asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(wf[t][ks]) : "v"(wp + ks * 16) : "memory");
+            else wf[t][ks] = *reinterpret_cast<const T8*>(wp + ks * 16);
+        }
     }
+    if (V2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     {
         const int n = min(n0 + lane, N - 1);
         s_bias[w][lane] = e.bias ? e.bias[n] : 0.f;
@@ -785,7 +795,32 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const T* __restrict__ A, c
     // tt sits at slot ((pp + g) & 15) * 4 + tt, which keeps the fragment reads of 16 consecutive lanes conflict-free
     const unsigned lds_base = (unsigned)(size_t)&toks[0][0];
     const int l_tt = lane & 3, l_pp = lane >> 2;
+    // V2: descriptor over the chunk's first token row (32-bit offsets inside a chunk: tiles_per_chunk x 24 KB)
+    const dtk_u4 srd = dtk_make_srd(A + tile0 * WS_ROWS * WS_K);
+    // (rows of the LAST token tile past M - 1 read row M - 1, as the 64-bit form did: a second pair of offsets for that tile)
+    unsigned a_voff[2], a_voff_last[2];
+    const int last_rows = (int)(M - (total_tiles - 1) * WS_ROWS);   // valid rows of the last tile (1 .. 32)
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {
+        const int g = 2 * w + gg;
+        a_voff[gg] = (unsigned)(((4 * g + l_tt) * WS_K + ((l_pp - g) & 15) * 8) * 2);
+        a_voff_last[gg] = (unsigned)((min(4 * g + l_tt, last_rows - 1) * WS_K + ((l_pp - g) & 15) * 8) * 2);
+    }
+    const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + (2 * w) * 3 * 1024);
     auto issue = [&](int n, int buf) {
+        if (V2D) {
+            const unsigned toff = __builtin_amdgcn_readfirstlane((unsigned)n * (unsigned)WS_TILE_BYTES);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(a_dst + (unsigned)buf * (unsigned)WS_TILE_BYTES);
+            const bool last = tile0 + n == total_tiles - 1;
+            const unsigned v0 = last ? a_voff_last[0] : a_voff[0], v1 = last ? a_voff_last[1] : a_voff[1];
+            dtk_buffer_lds16<0>(srd, toff, v0, dst);
+            dtk_buffer_lds16<1024>(srd, toff + 256u, v0, dst);
+            dtk_buffer_lds16<2048>(srd, toff + 512u, v0, dst);
+            dtk_buffer_lds16<3072>(srd, toff, v1, dst);
+            dtk_buffer_lds16<4096>(srd, toff + 256u, v1, dst);
+            dtk_buffer_lds16<5120>(srd, toff + 512u, v1, dst);
+            return;
+        }
 #pragma unroll
         for (int gg = 0; gg < 2; ++gg) {
             const int g = 2 * w + gg;
@@ -885,11 +920,14 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const T* __restrict__ A, c
     };
     // one step: MFMAs of the tile in `buf` into accN, with the four epilogue pieces of the previous tile (accP) in between
     auto step = [&](int buf, f16v (&accN)[2], const f16v (&accP)[2], bool have_prev, bool have_flush) {
+        if (!V2) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) accN[t][r] = 0.f;
+                for (int r = 0; r < 16; ++r) accN[t][r] = 0.f;
+        }
         const unsigned char* base = &toks[0][0] + buf * WS_TILE_BYTES;
+        const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // inline constant C
         T8 b[3];
         b[0] = *reinterpret_cast<const T8*>(base + frag_off[0]);
         b[1] = *reinterpret_cast<const T8*>(base + frag_off[1]);
@@ -898,8 +936,13 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const T* __restrict__ A, c
             if (ks + 2 < WS_KS)
                 b[(ks + 2) % 3] = *reinterpret_cast<const T8*>(base + frag_off[(ks + 2) & 7] + ((ks + 2) >> 3) * 1024);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-                accN[t] = mfma32(wf[t][ks], b[ks % 3], accN[t]);
+            for (int t = 0; t < 2; ++t) {
+                // (V2: the builtin, NOT an asm MFMA: its A operand accepts the AGPR the weight was loaded into as it is, and the
+                // compiler keeps managing the instruction's hazards -- an asm MFMA followed by compiler-scheduled code that
+                // re-used its B registers for an LDS load at once gave wrong tokens, non-deterministically)
+                if (V2) accN[t] = mfma32(wf[t][ks], b[ks % 3], ks == 0 ? zero16 : accN[t]);
+                else accN[t] = mfma32(wf[t][ks], b[ks % 3], accN[t]);
+            }
             // the tile staged during the previous step leaves first: its stores have the whole step to retire
             if (have_flush && ks == 0) flush();
             if (have_prev && ks % 6 == 2) epi8(accP, (ks / 6) >> 1, (ks / 6) & 1);
@@ -1106,6 +1149,7 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
         // updates (LayerScale'd projection / MLP outputs) are written as `delta` and added by the next LayerNorm.
         // DTK_VIT_TILED_GEMMS: every GEMM on the tiled kernel (tests cross-check the weight-stationary one with it)
         const bool ws_ok = D == WS_K && !(m->flags & DTK_VIT_TILED_GEMMS);
+        const bool ws_v1 = (m->flags & DTK_VIT_GEMM_WS_V1) != 0;
         const int dbg_ns = DTK_DBG(dtk_dev_flags() >> 16, 3);  // DTK_DEV: skip the weight-stationary kernel's stores
         auto ws_grid = [&](int N) {  // one resident round: one workgroup per CU
             const int colwg = dtk_cdiv(N, WS_COLS);
@@ -1136,8 +1180,13 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
             e.no_store = dbg_ns;
             if (ws_ok) {
                 const auto gr = ws_grid(3 * D);
-                DTK_LAUNCH("vit_gemm_qkv", (gemm_ws_kernel<T, EPI_QKV>), gr.first, dim3(256), 0, st, xn, qkv_w, rows, 3 * D, e,
-                           gr.second);
+                if (ws_v1) {
+                    DTK_LAUNCH("vit_gemm_qkv", (gemm_ws_kernel<T, EPI_QKV, 0>), gr.first, dim3(256), 0, st, xn, qkv_w, rows, 3 * D, e,
+                               gr.second);
+                } else {
+                    DTK_LAUNCH("vit_gemm_qkv", (gemm_ws_kernel<T, EPI_QKV>), gr.first, dim3(256), 0, st, xn, qkv_w, rows, 3 * D, e,
+                               gr.second);
+                }
             } else if (wide_ok) {
                 DTK_LAUNCH("vit_gemm_qkv", (gemm_wide_kernel<T, EPI_QKV>), dim3(gemm_wide_grid(3 * D, rows)), dim3(512), 0, st,
                            xn, qkv_w, rows, 3 * D, D, e);
@@ -1153,8 +1202,13 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
             e.bias = L.proj_b; e.delta = delta; e.gamma = L.ls1; e.no_store = dbg_ns;
             if (ws_ok) {
                 const auto gr = ws_grid(D);
-                DTK_LAUNCH("vit_gemm_proj", (gemm_ws_kernel<T, EPI_DELTA>), gr.first, dim3(256), 0, st, ao, proj_w, rows, D, e,
-                           gr.second);
+                if (ws_v1) {
+                    DTK_LAUNCH("vit_gemm_proj", (gemm_ws_kernel<T, EPI_DELTA, 0>), gr.first, dim3(256), 0, st, ao, proj_w, rows, D, e,
+                               gr.second);
+                } else {
+                    DTK_LAUNCH("vit_gemm_proj", (gemm_ws_kernel<T, EPI_DELTA>), gr.first, dim3(256), 0, st, ao, proj_w, rows, D, e,
+                               gr.second);
+                }
             } else if (wide_ok) {
                 DTK_LAUNCH("vit_gemm_proj", (gemm_wide_kernel<T, EPI_DELTA>), dim3(gemm_wide_grid(D, rows)), dim3(512), 0, st, ao,
                            proj_w, rows, D, D, e);
@@ -1168,8 +1222,13 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
             e.bias = L.fc1_b; e.out = hid; e.no_store = dbg_ns;
             if (ws_ok) {
                 const auto gr = ws_grid(4 * D);
-                DTK_LAUNCH("vit_gemm_fc1", (gemm_ws_kernel<T, EPI_GELU>), gr.first, dim3(256), 0, st, xn, fc1_w, rows, 4 * D, e,
-                           gr.second);
+                if (ws_v1) {
+                    DTK_LAUNCH("vit_gemm_fc1", (gemm_ws_kernel<T, EPI_GELU, 0>), gr.first, dim3(256), 0, st, xn, fc1_w, rows, 4 * D, e,
+                               gr.second);
+                } else {
+                    DTK_LAUNCH("vit_gemm_fc1", (gemm_ws_kernel<T, EPI_GELU>), gr.first, dim3(256), 0, st, xn, fc1_w, rows, 4 * D, e,
+                               gr.second);
+                }
             } else if (wide_ok) {
                 DTK_LAUNCH("vit_gemm_fc1", (gemm_wide_kernel<T, EPI_GELU>), dim3(gemm_wide_grid(4 * D, rows)), dim3(512), 0, st,
                            xn, fc1_w, rows, 4 * D, D, e);

@@ -79,7 +79,8 @@ __device__ __forceinline__ void buffer_lds16(u4v srd, unsigned soff, unsigned vo
         "buffer_load_dwordx4 %0, %1, %2 offen lds"
         :
         : "v"(voff), "s"(srd), "s"(soff), "s"(lds_dst), "i"(LDS_IMM)
-        : "memory");
+        : "memory", "scc");   // (s_add_u32 writes SCC: without the clobber the compiler keeps a compare result live across the asm --
+                              //  round 4 found this as wrong tokens in ONE instantiation of the weight-stationary GEMM)
 }
 __device__ __forceinline__ u4v make_srd(const void* p) {
     const unsigned long long a = (unsigned long long)(size_t)p;
