@@ -19,3 +19,10 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_wr -o wr -- $CMD1 > /dev/
 rd=$(find /tmp/prof_rd -name "*.db" | head -1); wr=$(find /tmp/prof_wr -name "*.db" | head -1)
 python $R/scripts/pmc_traffic.py $rd $wr > $R/gpurun_out/${TAG}_pmc_traffic.json 2>> $R/gpurun_out/${TAG}_rd.err
 head -30 $R/gpurun_out/${TAG}_kernel_trace_table.md; cat $R/gpurun_out/${TAG}_pmc_traffic.json | head -40
+# (3) one SQ-counter pass: where the waves of each kernel spend their cycles (scripts/pmc_sq.py)
+rm -rf /tmp/prof_sq
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES \
+    -d /tmp/prof_sq -o sq -- $CMD1 > /dev/null 2> $R/gpurun_out/${TAG}_sq.err
+sq=$(find /tmp/prof_sq -name "*.db" | head -1)
+python $R/scripts/pmc_sq.py $sq > $R/gpurun_out/${TAG}_pmc_sq.md 2>> $R/gpurun_out/${TAG}_sq.err
+head -24 $R/gpurun_out/${TAG}_pmc_sq.md
