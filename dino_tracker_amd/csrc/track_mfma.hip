@@ -82,6 +82,36 @@ __global__ __launch_bounds__(256) void feat16_kernel(const float* __restrict__ f
     }
 }
 
+// ---- split-fp16 copy of the feature volume (C = 384), the streamed operand of refine_corr_dma ---------------------------
+// fs[cell][chunk kc of 32 channels][hi 32 | lo 32]: x * 32 = hi + lo, both fp16 -- exactly the halves the window
+// correlation otherwise makes while it stages fp32 rows into LDS, made ONCE per volume.  A (cell, chunk) is one 128-byte
+// line, so an LDS-DMA request of 8 cells fetches 8 whole lines and a step needs no VALU and no ds_write at all.
+constexpr float RC_SCALE = 32.f;
+__host__ __device__ inline size_t split_planes_offset(const dtk_geom* g) {
+    return ((size_t)g->T * hw_pad(g->ph, g->pw) * g->C * 2 + 255) / 256 * 256;
+}
+__host__ __device__ inline bool has_split_planes(const dtk_geom* g) {
+    return g->C == 384 && (long long)g->T * g->ph * g->pw * g->C * 4 < (1LL << 32);  // (32-bit offsets in the descriptor)
+}
+__global__ __launch_bounds__(256) void featsplit_kernel(const float* __restrict__ feat, half_t* __restrict__ fs,
+                                                        long long n8) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // one 8-channel piece
+    if (i >= n8) return;
+    const float4 a = *reinterpret_cast<const float4*>(feat + i * 8), b = *reinterpret_cast<const float4*>(feat + i * 8 + 4);
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float xs = x[e] * RC_SCALE;
+        hi[e] = (half_t)xs;
+        lo[e] = (half_t)(xs - (float)hi[e]);
+    }
+    const long long chunk = i >> 2;  // 32 channels = 4 pieces; C % 32 == 0, so chunks never straddle cells
+    const int piece = (int)(i & 3);
+    *reinterpret_cast<h8*>(fs + chunk * 64 + piece * 8) = hi;
+    *reinterpret_cast<h8*>(fs + chunk * 64 + 32 + piece * 8) = lo;
+}
+
 // ---- sources of a chunk -> fp16 unit vectors; one wave per source ---------------------------------------------------
 __global__ __launch_bounds__(256) void src16_kernel(const float* __restrict__ emb, const int32_t* __restrict__ src_row,
                                                     half_t* __restrict__ s16, int m0, int count, int M,
@@ -1116,7 +1146,6 @@ __global__ __launch_bounds__(256) void scatter_kernel(dtk_geom g, const int32_t*
 //     16x the f32-input MFMA rate instead of one (64 sources x 256 cells x 384 channels on the f32 MFMA alone cost
 //     more than the whole round-1 kernel).
 constexpr int RC_SRC = 64;
-constexpr float RC_SCALE = 32.f;
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const float* __restrict__ feat,
                                                           const float* __restrict__ norms,
@@ -1281,6 +1310,212 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const floa
                 }
             }
         }
+    }
+}
+
+// The same correlations for C = 32 NKC known at compile time (C = 384: NKC = 12), restructured around what the counters
+// showed (profiles/r04_pmc_sq.md, refine_corr: waves parked 61 %, 25 % issuing -- two thirds of it the hi / lo split of every
+// staged element --, MFMA pipe 13 % busy; neither a deeper register pipeline nor source-stationary operands alone moved it):
+//   * the CELLS come pre-split from the volume's split-plane copy (featsplit_kernel) by LDS-DMA, 8 whole 128-byte lines per
+//     request, into a ring of NS stages requested NS - 1 steps ahead: a step costs a wave two requests, eight fragment reads
+//     and twelve MFMAs -- no VALU, no ds_write;
+//   * the SOURCES are stationary: a wave owns ONE M tile, reads its 16 source rows once per tile and keeps them as split
+//     fp16 A fragments (NKC x (hi, lo) x 4 = 96 registers);
+//   * the (64-cell block, 32-channel chunk) steps of a group form one sequence, so the pipeline never restarts inside a box.
+// LDS image of a stage: [64 cells][8 pieces of 16 B] (pieces 0-3: hi, 4-7: lo), piece p of cell c in slot p ^ ((c >> 1) & 7)
+// (through the SOURCE address of the DMA, whose LDS side is lane-linear): the fragment reads are conflict-free ds_read_b128.
+// Values and summation order are those of refine_corr_kernel: the results are bit-identical.
+// vmcnt bookkeeping (gfx9: loads and stores share the counter and retire in order): every wave issues the SAME VMEM stream --
+// two requests per step, 16 window stores per block as buffer stores whose switched-off lanes carry an out-of-range offset
+// (no branch, so the count is static); the norms of the box come from LDS (a compiler-managed global load here would be
+// waited for with vmcnt(0) and drain the ring).
+template <int NKC>
+__global__ __launch_bounds__(256, 3) void refine_corr_dma_kernel(dtk_geom g, const half_t* __restrict__ fs,
+                                                              const float* __restrict__ norms,
+                                                              const float* __restrict__ emb,
+                                                              const int32_t* __restrict__ src_row,
+                                                              const int32_t* __restrict__ tgt,
+                                                              const int32_t* __restrict__ kstar,
+                                                              const float* __restrict__ snorm,
+                                                              const int32_t* __restrict__ perm,
+                                                              const int32_t* __restrict__ nvalid,
+                                                              float* __restrict__ xwin, unsigned xwin_bytes, int m0,
+                                                              int ntiles) {
+    constexpr int NS = 4;              // stages of the LDS ring
+    constexpr int STAGE = 64 * 128;    // bytes: 64 cells x (32 hi + 32 lo) halves
+    static_assert(NKC % NS == 0 && NKC >= NS, "the stage of a step is chosen at compile time");
+    constexpr int C = NKC * 32;
+    __shared__ float s_sn[RC_SRC];
+    __shared__ int s_row[RC_SRC], s_f[RC_SRC], s_k[RC_SRC], s_m[RC_SRC], s_grp[RC_SRC], s_box[RC_SRC * 4], s_first[RC_SRC],
+        s_last[RC_SRC], s_ng;
+    __shared__ float s_fn[NB_MAX];
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[NS * STAGE];
+    const int ph = g.ph, pw = g.pw, HW = ph * pw;
+    const int nv = *nvalid;
+    const int per = (ntiles + 7) / 8;
+    const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int t0 = tile * RC_SRC;
+    if ((int)(blockIdx.x >> 3) >= per || tile >= ntiles || t0 >= nv) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < RC_SRC) {
+        const bool ok = t0 + tid < nv;
+        const int i = perm[ok ? t0 + tid : t0];  // index inside the round
+        const int m = m0 + i;
+        s_m[tid] = m;
+        s_row[tid] = src_row ? src_row[m] : m;
+        s_f[tid] = ok ? min(max(tgt[m], 0), g.T - 1) : -1;
+        s_k[tid] = kstar[i];
+        s_sn[tid] = snorm[i];
+    }
+    __syncthreads();
+    // greedy grouping: consecutive (key-sorted) sources with the same frame whose window union stays small
+    if (tid == 0) {
+        int ng = 0, cf = -2, r0 = 0, r1 = 0, c0 = 0, c1 = 0;
+        for (int s = 0; s < RC_SRC; ++s) {
+            s_grp[s] = -1;
+            if (s_f[s] < 0) continue;
+            const int kr = s_k[s] / pw, kc = s_k[s] % pw;
+            const int a0 = max(kr - (RD + 2), 0), a1 = min(kr + (RD + 2), ph - 1);
+            const int b0 = max(kc - (RD + 2), 0), b1 = min(kc + (RD + 2), pw - 1);
+            bool fits = false;
+            if (ng > 0 && s_f[s] == cf) {
+                const int n0 = min(r0, a0), n1 = max(r1, a1), e0 = min(c0, b0), e1 = max(c1, b1);
+                if ((n1 - n0 + 1) * (e1 - e0 + 1) <= NB_MAX) { r0 = n0; r1 = n1; c0 = e0; c1 = e1; fits = true; }
+            }
+            if (!fits) { ++ng; cf = s_f[s]; r0 = a0; r1 = a1; c0 = b0; c1 = b1; s_first[ng - 1] = s; }
+            s_grp[s] = ng - 1;
+            s_last[ng - 1] = s;
+            s_box[(ng - 1) * 4 + 0] = r0; s_box[(ng - 1) * 4 + 1] = r1;
+            s_box[(ng - 1) * 4 + 2] = c0; s_box[(ng - 1) * 4 + 3] = c1;
+        }
+        s_ng = ng;
+    }
+    __syncthreads();
+    const int ng = s_ng;
+
+    const int fj = lane & 15, fg = lane >> 4;
+    // A fragments of this wave's sources: lane (fj, fg) holds k = 32 kc + 8 fg .. + 7 of source 16 w + fj
+    h8 ah[NKC], al[NKC];
+    {
+        const float* ap = emb + (size_t)s_row[16 * w + fj] * C + fg * 8;
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            const float4 u = *reinterpret_cast<const float4*>(ap + kc * 32), v = *reinterpret_cast<const float4*>(ap + kc * 32 + 4);
+            const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xs = x[e] * RC_SCALE;
+                ah[kc][e] = (half_t)xs;
+                al[kc][e] = (half_t)(xs - (float)ah[kc][e]);
+            }
+        }
+    }
+    const dtk_u4 srd = dtk_make_srd(fs);
+    dtk_u4 srd_x;  // window stores: range-checked, so that an offset of ~0 switches a lane off
+    {
+        const unsigned long long xa = (unsigned long long)(size_t)xwin;
+        srd_x = dtk_u4{(unsigned)xa, (unsigned)(xa >> 32) & 0xffffu, xwin_bytes, 0x00020000u};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) srd_x[k] = __builtin_amdgcn_readfirstlane(srd_x[k]);
+    }
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ring + (unsigned)w * 2048u);  // this wave's 16 cells
+    // fragment reads: cell nt * 16 + fj, hi piece fg / lo piece 4 + fg ((c >> 1) & 7 does not depend on nt)
+    const int rd_hi = fj * 128 + ((fg ^ ((fj >> 1) & 7)) << 4), rd_lo = fj * 128 + (((4 + fg) ^ ((fj >> 1) & 7)) << 4);
+    // requests: lane l of request q fetches, for cell 16 w + 8 q + (l >> 3) of the block, the piece that lands in slot l & 7
+    const int dq = lane >> 3;
+    for (int gi = 0; gi < ng; ++gi) {
+        const int rmin = s_box[gi * 4], rmax = s_box[gi * 4 + 1], cmin = s_box[gi * 4 + 2], cmax = s_box[gi * 4 + 3];
+        const int nc = cmax - cmin + 1, ncells = (rmax - rmin + 1) * nc;
+        const bool active = 16 * w <= s_last[gi] && 16 * w + 15 >= s_first[gi];  // wave-uniform: members are consecutive
+        const int gf = s_f[s_first[gi]];
+        auto req_off = [&](int blk, int q) {  // clamped: results of padded cells are never stored
+            const int c = 16 * w + 8 * q + dq;
+            const int l = min(blk + c, ncells - 1);
+            const unsigned cell = (unsigned)(gf * HW + (rmin + l / nc) * pw + cmin + l % nc);
+            return cell * (unsigned)(C * 4) + (unsigned)((((lane & 7) ^ ((c >> 1) & 7))) << 4);
+        };
+        // this lane's four sources (rows 4 fg + r of the D fragments): window origin, output offset, norm, membership
+        int krow[4], kcol[4];
+        unsigned xoff[4];
+        float sn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int sidx = 16 * w + 4 * fg + r;
+            krow[r] = s_grp[sidx] == gi ? s_k[sidx] / pw - (RD + 2) : -100000;  // a non-member never matches a window
+            kcol[r] = s_k[sidx] % pw - (RD + 2);
+            xoff[r] = (unsigned)(s_m[sidx] - m0) * (unsigned)(WX * WX);
+            sn[r] = s_sn[sidx];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // the previous group is done with the ring and with s_fn
+        for (int c = tid; c < ncells; c += 256) s_fn[c] = norms[(size_t)gf * HW + (rmin + c / nc) * pw + cmin + c % nc];
+        unsigned vc[2] = {req_off(0, 0), req_off(0, 1)}, vn[2] = {0u, 0u};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the norms: the counting below starts from an empty queue)
+#define RC_ISSUE(STG, V, KC)                                                                  \
+    do {                                                                                      \
+        dtk_buffer_lds16<0>(srd, (unsigned)((KC) * 128), V[0], lds_w + (unsigned)((STG) * STAGE));         \
+        dtk_buffer_lds16<0>(srd, (unsigned)((KC) * 128), V[1], lds_w + (unsigned)((STG) * STAGE + 1024));  \
+    } while (0)
+#pragma unroll
+        for (int d = 0; d < NS - 1; ++d) RC_ISSUE(d, vc, d);
+        for (int blk = 0; blk < ncells; blk += 64) {
+            const bool last_blk = blk + 64 >= ncells;
+            if (!last_blk) { vn[0] = req_off(blk + 64, 0); vn[1] = req_off(blk + 64, 1); }
+            f4 acc[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < NKC; ++kc) {
+                const int stg = kc % NS;
+                // the requests of this step have landed when at most those issued after them are outstanding: the requests of
+                // the next two steps (where those exist) and, in the first three steps of a later block, the 16 window stores
+                // of the previous block (issued between the request of step 2 and that of step 3)
+                if (kc < NS - 1) {
+                    if (blk > 0) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else if (kc < NKC - 2) {
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else if (kc == NKC - 2) {
+                    if (last_blk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else {
+                    if (last_blk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                }
+                __syncthreads();  // every wave's part of this stage has landed; stage (kc - 1) % NS is free again
+                if (kc + NS - 1 < NKC) RC_ISSUE((kc + NS - 1) % NS, vc, kc + NS - 1);
+                else if (!last_blk) RC_ISSUE((kc + NS - 1) % NS, vn, kc + NS - 1 - NKC);
+                if (active) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const h8 bh = *reinterpret_cast<const h8*>(&ring[stg * STAGE + nt * 2048 + rd_hi]);
+                        const h8 bl = *reinterpret_cast<const h8*>(&ring[stg * STAGE + nt * 2048 + rd_lo]);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kc], bh, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kc], bl, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kc], bh, acc[nt], 0, 0, 0);
+                    }
+                }
+            }
+            vc[0] = vn[0]; vc[1] = vn[1];
+            // windows of the block: D fragment, lane (fj, fg): sources 16 w + 4 fg + r (rows) of cell nt * 16 + fj (column)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int ci = blk + nt * 16 + fj;
+                const int cic = min(ci, ncells - 1);
+                const int cr = rmin + cic / nc, ccol = cmin + cic % nc;
+                const float fn = s_fn[cic];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int dr = cr - krow[r], dc = ccol - kcol[r];
+                    const bool ok = active && ci < ncells && (unsigned)dr < (unsigned)WX && (unsigned)dc < (unsigned)WX;
+                    const float val = fmaxf(acc[nt][r] * (1.f / (RC_SCALE * RC_SCALE)) / fmaxf(sn[r] * fn, 1e-8f), 0.f);
+                    const unsigned off = ok ? (xoff[r] + (unsigned)(dr * WX + dc)) * 4u : 0xfffffff0u;
+                    asm volatile("buffer_store_dword %0, %1, %2, 0 offen" : : "v"(val), "v"(off), "s"(srd_x) : "memory");
+                }
+            }
+        }
+#undef RC_ISSUE
     }
 }
 
@@ -1561,7 +1796,8 @@ extern "C" int dtk_debug_counters(unsigned long long* out4) {
 
 extern "C" size_t dtk_feat_f16_bytes(const dtk_geom* g) {
     if (!g || g->T <= 0 || g->C <= 0) return 0;
-    return (size_t)g->T * hw_pad(g->ph, g->pw) * g->C * 2;
+    const size_t unit = (size_t)g->T * hw_pad(g->ph, g->pw) * g->C * 2;
+    return has_split_planes(g) ? split_planes_offset(g) + (size_t)g->T * g->ph * g->pw * g->C * 4 : unit;
 }
 
 extern "C" int dtk_make_feat_f16(const dtk_geom* g, const float* feat, const float* norms, void* feat_f16, void* stream) {
@@ -1571,6 +1807,11 @@ extern "C" int dtk_make_feat_f16(const dtk_geom* g, const float* feat, const flo
     const long long cells = (long long)g->T * HWp;
     DTK_LAUNCH("feat16", feat16_kernel, dim3(dtk_cdiv(cells, 4)), dim3(256), 0, dtk_stream(stream), feat, norms,
                reinterpret_cast<half_t*>(feat_f16), g->T, g->ph, g->pw, pw_pad(g->pw), g->C);
+    if (has_split_planes(g)) {
+        const long long n8 = (long long)g->T * g->ph * g->pw * g->C / 8;
+        DTK_LAUNCH("featsplit", featsplit_kernel, dim3(dtk_cdiv(n8, 256)), dim3(256), 0, dtk_stream(stream), feat,
+                   reinterpret_cast<half_t*>(reinterpret_cast<unsigned char*>(feat_f16) + split_planes_offset(g)), n8);
+    }
     return DTK_OK;
 }
 
@@ -1684,8 +1925,14 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
                    perm, L.HWk, (int)s0, scnt);
         {
             const int rtiles = dtk_cdiv(scnt, RC_SRC);
-            DTK_LAUNCH("refine_corr", refine_corr_kernel, dim3(8 * dtk_cdiv(rtiles, 8)), dim3(256), 0, st, *g, feat, norms, emb,
-                       in.src_row, in.tgt, kstar, snorm, perm, nvalid, xwin, (int)s0, rtiles, dbg);
+            if (has_split_planes(g) && !DTK_DBG(dbg, 131072) && (size_t)L.super * WX * WX * 4 < (1ull << 32))
+                DTK_LAUNCH("refine_corr", refine_corr_dma_kernel<12>, dim3(8 * dtk_cdiv(rtiles, 8)), dim3(256), 0, st, *g,
+                           reinterpret_cast<const half_t*>(reinterpret_cast<const unsigned char*>(f16) + split_planes_offset(g)),
+                           norms, emb, in.src_row, in.tgt, kstar, snorm, perm, nvalid, xwin, (unsigned)((size_t)scnt * WX * WX * 4),
+                           (int)s0, rtiles);
+            else
+                DTK_LAUNCH("refine_corr", refine_corr_kernel, dim3(8 * dtk_cdiv(rtiles, 8)), dim3(256), 0, st, *g, feat, norms,
+                           emb, in.src_row, in.tgt, kstar, snorm, perm, nvalid, xwin, (int)s0, rtiles, dbg);
         }
         DTK_LAUNCH("refine_head", refine_head_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, *g, head, in.src_row, in.tgt,
                    in.out_idx, out_xy, rec, kstar, xwin, reinterpret_cast<const float*>(wpk) + 152, redo, uncert,

@@ -317,8 +317,12 @@ int dtk_bb_nms(const dtk_geom* g, const float* feat, const float* norms, const f
                const int32_t* tgt, float box_size, float iou_thresh, int topk, float* peak_affs, float* r, int M,
                void* workspace, size_t workspace_bytes, void* stream);
 
-/* fp16 unit-norm copy of the feature volume consumed by DTK_TRACK_MFMA: f16[t][row][col][c] = 32 F/|F| with every map
- * row padded with zero cells to a multiple of 128 columns (an N-tile of the GEMM is one map row); C % 32 == 0. */
+/* 16-bit copies of the feature volume consumed by DTK_TRACK_MFMA (C % 32 == 0), one buffer of dtk_feat_f16_bytes(g):
+ *   - f16[t][row][col][c] = 32 F/|F|, every map row padded with zero cells to a multiple of 128 columns (an N-tile of the
+ *     candidate GEMM is one map row);
+ *   - at C = 384, behind it (256-byte aligned): the split planes of the window correlation, [t][cell][chunk of 32
+ *     channels][hi 32 | lo 32] with 32 F = hi + lo (fp16 both) -- T*ph*pw*C*4 more bytes, made once per volume instead of
+ *     once per staged element of every window box. */
 size_t dtk_feat_f16_bytes(const dtk_geom* g);
 int dtk_make_feat_f16(const dtk_geom* g, const float* feat, const float* norms, void* feat_f16, void* stream);
 
