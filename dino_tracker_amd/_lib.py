@@ -107,6 +107,14 @@ SIGNATURES = {
     "dtk_conv_wgrad_split_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "dtk_conv_wgrad_split": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                      c_int, c_void_p, c_size_t, c_void_p]),
+    "dtk_gemm_nt_f32_indexed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.c_int64, c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_int, c_int,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dtk_contrastive_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dtk_contrastive_forward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_float, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dtk_contrastive_backward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_float, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dtk_emb_reg_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dtk_emb_reg_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dtk_corr_window_backward": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

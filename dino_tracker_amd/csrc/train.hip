@@ -468,13 +468,14 @@ __global__ __launch_bounds__(256) void gemm_nt_split_kernel(const float* __restr
                                                             float* __restrict__ C, int M, int N, int K, long long lda,
                                                             long long ldb, long long ldc, long long sA, long long sB,
                                                             long long sC, int split_k, int k_chunk, int accumulate,
-                                                            const float* __restrict__ scale_a, const float* __restrict__ scale_b) {
+                                                            const float* __restrict__ scale_a, const float* __restrict__ scale_b,
+                                                            const int32_t* __restrict__ idx_b, const int32_t* __restrict__ idx_c) {
     __shared__ __attribute__((aligned(16))) half_t Ah[GT * GRP], Al[GT * GRP], Bh[GT * GRP], Bl[GT * GRP];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int bz = blockIdx.z / split_k, ks = blockIdx.z - bz * split_k;
     A += bz * sA;
-    B += bz * sB;
-    C += bz * sC;
+    B += (idx_b ? idx_b[bz] : bz) * sB;   // (optional: batch b reads operand B / writes output C number idx[b])
+    C += (idx_c ? idx_c[bz] : bz) * sC;
     const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
     const int k0 = ks * k_chunk, k1 = min(K, k0 + k_chunk);
     if (k0 >= k1) return;
@@ -700,9 +701,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 
 }  // namespace
 
-extern "C" int dtk_gemm_nt_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb,
-                               int64_t ldc, int32_t batch, int64_t stride_a, int64_t stride_b, int64_t stride_c, int32_t split_k,
-                               int32_t accumulate, const float* scale_a, const float* scale_b, void* stream) {
+extern "C" int dtk_gemm_nt_f32_indexed(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda,
+                                       int64_t ldb, int64_t ldc, int32_t batch, int64_t stride_a, int64_t stride_b, int64_t stride_c,
+                                       int32_t split_k, int32_t accumulate, const float* scale_a, const float* scale_b,
+                                       const int32_t* index_b, const int32_t* index_c, void* stream) {
     DTK_REQUIRE(A && B && C, "dtk_gemm_nt_f32: null pointer");
     DTK_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0 && split_k > 0, "dtk_gemm_nt_f32: bad sizes");
     DTK_REQUIRE(lda >= K && ldb >= K && ldc >= N, "dtk_gemm_nt_f32: leading dimensions");
@@ -714,12 +716,19 @@ extern "C" int dtk_gemm_nt_f32(const float* A, const float* B, float* C, int32_t
     if (vec)
         DTK_LAUNCH("train_gemm", gemm_nt_split_kernel<true>, grid, dim3(256), 0, dtk_stream(stream), A, B, C, M, N, K, (long long)lda,
                    (long long)ldb, (long long)ldc, (long long)stride_a, (long long)stride_b, (long long)stride_c, split_k, k_chunk,
-                   accumulate, scale_a, scale_b);
+                   accumulate, scale_a, scale_b, index_b, index_c);
     else
         DTK_LAUNCH("train_gemm", gemm_nt_split_kernel<false>, grid, dim3(256), 0, dtk_stream(stream), A, B, C, M, N, K, (long long)lda,
                    (long long)ldb, (long long)ldc, (long long)stride_a, (long long)stride_b, (long long)stride_c, split_k, k_chunk,
-                   accumulate, scale_a, scale_b);
+                   accumulate, scale_a, scale_b, index_b, index_c);
     return DTK_OK;
+}
+
+extern "C" int dtk_gemm_nt_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb,
+                               int64_t ldc, int32_t batch, int64_t stride_a, int64_t stride_b, int64_t stride_c, int32_t split_k,
+                               int32_t accumulate, const float* scale_a, const float* scale_b, void* stream) {
+    return dtk_gemm_nt_f32_indexed(A, B, C, M, N, K, lda, ldb, ldc, batch, stride_a, stride_b, stride_c, split_k, accumulate, scale_a,
+                                   scale_b, nullptr, nullptr, stream);
 }
 
 extern "C" int dtk_im2col(const float* x, float* cols, int32_t n, int32_t C, int32_t H, int32_t W, int32_t ksize, int32_t pad,
@@ -1210,5 +1219,190 @@ extern "C" int dtk_emb_reg_backward(const float* x, const float* raw, const floa
     const long long cells = (long long)F * n;
     DTK_LAUNCH("train_emb_reg_bwd", emb_reg_backward_kernel, dim3(dtk_cdiv(cells, 256)), dim3(256), 0, dtk_stream(stream), x, raw,
                cell_sums, grad_out2, dx, C, (long long)n, cells);
+    return DTK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// N1: the contrastive (InfoNCE) terms of the training loss (dino_tracker.py:141-243, :327-343) without the affinity tensors
+// of torch.bmm + ATen.  One "problem" q = B anchor embeddings a[q][i] against ALL n cells of frame fidx[q] of the batch's
+// frame embeddings fe[F][C][n] (the layout the model keeps them in):
+//     s[i][j] = a_i . f_j / max(|a_i| |f_j|, eps),      lse[i] = log sum_j exp(s[i][j] / temp)
+// (the reference's term is  -log( exp(cos(a_i, b_i) / temp) / sum_j exp(s[i][j] / temp) ) = lse[i] - cos(a_i, b_i) / temp;
+//  |s / temp| <= 1 / temp, so the plain sum the reference takes is safe in fp32).  Both directions of every frame pair are
+// problems of ONE call.  The products run on dtk_gemm_nt_f32 (fp32-grade split-fp16 MFMA, batch -> frame through an index):
+//   forward   S[q]  [B][n] = a[q] [B][C] . feT[fidx[q]] [n][C]          feT = token-major copy (dtk_pack_features, + |f_j|)
+//   backward  with G = dL/ds = g_i exp(s / temp - lse_i) / temp and G1 = G / (|a_i| |f_j|):
+//             da_i  = sum_j G1[i][j] f_j - (sum_j G[i][j] s[i][j]) a_i / |a_i|^2         dA[q] = G1[q] [B][n] . fe[fidx[q]] [C][n]
+//             dfe_j = sum_i G1[i][j] a_i - (sum_i G[i][j] s[i][j]) f_j / |f_j|^2         dfe[fidx[q]] [C][n] += aT[q] [C][B] . G1T[q] [n][B]
+//   (the clamp at eps is treated as inactive in the gradient, as it is for every vector the model produces).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr float CL_EPS = 1e-8f;
+
+// one workgroup per row (q, i): cosines in place, lse
+__global__ __launch_bounds__(256) void cl_lse_kernel(float* __restrict__ S, const float* __restrict__ na, const float* __restrict__ nf,
+                                                     const int32_t* __restrict__ fidx, float* __restrict__ lse, int B, int n, int np,
+                                                     float inv_temp) {
+    __shared__ float red[4];
+    const long long row = blockIdx.x;
+    const int q = (int)(row / B);
+    float* sp = S + row * np;
+    const float* nfp = nf + (long long)fidx[q] * n;
+    const float a = na[row];
+    float acc = 0.f;
+    for (int j = threadIdx.x; j < np; j += 256) {
+        float v = 0.f;
+        if (j < n) {
+            v = sp[j] / fmaxf(a * nfp[j], CL_EPS);
+            acc += __expf(v * inv_temp);
+        }
+        sp[j] = v;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) lse[row] = logf(red[0] + red[1] + red[2] + red[3]);
+}
+
+// 64 x 64 tile of problem q: G1 (row-major and transposed), row sums r_i = sum_j G s, column sums c_j = sum_i G s, max |G1|
+__global__ __launch_bounds__(256) void cl_grad_tile_kernel(const float* __restrict__ S, const float* __restrict__ lse,
+                                                           const float* __restrict__ g, const float* __restrict__ na,
+                                                           const float* __restrict__ nf, const int32_t* __restrict__ fidx,
+                                                           float* __restrict__ G1, float* __restrict__ G1T, float* __restrict__ rsum,
+                                                           float* __restrict__ csum, unsigned* __restrict__ gmax, int B, int n, int np,
+                                                           float inv_temp) {
+    __shared__ float t[64][65];
+    const int q = blockIdx.z, i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j = j0 + tx;
+    const float* nfp = nf + (long long)fidx[q] * n;
+    const float fnorm = j < n ? nfp[j] : 1.f;
+    float cs = 0.f, mx = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int il = ty + 4 * k, i = i0 + il;
+        float g1 = 0.f, gs = 0.f;
+        if (i < B && j < n) {
+            const long long row = (long long)q * B + i;
+            const float s = S[row * np + j];
+            const float G = g[row] * __expf(s * inv_temp - lse[row]) * inv_temp;
+            g1 = G / fmaxf(na[row] * fnorm, CL_EPS);
+            gs = G * s;
+        }
+        if (i < B && j < np) G1[((long long)q * B + i) * np + j] = g1;   // (columns n .. np-1: zero padding of the reduction)
+        t[il][tx] = g1;
+        cs += gs;
+        mx = fmaxf(mx, fabsf(g1));
+        const float rs = wave_sum(gs);   // a wave = the 64 columns of one row
+        if (tx == 0 && i < B) atomicAdd(&rsum[(long long)q * B + i], rs);
+    }
+    if (j < n) atomicAdd(&csum[(long long)q * n + j], cs);
+    mx = wave_max(mx);
+    if (tx == 0) atomicMax(gmax, __float_as_uint(mx));   // (non-negative floats order like their bit patterns)
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int jl = ty + 4 * k, jj = j0 + jl, i = i0 + tx;
+        if (jj < n && i < B) G1T[((long long)q * n + jj) * B + i] = t[tx][jl];
+    }
+}
+
+// power-of-two operand scale that brings max |x| to ~2^13 (fp16 hi halves well inside the normal range)
+__global__ void cl_scale_kernel(const unsigned* __restrict__ gmax, float* __restrict__ scale) {
+    const float m = __uint_as_float(*gmax);
+    *scale = m > 0.f ? exp2f(fminf(fmaxf(13.f - ceilf(log2f(m)), -60.f), 60.f)) : 1.f;
+}
+
+// da[row][c] -= (r_row / |a_row|^2) a[row][c]
+__global__ __launch_bounds__(256) void cl_da_fix_kernel(float* __restrict__ da, const float* __restrict__ a, const float* __restrict__ rsum,
+                                                        const float* __restrict__ na, long long rows, int C) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * C) return;
+    const long long row = idx / C;
+    const float nn = na[row] * na[row];
+    if (nn > 1e-30f) da[idx] -= rsum[row] / nn * a[idx];
+}
+
+// dfe[f][c][j] -= (sum over the problems q on frame f of c_q[j]) / |f_j|^2 * fe[f][c][j];  one thread per (f, j)
+__global__ __launch_bounds__(256) void cl_dfe_fix_kernel(float* __restrict__ dfe, const float* __restrict__ fe, const float* __restrict__ csum,
+                                                         const float* __restrict__ nf, const int32_t* __restrict__ fidx, int Q, int C, int n,
+                                                         int F) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)F * n) return;
+    const int f = (int)(idx / n), j = (int)(idx - (long long)f * n);
+    float cs = 0.f;
+    for (int q = 0; q < Q; ++q)
+        if (fidx[q] == f) cs += csum[(long long)q * n + j];
+    const float nn = nf[idx] * nf[idx];
+    if (cs == 0.f || !(nn > 1e-30f)) return;
+    const float k = cs / nn;
+    const float* fp = fe + (long long)f * C * n + j;
+    float* dp = dfe + (long long)f * C * n + j;
+    for (int c = 0; c < C; ++c) dp[(long long)c * n] -= k * fp[(long long)c * n];
+}
+
+inline size_t cl_al(size_t x) { return (x + 255) / 256 * 256; }
+
+}  // namespace
+
+extern "C" size_t dtk_contrastive_workspace_bytes(int Q, int B, int C, int n) {
+    if (Q <= 0 || B <= 0 || C <= 0 || n <= 0) return 0;
+    const size_t np = ((size_t)n + 3) / 4 * 4;
+    return cl_al((size_t)Q * B * np * 4) + cl_al((size_t)Q * n * B * 4) + cl_al((size_t)Q * C * B * 4) + cl_al((size_t)Q * B * 4) +
+           cl_al((size_t)Q * n * 4) + 512;
+}
+
+extern "C" int dtk_contrastive_forward(const float* fe, const float* a, const int32_t* fidx, float temp, int Q, int B, int C, int n,
+                                       int F, float* fet, float* nf, float* na, float* S, float* lse, void* stream) {
+    DTK_REQUIRE(fe && a && fidx && fet && nf && na && S && lse, "dtk_contrastive_forward: null pointer");
+    DTK_REQUIRE(Q > 0 && B > 0 && C > 0 && n > 0 && F > 0 && temp > 0.f, "dtk_contrastive_forward: bad sizes");
+    const int np = (n + 3) / 4 * 4;
+    int rc = dtk_pack_features(fe, fet, nf, F, C, n, stream);                 // token-major copy of the frames + |f_j|
+    if (rc != DTK_OK) return rc;
+    rc = dtk_feature_norms(a, na, Q, C, B, stream);                            // |a_i|
+    if (rc != DTK_OK) return rc;
+    rc = dtk_gemm_nt_f32_indexed(a, fet, S, B, n, C, C, C, np, Q, (int64_t)B * C, (int64_t)n * C, (int64_t)B * np, 1, 0, nullptr,
+                                 nullptr, fidx, nullptr, stream);
+    if (rc != DTK_OK) return rc;
+    DTK_LAUNCH("train_cl_lse", cl_lse_kernel, dim3((unsigned)(Q * B)), dim3(256), 0, dtk_stream(stream), S, na, nf, fidx, lse, B, n, np,
+               1.f / temp);
+    return DTK_OK;
+}
+
+extern "C" int dtk_contrastive_backward(const float* fe, const float* a, const int32_t* fidx, float temp, int Q, int B, int C, int n,
+                                        int F, const float* nf, const float* na, const float* S, const float* lse, const float* g,
+                                        float* da, float* dfe, void* workspace, size_t workspace_bytes, void* stream) {
+    DTK_REQUIRE(fe && a && fidx && nf && na && S && lse && g && da && dfe && workspace, "dtk_contrastive_backward: null pointer");
+    DTK_REQUIRE(Q > 0 && B > 0 && C > 0 && n > 0 && F > 0 && temp > 0.f, "dtk_contrastive_backward: bad sizes");
+    DTK_REQUIRE(workspace_bytes >= dtk_contrastive_workspace_bytes(Q, B, C, n), "dtk_contrastive_backward: workspace too small");
+    const int np = (n + 3) / 4 * 4;
+    hipStream_t st = dtk_stream(stream);
+    unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
+    float* G1 = reinterpret_cast<float*>(w);   w += cl_al((size_t)Q * B * np * 4);
+    float* G1T = reinterpret_cast<float*>(w);  w += cl_al((size_t)Q * n * B * 4);
+    float* aT = reinterpret_cast<float*>(w);   w += cl_al((size_t)Q * C * B * 4);
+    float* rsum = reinterpret_cast<float*>(w); w += cl_al((size_t)Q * B * 4);
+    float* csum = reinterpret_cast<float*>(w); w += cl_al((size_t)Q * n * 4);
+    unsigned* gmax = reinterpret_cast<unsigned*>(w);
+    float* scale = reinterpret_cast<float*>(w + 256);
+    DTK_HIP(hipMemsetAsync(rsum, 0, cl_al((size_t)Q * B * 4) + cl_al((size_t)Q * n * 4) + 512, st));   // rsum, csum, gmax, scale
+    DTK_HIP(hipMemsetAsync(dfe, 0, (size_t)F * C * n * 4, st));
+    DTK_LAUNCH("train_cl_grad", cl_grad_tile_kernel, dim3(dtk_cdiv(np, 64), dtk_cdiv(B, 64), Q), dim3(256), 0, st, S, lse, g, na, nf, fidx,
+               G1, G1T, rsum, csum, gmax, B, n, np, 1.f / temp);
+    DTK_LAUNCH("train_cl_scale", cl_scale_kernel, dim3(1), dim3(1), 0, st, gmax, scale);
+    // dA[q] [B][C] = G1[q] [B][n] . fe[fidx[q]] [C][n]
+    int rc = dtk_gemm_nt_f32_indexed(G1, fe, da, B, C, n, np, n, C, Q, (int64_t)B * np, (int64_t)C * n, (int64_t)B * C, 1, 0, scale, nullptr,
+                                     fidx, nullptr, stream);
+    if (rc != DTK_OK) return rc;
+    DTK_LAUNCH("train_cl_da", cl_da_fix_kernel, dim3(dtk_cdiv((long long)Q * B * C, 256)), dim3(256), 0, st, da, a, rsum, na,
+               (long long)Q * B, C);
+    // dfe[fidx[q]] [C][n] += aT[q] [C][B] . G1T[q] [n][B]   (atomic: several problems may share a frame)
+    rc = dtk_transpose_f32(a, aT, B, C, Q, stream);
+    if (rc != DTK_OK) return rc;
+    rc = dtk_gemm_nt_f32_indexed(aT, G1T, dfe, C, n, B, B, B, n, Q, (int64_t)C * B, (int64_t)n * B, (int64_t)C * n, 1, 2, nullptr, scale,
+                                 nullptr, fidx, stream);
+    if (rc != DTK_OK) return rc;
+    DTK_LAUNCH("train_cl_dfe", cl_dfe_fix_kernel, dim3(dtk_cdiv((long long)F * n, 256)), dim3(256), 0, st, dfe, fe, csum, nf, fidx, Q, C, n, F);
     return DTK_OK;
 }

@@ -421,3 +421,37 @@ def emb_reg_backward(x: torch.Tensor, raw: torch.Tensor, sums: torch.Tensor, gou
     check(lib().dtk_emb_reg_backward(_p(x, torch.float32), _p(raw, torch.float32), _p(sums, torch.float32), _p(gout, torch.float32),
                                      f, c, h * w, _p(dx), _stream()))
     return dx
+
+
+def contrastive_forward(fe: torch.Tensor, a: torch.Tensor, fidx: torch.Tensor, temp: float):
+    """dtk_contrastive_forward: fe [F, C, h, w], a [Q, B, C], fidx [Q] int32 -> (lse [Q, B], saved tensors for backward)."""
+    F, C = fe.shape[:2]
+    n = fe.shape[2] * fe.shape[3]
+    Q, B = a.shape[:2]
+    np_ = (n + 3) // 4 * 4
+    dev = fe.device
+    fet = torch.empty(F * n * C, dtype=torch.float32, device=dev)
+    nf = torch.empty(F, n, dtype=torch.float32, device=dev)
+    na = torch.empty(Q, B, dtype=torch.float32, device=dev)
+    S = torch.empty(Q, B, np_, dtype=torch.float32, device=dev)
+    lse = torch.empty(Q, B, dtype=torch.float32, device=dev)
+    check(lib().dtk_contrastive_forward(_p(fe, torch.float32), _p(a, torch.float32), _p(fidx, torch.int32), float(temp), Q, B, C, n, F,
+                                        _p(fet), _p(nf), _p(na), _p(S), _p(lse), _stream()))
+    return lse, (nf, na, S)
+
+
+def contrastive_backward(fe: torch.Tensor, a: torch.Tensor, fidx: torch.Tensor, temp: float, saved, lse: torch.Tensor,
+                         g: torch.Tensor):
+    """dtk_contrastive_backward -> (da [Q, B, C], dfe like fe)."""
+    F, C = fe.shape[:2]
+    n = fe.shape[2] * fe.shape[3]
+    Q, B = a.shape[:2]
+    nf, na, S = saved
+    da = torch.empty_like(a)
+    dfe = torch.empty_like(fe)
+    nbytes = int(lib().dtk_contrastive_workspace_bytes(Q, B, C, n))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=fe.device)
+    check(lib().dtk_contrastive_backward(_p(fe, torch.float32), _p(a, torch.float32), _p(fidx, torch.int32), float(temp), Q, B, C, n, F,
+                                         _p(nf, torch.float32), _p(na, torch.float32), _p(S, torch.float32), _p(lse, torch.float32),
+                                         _p(g, torch.float32), _p(da), _p(dfe), _p(ws), nbytes, _stream()))
+    return da, dfe

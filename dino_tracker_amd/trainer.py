@@ -50,6 +50,50 @@ def contrastive_terms(a: torch.Tensor, b: torch.Tensor, fa: torch.Tensor, fb: to
     return l_st, l_ts
 
 
+class _CosLse(torch.autograd.Function):
+    """lse[q][i] = log sum_j exp(cos(a[q][i], cell j of frame fidx[q]) / temp) on hand-written kernels, both ways
+    (csrc/train.hip: dtk_contrastive_forward / _backward): no [Q, B, n] tensor is handed to torch, the frames are indexed, not
+    gathered."""
+
+    @staticmethod
+    def forward(ctx, a, fe, fidx, temp):
+        from . import ops
+        a, fe = a.contiguous(), fe.contiguous()
+        fidx = fidx.to(torch.int32).contiguous()
+        lse, saved = ops.contrastive_forward(fe, a, fidx, temp)
+        ctx.save_for_backward(a, fe, fidx, lse, *saved)
+        ctx.temp = temp
+        return lse
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        a, fe, fidx, lse, nf, na, S = ctx.saved_tensors
+        da, dfe = ops.contrastive_backward(fe, a, fidx, ctx.temp, (nf, na, S), lse, g.contiguous())
+        return da, dfe, None, None
+
+
+def contrastive_terms_indexed(a: torch.Tensor, b: torch.Tensor, fe: torch.Tensor, s_sel: torch.Tensor, t_sel: torch.Tensor,
+                              temp: float):
+    """contrastive_terms for frames given as INDICES into the frame embeddings fe [F, C, h, w] (device path): a, b [P, B, C];
+    a's negatives are the cells of frame t_sel[p], b's those of frame s_sel[p].  Same values as
+    contrastive_terms(a, b, frame_cells(fe, s_sel), frame_cells(fe, t_sel), temp) up to fp32 rounding:
+    -log(exp(bb / temp) / sum_j exp(s_j / temp)) = lse - bb / temp."""
+    P = a.shape[0]
+    bb = (a * b).sum(dim=2) / torch.clamp(a.norm(dim=2) * b.norm(dim=2), min=EPS)
+    lse = _CosLse.apply(torch.cat([a, b]), fe, torch.cat([t_sel, s_sel]), temp)
+    return lse[:P] - bb / temp, lse[P:] - bb / temp
+
+
+def cells_at(frame_embeddings: torch.Tensor, sel: torch.Tensor, cells: torch.Tensor) -> torch.Tensor:
+    """[F, C, h, w], sel [P], cells [P, B] -> [P, B, C]: the embeddings of the given cells of frame sel[p] (no per-frame copy)."""
+    return frame_embeddings.flatten(2)[sel[:, None], :, cells]
+
+
+def fused_contrastive(fe: torch.Tensor) -> bool:
+    return fe.is_cuda and fe.dtype == torch.float32 and fe.shape[1] % 4 == 0 and os.environ.get("DTK_CL_TERMS", "fused") == "fused"
+
+
 def frame_cells(frame_embeddings: torch.Tensor, sel: torch.Tensor) -> torch.Tensor:
     """[F, C, h, w], sel [P] -> [P, n, C]: rearrange(frame_embeddings[sel_p], 'c h w -> (h w) c') for every p.
     On the device the selection is a product with the one-hot matrix of `sel` (exact: every output is one input times 1 plus
@@ -279,7 +323,10 @@ def make_trainer(base):
             frame set, picks [P, B] index the flat best-buddy table, ok [P, B] switches slots off."""
             fe = model.frame_embeddings
             a, b, w = self.dino_bb_operands(model, s_sel, t_sel, picks, ok)
-            l_st, l_ts = contrastive_terms(a, b, frame_cells(fe, s_sel), frame_cells(fe, t_sel), self.config["cl_temp"])
+            if fused_contrastive(fe):
+                l_st, l_ts = contrastive_terms_indexed(a, b, fe, s_sel, t_sel, self.config["cl_temp"])
+            else:
+                l_st, l_ts = contrastive_terms(a, b, frame_cells(fe, s_sel), frame_cells(fe, t_sel), self.config["cl_temp"])
             div = self.config["cl_div_dino_bb"]
             return ((l_st * w / div).sum() + (l_ts * w / div).sum()) / 2
 
@@ -305,11 +352,15 @@ def make_trainer(base):
         def refined_bb_terms(self, model, s_sel, t_sel, src_cells, tgt_cells, ok):
             """Deterministic part of dino_tracker.py:245-325 for explicit selections (cells of the token grid)."""
             fe = model.frame_embeddings
-            sf, tf = frame_cells(fe, s_sel), frame_cells(fe, t_sel)
-            C = sf.shape[2]
-            a = sf.gather(1, src_cells[:, :, None].expand(-1, -1, C))
-            b = tf.gather(1, tgt_cells[:, :, None].expand(-1, -1, C))
-            l_st, l_ts = contrastive_terms(a, b, sf, tf, self.config["cl_temp"])
+            if fused_contrastive(fe):
+                a, b = cells_at(fe, s_sel, src_cells), cells_at(fe, t_sel, tgt_cells)
+                l_st, l_ts = contrastive_terms_indexed(a, b, fe, s_sel, t_sel, self.config["cl_temp"])
+            else:
+                sf, tf = frame_cells(fe, s_sel), frame_cells(fe, t_sel)
+                C = sf.shape[2]
+                a = sf.gather(1, src_cells[:, :, None].expand(-1, -1, C))
+                b = tf.gather(1, tgt_cells[:, :, None].expand(-1, -1, C))
+                l_st, l_ts = contrastive_terms(a, b, sf, tf, self.config["cl_temp"])
             with torch.no_grad():
                 aff = (a * b).sum(dim=2) / torch.clamp(a.norm(dim=2) * b.norm(dim=2), min=EPS)
                 w = torch.clamp(2 * aff ** 3, 0) * ok.to(aff.dtype)
@@ -325,12 +376,16 @@ def make_trainer(base):
             s1, t1, picks, ok1 = bb_sel
             s2, t2, src_cells, tgt_cells, ok2 = ref_sel
             P = s1.shape[0]
-            cells = frame_cells(fe, torch.cat([s1, s2, t1, t2]))          # [4 P, n, C]: one gather of the frames' cells
-            sf, tf = cells[:2 * P], cells[2 * P:]
-            C = sf.shape[2]
+            fused = fused_contrastive(fe)
             a1, b1, w1 = self.dino_bb_operands(model, s1, t1, picks, ok1)
-            a2 = sf[P:].gather(1, src_cells[:, :, None].expand(-1, -1, C))
-            b2 = tf[P:].gather(1, tgt_cells[:, :, None].expand(-1, -1, C))
+            if fused:   # the frames stay where they are: the kernels index them (csrc/train.hip, dtk_contrastive_*)
+                a2, b2 = cells_at(fe, s2, src_cells), cells_at(fe, t2, tgt_cells)
+            else:
+                cells = frame_cells(fe, torch.cat([s1, s2, t1, t2]))          # [4 P, n, C]: one gather of the frames' cells
+                sf, tf = cells[:2 * P], cells[2 * P:]
+                C = sf.shape[2]
+                a2 = sf[P:].gather(1, src_cells[:, :, None].expand(-1, -1, C))
+                b2 = tf[P:].gather(1, tgt_cells[:, :, None].expand(-1, -1, C))
             # the two selections may differ in width (a pair has fewer DINO best buddies than cl_points_per_pair): the narrower
             # one is padded with copies of its first slot at weight 0
             B = max(a1.shape[1], a2.shape[1])
@@ -345,7 +400,11 @@ def make_trainer(base):
             a1, b1, a2, b2 = pad(a1), pad(b1), pad(a2), pad(b2)
             w1 = pad(w1, value_from_first=False)
             ok2 = pad(ok2, value_from_first=False)
-            l_st, l_ts = contrastive_terms(torch.cat([a1, a2]), torch.cat([b1, b2]), sf, tf, self.config["cl_temp"])
+            if fused:
+                l_st, l_ts = contrastive_terms_indexed(torch.cat([a1, a2]), torch.cat([b1, b2]), fe, torch.cat([s1, s2]),
+                                                       torch.cat([t1, t2]), self.config["cl_temp"])
+            else:
+                l_st, l_ts = contrastive_terms(torch.cat([a1, a2]), torch.cat([b1, b2]), sf, tf, self.config["cl_temp"])
             with torch.no_grad():
                 aff = (a2 * b2).sum(dim=2) / torch.clamp(a2.norm(dim=2) * b2.norm(dim=2), min=EPS)
                 w2 = torch.clamp(2 * aff ** 3, 0) * ok2.to(aff.dtype)

@@ -234,6 +234,20 @@ int dtk_conv_wgrad_split(const float* x, const float* dy, float* dw, int N, int 
                          int reflect_pad, const float* scale_dy, int fp16_only, void* workspace, size_t workspace_bytes,
                          void* stream);
 
+/* The contrastive (InfoNCE) terms of the training loss (dino_tracker.py:141-243, :327-343) without the affinity tensors:
+ * problem q < Q = B anchor embeddings a[q][i][C] against all n cells of frame fidx[q] of fe[F][C][n]:
+ *     s[i][j] = cos(a_i, f_j) (clamped at 1e-8 like the reference),   lse[q][i] = log sum_j exp(s[i][j] / temp)
+ * so that the reference's term -log(exp(cos(a_i, b_i) / temp) / sum_j exp(s[i][j] / temp)) = lse - cos(a_i, b_i) / temp.
+ * forward writes lse and keeps for backward: nf[F][n] = |f_j|, na[Q][B] = |a_i|, S[Q][B][np] = the cosines (np = n rounded up
+ * to a multiple of 4); fet [F][n][C] is scratch.  backward: g[Q][B] = dL/dlse -> da[Q][B][C] (written) and dfe[F][C][n]
+ * (ZEROED and written: the sum over the problems of each frame; float atomics, so the last bits depend on the order). */
+size_t dtk_contrastive_workspace_bytes(int Q, int B, int C, int n);
+int dtk_contrastive_forward(const float* fe, const float* a, const int32_t* fidx, float temp, int Q, int B, int C, int n, int F,
+                            float* fet, float* nf, float* na, float* S, float* lse, void* stream);
+int dtk_contrastive_backward(const float* fe, const float* a, const int32_t* fidx, float temp, int Q, int B, int C, int n, int F,
+                             const float* nf, const float* na, const float* S, const float* lse, const float* g, float* da,
+                             float* dfe, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The embedding regularisers of the training loss (dino_tracker.py:128-139): out2 = (mean | |x| / |raw| - 1 |, mean | cos(x, raw) - 1 |)
  * over the F * n cells of x, raw [F][C][n]; cell_sums [3][F * n] keeps the per-cell sums for dtk_emb_reg_backward, which writes
  * dx [F][C][n] for the upstream gradients grad_out2 (device, two floats). */
@@ -407,6 +421,12 @@ int dtk_blurpool_backward(const float* dy, float* dx, int64_t planes, int32_t H,
 int dtk_gemm_nt_f32(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb,
                     int64_t ldc, int32_t batch, int64_t stride_a, int64_t stride_b, int64_t stride_c, int32_t split_k,
                     int32_t accumulate, const float* scale_a, const float* scale_b, void* stream);
+/* the same with an optional batch -> operand map: batch b reads B operand number index_b[b] and writes (accumulate 2: adds to)
+ * output number index_c[b]; either may be NULL (identity). */
+int dtk_gemm_nt_f32_indexed(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb,
+                            int64_t ldc, int32_t batch, int64_t stride_a, int64_t stride_b, int64_t stride_c, int32_t split_k,
+                            int32_t accumulate, const float* scale_a, const float* scale_b, const int32_t* index_b,
+                            const int32_t* index_c, void* stream);
 int dtk_im2col(const float* x, float* cols, int32_t n, int32_t C, int32_t H, int32_t W, int32_t ksize, int32_t pad, int32_t dil,
                int32_t reflect, int32_t layout, int32_t Kp, int64_t Lp, void* stream);
 int dtk_col2im(const float* dcols, float* dx, int32_t n, int32_t C, int32_t H, int32_t W, int32_t ksize, int32_t pad, int32_t dil,

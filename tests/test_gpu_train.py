@@ -307,6 +307,41 @@ def test_conv_fp16_operand_mode():
     assert all(e < 3e-6 for e in errs["split"]), errs
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 5, 7, 4, 20), (5, 384, 9, 13, 6, 70)])
+def test_contrastive_kernels_match_float64(shape):
+    """trainer.contrastive_terms_indexed (dtk_contrastive_forward / _backward: affinity products on the split-fp16 MFMA GEMM
+    with the frames indexed, row log-sum-exp, both gradients) vs trainer.contrastive_terms on gathered frames in float64:
+    values and the gradients with respect to the anchors and to the frame embeddings.  Sizes that are no multiple of any tile
+    (n = 35 / 117 cells, B = 20 / 70 anchors), several problems on the same frame, a zero-weight row."""
+    from dino_tracker_amd import trainer as T
+    F_, C, h, w, P, B = shape
+    g = torch.Generator().manual_seed(11)
+    fe = torch.randn(F_, C, h, w, generator=g) * 1.5 + 0.3
+    a = torch.randn(P, B, C, generator=g)
+    b = torch.randn(P, B, C, generator=g)
+    s_sel = torch.randint(0, F_, (P,), generator=g)
+    t_sel = torch.randint(0, F_, (P,), generator=g)
+    s_sel[1], t_sel[1] = s_sel[0], t_sel[0]                     # two pairs on the same frames: their gradients add up
+    wgt = torch.rand(P, B, generator=g)
+    wgt[0, 3] = 0.0
+    temp = 0.1
+
+    def loss(l_st, l_ts, ww):
+        return (l_st * ww).sum() + 0.5 * (l_ts * ww).sum()
+
+    fd, ad, bd = fe.cuda().requires_grad_(True), a.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    l_st, l_ts = T.contrastive_terms_indexed(ad, bd, fd, s_sel.cuda(), t_sel.cuda(), temp)
+    loss(l_st, l_ts, wgt.cuda()).backward()
+    f64, a64, b64 = fe.double().requires_grad_(True), a.double().requires_grad_(True), b.double().requires_grad_(True)
+    r_st, r_ts = T.contrastive_terms(a64, b64, T.frame_cells(f64, s_sel), T.frame_cells(f64, t_sel), temp)
+    loss(r_st, r_ts, wgt.double()).backward()
+    ev = max(float((l_st.double().cpu() - r_st).abs().max()), float((l_ts.double().cpu() - r_ts).abs().max()))
+    rel = lambda x, y: float((x.double().cpu() - y).abs().max() / y.abs().max())
+    ea, eb, ef = rel(ad.grad, a64.grad), rel(bd.grad, b64.grad), rel(fd.grad, f64.grad)
+    print(f"terms max abs err {ev:.2e} (|term| ~ {float(r_st.abs().mean()):.2f}); gradient rel err: a {ea:.1e}, b {eb:.1e}, frames {ef:.1e}")
+    assert ev < 2e-5 and ea < 2e-5 and eb < 2e-5 and ef < 2e-5
+
+
 def test_embedding_regularisers_kernel_matches_float64():
     """trainer.emb_regularization_terms on the device (dtk_emb_reg_forward / _backward: both terms and their gradient in one pass
     each way) vs the traced statement in float64 on the host, incl. cells where the refined embedding is shorter / longer than the
