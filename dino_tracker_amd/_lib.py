@@ -53,7 +53,7 @@ OPERAND_F16, OPERAND_BF16, OPERAND_ATTENTION_V2 = 0, 1, 0x100
 class TrackOpts(ctypes.Structure):
     """struct dtk_track_opts."""
     _fields_ = [("method", ctypes.c_int32), ("normalized", ctypes.c_int32), ("round_sources", ctypes.c_int32),
-                ("tier", ctypes.c_int32)]
+                ("tier", ctypes.c_int32), ("emb_rows", ctypes.c_int32)]
 
 
 class TrackStats(ctypes.Structure):

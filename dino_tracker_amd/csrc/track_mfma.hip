@@ -520,7 +520,8 @@ __device__ __forceinline__ void peaks_dma(dtk_u4 srd, unsigned toff, unsigned vo
 template <int KS, int VAR, int CB>
 __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_t* __restrict__ f16,
                                                          const half_t* __restrict__ s16, const int32_t* __restrict__ tgt,
-                                                         Rec* __restrict__ rec, int m0, int count, int HWp) {
+                                                         Rec* __restrict__ rec, int m0, int count, int HWp,
+                                                         const int32_t* __restrict__ row_of) {
     constexpr int C = KS * 16;
     constexpr int PK_CELLS = 32 * CB;            // cells per step: CB 32-cell blocks
     constexpr int TSH = CB > 1 ? 5 : 4;          // position tag: step << TSH | cell block << 4 | accumulator register
@@ -556,7 +557,10 @@ __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int i = src0 + t * 32 + j;
-        const half_t* sp = s16 + (size_t)min(i, count - 1) * C + h * 8;
+        // row_of != NULL: s16 is the fp16 table of ALL rows of emb, made once per call (a source is row row_of[m]); else the
+        // round's sources converted in order by src16_kernel
+        const int ic = min(i, count - 1);
+        const half_t* sp = s16 + (size_t)(row_of ? row_of[m0 + ic] : ic) * C + h * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
             asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(bs[t][ks]) : "v"(sp + ks * 16) : "memory");
@@ -1829,7 +1833,7 @@ struct SrcLists {
 int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const float* feat, const float* norms,
                const half_t* f16, const float* head, const float* emb, SrcLists in, float* out_xy, int count,
                int normalized, bool fast, Redo redo, Redo uncert, size_t lds_head, hipStream_t st, int dbg,
-               int32_t* arg_cell = nullptr, float* arg_cos = nullptr) {
+               int32_t* arg_cell = nullptr, float* arg_cos = nullptr, bool row_table = false) {
     half_t* s16 = reinterpret_cast<half_t*>(ws + L.s16);
     half_t* maps = reinterpret_cast<half_t*>(ws + L.maps);
     Rec* rec = reinterpret_cast<Rec*>(ws + L.rec);
@@ -1853,8 +1857,10 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
                            L.HWp % pk_cells == 0 && pw_pad(g->pw) % pk_cells == 0 && !DTK_DBG(dbg, 2048) &&
                            (long long)g->T * L.HWp * g->C * 2 < (1LL << 32);   // (32-bit tile offsets of the LDS-DMA descriptor)
         if (peaks) {
-            DTK_LAUNCH("src16", src16_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, emb, in.src_row, s16, (int)s0, scnt, M,
-                       nodm, g->C, PK_SRC_SCALE);
+            const int32_t* row_of = row_table ? in.src_row : nullptr;   // (the table: dtk_track_mfma)
+            if (!row_of)
+                DTK_LAUNCH("src16", src16_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, emb, in.src_row, s16, (int)s0, scnt, M,
+                           nodm, g->C, PK_SRC_SCALE);
             const dim3 pgrid(dtk_cdiv(scnt, PK_SRC));
 #define DTK_PEAKS(V, CBV)                                                                                                    \
     do {                                                                                                                     \
@@ -1863,7 +1869,7 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
                                                             (int)peaks_lds_bytes(CBV));                                      \
         DTK_HIP(attr_);                                                                                                      \
         DTK_LAUNCH("corr_peaks", (corr_peaks_kernel<24, V, CBV>), pgrid, dim3(256), peaks_lds_bytes(CBV), st, *g, f16, s16,  \
-                   in.tgt, rec, (int)s0, scnt, L.HWp);                                                                       \
+                   in.tgt, rec, (int)s0, scnt, L.HWp, row_of);                                                               \
     } while (0)
 #ifdef DTK_DEV
             if (pk_cb == 2) {
@@ -1991,8 +1997,17 @@ int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, con
     DTK_HIP(hipMemsetAsync(ws + L.maps, 0, (size_t)L.chunk * L.MP * 2, st));  // zero borders of the padded maps
     const half_t* f16 = reinterpret_cast<const half_t*>(feat_f16);
     const bool fast_ok = opts->tier != DTK_TIER_WHOLE_MAP && !DTK_DBG(dbg, 512);
+    // Sources that are rows of a small matrix (the anchor stage: N T rows for N T (T + 1) sources): convert the ROWS to fp16 unit
+    // vectors once per call instead of every round's sources in order (2.9 ms per benchmark step, 0.4 GB of copies per round);
+    // corr_peaks then gathers its 64 sources per wave through src_row.  Needs the row count from the caller (opts->emb_rows).
+    const bool row_table = fast_ok && src_row != nullptr && opts->emb_rows > 0 && opts->emb_rows <= L.super && g->C == 384 &&
+                           !DTK_DBG(dbg, 262144);
+    if (row_table)
+        DTK_LAUNCH("src16", src16_kernel, dim3(dtk_cdiv(opts->emb_rows, 4)), dim3(256), 0, st, emb, (const int32_t*)nullptr,
+                   reinterpret_cast<half_t*>(ws + L.s16), 0, opts->emb_rows, opts->emb_rows, (const int32_t*)nullptr, g->C,
+                   PK_SRC_SCALE);
     int rc = mfma_phase(g, L, ws, feat, norms, f16, head, emb, SrcLists{src_row, tgt, out_idx}, out_xy, count, normalized,
-                        fast_ok, redo, uncert, lds_head, st, dbg);
+                        fast_ok, redo, uncert, lds_head, st, dbg, nullptr, nullptr, row_table);
     if (rc) return rc;
     int32_t hc[2] = {0, 0};
     DTK_HIP(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, st));

@@ -118,7 +118,7 @@ def head_forward(g: Geom, head: torch.Tensor, maps: torch.Tensor, normalized: bo
 
 
 def track_workspace_bytes(g: Geom, M: int, method: int, round_sources: int = 0) -> int:
-    return int(lib().dtk_track_workspace_bytes(g, M, TrackOpts(method, 0, round_sources, TIER_AUTO)))
+    return int(lib().dtk_track_workspace_bytes(g, M, TrackOpts(method, 0, round_sources, TIER_AUTO, 0)))
 
 
 def feat_f16_bytes(g: Geom) -> int:
@@ -137,7 +137,7 @@ def track(g: Geom, feat: torch.Tensor, norms: torch.Tensor, feat_f16: Optional[t
           normalized: bool = False, method: int = TRACK_EXACT, round_sources: int = 0, tier: int = TIER_AUTO,
           stats: Optional[TrackStats] = None) -> torch.Tensor:
     """dtk_track.  `stats` (a TrackStats) receives the tier sizes / sync count of this call."""
-    opts = TrackOpts(method, int(normalized), round_sources, tier)
+    opts = TrackOpts(method, int(normalized), round_sources, tier, int(emb.shape[0]) if src_row is not None else 0)
     check(lib().dtk_track(g, _p(feat, torch.float32), _p(norms, torch.float32), _p(feat_f16), _p(head, torch.float32),
                           _p(emb, torch.float32), _p(src_row, torch.int32), _p(tgt, torch.int32),
                           _p(out_idx, torch.int32), _p(out_xy, torch.float32), M, _p(dM, torch.int32), opts, stats,

@@ -299,6 +299,8 @@ int dtk_corr_maps(const dtk_geom* g, const float* feat, const float* norms, cons
 #define DTK_TIER_WHOLE_MAP 1
 typedef struct dtk_track_opts {
     int32_t method, normalized, round_sources, tier;
+    int32_t emb_rows;        /* number of rows of `emb` when sources go through src_row (0 = unknown): lets DTK_TRACK_MFMA convert
+                              * the rows once per call instead of every round's sources */
 } dtk_track_opts;
 typedef struct dtk_track_stats {
     int32_t sources;         /* sources processed (min(M, *dM)) */
