@@ -37,7 +37,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)   # (the second step still meets one fresh multi-GB hipMalloc: docs/MEASUREMENTS.md)
     ap.add_argument("--frames", type=int, default=90)
     ap.add_argument("--queries", type=int, default=1024)
     ap.add_argument("--width", type=int, default=384, help="feature width C (384 = ViT-S/14)")
