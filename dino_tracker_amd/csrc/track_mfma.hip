@@ -1150,6 +1150,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(dtk_geom g, const int32_t*
 //     16x the f32-input MFMA rate instead of one (64 sources x 256 cells x 384 channels on the f32 MFMA alone cost
 //     more than the whole round-1 kernel).
 constexpr int RC_SRC = 64;
+constexpr int RCD_NS = 4, RCD_NBM = NB_MAX;   // refine_corr_dma: ring depth, largest group box (a 6-deep ring with 384-cell groups, still 3 workgroups per CU, measured 15.1 ms against 11.0)
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const float* __restrict__ feat,
                                                           const float* __restrict__ norms,
@@ -1317,6 +1318,17 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const floa
     }
 }
 
+// s_waitcnt vmcnt(n) for a count that is a compile-time constant after unrolling (n even, <= 32)
+__device__ __forceinline__ void vm_wait_n(int n) {
+    switch (n) {
+#define DTK_VMW(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+        DTK_VMW(0) DTK_VMW(2) DTK_VMW(4) DTK_VMW(6) DTK_VMW(8) DTK_VMW(10) DTK_VMW(12) DTK_VMW(14) DTK_VMW(16) DTK_VMW(18) DTK_VMW(20)
+        DTK_VMW(22) DTK_VMW(24) DTK_VMW(26) DTK_VMW(28) DTK_VMW(30) DTK_VMW(32)
+#undef DTK_VMW
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
 // The same correlations for C = 32 NKC known at compile time (C = 384: NKC = 12), restructured around what the counters
 // showed (profiles/r04_pmc_sq.md, refine_corr: waves parked 61 %, 25 % issuing -- two thirds of it the hi / lo split of every
 // staged element --, MFMA pipe 13 % busy; neither a deeper register pipeline nor source-stationary operands alone moved it):
@@ -1333,7 +1345,7 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const floa
 // two requests per step, 16 window stores per block as buffer stores whose switched-off lanes carry an out-of-range offset
 // (no branch, so the count is static); the norms of the box come from LDS (a compiler-managed global load here would be
 // waited for with vmcnt(0) and drain the ring).
-template <int NKC>
+template <int NKC, int NS, int NBM>
 __global__ __launch_bounds__(256, 3) void refine_corr_dma_kernel(dtk_geom g, const half_t* __restrict__ fs,
                                                               const float* __restrict__ norms,
                                                               const float* __restrict__ emb,
@@ -1345,14 +1357,14 @@ __global__ __launch_bounds__(256, 3) void refine_corr_dma_kernel(dtk_geom g, con
                                                               const int32_t* __restrict__ nvalid,
                                                               float* __restrict__ xwin, unsigned xwin_bytes, int m0,
                                                               int ntiles) {
-    constexpr int NS = 4;              // stages of the LDS ring
+    // NS = stages of the LDS ring, NBM = largest union box (cells) correlated as one group
     constexpr int STAGE = 64 * 128;    // bytes: 64 cells x (32 hi + 32 lo) halves
     static_assert(NKC % NS == 0 && NKC >= NS, "the stage of a step is chosen at compile time");
     constexpr int C = NKC * 32;
     __shared__ float s_sn[RC_SRC];
     __shared__ int s_row[RC_SRC], s_f[RC_SRC], s_k[RC_SRC], s_m[RC_SRC], s_grp[RC_SRC], s_box[RC_SRC * 4], s_first[RC_SRC],
         s_last[RC_SRC], s_ng;
-    __shared__ float s_fn[NB_MAX];
+    __shared__ float s_fn[NBM];
     __shared__ __attribute__((aligned(1024))) unsigned char ring[NS * STAGE];
     const int ph = g.ph, pw = g.pw, HW = ph * pw;
     const int nv = *nvalid;
@@ -1385,7 +1397,7 @@ __global__ __launch_bounds__(256, 3) void refine_corr_dma_kernel(dtk_geom g, con
             bool fits = false;
             if (ng > 0 && s_f[s] == cf) {
                 const int n0 = min(r0, a0), n1 = max(r1, a1), e0 = min(c0, b0), e1 = max(c1, b1);
-                if ((n1 - n0 + 1) * (e1 - e0 + 1) <= NB_MAX) { r0 = n0; r1 = n1; c0 = e0; c1 = e1; fits = true; }
+                if ((n1 - n0 + 1) * (e1 - e0 + 1) <= NBM) { r0 = n0; r1 = n1; c0 = e0; c1 = e1; fits = true; }
             }
             if (!fits) { ++ng; cf = s_f[s]; r0 = a0; r1 = a1; c0 = b0; c1 = b1; s_first[ng - 1] = s; }
             s_grp[s] = ng - 1;
@@ -1475,18 +1487,10 @@ __global__ __launch_bounds__(256, 3) void refine_corr_dma_kernel(dtk_geom g, con
                 // the requests of this step have landed when at most those issued after them are outstanding: the requests of
                 // the next two steps (where those exist) and, in the first three steps of a later block, the 16 window stores
                 // of the previous block (issued between the request of step 2 and that of step 3)
-                if (kc < NS - 1) {
-                    if (blk > 0) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                } else if (kc < NKC - 2) {
-                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                } else if (kc == NKC - 2) {
-                    if (last_blk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                } else {
-                    if (last_blk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                }
+                // (requests younger than this step's: two per existing step among the next NS - 2; in the last block those
+                //  past the end do not exist)
+                const int young = 2 * (last_blk ? min(NKC - 1 - kc, NS - 2) : NS - 2) + ((blk > 0 && kc < NS - 1) ? 16 : 0);
+                vm_wait_n(young);
                 __syncthreads();  // every wave's part of this stage has landed; stage (kc - 1) % NS is free again
                 if (kc + NS - 1 < NKC) RC_ISSUE((kc + NS - 1) % NS, vc, kc + NS - 1);
                 else if (!last_blk) RC_ISSUE((kc + NS - 1) % NS, vn, kc + NS - 1 - NKC);
@@ -1932,7 +1936,7 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
         {
             const int rtiles = dtk_cdiv(scnt, RC_SRC);
             if (has_split_planes(g) && !DTK_DBG(dbg, 131072) && (size_t)L.super * WX * WX * 4 < (1ull << 32))
-                DTK_LAUNCH("refine_corr", refine_corr_dma_kernel<12>, dim3(8 * dtk_cdiv(rtiles, 8)), dim3(256), 0, st, *g,
+                DTK_LAUNCH("refine_corr", (refine_corr_dma_kernel<12, RCD_NS, RCD_NBM>), dim3(8 * dtk_cdiv(rtiles, 8)), dim3(256), 0, st, *g,
                            reinterpret_cast<const half_t*>(reinterpret_cast<const unsigned char*>(f16) + split_planes_offset(g)),
                            norms, emb, in.src_row, in.tgt, kstar, snorm, perm, nvalid, xwin, (unsigned)((size_t)scnt * WX * WX * 4),
                            (int)s0, rtiles);
