@@ -249,7 +249,9 @@ def main():
                         "frac": None, "traffic": None}
         # HBM-side bytes per launch of that kernel: NOT measured by this process (PMC counters need a rocprofv3 wrapper
         # around it) -- read from the newest committed PMC pass of the same command (scripts/pmc_traffic.py)
-        for prof_file in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        # (the committed passes are of the DEFAULT workload: another width / frame count / query count gets no traffic figure)
+        default_workload = args.width == 384 and args.frames == 90 and args.queries == 1024 and not args.videos
+        for prof_file in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if default_workload else ():
             try:
                 with open(os.path.join(ROOT, "profiles", prof_file)) as fh:
                     tr = json.load(fh)["kernels"].get(dom)
