@@ -63,7 +63,7 @@ def parse():
                     help="frames the oracle's ViT / Delta-DINO legs are timed on (also the from-the-video parity leg)")
     ap.add_argument("--operands", default="fp16", choices=["fp16", "bf16"], help="operand type of the ViT's matrix units")
     ap.add_argument("--vit-frame-batch", type=int, default=0, help="frames per pass of the ViT encoder (0 = library default)")
-    ap.add_argument("--track-round", type=int, default=0, help="sources per round of dtk_track (0 = library default, 524288)")
+    ap.add_argument("--track-round", type=int, default=0, help="sources per round of dtk_track (0 = library default, 4194304)")
     return ap.parse_args()
 
 

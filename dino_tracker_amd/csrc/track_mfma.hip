@@ -41,7 +41,8 @@ constexpr int CM = 64, CN = 128, CK = 32; // corr16 tile
 constexpr int NB_MAX = 1024;              // refine: largest window-union box (cells) correlated as one group
 constexpr int RD = 5;                     // disk radius in cells supported by refine32 (radius / stride <= 5)
 constexpr int MFMA_CHUNK = 16384;
-constexpr int MFMA_SUPER = 524288;
+constexpr int MFMA_SUPER = 4194304;   // sources per round (round 4: 524 288 -> 4 M, 285.5 -> 279.8 ms per benchmark step: fewer, fuller launches
+                                      // and denser key-sorted windows; 7.3 GB of workspace at full use)
 
 struct Rec {  // per source, written by head16, read by refine32
     float amax;

@@ -288,7 +288,7 @@ int dtk_corr_maps(const dtk_geom* g, const float* feat, const float* norms, cons
  *                 fp16 pass cannot decide.  The sizes of tiers 2 and 3 are read back: this method SYNCHRONISES
  *                 `stream` once per call (twice if tier 2 ran; once more if `dM` is given).
  * opts->normalized: 0 = pixels, 1 = [-1,1].
- * opts->round_sources: sources per round of the MFMA pipeline (0 = default 524 288; rounded up to a multiple of 256).
+ * opts->round_sources: sources per round of the MFMA pipeline (0 = default 4 194 304; rounded up to a multiple of 256).
  *                 The workspace size follows it.  Results do not depend on it (tests run several rounds with it).
  * opts->tier: DTK_TIER_AUTO, or DTK_TIER_WHOLE_MAP = skip the certificate, every source takes tier 2 (tests).
  * `dM` (device int32*, may be NULL): if given, the number of sources is min(M, *dM).

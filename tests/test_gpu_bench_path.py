@@ -40,7 +40,7 @@ def _tracker(feats, head, method=ops.TRACK_MFMA, T=None):
 
 
 def test_several_rounds_of_the_mfma_pipeline(full384):
-    """bench.py's anchor stage runs 16 rounds of 524 288 sources; here the round is shrunk to 512 sources through
+    """bench.py's anchor stage runs 2 rounds of 4 M sources (16 of 524 288 until round 4); here the round is shrunk to 512 sources through
     dtk_track_opts.round_sources so that 1 900 sources take 4 rounds (the last one ragged), unsorted target order."""
     T, C, feats, head = full384
     M = 1900
