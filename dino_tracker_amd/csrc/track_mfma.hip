@@ -1151,7 +1151,8 @@ __global__ __launch_bounds__(256) void scatter_kernel(dtk_geom g, const int32_t*
 //     16x the f32-input MFMA rate instead of one (64 sources x 256 cells x 384 channels on the f32 MFMA alone cost
 //     more than the whole round-1 kernel).
 constexpr int RC_SRC = 64;
-constexpr int RCD_NS = 4, RCD_NBM = NB_MAX;   // refine_corr_dma: ring depth, largest group box (a 6-deep ring with 384-cell groups, still 3 workgroups per CU, measured 15.1 ms against 11.0)
+constexpr int RCD_NW = 4, RCD_NS = 4, RCD_NBM = NB_MAX;   // refine_corr_dma: waves (= M tiles) per workgroup, ring depth, largest group box.
+// Measured against this form (10.1 ms per step): a 6-deep ring with 384-cell groups 15.1 ms; 8 waves / 128 sources with a 12-deep ring 19.5 ms
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const float* __restrict__ feat,
                                                           const float* __restrict__ norms,
@@ -1319,12 +1320,14 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const floa
     }
 }
 
-// s_waitcnt vmcnt(n) for a count that is a compile-time constant after unrolling (n even, <= 32)
+// s_waitcnt vmcnt(n) for a count that is a compile-time constant after unrolling (n <= 40)
 __device__ __forceinline__ void vm_wait_n(int n) {
     switch (n) {
 #define DTK_VMW(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-        DTK_VMW(0) DTK_VMW(2) DTK_VMW(4) DTK_VMW(6) DTK_VMW(8) DTK_VMW(10) DTK_VMW(12) DTK_VMW(14) DTK_VMW(16) DTK_VMW(18) DTK_VMW(20)
-        DTK_VMW(22) DTK_VMW(24) DTK_VMW(26) DTK_VMW(28) DTK_VMW(30) DTK_VMW(32)
+        DTK_VMW(0) DTK_VMW(1) DTK_VMW(2) DTK_VMW(3) DTK_VMW(4) DTK_VMW(5) DTK_VMW(6) DTK_VMW(7) DTK_VMW(8) DTK_VMW(9) DTK_VMW(10)
+        DTK_VMW(11) DTK_VMW(12) DTK_VMW(13) DTK_VMW(14) DTK_VMW(15) DTK_VMW(16) DTK_VMW(17) DTK_VMW(18) DTK_VMW(19) DTK_VMW(20)
+        DTK_VMW(21) DTK_VMW(22) DTK_VMW(23) DTK_VMW(24) DTK_VMW(25) DTK_VMW(26) DTK_VMW(27) DTK_VMW(28) DTK_VMW(29) DTK_VMW(30)
+        DTK_VMW(31) DTK_VMW(32) DTK_VMW(33) DTK_VMW(34) DTK_VMW(35) DTK_VMW(36) DTK_VMW(37) DTK_VMW(38) DTK_VMW(39) DTK_VMW(40)
 #undef DTK_VMW
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
@@ -1346,8 +1349,8 @@ __device__ __forceinline__ void vm_wait_n(int n) {
 // two requests per step, 16 window stores per block as buffer stores whose switched-off lanes carry an out-of-range offset
 // (no branch, so the count is static); the norms of the box come from LDS (a compiler-managed global load here would be
 // waited for with vmcnt(0) and drain the ring).
-template <int NKC, int NS, int NBM>
-__global__ __launch_bounds__(256, 3) void refine_corr_dma_kernel(dtk_geom g, const half_t* __restrict__ fs,
+template <int NKC, int NS, int NBM, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void refine_corr_dma_kernel(dtk_geom g, const half_t* __restrict__ fs,
                                                               const float* __restrict__ norms,
                                                               const float* __restrict__ emb,
                                                               const int32_t* __restrict__ src_row,
@@ -1362,20 +1365,23 @@ __global__ __launch_bounds__(256, 3) void refine_corr_dma_kernel(dtk_geom g, con
     constexpr int STAGE = 64 * 128;    // bytes: 64 cells x (32 hi + 32 lo) halves
     static_assert(NKC % NS == 0 && NKC >= NS, "the stage of a step is chosen at compile time");
     constexpr int C = NKC * 32;
-    __shared__ float s_sn[RC_SRC];
-    __shared__ int s_row[RC_SRC], s_f[RC_SRC], s_k[RC_SRC], s_m[RC_SRC], s_grp[RC_SRC], s_box[RC_SRC * 4], s_first[RC_SRC],
-        s_last[RC_SRC], s_ng;
+    // NW waves per workgroup, each ONE M tile: SRC = 16 NW key-consecutive sources share every streamed cell (NW = 8: half the
+    // stream per source; one workgroup of 8 waves per CU, hence the deeper ring)
+    constexpr int SRC = 16 * NW, NT = 64 * NW, REQ = 8 / NW, WCELLS = 64 / NW;
+    static_assert(NW == 4 || NW == 8, "a step is 8 DMA requests of 8 cells");
+    __shared__ float s_sn[SRC];
+    __shared__ int s_row[SRC], s_f[SRC], s_k[SRC], s_m[SRC], s_grp[SRC], s_box[SRC * 4], s_first[SRC], s_last[SRC], s_ng;
     __shared__ float s_fn[NBM];
     __shared__ __attribute__((aligned(1024))) unsigned char ring[NS * STAGE];
     const int ph = g.ph, pw = g.pw, HW = ph * pw;
     const int nv = *nvalid;
     const int per = (ntiles + 7) / 8;
     const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    const int t0 = tile * RC_SRC;
+    const int t0 = tile * SRC;
     if ((int)(blockIdx.x >> 3) >= per || tile >= ntiles || t0 >= nv) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid < RC_SRC) {
+    if (tid < SRC) {
         const bool ok = t0 + tid < nv;
         const int i = perm[ok ? t0 + tid : t0];  // index inside the round
         const int m = m0 + i;
@@ -1389,7 +1395,7 @@ __global__ __launch_bounds__(256, 3) void refine_corr_dma_kernel(dtk_geom g, con
     // greedy grouping: consecutive (key-sorted) sources with the same frame whose window union stays small
     if (tid == 0) {
         int ng = 0, cf = -2, r0 = 0, r1 = 0, c0 = 0, c1 = 0;
-        for (int s = 0; s < RC_SRC; ++s) {
+        for (int s = 0; s < SRC; ++s) {
             s_grp[s] = -1;
             if (s_f[s] < 0) continue;
             const int kr = s_k[s] / pw, kc = s_k[s] % pw;
@@ -1436,10 +1442,10 @@ __global__ __launch_bounds__(256, 3) void refine_corr_dma_kernel(dtk_geom g, con
 #pragma unroll
         for (int k = 0; k < 4; ++k) srd_x[k] = __builtin_amdgcn_readfirstlane(srd_x[k]);
     }
-    const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ring + (unsigned)w * 2048u);  // this wave's 16 cells
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ring + (unsigned)(w * WCELLS * 128));  // this wave's cells of a stage
     // fragment reads: cell nt * 16 + fj, hi piece fg / lo piece 4 + fg ((c >> 1) & 7 does not depend on nt)
     const int rd_hi = fj * 128 + ((fg ^ ((fj >> 1) & 7)) << 4), rd_lo = fj * 128 + (((4 + fg) ^ ((fj >> 1) & 7)) << 4);
-    // requests: lane l of request q fetches, for cell 16 w + 8 q + (l >> 3) of the block, the piece that lands in slot l & 7
+    // requests: lane l of request q fetches, for cell WCELLS w + 8 q + (l >> 3) of the block, the piece that lands in slot l & 7
     const int dq = lane >> 3;
     for (int gi = 0; gi < ng; ++gi) {
         const int rmin = s_box[gi * 4], rmax = s_box[gi * 4 + 1], cmin = s_box[gi * 4 + 2], cmax = s_box[gi * 4 + 3];
@@ -1447,7 +1453,7 @@ __global__ __launch_bounds__(256, 3) void refine_corr_dma_kernel(dtk_geom g, con
         const bool active = 16 * w <= s_last[gi] && 16 * w + 15 >= s_first[gi];  // wave-uniform: members are consecutive
         const int gf = s_f[s_first[gi]];
         auto req_off = [&](int blk, int q) {  // clamped: results of padded cells are never stored
-            const int c = 16 * w + 8 * q + dq;
+            const int c = WCELLS * w + 8 * q + dq;
             const int l = min(blk + c, ncells - 1);
             const unsigned cell = (unsigned)(gf * HW + (rmin + l / nc) * pw + cmin + l % nc);
             return cell * (unsigned)(C * 4) + (unsigned)((((lane & 7) ^ ((c >> 1) & 7))) << 4);
@@ -1466,19 +1472,19 @@ __global__ __launch_bounds__(256, 3) void refine_corr_dma_kernel(dtk_geom g, con
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // the previous group is done with the ring and with s_fn
-        for (int c = tid; c < ncells; c += 256) s_fn[c] = norms[(size_t)gf * HW + (rmin + c / nc) * pw + cmin + c % nc];
-        unsigned vc[2] = {req_off(0, 0), req_off(0, 1)}, vn[2] = {0u, 0u};
+        for (int c = tid; c < ncells; c += NT) s_fn[c] = norms[(size_t)gf * HW + (rmin + c / nc) * pw + cmin + c % nc];
+        unsigned vc[2] = {req_off(0, 0), req_off(0, REQ - 1)}, vn[2] = {0u, 0u};
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the norms: the counting below starts from an empty queue)
 #define RC_ISSUE(STG, V, KC)                                                                  \
     do {                                                                                      \
-        dtk_buffer_lds16<0>(srd, (unsigned)((KC) * 128), V[0], lds_w + (unsigned)((STG) * STAGE));         \
-        dtk_buffer_lds16<0>(srd, (unsigned)((KC) * 128), V[1], lds_w + (unsigned)((STG) * STAGE + 1024));  \
+        dtk_buffer_lds16<0>(srd, (unsigned)((KC) * 128), V[0], lds_w + (unsigned)((STG) * STAGE));                       \
+        if (REQ == 2) dtk_buffer_lds16<0>(srd, (unsigned)((KC) * 128), V[1], lds_w + (unsigned)((STG) * STAGE + 1024));  \
     } while (0)
 #pragma unroll
         for (int d = 0; d < NS - 1; ++d) RC_ISSUE(d, vc, d);
         for (int blk = 0; blk < ncells; blk += 64) {
             const bool last_blk = blk + 64 >= ncells;
-            if (!last_blk) { vn[0] = req_off(blk + 64, 0); vn[1] = req_off(blk + 64, 1); }
+            if (!last_blk) { vn[0] = req_off(blk + 64, 0); vn[1] = req_off(blk + 64, REQ - 1); }
             f4 acc[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[nt] = f4{0.f, 0.f, 0.f, 0.f};
@@ -1490,7 +1496,7 @@ __global__ __launch_bounds__(256, 3) void refine_corr_dma_kernel(dtk_geom g, con
                 // of the previous block (issued between the request of step 2 and that of step 3)
                 // (requests younger than this step's: two per existing step among the next NS - 2; in the last block those
                 //  past the end do not exist)
-                const int young = 2 * (last_blk ? min(NKC - 1 - kc, NS - 2) : NS - 2) + ((blk > 0 && kc < NS - 1) ? 16 : 0);
+                const int young = REQ * (last_blk ? min(NKC - 1 - kc, NS - 2) : NS - 2) + ((blk > 0 && kc < NS - 1) ? 16 : 0);
                 vm_wait_n(young);
                 __syncthreads();  // every wave's part of this stage has landed; stage (kc - 1) % NS is free again
                 if (kc + NS - 1 < NKC) RC_ISSUE((kc + NS - 1) % NS, vc, kc + NS - 1);
@@ -1936,11 +1942,14 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
                    perm, L.HWk, (int)s0, scnt);
         {
             const int rtiles = dtk_cdiv(scnt, RC_SRC);
-            if (has_split_planes(g) && !DTK_DBG(dbg, 131072) && (size_t)L.super * WX * WX * 4 < (1ull << 32))
-                DTK_LAUNCH("refine_corr", (refine_corr_dma_kernel<12, RCD_NS, RCD_NBM>), dim3(8 * dtk_cdiv(rtiles, 8)), dim3(256), 0, st, *g,
+            if (has_split_planes(g) && !DTK_DBG(dbg, 131072) && (size_t)L.super * WX * WX * 4 < (1ull << 32)) {
+                const int dtiles = dtk_cdiv(scnt, 16 * RCD_NW);
+                DTK_LAUNCH("refine_corr", (refine_corr_dma_kernel<12, RCD_NS, RCD_NBM, RCD_NW>), dim3(8 * dtk_cdiv(dtiles, 8)),
+                           dim3(64 * RCD_NW), 0, st, *g,
                            reinterpret_cast<const half_t*>(reinterpret_cast<const unsigned char*>(f16) + split_planes_offset(g)),
                            norms, emb, in.src_row, in.tgt, kstar, snorm, perm, nvalid, xwin, (unsigned)((size_t)scnt * WX * WX * 4),
-                           (int)s0, rtiles);
+                           (int)s0, dtiles);
+            }
             else
                 DTK_LAUNCH("refine_corr", refine_corr_kernel, dim3(8 * dtk_cdiv(rtiles, 8)), dim3(256), 0, st, *g, feat, norms,
                            emb, in.src_row, in.tgt, kstar, snorm, perm, nvalid, xwin, (int)s0, rtiles, dbg);
