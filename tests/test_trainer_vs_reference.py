@@ -306,3 +306,23 @@ def test_device_side_batch_sampler_properties():
     sampler2.fg_can_sample[:] = False
     s = sampler2.forward_device()
     assert not bool(s["valid"][:32].any()) and bool(s["valid"][32:].all()) and bool(torch.isfinite(s["t1_points"]).all())
+
+
+def test_cells_at_equals_gather_of_frame_cells_and_lse_identity():
+    """Host-side pieces of the fused contrastive path (round 4): trainer.cells_at reads the embeddings of given cells of
+    indexed frames without the per-frame copy of frame_cells + gather; and the identity the kernels rest on --
+    -log(exp(bb / t) / sum_j exp(s_j / t)) = logsumexp_j(s_j / t) - bb / t -- holds for trainer.contrastive_terms in float64."""
+    g = torch.Generator().manual_seed(5)
+    fe = torch.randn(5, 12, 4, 6, generator=g, dtype=torch.float64)
+    sel = torch.tensor([3, 0, 3])
+    cells = torch.randint(0, 24, (3, 7), generator=g)
+    got = T.cells_at(fe, sel, cells)
+    want = T.frame_cells(fe, sel).gather(1, cells[:, :, None].expand(-1, -1, 12))
+    assert got.shape == (3, 7, 12) and torch.equal(got, want)
+    a, b = torch.randn(3, 7, 12, generator=g, dtype=torch.float64), torch.randn(3, 7, 12, generator=g, dtype=torch.float64)
+    fa, fb = T.frame_cells(fe, sel), T.frame_cells(fe, torch.tensor([1, 2, 4]))
+    l_st, _ = T.contrastive_terms(a, b, fa, fb, 0.1)
+    cos = lambda x, y: (x @ y.transpose(1, 2)) / torch.clamp(x.norm(dim=2)[:, :, None] * y.norm(dim=2)[:, None, :], min=T.EPS)
+    bb = (a * b).sum(2) / torch.clamp(a.norm(dim=2) * b.norm(dim=2), min=T.EPS)
+    assert torch.allclose(l_st, torch.logsumexp(cos(a, fb) / 0.1, dim=2) - bb / 0.1, rtol=1e-12, atol=1e-12)
+    assert not T.fused_contrastive(fe)                      # a host tensor never takes the kernel path
