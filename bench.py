@@ -53,12 +53,18 @@ def parse():
                     help="vit: features come from the (random-weight) ViT on the synthetic video; synthetic: the "
                          "feature-level generator with dense anchors (worst case for the tracker stage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clock-power", action="store_true", help="skip the shader-clock / board-power sampling legs")
     ap.add_argument("--ab", default="", help="comma-separated A / B switches: attention_v2 (round 2-3 attention kernel), "
                                              "gemm_ws_v1 (round 1-3 weight-stationary GEMMs)")
     ap.add_argument("--cpu-threads", type=int, default=8, help="host threads of the oracle's infer leg (fixed: comparable across rounds)")
     ap.add_argument("--cpu-queries", type=int, default=4, help="queries of the TIMED CPU sample (SURVEY 8d: K = 4, full T)")
-    ap.add_argument("--parity-queries", type=int, default=16,
-                    help="queries of parity_sample (>= --cpu-queries; the extra ones go through the oracle untimed)")
+    ap.add_argument("--parity-queries", type=int, default=1024,
+                    help="queries of parity_sample: HIP infer vs the oracle run ON THE GPU in fp32, on the step's own refined volume "
+                         "(default: all of them; 0 disables the leg)")
+    ap.add_argument("--cpu-parity-queries", type=int, default=16,
+                    help="queries that also go through the oracle on the HOST (>= --cpu-queries; pins GPU-torch against CPU-torch)")
+    ap.add_argument("--parity-video-frames", type=int, default=90,
+                    help="frames of the from-the-video parity leg on the GPU oracle (oracle ViT -> refine -> infer; 0 disables it)")
     ap.add_argument("--cpu-vit-frames", type=int, default=2,
                     help="frames the oracle's ViT / Delta-DINO legs are timed on (also the from-the-video parity leg)")
     ap.add_argument("--operands", default="fp16", choices=["fp16", "bf16"], help="operand type of the ViT's matrix units")
@@ -176,7 +182,11 @@ def main():
             trk.cache_refined_embeddings()                # P2: dino + Delta-DINO(video)
         res = mi.infer(queries) if "track" in stages else (None, None)   # P3
         if "extract" in stages:
-            ex.check_overflow()
+            try:
+                ex.check_overflow()
+            except RuntimeError:
+                trk.refined_features = None    # the deferred pass saturated: nothing derived from its features may survive
+                raise
         return res
 
     def step():
@@ -203,6 +213,18 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    # shader clock / board power of whole steps: sampled over a REPEAT of the steps after the timed region (the polling thread
+    # shares the interpreter with the launch loop; the timed region stays untouched)
+    sampler = clock_power = None
+    if rank == 0 and world == 1 and not args.no_clock_power:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        from power_sampler import PowerSampler
+        sampler = PowerSampler(local).start()
+        c0 = time.perf_counter()
+        for _ in range(max(2, min(args.steps, 5))):
+            step()
+        torch.cuda.synchronize()
+        clock_power = {"steps_repeat": dict(sampler.stop(), ms_per_step=round((time.perf_counter() - c0) / max(2, min(args.steps, 5)) * 1e3, 2))}
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -268,6 +290,45 @@ def main():
         roofline["kernel_tflops"] = {k: round(algo[k][0] / (prof[k][0] * 1e-3) / 1e12, 1) for k in prof
                                      if k in algo and prof[k][0] > 0}
 
+    # ---- shader clock and board power DURING the dominant kernel: the stand-alone attention stage on the
+    # benchmark's shapes (90 frames x 6 heads, S = 8108, random 16-bit operands), launched back to back for a few hundred ms while a
+    # host thread polls the driver; the 2.5 PFLOP/s peak assumes 2.4 GHz, so frac_at_measured_clock = achieved / (peak * sclk / 2400)
+    if clock_power is not None and sampler.source is not None and C == 384 and roofline and roofline.get("kernel") == "vit_attention":
+        from dino_tracker_amd._lib import OPERAND_BF16, OPERAND_F16, check as _check, lib as _lib
+        Sx, heads = 67 * 121 + 1, C // 64
+        Spx = (Sx + 127) // 128 * 128
+        odt = torch.float16 if args.operands == "fp16" else torch.bfloat16
+        gq = torch.Generator(device=dev).manual_seed(5)
+        qa = (torch.randn(T, heads, Spx, 64, device=dev, generator=gq) * (0.125 * 1.4426950408889634)).to(odt)
+        ka = torch.randn(T, heads, Spx, 64, device=dev, generator=gq).to(odt)
+        va = torch.randn(T, heads, 64, Spx, device=dev, generator=gq).to(odt)
+        ka[:, :, Sx:] = 0
+        va[:, :, :, Sx:] = 0
+        oa = torch.empty(T, Sx, C, dtype=odt, device=dev)
+        ot = OPERAND_F16 if args.operands == "fp16" else OPERAND_BF16
+        launch = lambda: _check(_lib().dtk_vit_attention(ops._p(qa), ops._p(ka), ops._p(va), ops._p(oa), T, heads, Sx, Spx, ot, ops._stream()))  # noqa: E731
+        for _ in range(3):
+            launch()
+        torch.cuda.synchronize()
+        nl = 40
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sampler.start()
+        e0.record()
+        for _ in range(nl):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+        cp = sampler.stop()
+        ms_l = e0.elapsed_time(e1) / nl
+        tf = 4.0 * Sx * Sx * C * T / (ms_l * 1e-3) / 1e12
+        cp.update({"launches": nl, "avg_launch_ms": round(ms_l, 4), "achieved_tflops": round(tf, 1),
+                   "note": "dtk_vit_attention alone, back to back, random operands of the benchmark's shape"})
+        sc = (cp.get("sclk_mhz") or {}).get("p50")
+        if sc:
+            cp["frac_of_peak_at_measured_clock"] = round(tf / (MFMA_F16_PEAK_TF * sc / 2400.0), 4)
+        clock_power["attention_loop"] = cp
+        del qa, ka, va, oa
+
     # ---- CPU baseline + parity sample: the oracle (torch fp32 port of the reference algorithm) on K queries at
     # full T with all their anchors, one frame of its ViT and of its Delta-DINO, combined by
     #     cpu_qpf = N T / (T t_vit + T t_delta + N t_query).
@@ -276,7 +337,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and "track" in stages:
         from oracle import ref_algo as A
         nq = max(1, min(N, args.cpu_queries))
-        npar = max(nq, min(N, args.parity_queries))
+        npar = max(nq, min(N, args.cpu_parity_queries))
         sel = torch.linspace(0, N - 1, npar).long()
         timed = torch.linspace(0, npar - 1, nq).long()          # the timed K queries, spread over the parity sample
         rest = torch.tensor([i for i in range(npar) if i not in set(timed.tolist())], dtype=torch.long)
@@ -332,13 +393,51 @@ def main():
                          f"N T / (T t_vit + T t_delta + N t_query), SURVEY 8d",
                "t_query_s": round(t_query, 3), "t_vit_s": round(t_vit, 3), "t_delta_s": round(t_delta, 3),
                "anchors_per_query": round(a_bar, 2), "host_threads": ncore, "thread_sweep_s": sweep,
-               "literal_over_port": literal_over_port(C)}
+               "literal_over_port": literal_over_port(C),
+               "literal_over_port_source": "committed file profiles/r03_cpu_reference_literal.json: measured in round 3 in the BUILD "
+                                           "container (where the un-modified reference runs) on that container's cores -- not on this box"}
         tg, og = mi.infer(queries[sel.to(dev)])
-        parity = {"queries": npar, "frames": T, "correlation_maps": int(npar * T + float((cs_all >= 0.7).sum()) * T),
-                  "max_dxy_px": round(float((tg.cpu() - rt).abs().max()), 6),
-                  "occ_mismatch": int((og.cpu() != ro).sum()), "occ_flags": int(ro.numel()),
-                  "tiers": dict(trk.last_track_stats),
-                  "note": "HIP infer vs oracle infer on the same refined volume (the one the timed step produced)"}
+        host_leg = {"queries": npar, "frames": T, "correlation_maps": int(npar * T + float((cs_all >= 0.7).sum()) * T),
+                    "max_dxy_px": round(float((tg.cpu() - rt).abs().max()), 6),
+                    "occ_mismatch": int((og.cpu() != ro).sum()), "occ_flags": int(ro.numel()),
+                    "note": "HIP infer vs the oracle ON THE HOST (the form pinned on the reference), same refined volume"}
+        parity = dict(host_leg, tiers=dict(trk.last_track_stats))
+        if args.parity_queries > 0:
+            # EVERY query: the same restatement on device tensors in fp32 (oracle/ref_algo.py takes its device
+            # from its inputs; no TF32 on gfx950, matmul precision "highest"), on the refined volume the timed step produced
+            torch.backends.cuda.matmul.allow_tf32 = False
+            torch.set_float32_matmul_precision("highest")
+            nfull = min(N, args.parity_queries)
+            selg = torch.linspace(0, N - 1, nfull).long().to(dev)
+            head_g = {k: v.to(dev) for k, v in head.items()}
+            refined_g = trk.refined_features
+            c0 = time.perf_counter()
+            gt_, go_, gcs_, _ = A.infer(refined_g, queries[selg], head_g, H, W, return_aux=True)
+            torch.cuda.synchronize()
+            t_oracle = time.perf_counter() - c0
+            th, oh = mi.infer(queries[selg])
+            err = (th - gt_).norm(dim=-1)
+            flagged = torch.nonzero(err > 1e-3).tolist()
+            arb = []
+            for n_, t_ in flagged[:64]:     # an fp32 near-tie of the map decided the other way, or a failure: float64 arbiter, fp32 band only
+                r_ = A.tie_arbiter(refined_g, queries[selg][n_], t_, th[n_, t_], head_g, H, W, A.fp32_dot_band(C))
+                arb.append({"query": n_, "frame": t_, "err_px": round(float(err[n_, t_]), 4), "gap64": r_["gap64"],
+                            "band": r_["delta"], "dist_px": r_["dist_px"], "ok": bool(r_["ok"] and r_["gap64"] <= r_["delta"])})
+            clean = torch.ones(nfull, dtype=torch.bool, device=dev)
+            clean[[a["query"] for a in arb if a["ok"]]] = False
+            # GPU-torch against CPU-torch on the host leg's queries
+            pin = (gt_[torch.searchsorted(selg, sel.to(dev))].cpu() - rt).abs().max() if nfull == N else None
+            parity = {"queries": nfull, "frames": T, "positions": int(nfull * T),
+                      "correlation_maps": int(nfull * T + float((gcs_ >= 0.7).sum()) * T),
+                      "max_dxy_px": round(float(err[err <= 1e-3].max()) if bool((err <= 1e-3).any()) else -1.0, 6),
+                      "points_beyond_1e-3px": len(flagged), "arbitrated_fp32_near_ties": arb,
+                      "mismatches": sum(0 if a["ok"] else 1 for a in arb) + max(0, len(flagged) - 64),
+                      "occ_mismatch": int((oh != go_).sum()),
+                      "occ_mismatch_queries_without_a_tie": int((oh[clean] != go_[clean]).sum()), "occ_flags": int(go_.numel()),
+                      "oracle": f"oracle/ref_algo.py infer on cuda tensors, fp32, {t_oracle:.1f} s",
+                      "oracle_cuda_vs_host_max_dxy_px": None if pin is None else round(float(pin), 6),
+                      "host_leg": host_leg, "tiers": dict(trk.last_track_stats),
+                      "note": "HIP infer vs oracle infer on the same refined volume (the one the timed step produced), every query"}
         if args.features == "vit" and nf >= 2:
             # from the VIDEO: the first nf frames through oracle ViT -> oracle refine -> oracle infer against the device's
             # ViT -> Delta-DINO -> infer on the same frames (what the 16-bit operands of P1 add; tests assert it at T = 8)
@@ -364,6 +463,49 @@ def main():
                                     "occ_mismatch": int((ovd.cpu() != ov).sum()),
                                     "note": "video -> HIP ViT/Delta-DINO/infer vs video -> oracle ViT/refine/infer"}
 
+        if parity is not None and args.features == "vit" and args.parity_queries > 0 and args.parity_video_frames > 0:
+            # from the VIDEO at full length on the GPU oracle: oracle ViT -> oracle refine -> oracle infer vs the step's own results
+            nfv = min(T, args.parity_video_frames)
+            sd_g = {k: v.to(dev) for k, v in vit_sd.items()}
+            delta_g = {k: v.to(dev) for k, v in delta.items()}
+            c0 = time.perf_counter()
+            dino_o = torch.stack([A.vit_tokens(videos[0][t:t + 1], sd_g, model_name) for t in range(nfv)])
+            refined_o = A.refine_features(videos[0][:nfv], dino_o, delta_g)
+            qv = queries[selg].clone()
+            ot, oo = A.infer(refined_o, qv, head_g, H, W)
+            torch.cuda.synchronize()
+            t_or = time.perf_counter() - c0
+            if nfv == T:
+                one_video(videos[0])
+                dv_ref, (tv_, ov_) = trk.refined_features, mi.infer(qv)
+            else:
+                trk3 = Tracker(video=videos[0][:nfv], dino_features=ex.encode(videos[0][:nfv]), dino_patch_size=14, stride=7,
+                               device=dev, track_method=method)
+                trk3.tracker_head.load_state_dict(head)
+                trk3.delta_dino.load_state_dict(delta)
+                trk3.to(dev).eval()
+                mi3 = ModelInference(trk3, RangeNormalizer((W, H, nfv), device=dev), 0.7, 0.6)
+                dv_ref, (tv_, ov_) = trk3.refined_features, mi3.infer(qv)
+            e2 = (tv_ - ot).norm(dim=-1)
+            fl = torch.nonzero(e2 > 1e-3).tolist()
+            arbv = []
+            for n_, t_ in fl[:128]:   # band: fp32 rounding + the MEASURED deviation of the two cosines in question (tie_arbiter)
+                r_ = A.tie_arbiter(refined_o, qv[n_], t_, tv_[n_, t_], head_g, H, W, A.fp32_dot_band(C), dev_feats=dv_ref)
+                arbv.append({"query": n_, "frame": t_, "err_px": round(float(e2[n_, t_]), 4), "gap64": r_["gap64"], "band": r_["delta"],
+                             "dist_px": r_["dist_px"], "ok": bool(r_["ok"] and r_["gap64"] <= r_["delta"])})
+            cl = torch.ones(len(qv), dtype=torch.bool, device=dev)
+            cl[[a["query"] for a in arbv if a["ok"]]] = False
+            ok_e = e2[e2 <= 1e-3]
+            parity["from_video_every_query"] = {
+                "frames": nfv, "queries": len(qv), "positions": int(e2.numel()),
+                "feature_rel_err_refined": round(float((dv_ref - refined_o).norm() / refined_o.norm()), 7),
+                "max_dxy_px": round(float(ok_e.max()), 6), "p99_dxy_px": round(float(e2.flatten().quantile(0.99)), 6),
+                "points_beyond_1e-3px": len(fl), "arbitrated_near_ties": arbv[:16],
+                "mismatches": sum(0 if a["ok"] else 1 for a in arbv) + max(0, len(fl) - 128),
+                "occ_mismatch": int((ov_ != oo).sum()), "occ_mismatch_queries_without_a_tie": int((ov_[cl] != oo[cl]).sum()),
+                "oracle": f"oracle ViT -> refine -> infer on cuda tensors, fp32, {t_or:.1f} s",
+                "note": "video -> HIP ViT/Delta-DINO/infer vs video -> oracle ViT/refine/infer, every query and frame"}
+
     if rank == 0:
         from dino_tracker_amd import delta_dino as _dd
         p2_mode = {0: "split-f16 conv operands (fp32-grade)", 1: "f16 conv operands"}[_dd.conv_operand_mode(None)]
@@ -386,7 +528,7 @@ def main():
                                                 for r in range(world)] if qpar else [T] * world),
                        "parallelism": (f"query-parallel x{world} (frames split for P1/P2, queries for P3)" if qpar
                                        else f"video-parallel x{world}")},
-            "roofline": roofline, "cpu_baseline": cpu, "parity_sample": parity,
+            "roofline": roofline, "clock_power": clock_power, "cpu_baseline": cpu, "parity_sample": parity,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

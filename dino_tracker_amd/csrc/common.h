@@ -99,7 +99,11 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 // immediate (+ 16 bytes per lane, the hardware's lane-linear image).  Three issue slots per request; the global_load_lds form
 // with a 64-bit per-lane pointer cost a lone wave ~13 (64-bit address arithmetic on the VALU per request, m0 saved and restored)
 // -- 9 % of the attention kernel, and more of corr_peaks.  A kernel that uses it must not use m0 otherwise (no indirect register
-// indexing, no GWS / sendmsg): the compiler reserves m0 but is not told about the write.
+// indexing, no GWS / sendmsg, no __builtin_amdgcn_global_load_lds in the same kernel): the compiler reserves m0 but is not told
+// about the write.  (ADVICE r4 asked for "m0" in the clobber list: hipcc 7.2 answers "inline asm clobber list contains reserved
+// registers: m0 ... may not be preserved across the asm statement" -- a reserved register in a clobber list is NOT honoured, so the
+// declaration would promise nothing; the rule above is what holds, and the kernels that use this helper -- attention4, gemm_ws,
+// corr_peaks V2D, refine_corr_dma -- contain no other m0 user: checked in the ISA, tests/test_abi.py::test_m0_users.)
 typedef unsigned dtk_u4 __attribute__((ext_vector_type(4)));
 template <int LDS_IMM>
 __device__ __forceinline__ void dtk_buffer_lds16(dtk_u4 srd, unsigned soff, unsigned voff, unsigned lds_dst) {
@@ -112,10 +116,14 @@ __device__ __forceinline__ void dtk_buffer_lds16(dtk_u4 srd, unsigned soff, unsi
         : "memory", "scc");   // (s_add_u32 writes SCC: without the clobber the compiler keeps a compare result live across the asm --
                               //  round 4 found this as wrong tokens in ONE instantiation of the weight-stationary GEMM)
 }
-// raw buffer descriptor (stride 0) over `p`; the range check is disabled by a maximal size -- callers clamp their offsets
+// raw buffer descriptor (stride 0) over `p`.  A raw buffer range-checks the per-lane offset (VGPR offset + immediate; the scalar
+// offset is NOT checked) against num_records and returns zeros beyond it, so the size is the largest one -- every 32-bit
+// per-lane offset is in range, callers clamp their own.  (Rounds 3-4 had 0x7fffffff here: refine_corr_dma_kernel, whose cell
+// offset lives in the VGPR, would have read zeros for cells past 2 GB of the split planes -- C = 384 volumes of 173 .. 344
+// frames at 854 x 476, which has_split_planes() admits; ADVICE r4.  tests/test_gpu_p3.py::test_split_planes_beyond_2gb.)
 __device__ __forceinline__ dtk_u4 dtk_make_srd(const void* p) {
     const unsigned long long a = (unsigned long long)(size_t)p;
-    dtk_u4 r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
+    dtk_u4 r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
 #pragma unroll
     for (int k = 0; k < 4; ++k) r[k] = __builtin_amdgcn_readfirstlane(r[k]);
     return r;

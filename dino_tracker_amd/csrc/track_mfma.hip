@@ -567,6 +567,12 @@ __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_
             asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(bs[t][ks]) : "v"(sp + ks * 16) : "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (the asm loads are invisible to the compiler's vmcnt bookkeeping: re-define every loaded register behind the wait -- empty
+    //  volatile asms keep their order, and no use of bs can be scheduled above its re-definition)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(bs[t][ks]));
     __syncthreads();
     const int fmin = min(min(s_fr[0], s_fr[1]), min(s_fr[2], s_fr[3]));
     const int fmax = max(max(s_fr[4], s_fr[5]), max(s_fr[6], s_fr[7]));

@@ -325,7 +325,21 @@ struct GemmEpi {
     const float* gamma;  // [N] LayerScale
     // EPI_F32 (tiled kernel only)
     float* out_f32;      // [M][N] fp32: A W^T + bias (the qkv facet output)
+    // fp16 range (round 5): EPI_QKV / EPI_GELU kernels OR bit 2 / 4 into *ovf when a value they store reaches the fp16 limit --
+    // every frame, inside the epilogue (no extra pass); NULL = not tracked (bf16 operands)
+    int* ovf;
 };
+
+// running |max| of the values an epilogue stores (the saturation test of the fp16 range, see GemmEpi::ovf): two values per
+// v_max3_f32 with |.| source modifiers.  NaN passes through fmaxf unnoticed: a non-finite activation surfaces in the next
+// residual update, which the LayerNorm kernel checks for every token (overflow bit 1).
+__device__ __forceinline__ float amax2(float m, float a, float b) { return fmaxf(fmaxf(m, fabsf(a)), fabsf(b)); }
+template <typename T, int EPI>
+__device__ __forceinline__ void amax_report(float amax, int* ovf) {
+    if (IsF16<T>::value && (EPI == EPI_QKV || EPI == EPI_GELU) && ovf) {
+        if (__any(amax >= 65504.f) && (threadIdx.x & 63) == 0) atomicOr(ovf, EPI == EPI_QKV ? 2 : 4);
+    }
+}
 
 __device__ __forceinline__ int gswz(int row, int piece) {
     const int f = (0x1230 >> (((row >> 2) & 3) * 4)) & 3;  // {0,3,2,1}: conflict-free ds_read_b128 fragments
@@ -335,7 +349,11 @@ __device__ __forceinline__ int gswz(int row, int piece) {
 // Epilogue of one 16x16 D tile: lane (fg, fj) holds rows mb .. mb+3 of column n (a[r]).  Shared by the tiled kernels.
 template <typename T, int EPI>
 __device__ __forceinline__ void gemm_store_tile(const f4& a, long long mb, int n, float bias, long long M, int N,
-                                                const GemmEpi<T>& e) {
+                                                const GemmEpi<T>& e, float& amax) {
+    if (IsF16<T>::value && (EPI == EPI_QKV || EPI == EPI_GELU)) {   // rows past M hold the repeated last row: harmless
+        const float sc = (EPI == EPI_QKV && n < e.D) ? e.qscale : 1.f;
+        amax = amax2(amax2(amax, (a[0] + bias) * sc, (a[1] + bias) * sc), (a[2] + bias) * sc, (a[3] + bias) * sc);
+    }
     if (EPI == EPI_QKV) {
         const int which = n / e.D, rem = n - which * e.D;
         const int head = rem >> 6, dh = rem & 63;
@@ -470,6 +488,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const T* __restrict__ A
         cur ^= 1;
     }
     // D fragment: lane (fg, fj) holds rows 4*fg + r (r = 0..3), column fj of each 16x16 tile
+    float amax = 0.f;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         const int n = n0 + wc * 64 + ni * 16 + fj;
@@ -478,9 +497,10 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const T* __restrict__ A
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const long long mb = m0 + wr * 64 + mi * 16 + fg * 4;
-            gemm_store_tile<T, EPI>(acc[mi][ni], mb, n, bias, M, N, e);
+            gemm_store_tile<T, EPI>(acc[mi][ni], mb, n, bias, M, N, e, amax);
         }
     }
+    amax_report<T, EPI>(amax, e.ovf);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -738,14 +758,16 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const T* __restrict__
         buf = (buf + 1) & 3;
     }
     ws_wait<0>();
+    float amax = 0.f;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         const int n = n0 + wc * 64 + ni * 16 + fj;
         const float bias = e.bias ? e.bias[n] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi)
-            gemm_store_tile<T, EPI>(acc[mi][ni], m0 + wr * 128 + mi * 16 + fg * 4, n, bias, M, N, e);
+            gemm_store_tile<T, EPI>(acc[mi][ni], m0 + wr * 128 + mi * 16 + fg * 4, n, bias, M, N, e, amax);
     }
+    amax_report<T, EPI>(amax, e.ovf);
 }
 
 // V2M (round 4, default 3): bit 0 = weights in AGPRs (loaded there by asm; the builtin MFMA takes them from there as they are)
@@ -786,7 +808,16 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const T* __restrict__ A, c
             else wf[t][ks] = *reinterpret_cast<const T8*>(wp + ks * 16);
         }
     }
-    if (V2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (V2) {
+        // the loads above are invisible to the compiler's own vmcnt bookkeeping: wait, then re-define every loaded register behind
+        // the wait (an empty volatile asm with a "+a" operand emits nothing, but volatile asms keep their order and no use of
+        // wf can be scheduled above its re-definition -- ADVICE r4: before, only scheduling luck kept uses behind the wait)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < WS_KS; ++ks) asm volatile("" : "+a"(wf[t][ks]));
+    }
     {
         const int n = min(n0 + lane, N - 1);
         s_bias[w][lane] = e.bias ? e.bias[n] : 0.f;
@@ -847,6 +878,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const T* __restrict__ A, c
     for (int k8 = 0; k8 < 8; ++k8)
         frag_off[k8] = (unsigned)((j >> 2) * 3 * 1024 + ((((2 * k8 + h + (j >> 2)) & 15) * 4 + (j & 3)) * 16));
     // epilogue of 8 values (row tile t, half hv of this lane's 16 features): features nb .. nb + 7
+    float amax = 0.f;
     auto epi8 = [&](const f16v (&acc)[2], int t, int hv) {
         const int fl = 32 * t + 16 * h + 8 * hv;  // feature offset inside the wave's 64
         const int nb = n0 + fl;
@@ -857,6 +889,10 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const T* __restrict__ A, c
         v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
         v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
         const bool ok = m_ep < M && nb < N && !DTK_DBG(e.no_store, 3);
+        if (IsF16<T>::value && (EPI == EPI_QKV || EPI == EPI_GELU)) {   // the fp16 range, every value of every frame (GemmEpi::ovf)
+#pragma unroll
+            for (int r = 0; r < 8; r += 2) amax = amax2(amax, v[r] * qsc, v[r + 1] * qsc);
+        }
         if (EPI == EPI_GELU) {
             T8 o;
 #pragma unroll
@@ -991,6 +1027,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const T* __restrict__ A, c
         for (int u = 0; u < 4; ++u) epi8(accB, u >> 1, u & 1);
     }
     flush();
+    amax_report<T, EPI>(amax, e.ovf);
     ws_wait<0>();
 }
 
@@ -1112,11 +1149,12 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
     T* hid = reinterpret_cast<T*>(ws + p.hid);
     T* delta = reinterpret_cast<T*>(ws + p.delta);
     int* ovf = m->overflow;
-    // Saturation of Q / K / V^T and of the MLP hidden (overflow bits 2 / 4): with DTK_VIT_CHECK_RANGE every frame of every
-    // block is scanned (a pass over 1.3 GB per block and 30 frames); without it the FIRST frame of the call is, every block
-    // (four small launches per block): the out-of-range activations of a trained ViT are systematic -- the same few
-    // channels / tokens in every image -- so a model that does not fit fp16 is reported on any video, at ~0.1 % of the step.
+    // Saturation of Q / K / V^T and of the MLP hidden (overflow bits 2 / 4): tracked for EVERY value of EVERY frame inside the
+    // epilogues of the QKV and fc1 GEMMs (GemmEpi::ovf, round 5: four v_max3 per eight values, no extra pass; rounds 3-4 scanned
+    // the first frame of a call only, so a later frame could saturate silently).  DTK_VIT_CHECK_RANGE additionally scans the
+    // stored tensors of every block (a pass over 1.3 GB per block and 30 frames): the cross-check of the tests.
     const bool scan_all = ovf && (m->flags & DTK_VIT_CHECK_RANGE);
+    int* const epi_ovf = IsF16<T>::value ? ovf : nullptr;
     const int S = p.S, Sp = p.Sp;
     // Q/K/V^T padding rows (s >= S) must be finite zeros: they are read by the last KV tile
     {
@@ -1131,8 +1169,6 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
             DTK_LAUNCH("vit_range_scan", range_scan_kernel<T>, dim3(blocks), dim3(256), 0, st, t, n / 8, ovf, bit);
             return DTK_OK;
         };
-        const bool scan_first = ovf && !scan_all && f0 == 0;
-        const long long frame_qkv = (long long)m->heads * Sp * 64;   // one frame's part of Q, of K and of V^T
         const bool pe_fits = (size_t)nf * video_h * video_w * 16 <= p.delta - p.hid &&
                              (size_t)D * PE_K * 4 <= p.total - p.delta;
         if (m->patch == PE_P && m->stride == PE_S && pe_fits) {
@@ -1189,6 +1225,7 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
             e.bias = L.qkv_b; e.q = q; e.k = k; e.vt = vt; e.S = S; e.Sp = Sp; e.heads = m->heads; e.D = D;
             e.qscale = 0.125f * 1.4426950408889634f;
             e.no_store = dbg_ns;
+            e.ovf = epi_ovf;
             if (ws_ok) {
                 const auto gr = ws_grid(3 * D);
                 if (ws_v1) {
@@ -1206,8 +1243,6 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                            qkv_w, rows, 3 * D, D, e);
             }
             if (scan_all && scan_range(q, (long long)(p.ao - p.q) / 2, 2)) return DTK_E_HIP;
-            if (scan_first && (scan_range(q, frame_qkv, 2) || scan_range(k, frame_qkv, 2) || scan_range(vt, frame_qkv, 2)))
-                return DTK_E_HIP;
             if (Att<T>::launch(q, k, vt, ao, S, Sp, m->heads, D, nf * m->heads, (m->flags & DTK_VIT_ATTENTION_V2) != 0, st)) return DTK_E_HIP;
             e = GemmEpi<T>{};
             e.bias = L.proj_b; e.delta = delta; e.gamma = L.ls1; e.no_store = dbg_ns;
@@ -1230,7 +1265,7 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
             DTK_LAUNCH("vit_layernorm", layernorm_kernel<T>, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x, (const T*)delta,
                        L.ln2_w, L.ln2_b, xn, rows, D, m->ln_eps, ovf);
             e = GemmEpi<T>{};
-            e.bias = L.fc1_b; e.out = hid; e.no_store = dbg_ns;
+            e.bias = L.fc1_b; e.out = hid; e.no_store = dbg_ns; e.ovf = epi_ovf;
             if (ws_ok) {
                 const auto gr = ws_grid(4 * D);
                 if (ws_v1) {
@@ -1248,7 +1283,6 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                            fc1_w, rows, 4 * D, D, e);
             }
             if (scan_all && scan_range(hid, rows * 4 * D, 4)) return DTK_E_HIP;
-            if (scan_first && scan_range(hid, (long long)S * 4 * D, 4)) return DTK_E_HIP;
             e = GemmEpi<T>{};
             e.bias = L.fc2_b; e.delta = delta; e.gamma = L.ls2;
             if (ws_ok && D == WD_N) {  // (ws_ok: the fast-path GEMMs are on, dtk_vit_model.flags)

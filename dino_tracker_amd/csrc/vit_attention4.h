@@ -84,7 +84,7 @@ __device__ __forceinline__ void buffer_lds16(u4v srd, unsigned soff, unsigned vo
 }
 __device__ __forceinline__ u4v make_srd(const void* p) {
     const unsigned long long a = (unsigned long long)(size_t)p;
-    u4v r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};   // raw buffer, stride 0, no bounds in the way
+    u4v r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};   // raw buffer, stride 0, no bounds in the way (common.h: dtk_make_srd)
 #pragma unroll
     for (int k = 0; k < 4; ++k) r[k] = __builtin_amdgcn_readfirstlane(r[k]);
     return r;

@@ -110,6 +110,7 @@ class LongRangeSampler(torch.nn.Module):
             lo = (self.gpu_batch_index % n_chunks) * self.CHUNK
             setattr(self, f"{name}_valid_trajectories", valid[lo:lo + self.CHUNK].cuda())
             setattr(self, f"{name}_can_sample", can[lo:lo + self.CHUNK].cuda())
+        self._can_host = {}   # the host copies the frame-set re-draw decides on (DinoTrackerSampler._draw_frame_set)
 
     def get_point_correspondences_for_num_frames(self, valid_trajectories, can_sample, batch_size):
         """dataset.py:167-193."""
@@ -186,8 +187,21 @@ class DinoTrackerSampler(LongRangeSampler):
         for _ in range(max_tries):
             frames = torch.randperm(t, generator=generator)[:self.num_frames]
             if int((can_h[:, frames].sum(dim=1) >= 2).sum()) >= 2:
-                break
+                return frames
+        # the reference loops forever here (dataset.py:173-179).  The batch built from this draw marks the rows of the starved set
+        # invalid (`valid` of forward_device; the trainer masks them out of every loss term), so training continues -- but a set that
+        # cannot supply two eligible trajectories in max_tries draws is a data problem and is said out loud, not returned silently.
+        # (The number of draws is variable, so the host generator's stream differs from a fixed-count draw: documented, harmless.)
+        import warnings
+        warnings.warn(f"DinoTrackerSampler: no set of {self.num_frames} frames with two eligible '{name}' trajectories in "
+                      f"{max_tries} draws (the reference would loop forever, data/dataset.py:173-179); the '{name}' rows of this "
+                      "batch are marked invalid", RuntimeWarning, stacklevel=2)
         return frames
+
+    def invalidate_host_tables(self):
+        """Drop the host copies of {fg,bg}_can_sample (call after changing those tensors IN PLACE; a replaced tensor is noticed by
+        identity, load_next_batch calls this itself)."""
+        self._can_host = {}
 
     def forward_device(self, generator=None):
         """The batch of `forward` with the frame sets drawn on the HOST (torch's CPU generator) and everything that touches

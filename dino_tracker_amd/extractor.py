@@ -14,8 +14,11 @@ attention-map facet and the key self-similarity are small torch expressions over
 
 Operand type of the matrix units: IEEE fp16 by default (`operand_dtype="fp16"`; the residual stream, the statistics and
 every accumulation are fp32) -- the same MFMA rate as bf16 with 8x less operand rounding.  fp16 ends at 65504: activations
-beyond that SATURATE on the device and set an overflow word, which `encode` turns into a RuntimeError naming
-`operand_dtype="bf16"` (fp32's range, 8 mantissa bits) as the way out.
+beyond that SATURATE on the device and set an overflow word -- for every value of every frame (residual updates in the
+LayerNorm that applies them; Q / K / V and the MLP hidden inside the epilogues of the GEMMs that store them).  What happens
+then is `on_overflow`: "bf16" (default) re-encodes the call with bf16 operands (fp32's range, 8 mantissa bits), counts it in
+`range_fallbacks`, warns once, and keeps the extractor on bf16 from then on (the out-of-range activations of a trained ViT
+are systematic: the same few channels in every image); "raise" turns the word into a RuntimeError as rounds 3-4 did.
 """
 from __future__ import annotations
 
@@ -41,14 +44,20 @@ class VitExtractor(nn.Module):
     KEY_LIST = [BLOCK_KEY, ATTN_KEY, PATCH_IMD_KEY, QKV_KEY]
 
     def __init__(self, model_name, stride, device, state_dict: Optional[Dict[str, torch.Tensor]] = None,
-                 random_seed: Optional[int] = None, operand_dtype: str = "fp16", check_range: bool = False):
+                 random_seed: Optional[int] = None, operand_dtype: str = "fp16", check_range: bool = False,
+                 on_overflow: str = "bf16"):
         super().__init__()
         if operand_dtype not in ("fp16", "bf16"):
             raise ValueError(f"operand_dtype {operand_dtype!r}: 'fp16' or 'bf16'")
+        if on_overflow not in ("bf16", "raise"):
+            raise ValueError(f"on_overflow {on_overflow!r}: 'bf16' (re-encode with bf16 operands) or 'raise'")
         self.operand_dtype = operand_dtype
-        # What is checked for fp16 saturation (include/dtk.h: dtk_vit_model.overflow): every residual update of every token
-        # (always); Q / K / V and the MLP hidden of the FIRST frame of each encode() call, every block (always); with
-        # check_range=True those tensors for every frame (one extra pass per block).
+        self.on_overflow = on_overflow
+        self.range_fallbacks = 0        # encode() calls that left the fp16 range and were re-run with bf16 operands
+        self.last_overflow = 0          # overflow word of the most recent check (bit 1 residual update, 2 Q/K/V, 4 MLP hidden)
+        # What is checked for fp16 saturation (include/dtk.h: dtk_vit_model.overflow): every residual update of every token,
+        # and every Q / K / V / MLP-hidden value of every frame (inside the GEMM epilogues) -- always.  check_range=True adds a
+        # scan of the stored tensors (one extra pass per block): the cross-check of the tests.
         self.check_range = check_range
         self.attention_v2 = False       # the round-2/3 attention kernel instead of the one-wave-per-SIMD one (cross-check)
         self.gemm_ws_v1 = False         # the round 1-3 form of the K = 384 weight-stationary GEMMs (A / B measurement)
@@ -69,12 +78,14 @@ class VitExtractor(nn.Module):
         self._sd = {k: v.detach().to(device=device, dtype=torch.float32).contiguous() for k, v in state_dict.items()
                     if k.startswith(("cls_token", "pos_embed", "patch_embed.", "blocks."))}
         self._keep = []      # device tensors referenced by the C structs
-        self._layers = None  # ctypes array
+        self._layers_of = {}  # operand type -> ctypes array of dtk_vit_layer (bf16 built on first need)
         self._pos_cache = {}
-        self._build_layers()
+        self._layers = self._build_layers(self.operand_dtype)
 
     # ---- weights -> C structs -----------------------------------------------------------------------------------
-    def _build_layers(self):
+    def _build_layers(self, operand_dtype):
+        if operand_dtype in self._layers_of:
+            return self._layers_of[operand_dtype]
         depth = self.cfg["depth"]
         arr = (VitLayer * depth)()
         sd = self._sd
@@ -84,7 +95,7 @@ class VitExtractor(nn.Module):
             self._keep.append(t)
             return t.data_ptr()
 
-        wdt = torch.float16 if self.operand_dtype == "fp16" else torch.bfloat16
+        wdt = torch.float16 if operand_dtype == "fp16" else torch.bfloat16
 
         def b16(name):  # matrix weights in the operand type of the MFMA kernels
             w = sd[name]
@@ -105,7 +116,8 @@ class VitExtractor(nn.Module):
             L.fc1_w, L.fc1_b = b16(p + "mlp.fc1.weight"), f32(p + "mlp.fc1.bias")
             L.fc2_w, L.fc2_b = b16(p + "mlp.fc2.weight"), f32(p + "mlp.fc2.bias")
             L.ls2 = f32(p + "ls2.gamma")
-        self._layers = arr
+        self._layers_of[operand_dtype] = arr
+        return arr
 
     def _pos_embed(self, ph: int, pw: int):
         """models/extractor.py:57-85 (`_fix_pos_enc`): bicubic, align_corners=False, scale_factor with the +0.1 fudge,
@@ -147,41 +159,64 @@ class VitExtractor(nn.Module):
             self._overflow = torch.zeros(1, dtype=torch.int32, device=self.device)
         ms, overflow = self._ms[bool(normalize)], self._overflow
         D = self.cfg["dim"]
-        flags = (VIT_TILED_GEMMS if self.tiled_gemms else 0) | (VIT_BF16 if self.operand_dtype == "bf16" else 0) | \
-            (VIT_CHECK_RANGE if self.check_range else 0) | (VIT_ATTENTION_V2 if self.attention_v2 else 0) | (VIT_GEMM_WS_V1 if self.gemm_ws_v1 else 0)
-        m = VitModel(D, self.cfg["heads"], layer + 1, patch, self.stride, 1e-6, flags,
-                     self._sd["patch_embed.proj.weight"].data_ptr(),
-                     self._sd["patch_embed.proj.bias"].data_ptr(), cls_pos.data_ptr(), pos.data_ptr(), ms.data_ptr(),
-                     ctypes.cast(self._layers, ctypes.POINTER(VitLayer)), int(self.frame_batch), overflow.data_ptr())
-        ws_bytes = int(lib().dtk_vit_workspace_bytes(m, H, W, n))
-        # the workspace (2.6 GB for 30 frames of 854 x 476) is kept between calls: handing it back to the caching allocator
-        # and asking again costs a device allocation (~25 ms) whenever the block has been split or released in between
-        ws = getattr(self, "_ws", None)
-        if ws is None or ws.numel() < ws_bytes or ws.device != frames.device:   # (frames.device carries the resolved index)
-            self._ws = ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
         S = ph * pw + 1
         if want not in ("tokens", "feat", "qkv"):
             raise ValueError(want)
-        tokens = torch.empty((n, S, D), dtype=torch.float32, device=self.device) if want == "tokens" else None
-        feat = torch.empty((n, ph * pw, D), dtype=torch.float32, device=self.device) if want == "feat" else None
-        qkv = torch.empty((n, S, 3 * D), dtype=torch.float32, device=self.device) if want == "qkv" else None
-        check(lib().dtk_vit_forward(m, ops._p(frames), n, H, W, ops._p(tokens), ops._p(feat), ops._p(qkv), ops._p(ws),
-                                    ws_bytes, ops._stream()))
-        # (`ms`, `ws`, the position encoding and the overflow word are members: they outlive the launches)
-        if not defer_check:
-            self.check_overflow()
-        return {"tokens": tokens, "feat": feat, "qkv": qkv}[want]
 
-    def check_overflow(self):
-        """Reads (one stream synchronisation) and clears the overflow word of the encode() calls since the last check."""
+        def run(operand_dtype):
+            flags = (VIT_TILED_GEMMS if self.tiled_gemms else 0) | (VIT_BF16 if operand_dtype == "bf16" else 0) | \
+                (VIT_CHECK_RANGE if self.check_range else 0) | (VIT_ATTENTION_V2 if self.attention_v2 else 0) | \
+                (VIT_GEMM_WS_V1 if self.gemm_ws_v1 else 0)
+            m = VitModel(D, self.cfg["heads"], layer + 1, patch, self.stride, 1e-6, flags,
+                         self._sd["patch_embed.proj.weight"].data_ptr(),
+                         self._sd["patch_embed.proj.bias"].data_ptr(), cls_pos.data_ptr(), pos.data_ptr(), ms.data_ptr(),
+                         ctypes.cast(self._build_layers(operand_dtype), ctypes.POINTER(VitLayer)), int(self.frame_batch),
+                         overflow.data_ptr())
+            ws_bytes = int(lib().dtk_vit_workspace_bytes(m, H, W, n))
+            # the workspace (2.6 GB for 30 frames of 854 x 476) is kept between calls: handing it back to the caching allocator
+            # and asking again costs a device allocation (~25 ms) whenever the block has been split or released in between
+            ws = getattr(self, "_ws", None)
+            if ws is None or ws.numel() < ws_bytes or ws.device != frames.device:   # (frames.device carries the resolved index)
+                self._ws = ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+            tokens = torch.empty((n, S, D), dtype=torch.float32, device=self.device) if want == "tokens" else None
+            feat = torch.empty((n, ph * pw, D), dtype=torch.float32, device=self.device) if want == "feat" else None
+            qkv = torch.empty((n, S, 3 * D), dtype=torch.float32, device=self.device) if want == "qkv" else None
+            check(lib().dtk_vit_forward(m, ops._p(frames), n, H, W, ops._p(tokens), ops._p(feat), ops._p(qkv), ops._p(ws),
+                                        ws_bytes, ops._stream()))
+            # (`ms`, `ws`, the position encoding and the overflow word are members: they outlive the launches)
+            return {"tokens": tokens, "feat": feat, "qkv": qkv}[want]
+
+        out = run(self.operand_dtype)
+        if not defer_check and self.check_overflow(heal=True):
+            out = run(self.operand_dtype)          # the fp16 pass saturated: the same call on bf16 operands (sticky, see check_overflow)
+            self.check_overflow()                  # (bf16 sets no bits; a non-finite residual update would still raise)
+        return out
+
+    def check_overflow(self, heal: bool = False) -> bool:
+        """Reads (one stream synchronisation) and clears the overflow word of the encode() calls since the last check.
+        A non-zero word means those calls' features are not trustworthy.  With on_overflow="bf16" and fp16 operands the
+        extractor switches to bf16 operands for the rest of its life and counts the event; `heal=True` (encode's own call)
+        then returns True so that the caller re-runs the pass.  Otherwise -- "raise", a deferred check whose features were
+        already handed on, or bf16 operands (only non-finite values can set the word there) -- RuntimeError."""
         if not hasattr(self, "_overflow"):
-            return
+            return False
         self.last_overflow = int(self._overflow.item())
-        if self.last_overflow:
-            self._overflow.zero_()
-            what = [n for b, n in ((1, "a residual update"), (2, "Q / K / V"), (4, "the MLP hidden")) if self.last_overflow & b]
-            raise RuntimeError(f"dtk_vit_forward: {' and '.join(what)} left the fp16 range (saturated at 65504); "
-                               "construct the extractor with operand_dtype='bf16'")
+        if not self.last_overflow:
+            return False
+        self._overflow.zero_()
+        what = " and ".join(n for b, n in ((1, "a residual update"), (2, "Q / K / V"), (4, "the MLP hidden")) if self.last_overflow & b)
+        if self.operand_dtype == "fp16" and self.on_overflow == "bf16":
+            self.operand_dtype = "bf16"
+            self.range_fallbacks += 1
+            import warnings
+            warnings.warn(f"VitExtractor: {what} left the fp16 range (saturated at 65504); this extractor now runs on bf16 "
+                          "operands (range_fallbacks counts the re-encoded calls)", RuntimeWarning, stacklevel=3)
+            if heal:
+                return True
+            raise RuntimeError(f"dtk_vit_forward: {what} left the fp16 range in a call whose check was deferred: its features "
+                               "are saturated and must be discarded -- encode the video again (this extractor is on bf16 now)")
+        raise RuntimeError(f"dtk_vit_forward: {what} left the fp16 range (saturated at 65504) or is not finite; "
+                           "construct the extractor with operand_dtype='bf16'")
 
     def release_workspace(self):
         """Frees the encoder's activation workspace (2.6 GB for 30 frames of 854 x 476): preprocessing is done."""

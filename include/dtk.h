@@ -102,9 +102,10 @@ typedef struct dtk_vit_model {
     int32_t frame_batch;          /* frames per pass of the encoder (workspace grows with it: 87 MB per frame at 854 x 476, ViT-S); 0 = the library's default (90) */
     int32_t* overflow;            /* DEVICE word or NULL; OR-ed with 1 when a residual update (projection / MLP output) reached
                                    * the fp16 limit 65504 or is not finite (every token of every frame: the LayerNorm that
-                                   * applies the update checks it), with 2 / 4 when Q, K, V / the MLP hidden did: those are
-                                   * scanned for the FIRST frame of the call in every block, and for every frame with
-                                   * DTK_VIT_CHECK_RANGE.  The caller zeroes it.  fp16 activations
+                                   * applies the update checks it), with 2 / 4 when a value the QKV / fc1 GEMM stores (Q, K, V /
+                                   * the MLP hidden) did: tracked inside those GEMMs' epilogues for every value of every
+                                   * frame (round 5; DTK_VIT_CHECK_RANGE adds a scan of the stored tensors, the tests'
+                                   * cross-check).  The caller zeroes it.  fp16 activations
                                    * SATURATE (FP16_OVFL mode) instead of becoming inf; a non-zero word means the features
                                    * are not trustworthy and the model should be run with DTK_VIT_BF16. */
 } dtk_vit_model;

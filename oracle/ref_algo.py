@@ -17,6 +17,14 @@ Pinning status (see tests/test_oracle_vs_reference.py and tests/golden/):
     INSIDE that module is restated from upstream's published definition and cross-checked against the independent
     `transformers.Dinov2Model` port: "parity unpinned" for the blocks themselves.
 
+Device form (round 5): every function takes its device from its inputs, so the same restatement runs on `cuda` in fp32 --
+the full benchmark configuration (854 x 476 x 90, 1024 queries: 8.4 M correlation maps) costs seconds there and the parity
+tests compare EVERY position with it.  On a CUDA tensor the vendor convolution / attention libraries are avoided on purpose
+(MIOpen may pick Winograd or JIT-compile per shape; SDPA may pick a fused kernel): convolutions become unfold + matmul,
+BatchNorm / BlurPool explicit arithmetic, attention softmax(QK^T)V -- plain fp32 sums either way (`_plain` below).  The CPU
+path is unchanged (it is the one pinned against the reference); tests/test_gpu_fullsize.py pins the device form against the
+CPU form on a sample.
+
 All citations are file:line in /root/reference.
 """
 from __future__ import annotations
@@ -28,6 +36,34 @@ import torch
 import torch.nn.functional as F
 
 EPS = 1e-8  # models/tracker.py:14
+
+
+def _plain(x: torch.Tensor) -> bool:
+    """True on a device tensor: use plain-arithmetic forms instead of the vendor convolution / attention libraries."""
+    return x.is_cuda
+
+
+def _conv2d(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], padding: int = 0, dilation: int = 1,
+            stride: int = 1) -> torch.Tensor:
+    """F.conv2d; on a device tensor the same sums as unfold (im2col) + fp32 matrix products, a few images at a time (the
+    column matrix of a 5x5 Delta-DINO layer is 0.65 GB per frame at 238 x 427, that of the head's second layer 4.7 MB per map)."""
+    if not _plain(x):
+        return F.conv2d(x, w, b, padding=padding, dilation=dilation, stride=stride)
+    n, ci, h, wd = x.shape
+    co, _, kh, kw = w.shape
+    ho = (h + 2 * padding - dilation * (kh - 1) - 1) // stride + 1
+    wo = (wd + 2 * padding - dilation * (kw - 1) - 1) // stride + 1
+    wm = w.reshape(co, -1)
+    out = x.new_empty((n, co, ho, wo))
+    per_image = ci * kh * kw * ho * wo * 4
+    bs = max(1, (1 << 31) // per_image)
+    for i in range(0, n, bs):
+        cols = F.unfold(x[i:i + bs], (kh, kw), dilation=dilation, padding=padding, stride=stride)   # [bs, ci kh kw, L]
+        y = torch.matmul(wm, cols)
+        if b is not None:
+            y = y + b[None, :, None]
+        out[i:i + bs] = y.reshape(-1, co, ho, wo)
+    return out
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -46,8 +82,8 @@ def points_to_grid_coords(points: torch.Tensor, video_h: int, video_w: int, patc
     last_w = ((video_w - patch) // stride) * stride + half
     ah, aw = 2 / (last_h - half), 2 / (last_w - half)
     bh, bw = 1 - last_h * 2 / (last_h - half), 1 - last_w * 2 / (last_w - half)
-    a = torch.tensor([[aw, ah, 1.0]], dtype=points.dtype)
-    b = torch.tensor([[bw, bh, 0.0]], dtype=points.dtype)
+    a = torch.tensor([[aw, ah, 1.0]], dtype=points.dtype, device=points.device)
+    b = torch.tensor([[bw, bh, 0.0]], dtype=points.dtype, device=points.device)
     return a * points + b
 
 
@@ -107,6 +143,21 @@ def head_refiner(x: torch.Tensor, head: Dict[str, torch.Tensor]) -> torch.Tensor
     """cnn_refiner of TrackerHead (models/networks/tracker_head.py:54-58): x [B,1,h,w] -> z [B,1,h,w]."""
     w1 = normalized_conv_weight(head["cnn_refiner.0.weight"])
     w2 = normalized_conv_weight(head["cnn_refiner.2.weight"])
+    if _plain(x):
+        # device form: the two 3x3 layers as two plain fp32 matrix products over all cells of all maps, channel-last
+        #   hid[cell, 16] = relu(taps[cell, 9] W1^T + b1);  P[cell, 9] = hid W2 (one plane per tap);  z = b2 + sum of the shifted planes
+        n, _, h, w = x.shape
+        co = w1.shape[0]
+        xp = F.pad(x[:, 0], (1, 1, 1, 1))
+        taps = torch.stack([xp[:, dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3)], dim=-1)
+        hid = F.relu(taps.reshape(-1, 9) @ w1.reshape(co, 9).t() + head["cnn_refiner.0.bias"])
+        pp = F.pad((hid @ w2.reshape(co, 9)).reshape(n, h, w, 9), (0, 0, 1, 1, 1, 1))
+        z = None
+        for dy in range(3):
+            for dx in range(3):
+                term = pp[:, dy:dy + h, dx:dx + w, dy * 3 + dx]
+                z = term if z is None else z + term
+        return (z + head["cnn_refiner.2.bias"])[:, None]
     hid = F.relu(F.conv2d(x, w1, head["cnn_refiner.0.bias"], padding=1))
     return F.conv2d(hid, w2, head["cnn_refiner.2.bias"], padding=1)
 
@@ -124,8 +175,8 @@ def tracker_head(x: torch.Tensor, head: Dict[str, torch.Tensor], video_h: int, v
     z = head_refiner(x[:, None], head)[:, 0]
     p = torch.softmax(z.reshape(b, -1), dim=1).reshape(b, h, w)  # :100-105
     half = patch // 2
-    ys = torch.arange(h, dtype=torch.float32) * stride + half  # :72-78
-    xs = torch.arange(w, dtype=torch.float32) * stride + half
+    ys = torch.arange(h, dtype=torch.float32, device=x.device) * stride + half  # :72-78
+    xs = torch.arange(w, dtype=torch.float32, device=x.device) * stride + half
     px, py = (col * stride + half).float(), (row * stride + half).float()
     d2 = (xs[None, None, :] - px[:, None, None]) ** 2 + (ys[None, :, None] - py[:, None, None]) ** 2
     mask = d2.sqrt() <= radius  # :84
@@ -145,14 +196,19 @@ def tracker_head(x: torch.Tensor, head: Dict[str, torch.Tensor], video_h: int, v
 
 
 def track(src: torch.Tensor, feats: torch.Tensor, tgt: torch.Tensor, head: Dict[str, torch.Tensor], video_h: int,
-          video_w: int, patch: int = 14, stride: int = 7, chunk: int = 64) -> torch.Tensor:
+          video_w: int, patch: int = 14, stride: int = 7, chunk: Optional[int] = None,
+          src_row: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Track source embeddings src [M,C] into frames tgt [M] of feats [T,C,h,w]; returns pixel (x,y) [M,2]
     (models/tracker.py:171-180 + model_inference.py:52 un-normalisation).  Sources are grouped by target frame so
-    that each frame's maps are one matrix product (the same sums as `cosine_maps`, which gathers a frame per source)."""
-    m = src.shape[0]
+    that each frame's maps are one matrix product (the same sums as `cosine_maps`, which gathers a frame per source).
+    src_row [M] (optional): source m is row src_row[m] of the table `src` (the anchor stage repeats every trajectory
+    embedding once per anchor frame; the table form keeps 8.3 M x C floats from being materialised)."""
+    m = src.shape[0] if src_row is None else src_row.shape[0]
     out = src.new_zeros((m, 2))
     if m == 0:
         return out
+    if chunk is None:
+        chunk = 4096 if _plain(src) else 64   # maps per product: a host-cache-sized slice, or a launch-amortising one
     _, c, h, w = feats.shape
     order = torch.argsort(tgt, stable=True)
     frames, counts = torch.unique_consecutive(tgt[order], return_counts=True)
@@ -165,39 +221,63 @@ def track(src: torch.Tensor, feats: torch.Tensor, tgt: torch.Tensor, head: Dict[
         fnorm = fr.norm(dim=0)
         for i in range(0, n, chunk):
             ii = idx[i:i + chunk]
-            x = (src[ii] @ fr) / (snorm[ii, None] * fnorm[None]).clamp(min=EPS)
+            rows = ii if src_row is None else src_row[ii]
+            x = (src[rows] @ fr) / (snorm[rows, None] * fnorm[None]).clamp(min=EPS)
             o = tracker_head(F.relu(x).reshape(-1, h, w), head, video_h, video_w, patch, stride)
             out[ii] = torch.stack([(o[:, 0] + 1) / 2 * (video_w - 1), (o[:, 1] + 1) / 2 * (video_h - 1)], dim=1)
     return out
 
 
+def fp32_dot_band(c: int) -> float:
+    """What fp32 rounding can move a cosine of two C-vectors by, between two evaluations that sum in different orders:
+    sqrt(C) 2^-24 per evaluation (the standard probabilistic bound on a length-C dot product of unit vectors; the worst case
+    C 2^-24 is 20 x larger and never approached), one evaluation on each side -> 2 sqrt(C) 2^-24 (2.3e-6 at C = 384; the
+    near-ties met so far differ by 1 - 3 fp32 ulps of a cosine, 6e-8 - 1.9e-7)."""
+    return 2.0 * math.sqrt(c) * 2.0 ** -24
+
+
 def tie_arbiter(feats: torch.Tensor, q_xy_t: torch.Tensor, t: int, got_xy: torch.Tensor, head: Dict[str, torch.Tensor],
                 video_h: int, video_w: int, delta: float, patch: int = 14, stride: int = 7, tol_px: float = 1e-3,
-                max_cells: int = 256) -> Dict[str, float]:
+                max_cells: int = 256, dev_feats: Optional[torch.Tensor] = None) -> Dict[str, float]:
     """Test helper (not in the reference): decides whether a position `got_xy` that differs from this oracle's for the
     query q_xy_t = (x, y, t_q) in frame t is the reference's answer for a map whose near-tie went the other way.
-    The cosine map is evaluated in FLOAT64 from the fp32 features; every cell whose float64 cosine is within `delta` of the
-    float64 maximum is admissible (the caller derives delta from a bound on what can move a cosine: fp32 rounding of the
-    dot products, C * 2^-24, plus the measured deviation of the features a device path computed), and for each admissible
-    cell the head (models/networks/tracker_head.py:68-121, fp32 as the reference runs it) is evaluated with its arg-max
-    forced there.  Returns the float64 gap of the best-matching admissible cell, its distance to got_xy, and the counts."""
-    tq = q_xy_t[2:3].long()
-    q = sample_bilinear(feats.double(), q_xy_t[None, :2].double(), tq, video_h, video_w, patch, stride)[0]
+    The cosine map is evaluated in FLOAT64 from the fp32 features.  A cell k is admissible when its float64 cosine is within
+    its band of the float64 maximum:
+        band(k) = delta                                          (the caller's bound on fp32 rounding: fp32_dot_band(C))
+                + dev(k*) + dev(k)   if dev_feats is given       (MEASURED, for this map and these cells only: dev(k) = |cos64 of
+                                                                  the same query / frame evaluated from the features a device
+                                                                  path computed - cos64 from the oracle's features|)
+    and for each admissible cell the head (models/networks/tracker_head.py:68-121, fp32 as the reference runs it) is evaluated
+    with its arg-max forced there.  Returns the float64 gap of the best-matching admissible cell, its band, its distance to
+    got_xy, and the counts.  (Round 4 used one global band of twice the relative feature deviation, 6.6e-4: 3000 x the gap it
+    had to cover.  A genuinely wrong cell now has to sit within the fp32 band plus what the device's features measurably
+    moved THESE two cosines by.)"""
+    tq = int(q_xy_t[2])
     _, c, h, w = feats.shape
-    fr = feats[t].double().reshape(c, h * w)
-    m64 = F.relu((q @ fr) / (q.norm() * fr.norm(dim=0)).clamp(min=EPS))
+
+    def map64(vol):
+        q = sample_bilinear(vol[tq:tq + 1].double(), q_xy_t[None, :2].double(), torch.zeros(1, dtype=torch.long, device=vol.device),
+                            video_h, video_w, patch, stride)[0]
+        fr = vol[t].double().reshape(c, h * w)
+        return F.relu((q @ fr) / (q.norm() * fr.norm(dim=0)).clamp(min=EPS))
+
+    m64 = map64(feats)
     top = m64.max()
-    cells = torch.nonzero(m64 >= top - delta)[:, 0]
+    band = torch.full_like(m64, float(delta))
+    if dev_feats is not None:
+        dev = (map64(dev_feats) - m64).abs()
+        band = band + dev + dev[m64.argmax()]
+    cells = torch.nonzero(m64 >= top - band)[:, 0]
     if cells.numel() > max_cells:
         cells = cells[torch.argsort(m64[cells], descending=True)[:max_cells]]
-    q32 = sample_bilinear(feats, q_xy_t[None, :2], tq, video_h, video_w, patch, stride)
+    q32 = sample_bilinear(feats, q_xy_t[None, :2], q_xy_t[2:3].long(), video_h, video_w, patch, stride)
     x32 = F.relu(cosine_maps(q32, feats[t][None]))  # the map the reference's head sees
     o = tracker_head(x32.expand(cells.numel(), -1, -1), head, video_h, video_w, patch, stride, force_argmax=cells)
     xy = torch.stack([(o[:, 0] + 1) / 2 * (video_w - 1), (o[:, 1] + 1) / 2 * (video_h - 1)], dim=1)
-    d = (xy - got_xy[None]).norm(dim=1)
+    d = (xy - got_xy[None].to(xy.device)).norm(dim=1)
     i = int(d.argmin())
     return {"admissible_cells": int(cells.numel()), "gap64": float(top - m64[cells[i]]), "dist_px": float(d[i]),
-            "cell": int(cells[i]), "ok": bool(d[i] <= tol_px), "delta": float(delta)}
+            "cell": int(cells[i]), "ok": bool(d[i] <= tol_px), "delta": float(band[cells[i]]), "fp32_band": float(delta)}
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -238,24 +318,26 @@ def infer(feats: torch.Tensor, queries: torch.Tensor, head: Dict[str, torch.Tens
     # 1-2: query embeddings and first-pass trajectories (:8-74)
     q_emb = sample_bilinear(feats, queries[:, :2], tq, video_h, video_w, patch, stride)
     src = q_emb[:, None].expand(n, t_len, -1).reshape(n * t_len, -1)
-    tgt = torch.arange(t_len).repeat(n)
+    tgt = torch.arange(t_len, device=feats.device).repeat(n)
     traj = track(src, feats, tgt, head, video_h, video_w, patch, stride).reshape(n, t_len, 2)
     # 4: embeddings along the trajectory and their cosine to the one at the query frame (:110-126)
     s_emb = sample_bilinear(feats, traj.reshape(-1, 2), tgt, video_h, video_w, patch, stride).reshape(n, t_len, -1)
-    ref = s_emb[torch.arange(n), tq]
+    ref = s_emb[torch.arange(n, device=feats.device), tq]
     cs = F.cosine_similarity(ref[:, None], s_emb, dim=-1)
     # 5-6: anchors and occlusion (:130-200).  The anchor trajectories of ALL queries go through `track` as one batch (it groups
     # its sources by target frame, so every frame's maps are a few large products instead of one small product per query:
     # the same dot products, ~5 x less wall time on a many-core host); per query they are then cut back out.
-    occ = torch.zeros(n, t_len, dtype=torch.bool)
+    occ = torch.zeros(n, t_len, dtype=torch.bool, device=feats.device)
     greens: List[torch.Tensor] = []
     anchors_of = [torch.nonzero(cs[i] >= anchor_th)[:, 0] for i in range(n)]
     for a in anchors_of:
         if a.numel() == 0:
             raise RuntimeError("stack expects a non-empty TensorList")  # torch.stack([]) at :152
-    a_src = torch.cat([s_emb[i][None].expand(a.numel(), t_len, -1).reshape(-1, s_emb.shape[-1]) for i, a in enumerate(anchors_of)])
+    # source (i, a, t) = the embedding at traj[i, t], tracked into anchor frame a: row i T + t of the table of trajectory embeddings
+    t_ar = torch.arange(t_len, device=feats.device)
+    a_row = torch.cat([(i * t_len + t_ar)[None].expand(a.numel(), -1).reshape(-1) for i, a in enumerate(anchors_of)])
     a_tgt = torch.cat([a[:, None].expand(-1, t_len).reshape(-1) for a in anchors_of])
-    g_all = track(a_src, feats, a_tgt, head, video_h, video_w, patch, stride)
+    g_all = track(s_emb.reshape(n * t_len, -1), feats, a_tgt, head, video_h, video_w, patch, stride, src_row=a_row)
     pos = 0
     for i, a in enumerate(anchors_of):
         g = g_all[pos:pos + a.numel() * t_len].reshape(a.numel(), t_len, 2)
@@ -272,9 +354,19 @@ def infer(feats: torch.Tensor, queries: torch.Tensor, head: Dict[str, torch.Tens
 # --------------------------------------------------------------------------------------------------------------
 def blur_pool(x: torch.Tensor) -> torch.Tensor:
     """antialiased_cnns.BlurPool(stride=2, filt_size=4, reflect): see oracle/shims/antialiased_cnns (unpinned)."""
-    a = torch.tensor([1.0, 3.0, 3.0, 1.0])
-    k = (a[:, None] * a[None, :] / 64.0)[None, None].repeat(x.shape[1], 1, 1, 1)
-    return F.conv2d(F.pad(x, (1, 2, 1, 2), mode="reflect"), k, stride=2, groups=x.shape[1])
+    a = torch.tensor([1.0, 3.0, 3.0, 1.0], device=x.device)
+    k2 = a[:, None] * a[None, :] / 64.0
+    xp = F.pad(x, (1, 2, 1, 2), mode="reflect")
+    if _plain(x):   # the depthwise 4x4 / stride-2 filter as 16 shifted, weighted slices (no grouped-convolution library call)
+        ho, wo = (xp.shape[-2] - 4) // 2 + 1, (xp.shape[-1] - 4) // 2 + 1
+        out = None
+        for i in range(4):
+            for j in range(4):
+                term = k2[i, j] * xp[..., i:i + 2 * ho - 1:2, j:j + 2 * wo - 1:2]
+                out = term if out is None else out + term
+        return out
+    k = k2[None, None].repeat(x.shape[1], 1, 1, 1)
+    return F.conv2d(xp, k, stride=2, groups=x.shape[1])
 
 
 def delta_dino_cnn(frames: torch.Tensor, sd: Dict[str, torch.Tensor], bn_eps: float = 1e-5) -> torch.Tensor:
@@ -285,10 +377,15 @@ def delta_dino_cnn(frames: torch.Tensor, sd: Dict[str, torch.Tensor], bn_eps: fl
     for li, (ci, bi) in enumerate(zip(conv_ids, bn_ids)):
         dil = 2 if li == 3 else 1
         pad = 2 * dil
-        x = F.conv2d(F.pad(x, (pad,) * 4, mode="reflect"), sd[f"layers.{ci}.weight"], sd[f"layers.{ci}.bias"],
-                     dilation=dil)
-        x = F.batch_norm(x, sd[f"layers.{bi}.running_mean"], sd[f"layers.{bi}.running_var"],
-                         sd[f"layers.{bi}.weight"], sd[f"layers.{bi}.bias"], training=False, eps=bn_eps)
+        x = _conv2d(F.pad(x, (pad,) * 4, mode="reflect"), sd[f"layers.{ci}.weight"], sd[f"layers.{ci}.bias"],
+                    dilation=dil)
+        if _plain(x):   # eval-mode BatchNorm spelled out: (x - mean) / sqrt(var + eps) * weight + bias
+            inv = torch.rsqrt(sd[f"layers.{bi}.running_var"] + bn_eps) * sd[f"layers.{bi}.weight"]
+            x = (x - sd[f"layers.{bi}.running_mean"][None, :, None, None]) * inv[None, :, None, None] \
+                + sd[f"layers.{bi}.bias"][None, :, None, None]
+        else:
+            x = F.batch_norm(x, sd[f"layers.{bi}.running_mean"], sd[f"layers.{bi}.running_var"],
+                             sd[f"layers.{bi}.weight"], sd[f"layers.{bi}.bias"], training=False, eps=bn_eps)
         if li < 3:
             x = blur_pool(F.relu(x))
     return x
@@ -300,8 +397,8 @@ def align_to_vit_grid(cnn: torch.Tensor, vit_h: int, vit_w: int, patch: int = 14
     at the ViT token centres 7i+7."""
     ch, cw = cnn.shape[-2:]
     br_y, br_x = (ch - 1) * cnn_stride, (cw - 1) * cnn_stride
-    vx = torch.arange(vit_w, dtype=torch.float32) * vit_stride + patch / 2.0
-    vy = torch.arange(vit_h, dtype=torch.float32) * vit_stride + patch / 2.0
+    vx = torch.arange(vit_w, dtype=torch.float32, device=cnn.device) * vit_stride + patch / 2.0
+    vy = torch.arange(vit_h, dtype=torch.float32, device=cnn.device) * vit_stride + patch / 2.0
     gx = -1.0 - 1.0 / br_x + 2.0 * vx / br_x
     gy = -1.0 - 1.0 / br_y + 2.0 * vy / br_y
     grid = torch.stack(torch.meshgrid(gx, gy, indexing="xy"), dim=-1)[None].expand(cnn.shape[0], -1, -1, -1)
@@ -351,7 +448,10 @@ def vit_block(x: torch.Tensor, sd: Dict[str, torch.Tensor], i: int, heads: int, 
     qkv_flat = F.linear(y, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"])
     qkv = qkv_flat.reshape(b, s, 3, heads, d // heads)
     q, k, v = qkv.permute(2, 0, 3, 1, 4)
-    a = F.scaled_dot_product_attention(q, k, v)
+    if _plain(x):   # softmax(Q K^T / sqrt(d)) V spelled out in fp32 (no fused-attention backend)
+        a = torch.softmax((q @ k.transpose(-1, -2)) * (q.shape[-1] ** -0.5), dim=-1) @ v
+    else:
+        a = F.scaled_dot_product_attention(q, k, v)
     a = a.transpose(1, 2).reshape(b, s, d)
     x = x + sd[p + "ls1.gamma"] * F.linear(a, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
     y = F.layer_norm(x, (d,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps=1e-6)
@@ -374,11 +474,11 @@ def vit_all_tokens(frame: torch.Tensor, sd: Dict[str, torch.Tensor], model_name:
     layer = cfg["depth"] - 1 if layer is None else layer
     x = frame
     if normalize:
-        m = torch.tensor(IMAGENET_MEAN, dtype=frame.dtype).view(1, 3, 1, 1)
-        s = torch.tensor(IMAGENET_STD, dtype=frame.dtype).view(1, 3, 1, 1)
+        m = torch.tensor(IMAGENET_MEAN, dtype=frame.dtype, device=frame.device).view(1, 3, 1, 1)
+        s = torch.tensor(IMAGENET_STD, dtype=frame.dtype, device=frame.device).view(1, 3, 1, 1)
         x = (x - m) / s
     ph, pw = feature_grid(frame.shape[-2], frame.shape[-1], patch, stride)
-    tok = F.conv2d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=stride)
+    tok = _conv2d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=stride)
     tok = tok.flatten(2).transpose(1, 2)
     tok = torch.cat([sd["cls_token"].expand(tok.shape[0], -1, -1), tok], dim=1) + vit_pos_embed(sd, ph, pw)
     qkv = None
@@ -451,7 +551,7 @@ def best_buddies_pair(fs: torch.Tensor, ft: torch.Tensor):
     aff = aff / torch.clamp(fs.norm(dim=1)[:, None] * ft.norm(dim=1)[None], min=1e-8)
     smax = torch.argmax(aff, dim=1)
     tmax = torch.argmax(aff, dim=0)
-    rng = torch.arange(fs.shape[0])
+    rng = torch.arange(fs.shape[0], device=fs.device)
     keep = rng == tmax[smax]
     return rng[keep], smax[keep], aff[rng[keep], smax[keep]]
 
@@ -479,7 +579,7 @@ def bb_nms_ratio(aff: torch.Tensor, pw: int, box_size: float = 50.0, iou_thresh:
     neg = torch.full_like(vals, float("-inf"))
     second = torch.where(~supp, vals, neg)[:, 1:].max(dim=1).values if topk > 1 else neg[:, 0]
     nsupp = supp.sum(dim=1)
-    zero1 = torch.where(nsupp >= 1, torch.zeros(b), neg[:, 0])
-    zero2 = torch.where(nsupp >= 2, torch.zeros(b), neg[:, 0])
+    zero1 = torch.where(nsupp >= 1, torch.zeros(b, device=aff.device), neg[:, 0])
+    zero2 = torch.where(nsupp >= 2, torch.zeros(b, device=aff.device), neg[:, 0])
     top2 = torch.stack([vals[:, 0], second, zero1, zero2], dim=1).topk(2, dim=1).values
     return top2, top2[:, 1] / top2[:, 0]

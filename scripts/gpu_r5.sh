@@ -1,0 +1,31 @@
+#!/bin/bash
+# Round-5 GPU work, one gpurun call per invocation: scripts/gpu_r5.sh <step> [<step> ...]; outputs under gpurun_out/.
+#   new_tests     the tests this round added (full-size parity, fp16 range in every frame, > 2 GB split planes, weights file)
+#   tests         the whole -m gpu suite;   tests:<expr>  pytest -k <expr>
+#   bench         bench.py with the driver's flags (--steps 20 --warmup 5);  bench_quick  --steps 5 --warmup 2 --no-cpu-baseline
+#   profile       scripts/gpu_profile.sh r05: kernel trace + stats, PMC traffic passes, SQ pass -> gpurun_out/r05_*
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+for WHAT in "$@"; do
+  echo "=== $WHAT"
+  case $WHAT in
+    new_tests)
+      timeout 1500 python -m pytest -m gpu -x -q -s tests/test_gpu_fullsize.py tests/test_gpu_p3.py::test_split_planes_beyond_2gb \
+          "tests/test_gpu_p1.py::test_fp16_saturation_is_reported_and_bf16_is_the_way_out" \
+          "tests/test_gpu_p1.py::test_saturation_in_a_late_frame_is_caught_and_healed" \
+          "tests/test_gpu_p1.py::test_weights_from_an_upstream_named_checkpoint_file" \
+          "tests/test_gpu_p1.py::test_outlier_tokens_stay_in_fp16_range" 2>&1 | tail -40 | tee gpurun_out/new_tests.log ;;
+    tests)
+      timeout 2400 python -m pytest -m gpu -x -q tests 2>&1 | tail -25 | tee gpurun_out/tests.log ;;
+    tests:*)
+      timeout 2400 python -m pytest -m gpu -x -q -s tests -k "${WHAT#tests:}" 2>&1 | tail -40 | tee gpurun_out/tests_k.log ;;
+    bench)
+      timeout 1500 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err ;;
+    bench_quick)
+      timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_quick.json 2> gpurun_out/bench_quick.err; cat gpurun_out/bench_quick.json; tail -5 gpurun_out/bench_quick.err ;;
+    profile)
+      bash scripts/gpu_profile.sh r05 ;;
+    *) echo "unknown step $WHAT" ;;
+  esac
+done

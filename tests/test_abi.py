@@ -77,3 +77,37 @@ def test_struct_layouts_match_header():
         planes = 3 * g.ph * g.pw * C * 4
         assert total == ((unit + 255) // 256 * 256 + planes if extra else unit), (C, total, unit, planes)
     assert handle.dtk_contrastive_workspace_bytes(16, 256, 384, 8107) > 16 * 256 * 8108 * 4 * 2
+
+
+def test_m0_users(handle, tmp_path):
+    """csrc/common.h dtk_buffer_lds16 (and its copy in vit_attention4.h) writes m0 inside an asm statement the compiler cannot be
+    told about (hipcc refuses reserved registers in clobber lists), so the rule is structural: a kernel that contains the
+    descriptor form of LDS-DMA (`s_add_u32 m0, ...` + `buffer_load_dwordx4 ... lds`) has NO other instruction that reads or writes
+    m0.  Checked in the ISA of the built objects."""
+    import os
+    import re
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    csrc = os.path.dirname(_lib.LIB_PATH)
+    seen = 0
+    for name in ("vit", "track_mfma"):
+        fat, co = str(tmp_path / f"{name}.fatbin"), str(tmp_path / f"{name}.co")
+        subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", os.path.join(csrc, f"{name}.o"), fat], check=True)
+        subprocess.run([f"{llvm}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}",
+                        f"--output={co}", "--unbundle"], check=True)
+        asm = subprocess.run([f"{llvm}/llvm-objdump", "-d", co], capture_output=True, text=True, check=True).stdout
+        kern, users = None, {}
+        for line in asm.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+            if m:
+                kern = m.group(1)
+                continue
+            ins = line.split("//")[0].strip()
+            if re.search(r"\bm0\b", ins):
+                users.setdefault(kern, []).append(ins)
+        for kern, ins in users.items():
+            dma = [i for i in ins if i.startswith("s_add_u32 m0,")]
+            if dma:
+                seen += 1
+                assert len(dma) == len(ins), (kern, [i for i in ins if not i.startswith("s_add_u32 m0,")][:4])
+    assert seen >= 4   # attention4 (x2 operand types), gemm_ws V2D forms, corr_peaks, refine_corr_dma

@@ -340,11 +340,13 @@ def test_outlier_tokens_stay_in_fp16_range():
 
 
 def test_fp16_saturation_is_reported_and_bf16_is_the_way_out():
-    """An MLP output beyond 65504 cannot be an fp16 residual update: the device saturates it (no inf / NaN downstream),
-    sets the overflow word, and `encode` raises naming operand_dtype='bf16' -- which then runs (bf16 tolerance)."""
+    """An MLP output beyond 65504 cannot be an fp16 residual update: the device saturates it (no inf / NaN downstream) and
+    sets the overflow word.  on_overflow="raise": `encode` raises naming operand_dtype='bf16'.  Default (round 5): the call
+    is re-encoded on bf16 operands -- bit-identical to an extractor built with operand_dtype="bf16" --, counted, and the
+    extractor stays on bf16."""
     sd = _outlier_weights(scale_fc2=3.0e5)
     video = synth.synth_video(1, 140, 210, seed=81)
-    ex = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd)
+    ex = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd, on_overflow="raise")
     with pytest.raises(RuntimeError, match="operand_dtype='bf16'"):
         ex.encode(video, layer=4)
     assert ex.last_overflow & 1
@@ -353,6 +355,114 @@ def test_fp16_saturation_is_reported_and_bf16_is_the_way_out():
     ref = A.vit_tokens(video, sd, "dinov2_vits14", layer=4).permute(1, 2, 0).reshape(-1, 384)
     assert torch.isfinite(feat).all()
     _check(feat[0], ref, **BF16_TOL)
+    exh = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd)
+    with pytest.warns(RuntimeWarning, match="bf16"):
+        healed = exh.encode(video, layer=4).cpu()
+    assert exh.range_fallbacks == 1 and exh.operand_dtype == "bf16" and exh.last_overflow == 0
+    assert torch.equal(healed, feat)
+    assert torch.equal(exh.encode(video, layer=4).cpu(), feat) and exh.range_fallbacks == 1   # sticky: no second fp16 attempt
+    # a deferred check cannot heal (the features were handed on): it raises, and the extractor is on bf16 afterwards
+    exd = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd)
+    exd.encode(video, layer=4, defer_check=True)
+    with pytest.warns(RuntimeWarning), pytest.raises(RuntimeError, match="deferred"):
+        exd.check_overflow()
+    assert exd.operand_dtype == "bf16" and torch.equal(exd.encode(video, layer=4).cpu(), feat)
+
+
+def _late_frame_saturation_case(which):
+    """ViT-S weights + a 40-frame clip in which ONLY frame 37 drives one value past the fp16 limit: `which` = "hidden" (one unit
+    of block 0's MLP hidden, overflow bit 4) or "qkv" (one key channel of block 0, bit 2).  Frames 0..36, 38, 39 are the same
+    dark image, frame 37 a bright one; the planted unit reads the difference of the two frames' LayerNorm outputs (computed
+    with the oracle on the CPU), so it is ~0 on the dark frames and ~1e5 on the bright one.  Rounds 3-4 scanned frame 0 only."""
+    T, H, W = 40, 98, 126
+    sd = {k: v.clone() for k, v in synth.make_vit_weights("dinov2_vits14", seed=21, layerscale=0.1).items()}
+    dark = 0.2 + 0.02 * torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(1))
+    bright = 0.8 + 0.02 * torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(2))
+    video = dark.repeat(T, 1, 1, 1)
+    video[37] = bright[0]
+
+    def ln_out(frame, norm):   # LayerNorm output that feeds block 0's qkv (norm1) / fc1 (norm2), all tokens
+        tok = A.vit_all_tokens(frame, sd, "dinov2_vits14", layer=-1 if norm == "norm1" else 0)
+        if norm == "norm2":    # x after the attention half of block 0 = what norm2 sees: recompute it from the block's definition
+            x0 = A.vit_all_tokens(frame, sd, "dinov2_vits14", layer=-1)
+            y = torch.nn.functional.layer_norm(x0, (384,), sd["blocks.0.norm1.weight"], sd["blocks.0.norm1.bias"], eps=1e-6)
+            qkv = torch.nn.functional.linear(y, sd["blocks.0.attn.qkv.weight"], sd["blocks.0.attn.qkv.bias"]).reshape(1, -1, 3, 6, 64)
+            q, k, v = qkv.permute(2, 0, 3, 1, 4)
+            a = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(1, -1, 384)
+            tok = x0 + sd["blocks.0.ls1.gamma"] * torch.nn.functional.linear(a, sd["blocks.0.attn.proj.weight"], sd["blocks.0.attn.proj.bias"])
+        return torch.nn.functional.layer_norm(tok, (384,), sd[f"blocks.0.{norm}.weight"], sd[f"blocks.0.{norm}.bias"], eps=1e-6)[0]
+
+    norm = "norm2" if which == "hidden" else "norm1"
+    yd, yb = ln_out(dark, norm), ln_out(bright, norm)
+    d = yb.mean(0) - yd.mean(0)
+    pd, pb = yd @ d, yb @ d                                 # every token's coordinate along the dark -> bright direction
+    sc = 7.0e4 / float(pb.max() - pd.max())                 # the largest dark token lands on 3e4, the largest bright one on 1e5
+    w = sc * d
+    b = 3.0e4 - sc * float(pd.max())
+    assert w.abs().max() < 3.0e4, w.abs().max()            # the planted weights themselves fit fp16
+    vals_d, vals_b = yd @ w + b, yb @ w + b
+    assert vals_d.abs().max() < 4.5e4 and vals_b.max() > 9.0e4, (vals_d.abs().max(), vals_b.max())
+    if which == "hidden":
+        sd["blocks.0.mlp.fc1.weight"][5] = w
+        sd["blocks.0.mlp.fc1.bias"][5] = b
+        sd["blocks.0.mlp.fc2.weight"][:, 5] = 0.0           # keep the residual update itself in range: only bit 4 may fire
+    else:
+        sd["blocks.0.attn.qkv.weight"][384 + 70] = w        # key channel 6 of head 1
+        sd["blocks.0.attn.qkv.bias"][384 + 70] = b
+    return sd, video
+
+
+@pytest.mark.parametrize("which,bit", [("hidden", 4), ("qkv", 2)])
+def test_saturation_in_a_late_frame_is_caught_and_healed(which, bit):
+    """Q / K / V and the MLP hidden are range-checked for EVERY frame inside the GEMM epilogues (no extra
+    pass) -- a clip whose frame 37 alone saturates is reported (on_overflow="raise"), agrees with the explicit scan
+    (check_range=True), and by default is re-encoded on bf16 operands."""
+    sd, video = _late_frame_saturation_case(which)
+    ex = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd, on_overflow="raise")
+    ex.encode(video[:37], layer=1)                          # the dark frames alone: in range
+    assert ex.last_overflow == 0
+    with pytest.raises(RuntimeError, match="fp16 range"):
+        ex.encode(video, layer=1)
+    assert ex.last_overflow & bit, ex.last_overflow
+    exs = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd, on_overflow="raise", check_range=True)
+    with pytest.raises(RuntimeError):
+        exs.encode(video, layer=1)
+    assert exs.last_overflow & bit
+    ext = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd, on_overflow="raise")
+    ext.tiled_gemms = True                                  # the generic GEMM kernels' epilogues track the range too
+    with pytest.raises(RuntimeError):
+        ext.encode(video, layer=1)
+    assert ext.last_overflow & bit
+    exh = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd)
+    with pytest.warns(RuntimeWarning):
+        healed = exh.encode(video, layer=1).cpu()
+    exb = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd, operand_dtype="bf16")
+    assert exh.range_fallbacks == 1 and torch.equal(healed, exb.encode(video, layer=1).cpu())
+    assert torch.isfinite(healed).all()
+    if which == "hidden":   # (a key channel of 1e5 makes the attention a near-one-hot lottery at ANY 16-bit key rounding: no oracle bound there)
+        ref = A.vit_tokens(video[37:38], sd, "dinov2_vits14", layer=1).permute(1, 2, 0).reshape(-1, 384)
+        _check(healed[37], ref, **BF16_TOL)
+
+
+def test_weights_from_an_upstream_named_checkpoint_file(tmp_path, monkeypatch):
+    """$DTK_DINOV2_WEIGHTS (extractor.py: the path torch.hub's dinov2_vits14_pretrain.pth would take; models/extractor.py:23-39
+    loads the hub model): a state dict in upstream naming WITH the keys the encoder does not use (`mask_token`, the final
+    `norm.*`, a `pos_embed` of 1 x 1370 x D) loads, and encodes exactly like the same weights passed as `state_dict=`."""
+    sd = synth.make_vit_weights("dinov2_vits14", seed=31, layerscale=0.1)
+    assert sd["pos_embed"].shape == (1, 1370, 384)
+    full = dict(sd)
+    full["mask_token"] = torch.zeros(1, 384)
+    full["norm.weight"], full["norm.bias"] = torch.ones(384), torch.zeros(384)
+    path = str(tmp_path / "dinov2_vits14_pretrain.pth")
+    torch.save(full, path)
+    video = synth.synth_video(2, 140, 210, seed=84)
+    want = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd).encode(video).cpu()
+    monkeypatch.setenv("DTK_DINOV2_WEIGHTS", path)
+    got = VitExtractor("dinov2_vits14", stride=7, device="cuda:0").encode(video).cpu()
+    assert torch.equal(got, want)
+    monkeypatch.delenv("DTK_DINOV2_WEIGHTS")
+    with pytest.raises(RuntimeError, match="no DINOv2 weights"):
+        VitExtractor("dinov2_vits14", stride=7, device="cuda:0")
 
 
 # ---- ViT-L/14: the reference's shipped configuration (config/preprocessing.yaml:10-13), no reference checkout needed --------

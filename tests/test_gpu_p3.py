@@ -156,3 +156,35 @@ def test_infer_vs_oracle_dense_anchors(method):
     assert (cs - rcs).abs().max() < 1e-5
     assert torch.equal(occ.cpu(), ro)
     assert int(mi.last_counts[2]) == 0 and int(mi.last_counts[0]) == int((rcs >= 0.7).sum())
+
+
+def test_split_planes_beyond_2gb():
+    """the window correlation streams the split-fp16 planes through a raw buffer descriptor whose PER-LANE
+    offset carries cell * C * 4 bytes -- the part a raw buffer range-checks.  With num_records = 0x7fffffff (rounds 3-4) cells past
+    2 GB would have read zeros; has_split_planes() admits volumes up to 4 GB.  176 frames of 67 x 121 cells at C = 384 put frames
+    173 .. 175 beyond 2^31 bytes: sources tracked into those frames (and into early ones) must match the oracle."""
+    from dino_tracker_amd.tracker import Tracker
+    H, W, T, C = 476, 854, 176, 384
+    assert T * 67 * 121 * C * 4 > (1 << 31) and 173 * 67 * 121 * C * 4 > (1 << 31) > 172 * 67 * 121 * C * 4
+    g = torch.Generator(device="cuda").manual_seed(3)
+    base = synth.synth_features(4, C, 67, 121, seed=51).cuda()                      # [4, C, h, w] smooth translating field
+    feats = base.repeat(T // 4, 1, 1, 1) + 0.05 * torch.randn(T, C, 67, 121, device="cuda", generator=g)
+    tm = feats.permute(0, 2, 3, 1).reshape(T, 67 * 121, C).contiguous()
+    head = synth.synth_head_weights(3)
+    trk = Tracker(video=torch.zeros(T, 3, H, W, device="cuda"), dino_features=tm, dino_patch_size=14, stride=7, device="cuda:0",
+                  track_method=ops.TRACK_MFMA)
+    trk.tracker_head.load_state_dict(head)
+    trk.to("cuda:0").eval()
+    trk.set_refined_packed(tm)
+    gc = torch.Generator().manual_seed(5)
+    M = 768
+    pts = torch.rand(M, 2, generator=gc) * torch.tensor([W - 1.0, H - 1.0])
+    ts = torch.randint(0, T, (M,), generator=gc)
+    tgt = torch.cat([torch.randint(173, T, (M // 2,), generator=gc), torch.randint(0, 173, (M // 2,), generator=gc)])
+    src = A.sample_bilinear(feats, pts.cuda(), ts.cuda(), H, W)
+    ref = A.track(src, feats, tgt.cuda(), {k: v.cuda() for k, v in head.items()}, H, W)
+    out = torch.empty(M, 2, device="cuda")
+    trk.track_sources(trk.features(), src.contiguous(), None, tgt.int().cuda(), None, out, M)
+    err = (out - ref).abs().max(dim=1).values
+    assert trk.last_track_stats["exact_tier"] < M // 8, trk.last_track_stats   # the fast tier (and its DMA window correlation) did the work
+    assert err[: M // 2].max() < PX_TOL and err[M // 2:].max() < PX_TOL, (err[: M // 2].max(), err[M // 2:].max())

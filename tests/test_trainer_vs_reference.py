@@ -304,7 +304,9 @@ def test_device_side_batch_sampler_properties():
     sampler2 = DinoTrackerSampler(batch_size=64, range_normalizer=rn, dst_range=(-1, 1), fg_trajectories=fg, bg_trajectories=bg,
                                   fg_traj_ratio=0.5, num_frames=4)
     sampler2.fg_can_sample[:] = False
-    s = sampler2.forward_device()
+    sampler2.invalidate_host_tables()                       # (changed in place: the host copy the re-draw decides on is stale)
+    with pytest.warns(RuntimeWarning, match="no set of 4 frames"):   # the reference would loop forever; here: said out loud, rows invalid
+        s = sampler2.forward_device()
     assert not bool(s["valid"][:32].any()) and bool(s["valid"][32:].all()) and bool(torch.isfinite(s["t1_points"]).all())
 
 
