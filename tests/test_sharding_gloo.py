@@ -125,3 +125,27 @@ def test_video_parallel_gather_world4():
     port = 32500 + (os.getpid() % 1000)
     mp.spawn(_worker, args=(world, port, n_videos, n, t, ret), nprocs=world, join=True)
     assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_video_parallel_gather_world8_davis_batch():
+    """north_star's 30-video batch on 8 ranks: 4/4/4/4/4/4/3/3 videos, four rounds, ranks 6 and 7 idle in the last one -- they
+    still take part in its gather (no 8-GPU node has ever run this, the gloo form is what pins it)."""
+    world, n_videos, n, t = 8, 30, 6, 5
+    assert [len(sharding.videos_of_rank(n_videos, r, world)) for r in range(world)] == [4, 4, 4, 4, 4, 4, 3, 3]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 33500 + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(world, port, n_videos, n, t, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_query_parallel_world8_t90():
+    """One 90-frame video on 8 ranks: frames 12 x 7 + 6, queries 1024 -> 128 per rank (here 100 -> 13 x 7 + 9)."""
+    world, t, hw, c, n = 8, 90, 2, 3, 100
+    assert [sharding.split_range(t, r, world)[1] - sharding.split_range(t, r, world)[0] for r in range(world)] == [12] * 7 + [6]
+    assert [sharding.split_range(n, r, world)[1] - sharding.split_range(n, r, world)[0] for r in range(world)] == [13] * 7 + [9]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 34500 + (os.getpid() % 1000)
+    mp.spawn(_qp_worker, args=(world, port, t, hw, c, n, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
