@@ -54,6 +54,7 @@ def parse():
                          "feature-level generator with dense anchors (worst case for the tracker stage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-power", action="store_true", help="skip the shader-clock / board-power sampling legs")
+    ap.add_argument("--no-videos30", action="store_true", help="skip the second timed phase (north_star's 30-video batch, strong scaling)")
     ap.add_argument("--ab", default="", help="comma-separated A / B switches: attention_v2 (round 2-3 attention kernel), "
                                              "gemm_ws_v1 (round 1-3 weight-stationary GEMMs)")
     ap.add_argument("--cpu-threads", type=int, default=8, help="host threads of the oracle's infer leg (fixed: comparable across rounds)")
@@ -197,8 +198,15 @@ def main():
             return res
         traj, occ = one_video(videos[0])
         if world > 1 and traj is not None:
-            return sharding.gather_results(traj, occ, N, T, dev)  # RCCL gather of the results only
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            res = sharding.gather_results(traj, occ, N, T, dev)  # RCCL gather of the results only
+            ev[1].record()
+            gather_events.append(ev)
+            return res
         return traj, occ
+
+    gather_events = []   # (start, end) events around the gather of every step: read after the timed region
 
     def barrier():
         if world > 1:
@@ -225,11 +233,40 @@ def main():
             step()
         torch.cuda.synchronize()
         clock_power = {"steps_repeat": dict(sampler.stop(), ms_per_step=round((time.perf_counter() - c0) / max(2, min(args.steps, 5)) * 1e3, 2))}
+    per_rank = None
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        # every rank's own wall time of the K steps (the line's value uses the MAX), and the time its result gather took
+        mine_t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        all_t = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(all_t, mine_t)
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in all_t]
+        dt = max(float(x.item()) for x in all_t)
+        timed_ev = gather_events[-args.steps:] if len(gather_events) >= args.steps else gather_events
+        g_ms = sum(a.elapsed_time(b) for a, b in timed_ev) / max(len(timed_ev), 1)
+        per_rank = {"ms_per_step_by_rank": [round(x, 3) for x in rank_ms], "max": round(max(rank_ms), 3), "min": round(min(rank_ms), 3),
+                    "result_gather_ms_rank0": round(g_ms, 4),
+                    "note": "wall time of the K timed steps on each rank (value uses the max); the gather is the only collective of a step"}
     videos_per_step = 1 if qpar else (args.videos if args.videos > 0 else world)
+
+    # ---- north_star's strong-scaling form in the SAME line: a batch of 30 videos sharded v = r (mod world),
+    # 4/4/4/4/4/4/3/3 on 8 ranks, one RCCL gather per round; a second timed phase (one step, the kernels are warm) so that the
+    # driver's plain `bench.py --gpus N` runs also carry the number north_star's ">= 6x at 8 GPUs on a 30-video batch" is about
+    videos30 = None
+    if args.videos == 0 and not qpar and not args.no_videos30 and stages == ["extract", "refine", "track"] and args.features == "vit":
+        V30 = 30
+        barrier()
+        c0 = time.perf_counter()
+        sharding.run_sharded(V30, N, T, dev, lambda v: one_video(videos[(v // world) % n_distinct]))
+        barrier()
+        d30 = time.perf_counter() - c0
+        if world > 1:
+            t30 = torch.tensor([d30], device=dev, dtype=torch.float64)
+            dist.all_reduce(t30, op=dist.ReduceOp.MAX)
+            d30 = float(t30.item())
+        videos30 = {"videos": V30, "value": round(V30 * N * T / d30, 1), "unit": "query-points*frames/s", "seconds": round(d30, 3),
+                    "scaling": "strong", "videos_by_rank": [len(sharding.videos_of_rank(V30, r, world)) for r in range(world)],
+                    "rounds": (V30 + world - 1) // world,
+                    "note": "one untimed-warm step of the 30-video batch (bench.py --videos 30 is the same thing as the line's own metric)"}
 
     # ---- per-kernel pass (separate from the timed region): hipEvents around every launch of the library ---------------
     pairs = int(mi.last_counts[0]) if hasattr(mi, "last_counts") else 0
@@ -528,7 +565,7 @@ def main():
                                                 for r in range(world)] if qpar else [T] * world),
                        "parallelism": (f"query-parallel x{world} (frames split for P1/P2, queries for P3)" if qpar
                                        else f"video-parallel x{world}")},
-            "roofline": roofline, "clock_power": clock_power, "cpu_baseline": cpu, "parity_sample": parity,
+            "videos30": videos30, "per_rank": per_rank, "roofline": roofline, "clock_power": clock_power, "cpu_baseline": cpu, "parity_sample": parity,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

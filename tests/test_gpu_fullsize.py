@@ -40,15 +40,22 @@ def test_oracle_device_form_matches_cpu_form():
     queries = torch.cat([synth.grid_queries(4, 3, H, W, 0), synth.grid_queries(2, 2, H, W, 3)])
     rt, ro, rcs, rg = A.infer(feats, queries, head, H, W, return_aux=True)
     gt, go, gcs, gg = A.infer(feats.cuda(), queries.cuda(), _cuda(head), H, W, return_aux=True)
-    assert (gt.cpu() - rt).abs().max() < 3e-4, (gt.cpu() - rt).abs().max()      # a few fp32 ulps of a coordinate ~ 800 (ulp 6e-5)
+    assert (gt.cpu() - rt).abs().max() < 5e-4, (gt.cpu() - rt).abs().max()      # a few fp32 ulps of a coordinate ~ 800 (ulp 6.1e-5; measured: up to 5)
     assert (gcs.cpu() - rcs).abs().max() < 5e-6
     assert torch.equal(go.cpu(), ro)
-    # anchor trajectories: 16 queries x ~8 anchors x 8 frames of maps; a map whose two best cells tie within fp32 rounding may flip
-    # between the two evaluation orders (that is what the tie arbiter is for) -- at most a handful, everything else to a few ulps
-    d = torch.cat([(a.cpu() - b).abs().amax(dim=-1).reshape(-1) for a, b in zip(gg, rg)])
-    print("anchor tracks cuda vs cpu:", int(d.numel()), "positions,", int((d > 3e-4).sum()), "beyond 3e-4 px, max of the rest",
-          float(d[d <= 3e-4].max()))
-    assert int((d > 3e-4).sum()) <= max(1, d.numel() // 500), (int((d > 3e-4).sum()), d.numel())
+    # anchor trajectories (16 queries x 8 anchors x 8 frames): to a few fp32 ulps, except where a map's two best cells tie within
+    # fp32 rounding and the two evaluation orders pick differently -- each such position is ARBITRATED (float64 map, fp32 band only)
+    flagged = 0
+    for i, (a, b) in enumerate(zip(gg, rg)):
+        anchors = torch.nonzero(rcs[i] >= 0.7)[:, 0]
+        d = (a.cpu() - b).norm(dim=-1)                                   # [A, T]
+        for ai, t in torch.nonzero(d > 5e-4).tolist():
+            flagged += 1
+            src_xyt = torch.cat([rt[i, t], torch.tensor([float(t)])])    # the source is the embedding at traj[i, t] in frame t
+            r = A.tie_arbiter(feats, src_xyt, int(anchors[ai]), a[ai, t].cpu(), head, H, W, A.fp32_dot_band(C))
+            assert r["ok"] and r["gap64"] <= r["delta"], (i, ai, t, float(d[ai, t]), r)
+    print("anchor tracks cuda vs cpu:", sum(int(b.shape[0] * b.shape[1]) for b in rg), "positions,", flagged, "arbitrated")
+    assert flagged <= 64
     # P1 / P2 on two full-resolution frames
     video = synth.synth_video(2, H, W, seed=2000)
     sd = synth.make_vit_weights("dinov2_vits14", seed=2, layerscale=0.1)
