@@ -1,20 +1,25 @@
 // track_mfma.hip -- DTK_TRACK_MFMA: the fast path of dtk_track.
 //
-// Per chunk of sources (sorted by target frame):
-//   src16_kernel     s^ = 32 s/|s| -> fp16                                           (A operand)
-//   corr16_kernel    rho~ = relu(<s^, F^>/1024), fp16 MFMA 16x16x32 (fp32 accumulate), 64 sources x 128 cells per
-//                    workgroup, LDS double-buffered, -> fp16 maps in an Infinity-Cache resident staging chunk
-//   head16_kernel    one workgroup per map: approximate max + candidate cells within EPS_C of it, the 3x3/3x3 refiner
-//                    with v_dot2 (fp16 operands, fp32 accumulate) over the whole map for the softmax statistics
-//                    (zmax, Z) -- needed only for the zero-mass fallback test of tracker_head.py:86-94
-//   refine_corr      16 consecutive sources per workgroup: candidates re-scored in fp32 -> exact argmax k*;
-//                    fp32 correlation of the union of the 15x15 windows around the k* with the f32-input MFMA
-//                    (16x16x4, bit-exact fmaf chains) -> per-source window buffers
-//   refine_head      one wave per source: fp32 refiner on the window; disk soft-argmax.
-//                    Everything that decides the output (argmax, logits inside the disk) is fp32; the fp16 pass only
-//                    supplies candidates and (zmax, Z), which cancel out of the result unless the fallback fires.
-//   sources whose fp16 pass is inconclusive (more than KC candidates, fallback test within its error band)
-//   are appended to a redo list and re-done by the exact path (track_exact.hip) -- device-side count, no host sync.
+// Per ROUND of up to 4 M sources (sorted by target frame; MFMA_SUPER), the pipeline since round 3-4:
+//   src16_kernel        the distinct source rows -> fp16 unit vectors s^ = 32 s/|s| (once per call when the caller passes a table)
+//   corr_peaks_kernel   source-stationary correlation rho~ = <s^, F^>/1024 on fp16 MFMA 32x32x16 (fp32 accumulate): 64 sources per
+//                       wave held in AGPRs, the frame's cells streamed by descriptor LDS-DMA; the maps are NEVER stored -- each lane
+//                       keeps a running top-6 (value, cell) list in registers, merged per source at the end -> Rec {amax, <= 10
+//                       candidate cells within EPS_C of the approximate maximum}
+//   rescore_kernel      the candidates re-scored in fp32 from the fp32 master -> exact arg-max k* (first index on ties)
+//   key_scan / scatter  counting sort of the round's sources by (frame, cell of k*): key-consecutive sources share window cells
+//   refine_corr_dma     16 x 4 key-consecutive sources per workgroup: fp32-grade correlation of the union of their 15 x 15 windows
+//                       around k*, split-fp16 MFMA 16x16x32 (hi hi + hi lo + lo hi) on cells streamed PRE-SPLIT by LDS-DMA
+//                       (featsplit_kernel, once per volume) -> per-source fp32 windows
+//   refine_head_kernel  one wave per source: the 3x3 / 3x3 refiner on the window as chained f32 MFMAs (exact fp32 products), a
+//                       CERTIFICATE that the zero-mass fallback of tracker_head.py:86-94 cannot fire (then the softmax statistics
+//                       of the whole map cancel out of the result), disk soft arg-max
+//   tier 2 (whole-map statistics: corr16_tiled + head16 + refine) and tier 3 (track_exact.hip, fp32 everything) take the sources
+//   the fast tier cannot certify or whose candidate list overflowed -- device-side lists and counts, no host synchronisation.
+// Everything that decides the output (arg-max, logits inside the disk, soft arg-max) is fp32; the fp16 pass only proposes
+// candidates, inside a proven band (tests/test_numeric_claims.py).
+// Rounds 1-2 history (kept as tier 2): corr16 -> fp16 maps in an Infinity-Cache-sized chunk -> head16 (v_dot2 refiner over the whole
+// map for (zmax, Z)) -> refine.
 #include <limits.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -1709,19 +1714,19 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
             }
             return;
         }
-        // softmax statistics (zw, 1): the ratio is independent of them, and sq >= 1 -- the zero-mass branch is dead
-        float sq = 0.f, sqx = 0.f, sqy = 0.f, cnt = 0.f, sxs = 0.f, sys = 0.f;
+        // softmax statistics (zw, 1): the ratio is independent of them, and sq >= 1 (the cell that attains zw contributes exp(0)) --
+        // the zero-mass branch of dtk_softargmax_finish is dead, so the three geometry sums it would need (count and coordinate
+        // sums of the disk) are not formed here (round 5: three wave reductions, ~6 % of this kernel's instructions)
+        float sq = 0.f, sqx = 0.f, sqy = 0.f;
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl)
             if (okc[sl]) {
                 const float q = expf(zv[sl] - zw);
                 sq += q; sqx += q * cx[sl]; sqy += q * cy[sl];
-                cnt += 1.f; sxs += cx[sl]; sys += cy[sl];
             }
         sq = wave_sum(sq); sqx = wave_sum(sqx); sqy = wave_sum(sqy);
-        cnt = wave_sum(cnt); sxs = wave_sum(sxs); sys = wave_sum(sys);
         if (lane == 0) {
-            dtk_softargmax_finish(g, sq, sqx, sqy, cnt, sxs, sys, normalized, s_out[w]);
+            dtk_softargmax_finish(g, sq, sqx, sqy, 1.f, 0.f, 0.f, normalized, s_out[w]);
             const int oi = out_idx ? out_idx[m] : m;
             out_xy[2 * (size_t)oi] = s_out[w][0];
             out_xy[2 * (size_t)oi + 1] = s_out[w][1];

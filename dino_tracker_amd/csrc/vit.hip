@@ -406,6 +406,48 @@ __device__ __forceinline__ void gemm_store_tile(const f4& a, long long mb, int n
     }
 }
 
+// Epilogue of one TRANSPOSED 16x16 D tile (gemm_wide_kernel, round 5: its MFMAs run as (W tile) x (token tile)^T, so a lane
+// holds four CONSECUTIVE output features nb .. nb+3 of ONE token m): one 8-byte store per tile and lane where the layout keeps
+// features contiguous (GELU hidden, residual update, Q, K) instead of four 2-byte stores -- 32 store instructions per lane and
+// 256 x 256 tile instead of 128 (the wide models' fc1 / qkv ran at 0.55 / 0.60 PF against fc2's 1.06 on the same main loop:
+// profiles/r04_bench_width1024.json).  V^T keeps tokens contiguous, so its four features go out as 2-byte stores of 16 lanes = 32 B.
+template <typename T, int EPI>
+__device__ __forceinline__ void gemm_store_tile_t(const f4& a, long long m, int nb, long long M, int N, const GemmEpi<T>& e,
+                                                  float& amax) {
+    typedef typename Vec<T>::t4 T4;
+    const float4 b4 = e.bias ? *reinterpret_cast<const float4*>(e.bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float v[4] = {a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w};
+    if (EPI == EPI_QKV) {
+        const int which = nb / e.D, rem = nb - which * e.D;
+        const int head = rem >> 6, dh = rem & 63;
+        const float sc = which == 0 ? e.qscale : 1.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= sc;
+        if (IsF16<T>::value) amax = amax2(amax2(amax, v[0], v[1]), v[2], v[3]);
+        if (m >= M) return;
+        const int f = (int)(m / e.S), sp = (int)(m - (long long)f * e.S);
+        if (which == 2) {
+            T* vp = e.vt + (((size_t)f * e.heads + head) * 64 + dh) * e.Sp + sp;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vp[(size_t)r * e.Sp] = (T)v[r];
+        } else {
+            T* dst = (which == 0 ? e.q : e.k) + (((size_t)f * e.heads + head) * e.Sp + sp) * 64 + dh;
+            *reinterpret_cast<T4*>(dst) = T4{(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+        }
+    } else if (EPI == EPI_GELU) {
+        if (IsF16<T>::value) amax = amax2(amax2(amax, v[0], v[1]), v[2], v[3]);
+        if (m >= M) return;
+        T4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (T)(0.5f * v[r] * (1.f + erff(v[r] * 0.70710678118654752f)));
+        *reinterpret_cast<T4*>(e.out + m * N + nb) = o;
+    } else {   // EPI_DELTA
+        if (m >= M) return;
+        const float4 g4 = *reinterpret_cast<const float4*>(e.gamma + nb);
+        *reinterpret_cast<T4*>(e.delta + m * N + nb) = T4{(T)(g4.x * v[0]), (T)(g4.y * v[1]), (T)(g4.z * v[2]), (T)(g4.w * v[3])};
+    }
+}
+
 // (Round 2 measured two LDS-DMA forms of this main loop on fc2, K = 1536: 64-wide stages, two in flight, two barriers per
 // stage: 17.9 ms; 32-wide stages in a ring of four, three in flight, one barrier per stage: 20.0 ms; this register-staged
 // form: 17.1-17.5 ms.  Kept.  The SQ counters (profiles/r02_pmc_sq.md) show why it is slow -- 64 % of the wave cycles
@@ -642,7 +684,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_delta_kernel(const T* __rest
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
                     acc[half * 4 + mi][ni] =
-                        mfma16(af[mi], bfr, acc[half * 4 + mi][ni]);
+                        mfma16(bfr, af[mi], acc[half * 4 + mi][ni]);   // (W tile) x (token tile)^T: D transposed (round 5), see the epilogue
             }
         }
         ws_wait<WD_REQ>();  // stage ks + 1 landed; the requests of ks + 2 stay in flight
@@ -650,20 +692,21 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_delta_kernel(const T* __rest
         buf = buf == 2 ? 0 : buf + 1;
     }
     ws_wait<0>();
-    // D fragment: lane (fg, fj) holds rows 4*fg + r (r = 0..3), column fj of each 16x16 tile
+    // D tiles are TRANSPOSED (round 5): lane (fg, fj) holds features 4 fg + r (r = 0..3) of token fj of each 16 x 16 tile -- four
+    // consecutive features of one token: ONE 8-byte store per tile and lane (48 per lane and 256 x 384 tile) where the
+    // token-major form needed four 2-byte stores (192)
 #pragma unroll
     for (int ni = 0; ni < 6; ++ni) {
-        const int n = wc * 96 + ni * 16 + fj;
-        const float bias = e.bias ? e.bias[n] : 0.f;
-        const float gm = e.gamma[n];
+        const int nb = wc * 96 + ni * 16 + fg * 4;
+        const float4 b4 = e.bias ? *reinterpret_cast<const float4*>(e.bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 g4 = *reinterpret_cast<const float4*>(e.gamma + nb);
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
-            const long long mb = m0 + wr * 128 + mi * 16 + fg * 4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long long m = mb + r;
-                if (m < M) e.delta[m * WD_N + n] = (T)(gm * (acc[mi][ni][r] + bias));
-            }
+            const long long m = m0 + wr * 128 + mi * 16 + fj;
+            const f4& a = acc[mi][ni];
+            if (m < M)
+                *reinterpret_cast<T4*>(e.delta + m * WD_N + nb) =
+                    T4{(T)(g4.x * (a[0] + b4.x)), (T)(g4.y * (a[1] + b4.y)), (T)(g4.z * (a[2] + b4.z)), (T)(g4.w * (a[3] + b4.w))};
         }
     }
 }
@@ -750,7 +793,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const T* __restrict__
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
                     acc[half * 4 + mi][ni] =
-                        mfma16(af[mi], bfr, acc[half * 4 + mi][ni]);
+                        mfma16(bfr, af[mi], acc[half * 4 + mi][ni]);   // (W tile) x (token tile)^T: D transposed, see the epilogue
             }
         }
         ws_wait<2 * W2_REQ>();  // stage ks + 1 landed; ks + 2 and ks + 3 stay in flight
@@ -758,14 +801,14 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const T* __restrict__
         buf = (buf + 1) & 3;
     }
     ws_wait<0>();
+    // D tiles are TRANSPOSED (the MFMAs above multiply (W tile) x (token tile)^T): lane (fg, fj) holds features 4 fg + r of token fj
     float amax = 0.f;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wc * 64 + ni * 16 + fj;
-        const float bias = e.bias ? e.bias[n] : 0.f;
+        const int nb = n0 + wc * 64 + ni * 16 + fg * 4;
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi)
-            gemm_store_tile<T, EPI>(acc[mi][ni], m0 + wr * 128 + mi * 16 + fg * 4, n, bias, M, N, e, amax);
+            gemm_store_tile_t<T, EPI>(acc[mi][ni], m0 + wr * 128 + mi * 16 + fj, nb, M, N, e, amax);
     }
     amax_report<T, EPI>(amax, e.ovf);
 }
