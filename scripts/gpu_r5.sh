@@ -23,7 +23,11 @@ for WHAT in "$@"; do
     bench)
       timeout 1500 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err ;;
     bench_quick)
-      timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_quick.json 2> gpurun_out/bench_quick.err; cat gpurun_out/bench_quick.json; tail -5 gpurun_out/bench_quick.err ;;
+      timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-videos30 > gpurun_out/bench_quick.json 2> gpurun_out/bench_quick.err; cat gpurun_out/bench_quick.json; tail -5 gpurun_out/bench_quick.err ;;
+    bench_w1024)
+      timeout 900 python bench.py --width 1024 --steps 2 --warmup 1 --no-cpu-baseline --no-clock-power --no-videos30 > gpurun_out/bench_w1024.json 2> gpurun_out/bench_w1024.err; cat gpurun_out/bench_w1024.json; tail -5 gpurun_out/bench_w1024.err ;;
+    files:*)
+      timeout 2400 python -m pytest -m gpu -x -q ${WHAT#files:} 2>&1 | tail -25 | tee gpurun_out/tests_files.log ;;
     profile)
       bash scripts/gpu_profile.sh r05 ;;
     *) echo "unknown step $WHAT" ;;
