@@ -406,48 +406,6 @@ __device__ __forceinline__ void gemm_store_tile(const f4& a, long long mb, int n
     }
 }
 
-// Epilogue of one TRANSPOSED 16x16 D tile (gemm_wide_kernel, round 5: its MFMAs run as (W tile) x (token tile)^T, so a lane
-// holds four CONSECUTIVE output features nb .. nb+3 of ONE token m): one 8-byte store per tile and lane where the layout keeps
-// features contiguous (GELU hidden, residual update, Q, K) instead of four 2-byte stores -- 32 store instructions per lane and
-// 256 x 256 tile instead of 128 (the wide models' fc1 / qkv ran at 0.55 / 0.60 PF against fc2's 1.06 on the same main loop:
-// profiles/r04_bench_width1024.json).  V^T keeps tokens contiguous, so its four features go out as 2-byte stores of 16 lanes = 32 B.
-template <typename T, int EPI>
-__device__ __forceinline__ void gemm_store_tile_t(const f4& a, long long m, int nb, long long M, int N, const GemmEpi<T>& e,
-                                                  float& amax) {
-    typedef typename Vec<T>::t4 T4;
-    const float4 b4 = e.bias ? *reinterpret_cast<const float4*>(e.bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float v[4] = {a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w};
-    if (EPI == EPI_QKV) {
-        const int which = nb / e.D, rem = nb - which * e.D;
-        const int head = rem >> 6, dh = rem & 63;
-        const float sc = which == 0 ? e.qscale : 1.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= sc;
-        if (IsF16<T>::value) amax = amax2(amax2(amax, v[0], v[1]), v[2], v[3]);
-        if (m >= M) return;
-        const int f = (int)(m / e.S), sp = (int)(m - (long long)f * e.S);
-        if (which == 2) {
-            T* vp = e.vt + (((size_t)f * e.heads + head) * 64 + dh) * e.Sp + sp;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) vp[(size_t)r * e.Sp] = (T)v[r];
-        } else {
-            T* dst = (which == 0 ? e.q : e.k) + (((size_t)f * e.heads + head) * e.Sp + sp) * 64 + dh;
-            *reinterpret_cast<T4*>(dst) = T4{(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
-        }
-    } else if (EPI == EPI_GELU) {
-        if (IsF16<T>::value) amax = amax2(amax2(amax, v[0], v[1]), v[2], v[3]);
-        if (m >= M) return;
-        T4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (T)(0.5f * v[r] * (1.f + erff(v[r] * 0.70710678118654752f)));
-        *reinterpret_cast<T4*>(e.out + m * N + nb) = o;
-    } else {   // EPI_DELTA
-        if (m >= M) return;
-        const float4 g4 = *reinterpret_cast<const float4*>(e.gamma + nb);
-        *reinterpret_cast<T4*>(e.delta + m * N + nb) = T4{(T)(g4.x * v[0]), (T)(g4.y * v[1]), (T)(g4.z * v[2]), (T)(g4.w * v[3])};
-    }
-}
-
 // (Round 2 measured two LDS-DMA forms of this main loop on fc2, K = 1536: 64-wide stages, two in flight, two barriers per
 // stage: 17.9 ms; 32-wide stages in a ring of four, three in flight, one barrier per stage: 20.0 ms; this register-staged
 // form: 17.1-17.5 ms.  Kept.  The SQ counters (profiles/r02_pmc_sq.md) show why it is slow -- 64 % of the wave cycles
@@ -600,6 +558,49 @@ __device__ __forceinline__ f2 gelu2(f2 x) {
     const f2 hx = x * f2{0.5f, 0.5f};
     return __builtin_elementwise_fma(hx, e, hx);
 }
+
+// Epilogue of one TRANSPOSED 16x16 D tile (gemm_wide_kernel, round 5: its MFMAs run as (W tile) x (token tile)^T, so a lane
+// holds four CONSECUTIVE output features nb .. nb+3 of ONE token m): one 8-byte store per tile and lane where the layout keeps
+// features contiguous (GELU hidden, residual update, Q, K) instead of four 2-byte stores -- 32 store instructions per lane and
+// 256 x 256 tile instead of 128 (the wide models' fc1 / qkv ran at 0.55 / 0.60 PF against fc2's 1.06 on the same main loop:
+// profiles/r04_bench_width1024.json).  V^T keeps tokens contiguous, so its four features go out as 2-byte stores of 16 lanes = 32 B.
+template <typename T, int EPI>
+__device__ __forceinline__ void gemm_store_tile_t(const f4& a, long long m, int nb, long long M, int N, const GemmEpi<T>& e,
+                                                  float& amax) {
+    typedef typename Vec<T>::t4 T4;
+    const float4 b4 = e.bias ? *reinterpret_cast<const float4*>(e.bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float v[4] = {a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w};
+    if (EPI == EPI_QKV) {
+        const int which = nb / e.D, rem = nb - which * e.D;
+        const int head = rem >> 6, dh = rem & 63;
+        const float sc = which == 0 ? e.qscale : 1.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= sc;
+        if (IsF16<T>::value) amax = amax2(amax2(amax, v[0], v[1]), v[2], v[3]);
+        if (m >= M) return;
+        const int f = (int)(m / e.S), sp = (int)(m - (long long)f * e.S);
+        if (which == 2) {
+            T* vp = e.vt + (((size_t)f * e.heads + head) * 64 + dh) * e.Sp + sp;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vp[(size_t)r * e.Sp] = (T)v[r];
+        } else {
+            T* dst = (which == 0 ? e.q : e.k) + (((size_t)f * e.heads + head) * e.Sp + sp) * 64 + dh;
+            *reinterpret_cast<T4*>(dst) = T4{(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+        }
+    } else if (EPI == EPI_GELU) {
+        if (IsF16<T>::value) amax = amax2(amax2(amax, v[0], v[1]), v[2], v[3]);
+        if (m >= M) return;
+        // (the packed polynomial GELU of the weight-stationary kernels: |error| < 6e-5, below the 16-bit rounding of the result;
+        //  libm's erff costs ~10 x the instructions, and this epilogue runs for 4096 features of every token in fc1)
+        const f2 g0 = gelu2(f2{v[0], v[1]}), g1 = gelu2(f2{v[2], v[3]});
+        *reinterpret_cast<T4*>(e.out + m * N + nb) = T4{(T)g0[0], (T)g0[1], (T)g1[0], (T)g1[1]};
+    } else {   // EPI_DELTA
+        if (m >= M) return;
+        const float4 g4 = *reinterpret_cast<const float4*>(e.gamma + nb);
+        *reinterpret_cast<T4*>(e.delta + m * N + nb) = T4{(T)(g4.x * v[0]), (T)(g4.y * v[1]), (T)(g4.z * v[2]), (T)(g4.w * v[3])};
+    }
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // wide-tile GEMM for N = 384 and long K (fc2 of ViT-S: K = 1536):  C[M][384] = A[M][K] . Wt[384][K]^T, EPI_DELTA epilogue
