@@ -161,7 +161,12 @@ int dtk_delta_dino_refine(const dtk_geom* g, const float* video, const float* di
                           void* stream);
 /* The same with the operand precision of the 5x5 convolutions of layers 2-4 chosen by the caller:
  *   DTK_DD_SPLIT  every fp32 operand as hi + lo fp16 halves, three MFMA products per term (fp32-grade: 3e-5 of the reference)
- *   DTK_DD_FP16   the hi halves only: plain fp16 operands, fp32 accumulation, one product per term */
+ *   DTK_DD_FP16   the hi halves only: plain fp16 operands, fp32 accumulation, one product per term
+ * DEFAULTS DIFFER BY ENTRY POINT, on purpose: dtk_delta_dino_refine (above, the round 1-3 entry) always means DTK_DD_SPLIT, so a
+ * C caller that never heard of the mode keeps the fp32-grade result; the Python mirror (dino_tracker_amd/delta_dino.py) calls
+ * THIS entry and defaults to DTK_DD_FP16 since round 4 (the end-to-end position error is unchanged to 1e-5 px behind the fp16
+ * ViT operands, profiles/r04_e2e_error_p2_operands.json; DTK_P2_OPERANDS=split or DeltaDINO.conv_operands = "split" restores the
+ * other).  tests/test_gpu_p2.py pins both modes against the reference-written golden, each with its own tolerance. */
 #define DTK_DD_SPLIT 0
 #define DTK_DD_FP16 1
 int dtk_delta_dino_refine_mode(const dtk_geom* g, const float* video, const float* dino, const float* const* packed,

@@ -35,6 +35,20 @@ def test_refine_matches_reference_golden_and_tracks():
     r, res = trk.get_refined_embeddings(sub)
     assert np.abs(r.cpu().numpy() - gold["refined"][[3, 0]]).max() < FEAT_TOL
     assert np.abs((r - res).cpu().numpy() - dino.numpy()[[3, 0]]).max() < 1e-6
+    # the library's DEFAULT operand mode (plain fp16 conv operands since round 4) against the same reference-written golden, with
+    # its own tolerance: refined features within 2e-3 of the residual's size, positions within 1e-3 px, flags equal
+    trk_d = make_tracker(video, dino, head, delta=delta, method=ops.TRACK_MFMA, p2_operands=None)
+    trk_d.eval()
+    mi_d = make_inference(trk_d, cfg["H"], cfg["W"], cfg["T"])
+    refined_d = trk_d.refined_features.cpu().numpy()
+    res_scale = float(np.abs(gold["refined"] - dino.numpy()).max())
+    err_d = float(np.abs(refined_d - gold["refined"]).max())
+    traj_d, occ_d = mi_d.infer(queries.cuda())
+    dpx = float(np.abs(traj_d.cpu().numpy() - gold["traj"]).max())
+    print(f"default (fp16-operand) Delta-DINO vs the reference golden: refined err {err_d:.3g} ({err_d / res_scale:.2g} of the residual), "
+          f"positions {dpx:.3g} px")
+    assert err_d < 2e-3 * res_scale and dpx < 1e-3
+    assert np.array_equal(occ_d.cpu().numpy(), gold["occ"])
 
 
 @pytest.mark.parametrize("C,H,W", [(384, 476, 854), (32, 98, 126)])
