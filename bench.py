@@ -310,7 +310,7 @@ def main():
         # around it) -- read from the newest committed PMC pass of the same command (scripts/pmc_traffic.py)
         # (the committed passes are of the DEFAULT workload: another width / frame count / query count gets no traffic figure)
         default_workload = args.width == 384 and args.frames == 90 and args.queries == 1024 and not args.videos
-        for prof_file in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if default_workload else ():
+        for prof_file in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if default_workload else ():
             try:
                 with open(os.path.join(ROOT, "profiles", prof_file)) as fh:
                     tr = json.load(fh)["kernels"].get(dom)

@@ -26,6 +26,10 @@ for WHAT in "$@"; do
       timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-videos30 > gpurun_out/bench_quick.json 2> gpurun_out/bench_quick.err; cat gpurun_out/bench_quick.json; tail -5 gpurun_out/bench_quick.err ;;
     bench_w1024)
       timeout 900 python bench.py --width 1024 --steps 2 --warmup 1 --no-cpu-baseline --no-clock-power --no-videos30 > gpurun_out/bench_w1024.json 2> gpurun_out/bench_w1024.err; cat gpurun_out/bench_w1024.json; tail -5 gpurun_out/bench_w1024.err ;;
+    bench_config2)   # BASELINE.json configs[1]: 854x480x50, 256 queries
+      timeout 900 python bench.py --frames 50 --queries 256 --steps 5 --warmup 2 --no-videos30 --parity-video-frames 50 > gpurun_out/bench_config2.json 2> gpurun_out/bench_config2.err; cat gpurun_out/bench_config2.json; tail -3 gpurun_out/bench_config2.err ;;
+    bench_w768)
+      timeout 900 python bench.py --width 768 --steps 2 --warmup 1 --no-cpu-baseline --no-clock-power --no-videos30 > gpurun_out/bench_w768.json 2> gpurun_out/bench_w768.err; cat gpurun_out/bench_w768.json; tail -3 gpurun_out/bench_w768.err ;;
     files:*)
       timeout 2400 python -m pytest -m gpu -x -q ${WHAT#files:} 2>&1 | tail -25 | tee gpurun_out/tests_files.log ;;
     profile)
