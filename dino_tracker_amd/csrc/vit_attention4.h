@@ -150,6 +150,21 @@ __global__ __launch_bounds__(256, 1) void attention4_kernel(const op_t* __restri
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *reinterpret_cast<const op8*>(Qb + (size_t)qrow * 64 + ks * 16 + hi * 8);
     }
+    // The key rows of the reference estimate (below): keys 0..31, 32..63 and the two query tiles' own 32 keys -- requested HERE, in
+    // ONE batch with the Q fragments and in front of the tile requests (round 5).  The prologue used to be three dependent trips to
+    // memory -- Q + the twelve tile requests drained (the compiler's wait for Q is a vmcnt(0) once asm-issued requests follow its
+    // loads), then the estimate's first three key blocks, then the fourth -- 10.2 k cycles of a workgroup's 247 k with nothing to
+    // overlap them (one workgroup per CU); batched it is one trip.  Same values, same arithmetic.
+    op8 kq[4][4];
+    if (!(ABL & 8)) {
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            const int kr0 = blk < 2 ? blk * 32 : q0 + (blk - 2) * 32;
+            const op_t* kp = Kb + (size_t)min(kr0 + lq, Sp - 1) * 64 + hi * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kq[blk][ks] = *reinterpret_cast<const op8*>(kp + ks * 16);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         issue_one(0, std::integral_constant<int, 0>{}, j);
@@ -178,11 +193,6 @@ __global__ __launch_bounds__(256, 1) void attention4_kernel(const op_t* __restri
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int e = 0; e < 4; ++e) pf[0][g][e] = pf[1][g][e] = 0u;
-#pragma unroll
-    for (int g = 0; g < 8; ++g)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) vf[g][e] = (op_t)0.f;   // E(0) multiplies them with P = 0
-
     // fragment addresses inside a ring buffer: K fragment f = (key block b = f & 1, d step ks = f >> 1) at ka[ks] + 4096 b,
     // V^T fragment g = (d block db = g & 1, 16-key group bj = g >> 1) at va[bj] + 4096 db; + 16384 * buffer: all immediates
     const int krow = (lq & 19) | ((lq & 4) << 1) | ((lq & 8) >> 1);
@@ -208,13 +218,10 @@ __global__ __launch_bounds__(256, 1) void attention4_kernel(const op_t* __restri
 #pragma unroll
             for (int blk = 0; blk < 3; ++blk) {
                 const int kr0 = blk < 2 ? blk * 32 : q0 + qt * 32;
-                const op_t* kp = Kb + (size_t)min(kr0 + lq, Sp - 1) * 64 + hi * 8;
-                op8 kq[4];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) kq[ks] = *reinterpret_cast<const op8*>(kp + ks * 16);
+                const int kb = blk < 2 ? blk : 2 + qt;   // the batch loaded in front of the tile requests
                 f16v so = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) so = ATT2_MFMA(kq[ks], qf[qt][ks], so, 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) so = ATT2_MFMA(kq[kb][ks], qf[qt][ks], so, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kr0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -230,6 +237,10 @@ __global__ __launch_bounds__(256, 1) void attention4_kernel(const op_t* __restri
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) negm[qt][r] = -m_run[qt];
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vf[g][e] = (op_t)0.f;   // E(0) multiplies them with P = 0 (initialised here: the registers held the estimate's key rows until now)
     vm_wait<0>();  // tiles 0 .. A4_AHEAD-1 have landed
     __syncthreads();
 

@@ -30,6 +30,8 @@ for WHAT in "$@"; do
       timeout 900 python bench.py --frames 50 --queries 256 --steps 5 --warmup 2 --no-videos30 --parity-video-frames 50 > gpurun_out/bench_config2.json 2> gpurun_out/bench_config2.err; cat gpurun_out/bench_config2.json; tail -3 gpurun_out/bench_config2.err ;;
     bench_w768)
       timeout 900 python bench.py --width 768 --steps 2 --warmup 1 --no-cpu-baseline --no-clock-power --no-videos30 > gpurun_out/bench_w768.json 2> gpurun_out/bench_w768.err; cat gpurun_out/bench_w768.json; tail -3 gpurun_out/bench_w768.err ;;
+    attn_ab)   # same-box A / B of the attention stage: scripts/ubench/libdtk_prev.so (a copy of the previous build) vs the tree's library
+      timeout 600 python scripts/attn_ab.py scripts/ubench/libdtk_prev.so dino_tracker_amd/csrc/libdtk.so 2>&1 | tee gpurun_out/attn_ab.log ;;
     files:*)
       timeout 2400 python -m pytest -m gpu -x -q ${WHAT#files:} 2>&1 | tail -25 | tee gpurun_out/tests_files.log ;;
     profile)
