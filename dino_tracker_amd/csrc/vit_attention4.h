@@ -439,14 +439,30 @@ __global__ __launch_bounds__(256, 1) void attention4_kernel(const op_t* __restri
         const int qi = q0 + qt * 32 + lq;
         if (qi < S) {
             op_t* orow = O + ((size_t)frame * S + qi) * D + head * 64;
+            // a lane (query lq, half hi) holds d = 8 rq + 4 hi .. + 3 of every row quad rq: 8-byte pieces.  The two halves of a query
+            // trade pieces (v_permlane32_swap: the upper half of the even quad's register <-> the lower half of the odd quad's), after
+            // which the lower lane owns all 8 values of the even quad and the upper lane all 8 of the odd one: 16-byte stores, half
+            // as many (round 5; the store tail of a workgroup is issue-bound, MI355X_MICROARCH.md T21)
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const int d = db * 32 + 8 * rq + 4 * hi;
-                    op4 v = {(op_t)(o[qt][db][4 * rq + 0] * inv), (op_t)(o[qt][db][4 * rq + 1] * inv),
-                             (op_t)(o[qt][db][4 * rq + 2] * inv), (op_t)(o[qt][db][4 * rq + 3] * inv)};
-                    *reinterpret_cast<op4*>(orow + d) = v;
+                for (int pr = 0; pr < 2; ++pr) {
+                    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+                    const op4 ve = {(op_t)(o[qt][db][8 * pr + 0] * inv), (op_t)(o[qt][db][8 * pr + 1] * inv),
+                                    (op_t)(o[qt][db][8 * pr + 2] * inv), (op_t)(o[qt][db][8 * pr + 3] * inv)};
+                    const op4 vo = {(op_t)(o[qt][db][8 * pr + 4] * inv), (op_t)(o[qt][db][8 * pr + 5] * inv),
+                                    (op_t)(o[qt][db][8 * pr + 6] * inv), (op_t)(o[qt][db][8 * pr + 7] * inv)};
+                    const u2v e = __builtin_bit_cast(u2v, ve), od = __builtin_bit_cast(u2v, vo);
+                    u4v out;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(e[k], od[k], false, false);
+                        const unsigned first = sw[0], second = sw[1];   // (copied to scalars first: see common.h, wave_allreduce_bits)
+                        out[k] = first;
+                        out[2 + k] = second;
+                    }
+                    const int d = db * 32 + 16 * pr + 8 * hi;   // lower lanes: quad 2 pr, upper lanes: quad 2 pr + 1
+                    *reinterpret_cast<u4v*>(orow + d) = out;
                 }
         }
     }
