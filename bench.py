@@ -62,8 +62,9 @@ def parse():
     ap.add_argument("--parity-queries", type=int, default=1024,
                     help="queries of parity_sample: HIP infer vs the oracle run ON THE GPU in fp32, on the step's own refined volume "
                          "(default: all of them; 0 disables the leg)")
-    ap.add_argument("--cpu-parity-queries", type=int, default=16,
-                    help="queries that also go through the oracle on the HOST (>= --cpu-queries; pins GPU-torch against CPU-torch)")
+    ap.add_argument("--cpu-parity-queries", type=int, default=8,
+                    help="queries that also go through the oracle on the HOST (>= --cpu-queries; pins GPU-torch against CPU-torch; 8 since "
+                         "every query goes through the GPU oracle -- a slow host spends 5 s per query here)")
     ap.add_argument("--parity-video-frames", type=int, default=90,
                     help="frames of the from-the-video parity leg on the GPU oracle (oracle ViT -> refine -> infer; 0 disables it)")
     ap.add_argument("--cpu-vit-frames", type=int, default=2,
