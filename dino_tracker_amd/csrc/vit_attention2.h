@@ -98,9 +98,10 @@ constexpr int NBUF = 3;
 // TAG: one instantiation per kernel family -- an out-of-line device function is compiled ONCE per instantiation with the
 // register budget of its most generous caller, and every caller then inherits that allocation (round 3: next to a
 // 256-register kernel the shared safe pass cost the 128-register kernel half its occupancy).
-template <int TAG>
-__device__ __noinline__ void safe_pass(const op_t* Qb, const op_t* Kb, const op_t* Vb, op_t* Ob, int q0, int nq, int S,
-                                       int Sp, int D) {
+// (safe_pass_impl: the body, inlined where the caller wants the pass inside its OWN register budget -- attention5 runs two waves
+//  per SIMD and an out-of-line callee is compiled to the caller's VGPR budget without knowing about its AGPRs)
+__device__ __forceinline__ void safe_pass_impl(const op_t* Qb, const op_t* Kb, const op_t* Vb, op_t* Ob, int q0, int nq, int S,
+                                               int Sp, int D) {
     const int lane = threadIdx.x & 63, lq = lane & 31, hi = lane >> 5;
     const int krow = (lq & 19) | ((lq & 4) << 1) | ((lq & 8) >> 1);
     const int ntiles = (S + 63) / 64;
@@ -180,6 +181,11 @@ __device__ __noinline__ void safe_pass(const op_t* Qb, const op_t* Kb, const op_
                 }
         }
     }
+}
+template <int TAG>
+__device__ __noinline__ void safe_pass(const op_t* Qb, const op_t* Kb, const op_t* Vb, op_t* Ob, int q0, int nq, int S,
+                                       int Sp, int D) {
+    safe_pass_impl(Qb, Kb, Vb, Ob, q0, nq, S, Sp, D);
 }
 
 // QT: 32-query tiles per wave (1: 256 queries per workgroup, <= 128 VGPRs; 2: 512 queries, <= 256 VGPRs)

@@ -119,6 +119,11 @@ typedef struct dtk_vit_model {
 #define DTK_OPERAND_F16 0
 #define DTK_OPERAND_BF16 1
 #define DTK_OPERAND_ATTENTION_V2 0x100  /* OR-ed into dtk_vit_attention's operand_type: the same selection for the stand-alone stage */
+#define DTK_OPERAND_ATTENTION_V5 0x200  /* stand-alone stage only: the round-5 EXPERIMENT kernel, two waves per SIMD alternating matrix /
+                                         * vector phases (csrc/vit_attention5.h); measured against the library's kernel by
+                                         * scripts/attn_ab.py, not used by dtk_vit_forward */
+#define DTK_OPERAND_ATTENTION_V5_INPHASE 0x400  /* with ..._V5: both wave halves in phase (the experiment's ablation); 0x800 / 0x1000 with
+                                                 * ..._V5: micro-benchmark ablations WITHOUT meaningful output (no vector / no matrix work) */
 
 /* frames [n][3][video_h][video_w] fp32 in [0,1] -> block output of layer depth-1 (before the final norm):
  * tokens_out [n][1 + ph*pw][D] (CLS first; what get_feature_from_input returns) and/or

@@ -1,5 +1,6 @@
 """Same-box A / B of the stand-alone attention stage between two builds of libdtk.so (ctypes handles of both in one process):
-    python scripts/attn_ab.py <lib A> <lib B> [frames]
+    python scripts/attn_ab.py <lib A>[:flags] <lib B>[:flags] [<lib C>[:flags] ...]      (flags: OR-ed into operand_type, e.g. 0x200 =
+    DTK_OPERAND_ATTENTION_V5, 0x600 = the same with both wave halves in phase, 0x100 = attention2)
 Benchmark shapes (frames x 6 heads, S = 8108, random fp16 operands), alternating blocks of launches, hipEvents around each block."""
 import ctypes
 import sys
@@ -18,8 +19,12 @@ def load(path):
 
 
 def main():
-    a, b = load(sys.argv[1]), load(sys.argv[2])
-    T = int(sys.argv[3]) if len(sys.argv) > 3 else 90
+    specs = [x for x in sys.argv[1:] if not x.isdigit()]
+    T = int([x for x in sys.argv[1:] if x.isdigit()][0]) if any(x.isdigit() for x in sys.argv[1:]) else 90
+    libs = []
+    for sp in specs:
+        path, _, fl = sp.partition(":")
+        libs.append((sp, load(path), int(fl, 0) if fl else 0))
     heads, S = 6, 67 * 121 + 1
     Sp = (S + 127) // 128 * 128
     g = torch.Generator(device="cuda").manual_seed(5)
@@ -28,32 +33,36 @@ def main():
     v = torch.randn(T, heads, 64, Sp, device="cuda", generator=g).half()
     k[:, :, S:] = 0
     v[:, :, :, S:] = 0
-    outs = [torch.empty(T, S, heads * 64, dtype=torch.float16, device="cuda") for _ in range(2)]
+    outs = [torch.full((T, S, heads * 64), float("nan"), dtype=torch.float16, device="cuda") for _ in libs]
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def run(h, o):
-        rc = h.dtk_vit_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), T, heads, S, Sp, 0, st)
-        assert rc == 0, rc
-    for h, o in ((a, outs[0]), (b, outs[1])):
+    def run(i):
+        _, h, fl = libs[i]
+        rc = h.dtk_vit_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), outs[i].data_ptr(), T, heads, S, Sp, fl, st)
+        assert rc == 0, (rc, libs[i][0])
+    for i in range(len(libs)):
         for _ in range(3):
-            run(h, o)
+            run(i)
     torch.cuda.synchronize()
-    print("outputs bit-identical:", bool(torch.equal(outs[0], outs[1])))
-    res = {0: [], 1: []}
+    for i in range(1, len(libs)):
+        d = (outs[i].float() - outs[0].float()).abs()
+        print(f"{libs[i][0]} vs {libs[0][0]}: bit-identical {bool(torch.equal(outs[i], outs[0]))}, max |diff| {float(d.max()):.3e} "
+              f"(max |ref| {float(outs[0].float().abs().max()):.3e}), finite {bool(torch.isfinite(outs[i]).all())}")
+    res = {i: [] for i in range(len(libs))}
     for rnd in range(6):
-        for i, (h, o) in enumerate(((a, outs[0]), (b, outs[1]))):
+        for i in range(len(libs)):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
-                run(h, o)
+                run(i)
             e1.record()
             torch.cuda.synchronize()
             res[i].append(e0.elapsed_time(e1) / 10)
     fl = 4.0 * S * S * 384 * T
-    for i, name in ((0, sys.argv[1]), (1, sys.argv[2])):
+    for i in range(len(libs)):
         ms = sorted(res[i])
         med = ms[len(ms) // 2]
-        print(f"{name}: median {med:.4f} ms per launch ({fl / med / 1e9:.1f} TFLOP/s), blocks {[round(x, 3) for x in res[i]]}")
+        print(f"{libs[i][0]}: median {med:.4f} ms per launch ({fl / med / 1e9:.1f} TFLOP/s), blocks {[round(x, 3) for x in res[i]]}")
 
 
 if __name__ == "__main__":

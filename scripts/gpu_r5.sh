@@ -32,6 +32,8 @@ for WHAT in "$@"; do
       timeout 900 python bench.py --width 768 --steps 2 --warmup 1 --no-cpu-baseline --no-clock-power --no-videos30 > gpurun_out/bench_w768.json 2> gpurun_out/bench_w768.err; cat gpurun_out/bench_w768.json; tail -3 gpurun_out/bench_w768.err ;;
     attn_ab)   # same-box A / B of the attention stage: scripts/ubench/libdtk_prev.so (a copy of the previous build) vs the tree's library
       timeout 600 python scripts/attn_ab.py scripts/ubench/libdtk_prev.so dino_tracker_amd/csrc/libdtk.so 2>&1 | tee gpurun_out/attn_ab.log ;;
+    attn_v5)   # the round-5 experiment kernel (two waves per SIMD) against the library's attention4, same process
+      timeout 600 python scripts/attn_ab.py dino_tracker_amd/csrc/libdtk.so dino_tracker_amd/csrc/libdtk.so:0x200 dino_tracker_amd/csrc/libdtk.so:0x600 dino_tracker_amd/csrc/libdtk.so:0x100 dino_tracker_amd/csrc/libdtk.so:0xa00 dino_tracker_amd/csrc/libdtk.so:0xe00 dino_tracker_amd/csrc/libdtk.so:0x1200 dino_tracker_amd/csrc/libdtk.so:0x1600 2>&1 | tee gpurun_out/attn_v5.log ;;
     files:*)
       timeout 2400 python -m pytest -m gpu -x -q ${WHAT#files:} 2>&1 | tail -25 | tee gpurun_out/tests_files.log ;;
     profile)
