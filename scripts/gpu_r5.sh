@@ -32,6 +32,23 @@ for WHAT in "$@"; do
       timeout 900 python bench.py --width 768 --steps 2 --warmup 1 --no-cpu-baseline --no-clock-power --no-videos30 > gpurun_out/bench_w768.json 2> gpurun_out/bench_w768.err; cat gpurun_out/bench_w768.json; tail -3 gpurun_out/bench_w768.err ;;
     attn_ab)   # same-box A / B of the attention stage: scripts/ubench/libdtk_prev.so (a copy of the previous build) vs the tree's library
       timeout 600 python scripts/attn_ab.py scripts/ubench/libdtk_prev.so dino_tracker_amd/csrc/libdtk.so 2>&1 | tee gpurun_out/attn_ab.log ;;
+    bench_ab)   # same-box A / B of the whole step: the tree's library, then scripts/ubench/libdtk_prev.so (a copy of the previous build), then the tree's again
+      F="--steps 5 --warmup 2 --no-cpu-baseline --no-clock-power --no-videos30 --parity-queries 0"
+      L=dino_tracker_amd/csrc/libdtk.so
+      timeout 600 python bench.py $F > gpurun_out/bench_ab_new1.json 2> gpurun_out/bench_ab.err
+      cp $L /tmp/libdtk_new.so && cp scripts/ubench/libdtk_prev.so $L
+      timeout 600 python bench.py $F > gpurun_out/bench_ab_prev.json 2>> gpurun_out/bench_ab.err
+      cp /tmp/libdtk_new.so $L
+      timeout 600 python bench.py $F > gpurun_out/bench_ab_new2.json 2>> gpurun_out/bench_ab.err
+      python - <<'PY'
+import json
+r = {k: json.load(open(f"gpurun_out/bench_ab_{k}.json")) for k in ("new1", "prev", "new2")}
+print("ms per step:", {k: v["ms_per_step"] for k, v in r.items()})
+keys = sorted(set().union(*[v["roofline"]["kernel_ms"] for v in r.values()]))
+for kk in keys:
+    print(f"  {kk:18s}", "  ".join(f"{k} {r[k]['roofline']['kernel_ms'].get(kk, float('nan')):8.3f}" for k in r))
+PY
+      ;;
     attn_v5)   # the round-5 experiment kernel (two waves per SIMD) against the library's attention4, same process
       timeout 600 python scripts/attn_ab.py dino_tracker_amd/csrc/libdtk.so dino_tracker_amd/csrc/libdtk.so:0x200 dino_tracker_amd/csrc/libdtk.so:0x600 dino_tracker_amd/csrc/libdtk.so:0x100 dino_tracker_amd/csrc/libdtk.so:0xa00 dino_tracker_amd/csrc/libdtk.so:0xe00 dino_tracker_amd/csrc/libdtk.so:0x1200 dino_tracker_amd/csrc/libdtk.so:0x1600 2>&1 | tee gpurun_out/attn_v5.log ;;
     files:*)
