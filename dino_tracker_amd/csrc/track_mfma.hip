@@ -1037,7 +1037,15 @@ __global__ __launch_bounds__(256) void rescore_kernel(dtk_geom g, const float* _
     bool redo_it = rc.ncand > KC || rc.ncand < 1;
     float best = -1.f;
     int bi = INT_MAX;
-    if (!redo_it) {
+    // One candidate whose approximate maximum is clearly positive IS the answer (round 5): the band proof puts the exact arg-max among
+    // the candidates, and amax - EPS_C > 0 makes the exact maximum positive -- the row of that cell need not be fetched at all (one
+    // dependent trip to memory less for the majority of the sources; the kernel is latency-bound).  dtk_argmax_cells wants the exact
+    // cosine and takes the full path.
+    const bool single = !redo_it && rc.ncand == 1 && rc.amax > 2.f * EPS_C && arg_cell == nullptr && !DTK_DBG(dbg, 2);
+    if (single) {
+        bi = min(max(rc.cand[0], 0), HW - 1);
+        best = rc.amax;
+    } else if (!redo_it) {
         const int ncd = DTK_DBG(dbg, 2) ? 1 : rc.ncand;
         for (int k = 0; k < ncd; ++k) {
             const int cell = min(max(rc.cand[k], 0), HW - 1);
