@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void featsplit_kernel(const float* __restrict_
 // ---- sources of a chunk -> fp16 unit vectors; one wave per source ---------------------------------------------------
 __global__ __launch_bounds__(256) void src16_kernel(const float* __restrict__ emb, const int32_t* __restrict__ src_row,
                                                     half_t* __restrict__ s16, int m0, int count, int M,
-                                                    const int32_t* __restrict__ dM, int C, float scale) {
+                                                    const int32_t* __restrict__ dM, int C, float scale,
+                                                    float* __restrict__ rown) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= count) return;
     const int lane = threadIdx.x & 63;
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(256) void src16_kernel(const float* __restrict__ em
         s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
     s = sqrtf(wave_sum(s));
+    if (rown && lane == 0) rown[i] = s;   // the table form: |row|, the same sum in the same order as rescore_kernel's own (it reads this instead)
     const float sc = s > 1e-30f ? scale / s : 0.f;
     for (int k = lane * 8; k < C; k += 512) {
         const float4 a = *reinterpret_cast<const float4*>(p + k), b = *reinterpret_cast<const float4*>(p + k + 4);
@@ -1014,7 +1016,8 @@ __global__ __launch_bounds__(256) void rescore_kernel(dtk_geom g, const float* _
                                                       int32_t* __restrict__ kstar, float* __restrict__ snorm,
                                                       int32_t* __restrict__ hist, int HWk, Redo redo, int m0, int count,
                                                       int M, const int32_t* __restrict__ dM, int dbg,
-                                                      int32_t* __restrict__ arg_cell, float* __restrict__ arg_cos) {
+                                                      int32_t* __restrict__ arg_cell, float* __restrict__ arg_cos,
+                                                      const float* __restrict__ rown) {
     const int HW = g.ph * g.pw, C = g.C;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1027,12 +1030,20 @@ __global__ __launch_bounds__(256) void rescore_kernel(dtk_geom g, const float* _
     const int row = src_row ? src_row[m] : m;
     const int f = min(max(tgt[m], 0), g.T - 1);
     const float* sp = emb + (size_t)row * C;
-    float ss = 0.f;
-    for (int k = lane * 4; k < C; k += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(sp + k);
-        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    // |source|: from the row table's norms when the sources are rows of one (round 5: the anchor stage tracks 92 k distinct rows
+    // into 90 frames each -- 8.3 M wave-wide sums of the same 92 k rows, and for a single-candidate source the only reason to touch the
+    // row at all), else summed here; both forms add the same terms in the same order
+    float sn;
+    if (rown) {
+        sn = rown[row];
+    } else {
+        float ss = 0.f;
+        for (int k = lane * 4; k < C; k += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(sp + k);
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        sn = sqrtf(wave_sum(ss));
     }
-    const float sn = sqrtf(wave_sum(ss));
     const Rec rc = rec[i];
     bool redo_it = rc.ncand > KC || rc.ncand < 1;
     float best = -1.f;
@@ -1762,7 +1773,7 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
 }
 
 struct MfmaLayout {
-    size_t s16, maps, rec, wpk, kstar, xwin, snorm, perm, hist, off, cursor, bsum, nvalid, redo_cnt, redo_lists, exact, total;
+    size_t s16, maps, rec, wpk, kstar, xwin, snorm, rown, perm, hist, off, cursor, bsum, nvalid, redo_cnt, redo_lists, exact, total;
     int HWk, nkeys, nblocks, cap;
     size_t unc_lists, trec;
     int MP;      // pitch (in halves) of one padded fp16 map: (ph+2) x (pw+4) + slack, multiple of 8
@@ -1794,6 +1805,7 @@ MfmaLayout mfma_layout(const dtk_geom* g, int M, int round_sources) {
     L.nkeys = g->T * L.HWk;
     L.nblocks = (L.nkeys + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
     L.snorm = off; off = al(off + (size_t)L.super * 4);
+    L.rown = off; off = al(off + (size_t)L.super * 4);      // |row| of the source-row table (written by src16 in its table form)
     L.perm = off; off = al(off + (size_t)L.super * 4);
     L.hist = off; off = al(off + (size_t)L.nkeys * 4);     // hist and cursor are contiguous: one memset
     L.cursor = off; off = al(off + (size_t)L.nkeys * 4);
@@ -1890,7 +1902,7 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
             const int32_t* row_of = row_table ? in.src_row : nullptr;   // (the table: dtk_track_mfma)
             if (!row_of)
                 DTK_LAUNCH("src16", src16_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, emb, in.src_row, s16, (int)s0, scnt, M,
-                           nodm, g->C, PK_SRC_SCALE);
+                           nodm, g->C, PK_SRC_SCALE, (float*)nullptr);
             const dim3 pgrid(dtk_cdiv(scnt, PK_SRC));
 #define DTK_PEAKS(V, CBV)                                                                                                    \
     do {                                                                                                                     \
@@ -1930,7 +1942,7 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
         for (long long m0 = s0; m0 < s0 + scnt && !peaks; m0 += L.chunk) {
             const int cnt = (int)((s0 + scnt - m0) < L.chunk ? (s0 + scnt - m0) : L.chunk);
             DTK_LAUNCH("src16", src16_kernel, dim3(dtk_cdiv(cnt, 4)), dim3(256), 0, st, emb, in.src_row, s16, (int)m0, cnt, M,
-                       nodm, g->C, FSCALE);
+                       nodm, g->C, FSCALE, (float*)nullptr);
             {
                 const int MT = dtk_cdiv(cnt, CM), NT = L.HWp / CN;
                 const int blocks = 8 * ((MT + 7) / 8) * 8 * ((NT + 7) / 8);
@@ -1952,7 +1964,8 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
         }
         DTK_HIP(hipMemsetAsync(ws + L.hist, 0, L.cursor + (size_t)L.nkeys * 4 - L.hist, st));
         DTK_LAUNCH("rescore", rescore_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, *g, feat, norms, emb, in.src_row,
-                   in.tgt, in.out_idx, rec, kstar, snorm, hist, L.HWk, redo, (int)s0, scnt, M, nodm, dbg, arg_cell, arg_cos);
+                   in.tgt, in.out_idx, rec, kstar, snorm, hist, L.HWk, redo, (int)s0, scnt, M, nodm, dbg, arg_cell, arg_cos,
+                   row_table ? reinterpret_cast<const float*>(ws + L.rown) : (const float*)nullptr);
         if (arg_cell) continue;  // arg-max only: no window refinement
         DTK_LAUNCH("key_scan", scan_blocksum_kernel, dim3(L.nblocks), dim3(256), 0, st, hist, bsum, L.nkeys);
         DTK_LAUNCH("key_scan", scan_top_kernel, dim3(1), dim3(256), 0, st, bsum, L.nblocks, nvalid);
@@ -2038,7 +2051,7 @@ int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, con
     if (row_table)
         DTK_LAUNCH("src16", src16_kernel, dim3(dtk_cdiv(opts->emb_rows, 4)), dim3(256), 0, st, emb, (const int32_t*)nullptr,
                    reinterpret_cast<half_t*>(ws + L.s16), 0, opts->emb_rows, opts->emb_rows, (const int32_t*)nullptr, g->C,
-                   PK_SRC_SCALE);
+                   PK_SRC_SCALE, reinterpret_cast<float*>(ws + L.rown));
     int rc = mfma_phase(g, L, ws, feat, norms, f16, head, emb, SrcLists{src_row, tgt, out_idx}, out_xy, count, normalized,
                         fast_ok, redo, uncert, lds_head, st, dbg, nullptr, nullptr, row_table);
     if (rc) return rc;
