@@ -1651,22 +1651,39 @@ __global__ __launch_bounds__(256) void refine_head_kernel(dtk_geom g, const floa
     // hidden cell (hy, hx) of the window is cell (kr - (RD+1) + hy, kc - (RD+1) + hx) of the map
     const unsigned rmask = __builtin_amdgcn_readfirstlane(inside(kr - (RD + 1), ph, WH));
     const bool colok = (inside(kc - (RD + 1), pw, WH) >> jq) & 1u;
+    // Two rows of the hidden window per pass, their MFMA chains INTERLEAVED (round 5): a row is a chain of 3 + 4 dependent f32
+    // MFMAs, and the compiler, reusing the same two accumulators for every row, emitted the 13 rows strictly one after the other
+    // with `s_nop 9` in front of every dependent read (ISA of round 4).  With two independent chains in flight every dependent
+    // MFMA has another row's MFMA between it and its producer.  Same arithmetic per row: results are bit-identical.
 #pragma unroll
-    for (int hy = 0; hy < WH; ++hy) {
-        const bool in = colok & (((rmask >> hy) & 1u) != 0);
-        f4 d1 = {0.f, 0.f, 0.f, 0.f};
+    for (int hy = 0; hy < WH; hy += 2) {
+        constexpr bool dummy = false; (void)dummy;
+        const bool two = hy + 1 < WH;
+        const bool inA = colok & (((rmask >> hy) & 1u) != 0);
+        const bool inB = two && (colok & (((rmask >> (hy + 1)) & 1u) != 0));
+        f4 d1a = {0.f, 0.f, 0.f, 0.f}, d1b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], xptr[ks][hy * XP], d1, 0, 0, 0);
-        f4 d2 = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < 3; ++ks) {
+            d1a = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], xptr[ks][hy * XP], d1a, 0, 0, 0);
+            if (two) d1b = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], xptr[ks][(hy + 1) * XP], d1b, 0, 0, 0);
+        }
+        f4 d2a = {0.f, 0.f, 0.f, 0.f}, d2b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kp = 0; kp < 4; ++kp) {
-            float relu;  // one v_max_f32 (fmaxf compiles to a canonicalising v_max x, x first); NaN -> 0 like fmaxf
-            asm("v_max_f32 %0, 0, %1" : "=v"(relu) : "v"(d1[kp]));
-            const float hv = in ? relu : 0.f;
-            d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[kp], hv, d2, 0, 0, 0);
+            float ra, rb;  // one v_max_f32 each (fmaxf compiles to a canonicalising v_max x, x first); NaN -> 0 like fmaxf
+            asm("v_max_f32 %0, 0, %1" : "=v"(ra) : "v"(d1a[kp]));
+            d2a = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[kp], inA ? ra : 0.f, d2a, 0, 0, 0);
+            if (two) {
+                asm("v_max_f32 %0, 0, %1" : "=v"(rb) : "v"(d1b[kp]));
+                d2b = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[kp], inB ? rb : 0.f, d2b, 0, 0, 0);
+            }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pptr[r][hy * WH] = d2[r];
+        for (int r = 0; r < 4; ++r) pptr[r][hy * WH] = d2a[r];
+        if (two) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pptr[r][(hy + 1) * WH] = d2b[r];
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
