@@ -158,3 +158,59 @@ def test_refiner_upper_bound_of_the_certificate():
                     lzub = zb + torch.log(n_brd + n_int * torch.exp(zi - zb))
                     assert lse <= lzub + tol_b
     assert old_form_violations > 0  # the sweep does reach the border case the one-bound form missed
+
+
+def test_single_candidate_shortcut_of_rescore():
+    """rescore_kernel (round 5) skips the exact re-scoring of a source whose candidate list holds ONE cell and whose approximate
+    maximum exceeds 2 EPS_C: (1) the exact arg-max is among the candidates (the band test above), so with one candidate it IS that
+    cell; (2) the exact maximum is positive -- |rho16 - rho| <= EPS_PK / 2 < EPS_C -- so the `best > 0` test the full path makes
+    cannot fail.  Checked on the constants of the source and on simulated maps: fp16-perturbed values within the proven bound,
+    candidates = cells within EPS_PK of the approximate maximum."""
+    src = _src("track_mfma.hip")
+    eps_pk = float(re.search(r"constexpr float EPS_PK = ([0-9.eE+-]+)f;", src).group(1))
+    eps_c = float(re.search(r"constexpr float EPS_C = ([0-9.eE+-]+)f;", src).group(1))
+    assert "rc.ncand == 1 && rc.amax > 2.f * EPS_C" in src
+    bound = 2.0 ** -10 + 2.0 ** -22 + 24 * 2.0 ** -24 + 2.0 ** -17    # sup |rho16 - rho| incl. accumulation and truncation
+    assert eps_pk >= 2 * bound and 2 * eps_c - bound > 0                # amax > 2 EPS_C  =>  exact maximum > 2 EPS_C - bound > 0
+    rng = np.random.default_rng(3)
+    singles = 0
+    for trial in range(400):
+        n = 8107
+        rho = np.clip(rng.normal(0.2, 0.15, n), -1, 1)
+        k = rng.integers(0, n)
+        rho[k] = rho.max() + rng.choice([1e-4, 1e-3, 3e-3, 2e-2])       # peaks from barely to clearly separated
+        rho16 = rho + rng.uniform(-bound, bound, n)
+        amax = rho16.max()
+        cand = np.nonzero(rho16 >= amax - eps_pk)[0]
+        assert int(rho.argmax()) in cand
+        if len(cand) == 1 and amax > 2 * eps_c:
+            singles += 1
+            assert int(cand[0]) == int(rho.argmax()) and rho.max() > 0
+    assert singles > 50
+
+
+def test_fp32_tie_band_of_the_arbiter():
+    """oracle.ref_algo.fp32_dot_band: 2 sqrt(C) 2^-24.  A float32 evaluation of a length-C dot product of unit vectors deviates
+    from float64 by far less than sqrt(C) 2^-24 per evaluation in practice (any summation order numpy / torch uses), so two
+    evaluations stay inside the band; the worst case C 2^-24 would be 20 x wider."""
+    from oracle import ref_algo as A
+    C = 384
+    band = A.fp32_dot_band(C)
+    assert abs(band - 2 * np.sqrt(C) * 2.0 ** -24) < 1e-12 and band < 0.11 * C * 2.0 ** -24 * 2
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for _ in range(300):
+        a = rng.standard_normal((64, C))
+        b = a + 0.3 * rng.standard_normal((64, C))
+        a /= np.linalg.norm(a, axis=1, keepdims=True)
+        b /= np.linalg.norm(b, axis=1, keepdims=True)
+        e64 = np.einsum("ij,ij->i", a, b)
+        a32, b32 = a.astype(np.float32), b.astype(np.float32)
+        fwd = np.einsum("ij,ij->i", a32, b32).astype(np.float64)
+        rev = np.einsum("ij,ij->i", a32[:, ::-1].copy(), b32[:, ::-1].copy()).astype(np.float64)
+        seq = np.array([float(np.float32(sum(np.float32(x) * np.float32(y) for x, y in zip(r, s)))) for r, s in zip(a32[:4], b32[:4])])
+        exact32 = np.einsum("ij,ij->i", a32.astype(np.float64), b32.astype(np.float64))
+        worst = max(worst, np.abs(fwd - exact32).max(), np.abs(rev - exact32).max(), np.abs(seq - exact32[:4]).max())
+        worst = max(worst, np.abs(fwd - rev).max())
+        del e64
+    assert worst < band / 2, (worst, band)
