@@ -525,11 +525,23 @@ __device__ __forceinline__ void peaks_dma(dtk_u4 srd, unsigned toff, unsigned vo
 // CB = 32-cell blocks per step.  CB = 2 (round 4 experiment): a step is 64 cells, so that FOUR accumulators (2 source tiles x 2
 // cell blocks) take turns instead of two and the barriers per cell halve -- measured SLOWER than CB = 1 (816 against 955 TFLOP/s,
 // profiles/r04_corr_peaks_ablations.txt), kept as a development variant.
+__device__ __forceinline__ int cell_key(int cell, int pw);
+// Round 5: a source whose list holds ONE candidate with a clearly positive approximate maximum is finished here -- that cell is
+// the exact arg-max (rescore_kernel's single-candidate case: the band proof, tests/test_numeric_claims.py), |source| comes from the
+// row table's norms -- so the record is marked done (ncand = -1), k*, |s| and the (frame, cell key) histogram are written from this
+// kernel's epilogue, and rescore_kernel's wave for the source returns at once.  kstar == nullptr: off (no row table, arg-max-only calls).
+struct PeaksDone {
+    int32_t* kstar;
+    float* snorm;
+    int32_t* hist;
+    const float* rown;
+    int HWk;
+};
 template <int KS, int VAR, int CB>
 __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_t* __restrict__ f16,
                                                          const half_t* __restrict__ s16, const int32_t* __restrict__ tgt,
                                                          Rec* __restrict__ rec, int m0, int count, int HWp,
-                                                         const int32_t* __restrict__ row_of) {
+                                                         const int32_t* __restrict__ row_of, PeaksDone done) {
     constexpr int C = KS * 16;
     constexpr int PK_CELLS = 32 * CB;            // cells per step: CB 32-cell blocks
     constexpr int TSH = CB > 1 ? 5 : 4;          // position tag: step << TSH | cell block << 4 | accumulator register
@@ -724,7 +736,7 @@ __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_
             if (h == 0 && tf[t] == f) {
                 const int amax_i = max(v[t][0], o[0]);
                 const int thr = amax_i - band;
-                int nc = 0;
+                int nc = 0, c0 = 0;
                 Rec* rr = rec + i;
                 const int PWP = pw_pad(g.pw);
 #pragma unroll
@@ -736,7 +748,9 @@ __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_
                         const int pc = st * PK_CELLS + cb * 32 + 8 * (r >> 2) + 2 * (r & 3) +
                                        ((k < PK_TOP ? 0 : 1) ^ ((st / tiles_per_row) & 1));
                         const int row = pc / PWP, col = pc - row * PWP;
-                        if (nc < KC) rr->cand[nc] = row * g.pw + min(col, g.pw - 1);
+                        const int cellc = row * g.pw + min(col, g.pw - 1);
+                        if (nc < KC) rr->cand[nc] = cellc;
+                        if (nc == 0) c0 = cellc;
                         ++nc;
                     }
                 }
@@ -744,9 +758,16 @@ __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_
                 if (v[t][PK_TOP - 1] >= thr || o[PK_TOP - 1] >= thr || thr <= 0) nc = KC + 1;
                 const float amax = (float)(amax_i >> PK_IDX_BITS) * (1.f / (float)(1 << PK_VAL_BITS));
                 rr->amax = amax;
-                rr->ncand = nc;
                 rr->zmax = 0.f;
                 rr->Z = -1.f;
+                if (done.kstar != nullptr && nc == 1 && amax > 2.f * EPS_C) {
+                    rr->ncand = -1;   // finished: rescore_kernel skips it
+                    done.kstar[i] = c0;
+                    done.snorm[i] = done.rown[row_of[m0 + i]];
+                    atomicAdd(&done.hist[(size_t)f * done.HWk + cell_key(c0, g.pw)], 1);
+                } else {
+                    rr->ncand = nc;
+                }
             }
         }
     }
@@ -1027,6 +1048,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(dtk_geom g, const float* _
         if (lane == 0) kstar[i] = -1;
         return;
     }
+    if (rec[i].ncand == -1) return;   // finished by corr_peaks' epilogue (PeaksDone): k*, |s| and the histogram are already written
     const int row = src_row ? src_row[m] : m;
     const int f = min(max(tgt[m], 0), g.T - 1);
     const float* sp = emb + (size_t)row * C;
@@ -1915,12 +1937,18 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
         const bool peaks = fast && g->C == 384 && L.HWp / pk_cells <= (1 << (PK_IDX_BITS - (pk_cb > 1 ? 5 : 4))) &&
                            L.HWp % pk_cells == 0 && pw_pad(g->pw) % pk_cells == 0 && !DTK_DBG(dbg, 2048) &&
                            (long long)g->T * L.HWp * g->C * 2 < (1LL << 32);   // (32-bit tile offsets of the LDS-DMA descriptor)
+        // (histogram and cursors of the round's counting sort: zeroed in front of corr_peaks, whose epilogue already counts)
+        DTK_HIP(hipMemsetAsync(ws + L.hist, 0, L.cursor + (size_t)L.nkeys * 4 - L.hist, st));
         if (peaks) {
             const int32_t* row_of = row_table ? in.src_row : nullptr;   // (the table: dtk_track_mfma)
             if (!row_of)
                 DTK_LAUNCH("src16", src16_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, emb, in.src_row, s16, (int)s0, scnt, M,
                            nodm, g->C, PK_SRC_SCALE, (float*)nullptr);
             const dim3 pgrid(dtk_cdiv(scnt, PK_SRC));
+            // single-candidate sources are finished in corr_peaks' epilogue when the row table (and its norms) exist
+            const bool fuse_done = row_table && arg_cell == nullptr && !DTK_DBG(dbg, 2);
+            const PeaksDone pdone = fuse_done ? PeaksDone{kstar, snorm, hist, reinterpret_cast<const float*>(ws + L.rown), L.HWk}
+                                              : PeaksDone{nullptr, nullptr, nullptr, nullptr, 0};
 #define DTK_PEAKS(V, CBV)                                                                                                    \
     do {                                                                                                                     \
         static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_peaks_kernel<24, V, CBV>),  \
@@ -1928,7 +1956,7 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
                                                             (int)peaks_lds_bytes(CBV));                                      \
         DTK_HIP(attr_);                                                                                                      \
         DTK_LAUNCH("corr_peaks", (corr_peaks_kernel<24, V, CBV>), pgrid, dim3(256), peaks_lds_bytes(CBV), st, *g, f16, s16,  \
-                   in.tgt, rec, (int)s0, scnt, L.HWp, row_of);                                                               \
+                   in.tgt, rec, (int)s0, scnt, L.HWp, row_of, pdone);                                                        \
     } while (0)
 #ifdef DTK_DEV
             if (pk_cb == 2) {
@@ -1979,7 +2007,6 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
                            rec + (m0 - s0), (int)m0, cnt, M, nodm, dbg);
             }
         }
-        DTK_HIP(hipMemsetAsync(ws + L.hist, 0, L.cursor + (size_t)L.nkeys * 4 - L.hist, st));
         DTK_LAUNCH("rescore", rescore_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, *g, feat, norms, emb, in.src_row,
                    in.tgt, in.out_idx, rec, kstar, snorm, hist, L.HWk, redo, (int)s0, scnt, M, nodm, dbg, arg_cell, arg_cos,
                    row_table ? reinterpret_cast<const float*>(ws + L.rown) : (const float*)nullptr);
