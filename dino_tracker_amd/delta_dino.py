@@ -75,9 +75,11 @@ def _refine(delta_dino, video: torch.Tensor, dino_thwc: torch.Tensor, g: Geom, w
     return out, norms
 
 
-def refine_video_packed(delta_dino, video: torch.Tensor, dino_thwc: torch.Tensor, g: Geom) -> torch.Tensor:
-    """All frames; token-major in, token-major out."""
-    return _refine(delta_dino, video, dino_thwc, g)[0]
+def refine_video_packed(delta_dino, video: torch.Tensor, dino_thwc: torch.Tensor, g: Geom, want_norms: bool = False):
+    """All frames; token-major in, token-major out.  want_norms: also the per-cell L2 norms of the refined volume, from the same
+    kernel that writes it (align_add sums the squares of the row it has in registers) -> (refined, norms)."""
+    out, norms = _refine(delta_dino, video, dino_thwc, g, want_norms=want_norms)
+    return (out, norms) if want_norms else out
 
 
 def refine_packed_subset(delta_dino, frames: torch.Tensor, dino_thwc: torch.Tensor, g: Geom) -> torch.Tensor:

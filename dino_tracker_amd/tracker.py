@@ -87,7 +87,7 @@ class Tracker(nn.Module):
         token-major on the device; or the in-memory volume passed as `dino_features`."""
         if self._dino_features_arg is not None:
             self._dino = self._dino_features_arg.to(self.device, torch.float32).contiguous()
-            self._dino_norms = ops.feature_norms(self._dino)
+            self._dino_norms = None      # on first use (_packed_dino): only tracking on the RAW features reads them
             self._dino_features_arg = None
             return
         assert os.path.exists(self.dino_embed_path)
@@ -104,7 +104,7 @@ class Tracker(nn.Module):
             raise RuntimeError(f"set_video: dino_features {tuple(dino_features.shape)} != (T, tokens, C)")
         self.video = video
         self._dino = dino_features.to(self.device, torch.float32).contiguous()
-        self._dino_norms = ops.feature_norms(self._dino)
+        self._dino_norms = None          # on first use (_packed_dino)
         self._dino_chw = self._dino_f16 = None
         self.refined_features = None
 
@@ -123,6 +123,8 @@ class Tracker(nn.Module):
         self._dino_f16 = None
 
     def _packed_dino(self):
+        if self._dino_norms is None:     # the raw volume's norms are needed by use_raw_features tracking only: made on demand
+            self._dino_norms = ops.feature_norms(self._dino)
         return self._dino, self._dino_norms
 
     def get_dino_embed_video(self, frames_set_t):
@@ -204,9 +206,8 @@ class Tracker(nn.Module):
     def cache_refined_embeddings(self, move_dino_to_cpu=False):
         """tracker.py:131-135: refined = dino + DeltaDINO(video) for all frames, kept token-major on the device."""
         from .delta_dino import refine_video_packed
-        dino, _ = self._packed_dino()
-        self._refined = refine_video_packed(self.delta_dino, self.video, dino, self.geom)
-        self._refined_norms = ops.feature_norms(self._refined)
+        # (the norms of the refined volume come out of the kernel that writes it: no second pass over 1.1 GB)
+        self._refined, self._refined_norms = refine_video_packed(self.delta_dino, self.video, self._dino, self.geom, want_norms=True)
         self._refined_f16 = None
         self._refined_chw = None
         self._refined_key = self._delta_key()
