@@ -57,6 +57,18 @@ class TrackOpts(ctypes.Structure):
                 ("tier", ctypes.c_int32), ("emb_rows", ctypes.c_int32)]
 
 
+ADAM_MAX_TENSORS, ADAM_MAX_GROUPS = 32, 4
+
+
+class AdamArgs(ctypes.Structure):
+    """struct dtk_adam_args (include/dtk.h): the tensors of one optimiser step, by value."""
+    _fields_ = [("param", ctypes.c_void_p * ADAM_MAX_TENSORS), ("grad", ctypes.c_void_p * ADAM_MAX_TENSORS),
+                ("exp_avg", ctypes.c_void_p * ADAM_MAX_TENSORS), ("exp_avg_sq", ctypes.c_void_p * ADAM_MAX_TENSORS),
+                ("numel", ctypes.c_int64 * ADAM_MAX_TENSORS), ("group", ctypes.c_int32 * ADAM_MAX_TENSORS),
+                ("step", ctypes.c_int32 * ADAM_MAX_TENSORS), ("n_tensors", ctypes.c_int32), ("lr", ctypes.c_double * ADAM_MAX_GROUPS),
+                ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double)]
+
+
 class TrackStats(ctypes.Structure):
     """struct dtk_track_stats (host side, filled by dtk_track)."""
     _fields_ = [("sources", ctypes.c_int32), ("whole_map_tier", ctypes.c_int32), ("exact_tier", ctypes.c_int32),
@@ -117,6 +129,7 @@ SIGNATURES = {
     "dtk_contrastive_backward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_float, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dtk_emb_reg_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dtk_adam_step": (c_int, [ctypes.POINTER(AdamArgs), c_void_p]),
     "dtk_emb_reg_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dtk_corr_window_backward": (c_int, [ctypes.POINTER(Geom), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_int, c_void_p]),

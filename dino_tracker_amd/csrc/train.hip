@@ -1406,3 +1406,62 @@ extern "C" int dtk_contrastive_backward(const float* fe, const float* a, const i
     DTK_LAUNCH("train_cl_dfe", cl_dfe_fix_kernel, dim3(dtk_cdiv((long long)F * n, 256)), dim3(256), 0, st, dfe, fe, csum, nf, fidx, Q, C, n, F);
     return DTK_OK;
 }
+
+
+// ---- fused Adam (round 5; include/dtk.h: dtk_adam_step) ------------------------------------------------------------------------
+// One launch over every parameter tensor of the training step.  Block b works on chunk b of the concatenation of the tensors in
+// chunks of ADAM_CHUNK elements (a tensor's last chunk is short); it finds its tensor by walking the <= 32 sizes in the argument block.
+namespace {
+constexpr int ADAM_CHUNK = 4096;   // elements per block (256 threads x 4 float4 ... tails handled per element)
+struct AdamScalars { float step_size[DTK_ADAM_MAX_TENSORS]; float inv_bc2_sqrt[DTK_ADAM_MAX_TENSORS]; float omb1, beta2, omb2, eps; };
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(dtk_adam_args a, AdamScalars sc) {
+    long long chunk = blockIdx.x;
+    int t = 0;
+    for (; t < a.n_tensors; ++t) {
+        const long long nc = (a.numel[t] + ADAM_CHUNK - 1) / ADAM_CHUNK;
+        if (chunk < nc) break;
+        chunk -= nc;
+    }
+    if (t >= a.n_tensors) return;
+    float* __restrict__ p = a.param[t];
+    const float* __restrict__ g = a.grad[t];
+    float* __restrict__ m = a.exp_avg[t];
+    float* __restrict__ v = a.exp_avg_sq[t];
+    const long long n = a.numel[t], base = chunk * ADAM_CHUNK;
+    const float step_size = sc.step_size[t], inv_bc2_sqrt = sc.inv_bc2_sqrt[t];
+    for (long long i = base + threadIdx.x; i < n && i < base + ADAM_CHUNK; i += 256) {
+        const float gi = g[i];
+        const float mi = m[i] + sc.omb1 * (gi - m[i]);                   // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = sc.beta2 * v[i] + sc.omb2 * gi * gi;            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * inv_bc2_sqrt + sc.eps;        // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+        p[i] = p[i] - step_size * (mi / denom);                          // param.addcdiv_(exp_avg, denom, value = -step_size)
+    }
+}
+}  // namespace
+
+extern "C" int dtk_adam_step(const dtk_adam_args* a, void* stream) {
+    DTK_REQUIRE(a && a->n_tensors > 0 && a->n_tensors <= DTK_ADAM_MAX_TENSORS, "dtk_adam_step: bad arguments");
+    DTK_REQUIRE(a->beta1 >= 0. && a->beta1 < 1. && a->beta2 >= 0. && a->beta2 < 1. && a->eps >= 0., "dtk_adam_step: bad betas / eps");
+    long long chunks = 0;
+    for (int t = 0; t < a->n_tensors; ++t) {
+        DTK_REQUIRE(a->param[t] && a->grad[t] && a->exp_avg[t] && a->exp_avg_sq[t] && a->numel[t] > 0 && a->group[t] >= 0 &&
+                        a->group[t] < DTK_ADAM_MAX_GROUPS && a->step[t] >= 1,
+                    "dtk_adam_step: tensor %d: null pointer, empty tensor, bad group or step < 1", t);
+        chunks += (a->numel[t] + ADAM_CHUNK - 1) / ADAM_CHUNK;
+    }
+    AdamScalars sc;
+    for (int t = 0; t < DTK_ADAM_MAX_TENSORS; ++t) {
+        const int st_ = t < a->n_tensors ? a->step[t] : 1;
+        const double bc1 = 1.0 - pow(a->beta1, (double)st_), bc2 = 1.0 - pow(a->beta2, (double)st_);
+        sc.step_size[t] = t < a->n_tensors ? (float)(a->lr[a->group[t]] / bc1) : 0.f;
+        sc.inv_bc2_sqrt[t] = (float)(1.0 / sqrt(bc2));
+    }
+    // torch forms its scalar coefficients in double and rounds them to fp32 once (1 - 0.999 = 0.001 there; 1.f - 0.999f = 0.00100004673)
+    sc.omb1 = (float)(1.0 - a->beta1); sc.beta2 = (float)a->beta2; sc.omb2 = (float)(1.0 - a->beta2); sc.eps = (float)a->eps;
+    hipStream_t st = dtk_stream(stream);
+    DTK_LAUNCH("adam_step", adam_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, st, *a, sc);
+    return DTK_OK;
+}

@@ -804,3 +804,77 @@ def head_forward(head, cost: torch.Tensor) -> torch.Tensor:
     xy = soft_argmax(p, peak, head.patch_size, head.step_h, float(head.argmax_radius))
     scale = torch.tensor([head.video_w - 1, head.video_h - 1], device=xy.device, dtype=xy.dtype)
     return 2.0 * xy / scale - 1.0
+
+
+# ---- fused Adam (round 5; csrc/train.hip: dtk_adam_step) ----------------------------------------------------------------------------
+def fused_adam_step(optimizer) -> None:
+    """One step of a torch.optim.Adam instance (dino_tracker.py:110-115: default betas / eps, no weight decay, no amsgrad, two
+    parameter groups whose learning rates the LambdaLR of optimization/schedulers.py:4-8 rewrites) as ONE kernel launch over all
+    parameter tensors.  The optimizer object stays torch's: its state dict keeps torch's keys (`step`, `exp_avg`, `exp_avg_sq`), so
+    checkpoints and the scheduler work unchanged.  Raises for options the kernel does not implement."""
+    import ctypes
+
+    from ._lib import ADAM_MAX_GROUPS, ADAM_MAX_TENSORS, AdamArgs, check, lib
+    from . import ops
+    groups = optimizer.param_groups
+    if len(groups) > ADAM_MAX_GROUPS:
+        raise NotImplementedError(f"fused Adam: {len(groups)} parameter groups (max {ADAM_MAX_GROUPS})")
+    a = AdamArgs()
+    n = 0
+    keep = []
+    for gi, grp in enumerate(groups):
+        if grp.get("weight_decay", 0) != 0 or grp.get("amsgrad", False) or grp.get("maximize", False):
+            raise NotImplementedError("fused Adam: weight_decay / amsgrad / maximize are not implemented")
+        if gi == 0:
+            a.beta1, a.beta2, a.eps = float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"])
+        elif (float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"])) != (float(groups[0]["betas"][0]), float(groups[0]["betas"][1]), float(groups[0]["eps"])):
+            raise NotImplementedError("fused Adam: per-group betas / eps")
+        a.lr[gi] = float(grp["lr"])
+        for p in grp["params"]:
+            if p.grad is None:
+                continue
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.dtype == torch.float32):
+                raise NotImplementedError("fused Adam: contiguous fp32 device parameters only")
+            st = optimizer.state[p]
+            if len(st) == 0:   # torch.optim.Adam's lazy state initialisation
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] += 1
+            s_now = int(st["step"].item()) if torch.is_tensor(st["step"]) else int(st["step"])
+            if n >= ADAM_MAX_TENSORS:
+                raise NotImplementedError(f"fused Adam: more than {ADAM_MAX_TENSORS} parameter tensors")
+            g = p.grad.contiguous()
+            keep.append(g)
+            a.param[n], a.grad[n] = p.data_ptr(), g.data_ptr()
+            a.exp_avg[n], a.exp_avg_sq[n] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            a.numel[n], a.group[n], a.step[n] = p.numel(), gi, s_now
+            n += 1
+    if n == 0:
+        return
+    a.n_tensors = n
+    with torch.no_grad():
+        check(lib().dtk_adam_step(ctypes.byref(a), ops._stream()))
+
+
+def install_fused_adam(optimizer):
+    """Replace `optimizer.step` of a plain torch.optim.Adam by the fused kernel (same object: the scheduler and the checkpoint code of
+    the reference keep working).  DTK_TRAIN_ADAM=torch keeps torch's own step.  Returns the optimizer."""
+    import os
+    if os.environ.get("DTK_TRAIN_ADAM", "fused") != "fused" or type(optimizer) is not torch.optim.Adam:
+        return optimizer
+    if any(g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False) or g.get("capturable", False)
+           for g in optimizer.param_groups):
+        return optimizer
+    if any(not p.is_cuda for g in optimizer.param_groups for p in g["params"]):
+        return optimizer
+
+    def step(closure=None):
+        loss = closure() if closure is not None else None
+        fused_adam_step(optimizer)
+        optimizer._opt_called = True        # (what torch's LR schedulers look at to check the step / scheduler call order)
+        return loss
+    step._wrapped_by_lr_sched = True        # an LRScheduler built on this optimizer wrapped the original step: keep its bookkeeping quiet
+    optimizer.step = step
+    optimizer._dtk_fused = True
+    return optimizer

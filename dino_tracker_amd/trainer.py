@@ -459,6 +459,8 @@ def make_trainer(base):
             self.load_dino_best_buddies()
             train_sampler = self.get_sampler()
             model, optimizer, scheduler = self.train_setup()
+            from .train_ops import install_fused_adam
+            install_fused_adam(optimizer)                     # the reference's own torch.optim.Adam object, its step on ONE kernel
             self.set_model_train(model)
             self.init_losses()
             self.prepare_tables(model)

@@ -455,6 +455,30 @@ int dtk_resample2d_forward(const float* src, float* dst, int64_t planes, int32_t
 int dtk_resample2d_backward(const float* ddst, float* dsrc, int64_t planes, int32_t hs, int32_t ws, int32_t hd, int32_t wd,
                             const int32_t* yranges, const float* ywhi, const int32_t* xranges, const float* xwhi, void* stream);
 
+/* ---- N1: the optimiser step of test-time training (dino_tracker.py:110-115: torch.optim.Adam over two parameter groups, default
+ * betas / eps, no weight decay, no amsgrad; optimization/schedulers.py:4-8 scales the groups' learning rates) ---------------------
+ * ONE launch updates every parameter tensor of the step: the tensors travel BY VALUE in the argument block (their gradients are
+ * new allocations every iteration, so a device-side table would need a copy per step).  torch.optim.Adam's arithmetic:
+ *   m <- m + (1 - beta1) (g - m);  v <- beta2 v + (1 - beta2) g g;
+ *   p <- p - (lr[group] / (1 - beta1^step)) m / (sqrt(v) / sqrt(1 - beta2^step) + eps),   step = the tensor's own count. */
+#define DTK_ADAM_MAX_TENSORS 32
+#define DTK_ADAM_MAX_GROUPS 4
+typedef struct dtk_adam_args {
+    float* param[DTK_ADAM_MAX_TENSORS];            /* device, fp32, updated in place */
+    const float* grad[DTK_ADAM_MAX_TENSORS];       /* device, fp32 */
+    float* exp_avg[DTK_ADAM_MAX_TENSORS];          /* device, fp32, updated in place (m) */
+    float* exp_avg_sq[DTK_ADAM_MAX_TENSORS];       /* device, fp32, updated in place (v) */
+    int64_t numel[DTK_ADAM_MAX_TENSORS];
+    int32_t group[DTK_ADAM_MAX_TENSORS];           /* index into lr[] */
+    int32_t step[DTK_ADAM_MAX_TENSORS];            /* per tensor: 1-based step count AFTER this update (its bias corrections; a
+                                                    * parameter that had no gradient in some iteration lags behind the others) */
+    int32_t n_tensors;
+    double lr[DTK_ADAM_MAX_GROUPS];                /* doubles, as torch keeps them: its scalar coefficients (1 - beta2 = 0.001, lr / (1 -
+                                                    * beta1^step) ...) are formed in double and rounded to fp32 ONCE; 1.f - 0.999f is 4.7e-5 off */
+    double beta1, beta2, eps;
+} dtk_adam_args;
+int dtk_adam_step(const dtk_adam_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,20 @@ def test_struct_layouts_match_header():
     assert handle.dtk_contrastive_workspace_bytes(16, 256, 384, 8107) > 16 * 256 * 8108 * 4 * 2
 
 
+def test_adam_args_layout_matches_header():
+    """dtk_adam_args travels by value: the ctypes mirror must have the header's fields in the header's order and its size."""
+    import re
+    text = open(entry.os.path.join(entry.ROOT, "include", "dtk.h")).read()
+    body = re.search(r"typedef struct dtk_adam_args \{(.*?)\} dtk_adam_args;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [re.sub(r"\[.*", "", f.strip()).strip("* ") for decl in re.findall(r"(?:float\*|const float\*|int64_t|int32_t|float|double)\s+([^;]+);", body)
+             for f in decl.split(",")]
+    assert names == [n for n, _ in _lib.AdamArgs._fields_], names
+    assert int(re.search(r"#define DTK_ADAM_MAX_TENSORS (\d+)", text).group(1)) == _lib.ADAM_MAX_TENSORS
+    assert int(re.search(r"#define DTK_ADAM_MAX_GROUPS (\d+)", text).group(1)) == _lib.ADAM_MAX_GROUPS
+    assert ctypes.sizeof(_lib.AdamArgs) == (4 * 8 + 8 + 4 + 4) * 32 + 4 + 4 + 4 * 8 + 3 * 8   # (4 bytes of padding in front of the doubles)
+
+
 def test_m0_users(handle, tmp_path):
     """csrc/common.h dtk_buffer_lds16 (and its copy in vit_attention4.h) writes m0 inside an asm statement the compiler cannot be
     told about (hipcc refuses reserved registers in clobber lists), so the rule is structural: a kernel that contains the

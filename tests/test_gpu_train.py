@@ -795,3 +795,44 @@ def test_fused_head_zero_mass_fallback():
         err_fb = float((cost_d.grad.double().cpu()[1] - cost_64.grad[1]).abs().max())
         print(f"exact route {exact}: max |d grad| {err:.2e} (fallback map {err_fb:.2e}) at gradient scale {scale:.2e}")
         assert err < 2e-5 * scale and err_fb < 1e-7 * scale
+
+
+
+def test_fused_adam_matches_torch_adam():
+    """dtk_adam_step (one launch over all parameter tensors, the tensors by value) against torch.optim.Adam on the reference's
+    optimiser set-up (dino_tracker.py:110-115: two parameter groups, defaults) with its LambdaLR (optimization/schedulers.py:4-8:
+    group 0 scaled by gamma^(it // every), group 1 constant): parameters and both moment buffers over 7 steps, and the state
+    dict keeps torch's keys."""
+    from dino_tracker_amd.train_ops import install_fused_adam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 3, 5, 5), (64,), (128, 64, 5, 5), (128,), (16, 1, 3, 3), (16,), (1, 16, 3, 3), (1,), (4097,)]
+
+    def make():
+        gg = torch.Generator().manual_seed(4)
+        ps = [torch.nn.Parameter(torch.randn(*s, generator=gg).cuda()) for s in shapes]
+        opt = torch.optim.Adam([{"params": ps[:4], "lr": 1e-3}, {"params": ps[4:], "lr": 3e-4}])
+        sch = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=[lambda e: 0.9 ** (e // 2), lambda e: 1])
+        return ps, opt, sch
+    pa, oa, sa = make()
+    pb, ob, sb = make()
+    install_fused_adam(ob)
+    assert getattr(ob, "_dtk_fused", False)
+    for it in range(7):
+        grads = [torch.randn(*s, generator=g) * (10.0 ** ((it % 3) - 1)) for s in shapes]
+        for ps, opt, sch in ((pa, oa, sa), (pb, ob, sb)):
+            opt.zero_grad(set_to_none=True)
+            for p, gr in zip(ps, grads):
+                p.grad = gr.cuda()
+            if it == 3:
+                ps[-1].grad = None   # a parameter without a gradient is skipped (and keeps its step count)
+            opt.step()
+            sch.step()
+    for p, q in zip(pa, pb):
+        assert (p - q).abs().max() <= 2e-6 * p.abs().max().clamp(min=1.0), float((p - q).abs().max())
+    for p, q in zip(pa[:-1], pb[:-1]):
+        sa_, sb_ = oa.state[p], ob.state[q]
+        assert set(sb_) == {"step", "exp_avg", "exp_avg_sq"} and float(sb_["step"]) == float(sa_["step"]) == 7
+        assert (sa_["exp_avg"] - sb_["exp_avg"]).abs().max() <= 1e-6 * sa_["exp_avg"].abs().max()
+        assert (sa_["exp_avg_sq"] - sb_["exp_avg_sq"]).abs().max() <= 1e-6 * sa_["exp_avg_sq"].abs().max()
+    assert float(ob.state[pb[-1]]["step"]) == float(oa.state[pa[-1]]["step"]) == 6   # skipped once: its own bias corrections
+    assert [gr["lr"] for gr in oa.param_groups] == [gr["lr"] for gr in ob.param_groups]
