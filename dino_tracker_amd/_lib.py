@@ -34,7 +34,8 @@ def make_geom(T: int, C: int, video_h: int, video_w: int, patch: int = 14, strid
 class VitLayer(ctypes.Structure):
     """struct dtk_vit_layer."""
     _fields_ = [(n, c_void_p) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1", "ln2_w", "ln2_b",
-                                        "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+                                        "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2",
+                                        "qkv_w_lo", "proj_w_lo", "fc1_w_lo", "fc2_w_lo")] + [("w_scale", ctypes.c_float)]
 
 
 class VitModel(ctypes.Structure):
@@ -94,6 +95,7 @@ SIGNATURES = {
     "dtk_vit_forward": (c_int, [ctypes.POINTER(VitModel), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_size_t, c_void_p]),
     "dtk_vit_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dtk_vit_attention_split": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dtk_delta_dino_packed_floats": (c_size_t, [c_int, c_int]),
     "dtk_delta_dino_pack": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                     c_void_p, c_void_p]),

@@ -1077,6 +1077,8 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const T* __restrict__ A, c
     ws_wait<0>();
 }
 
+#include "vit_split.h"
+
 __global__ __launch_bounds__(256) void zero_kernel(uint4* __restrict__ p, long long n16) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n16) p[i] = make_uint4(0, 0, 0, 0);
@@ -1137,7 +1139,11 @@ inline unsigned gemm_grid(int N, long long rows) {
 struct VitPlan {
     int S, Sp, FB;
     size_t x, xn, q, k, vt, ao, hid, delta, total;
+    bool split;                                    // some block runs on split operands (dtk_vit_layer.qkv_w_lo): the lo planes exist
+    size_t xn_lo, q_lo, k_lo, vt_lo, ao_lo, hid_lo;
 };
+
+inline bool vit_layer_split(const dtk_vit_layer& L) { return L.qkv_w_lo != nullptr; }
 
 VitPlan vit_plan(const dtk_vit_model* m, int ph, int pw, int frames) {
     VitPlan p;
@@ -1156,6 +1162,17 @@ VitPlan vit_plan(const dtk_vit_model* m, int ph, int pw, int frames) {
     p.ao = off; off = al(off + rows * m->D * 2);
     p.hid = off; off = al(off + rows * 4 * m->D * 2);
     p.delta = off; off = al(off + rows * m->D * 2);
+    p.split = false;
+    for (int l = 0; l < m->depth; ++l) p.split |= vit_layer_split(m->layers[l]);
+    p.xn_lo = p.q_lo = p.k_lo = p.vt_lo = p.ao_lo = p.hid_lo = 0;
+    if (p.split) {   // the lo planes of a split block's operands (same shapes as the hi planes; q / k / vt contiguous: zeroed together)
+        p.xn_lo = off; off = al(off + rows * m->D * 2);
+        p.q_lo = off; off = al(off + (size_t)p.FB * m->heads * p.Sp * 64 * 2);
+        p.k_lo = off; off = al(off + (size_t)p.FB * m->heads * p.Sp * 64 * 2);
+        p.vt_lo = off; off = al(off + (size_t)p.FB * m->heads * p.Sp * 64 * 2);
+        p.ao_lo = off; off = al(off + rows * m->D * 2);
+        p.hid_lo = off; off = al(off + rows * 4 * m->D * 2);
+    }
     p.total = off;
     return p;
 }
@@ -1233,6 +1250,12 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
     T* ao = reinterpret_cast<T*>(ws + p.ao);
     T* hid = reinterpret_cast<T*>(ws + p.hid);
     T* delta = reinterpret_cast<T*>(ws + p.delta);
+    T* xn_lo = reinterpret_cast<T*>(ws + p.xn_lo);
+    T* q_lo = reinterpret_cast<T*>(ws + p.q_lo);
+    T* k_lo = reinterpret_cast<T*>(ws + p.k_lo);
+    T* vt_lo = reinterpret_cast<T*>(ws + p.vt_lo);
+    T* ao_lo = reinterpret_cast<T*>(ws + p.ao_lo);
+    T* hid_lo = reinterpret_cast<T*>(ws + p.hid_lo);
     int* ovf = m->overflow;
     // Saturation of Q / K / V^T and of the MLP hidden (overflow bits 2 / 4): tracked for EVERY value of EVERY frame inside the
     // epilogues of the QKV and fc1 GEMMs (GemmEpi::ovf, round 5: four v_max3 per eight values, no extra pass; rounds 3-4 scanned
@@ -1245,6 +1268,10 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
     {
         const long long n16 = (long long)((p.ao - p.q) / 16);
         DTK_LAUNCH("vit_zero", zero_kernel, dim3(dtk_cdiv(n16, 256)), dim3(256), 0, st, reinterpret_cast<uint4*>(q), n16);
+        if (p.split) {
+            const long long m16 = (long long)((p.ao_lo - p.q_lo) / 16);
+            DTK_LAUNCH("vit_zero", zero_kernel, dim3(dtk_cdiv(m16, 256)), dim3(256), 0, st, reinterpret_cast<uint4*>(q_lo), m16);
+        }
     }
     for (int f0 = 0; f0 < nframes; f0 += p.FB) {
         const int nf = (nframes - f0) < p.FB ? (nframes - f0) : p.FB;
@@ -1292,15 +1319,61 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
         };
         // GEMMs of widths without a weight-stationary form: the 256 x 256 DMA kernel when the shape allows, else 128 x 128
         const bool wide_ok = !(m->flags & DTK_VIT_TILED_GEMMS) && D % W2_N == 0;
+        bool pending = false;   // `delta` holds a residual update that the next LayerNorm (or the final update) has to apply
         for (int l = 0; l < m->depth; ++l) {
             const dtk_vit_layer& L = m->layers[l];
             const T* qkv_w = reinterpret_cast<const T*>(L.qkv_w);
             const T* proj_w = reinterpret_cast<const T*>(L.proj_w);
             const T* fc1_w = reinterpret_cast<const T*>(L.fc1_w);
             const T* fc2_w = reinterpret_cast<const T*>(L.fc2_w);
+            if (vit_layer_split(L)) {
+                // ---- the escalated precision (vit_split.h): every product on hi + lo operands, updates straight into x ----
+                const T* qkv_wl = reinterpret_cast<const T*>(L.qkv_w_lo);
+                const T* proj_wl = reinterpret_cast<const T*>(L.proj_w_lo);
+                const T* fc1_wl = reinterpret_cast<const T*>(L.fc1_w_lo);
+                const T* fc2_wl = reinterpret_cast<const T*>(L.fc2_w_lo);
+                const float inv_ws = 1.f / (L.w_scale > 0.f ? L.w_scale : 1.f);
+                DTK_LAUNCH("vit_layernorm_split", layernorm_split_kernel<T>, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x,
+                           pending ? (const T*)delta : (const T*)nullptr, L.ln1_w, L.ln1_b, xn, xn_lo, rows, D, m->ln_eps, ovf);
+                pending = false;
+                SplitEpi<T> se{};
+                if (qkv_out && l == m->depth - 1) {
+                    se.bias = L.qkv_b; se.inv_wscale = inv_ws; se.out_f32 = qkv_out + (size_t)f0 * S * 3 * D;
+                    DTK_LAUNCH("vit_gemm_qkv_facet", (gemm_split_kernel<T, SEPI_F32>), dim3(gemm_split_grid(3 * D, rows)), dim3(256),
+                               0, st, xn, xn_lo, qkv_w, qkv_wl, rows, 3 * D, D, se);
+                    se = SplitEpi<T>{};
+                }
+                se.bias = L.qkv_b; se.inv_wscale = inv_ws; se.q_hi = q; se.q_lo = q_lo; se.k_hi = k; se.k_lo = k_lo; se.vt_hi = vt;
+                se.vt_lo = vt_lo; se.S = S; se.Sp = Sp; se.heads = m->heads; se.D = D; se.qscale = 0.125f * 1.4426950408889634f;
+                se.ovf = epi_ovf;
+                DTK_LAUNCH("vit_gemm_qkv_split", (gemm_split_kernel<T, SEPI_QKV>), dim3(gemm_split_grid(3 * D, rows)), dim3(256), 0, st,
+                           xn, xn_lo, qkv_w, qkv_wl, rows, 3 * D, D, se);
+                {
+                    const int nqb = dtk_cdiv(Sp, 128);
+                    DTK_LAUNCH("vit_attention_split", attention_split_kernel<T>, dim3((unsigned)(nf * m->heads * nqb)), dim3(256), 0, st,
+                               (const T*)q, (const T*)q_lo, (const T*)k, (const T*)k_lo, (const T*)vt, (const T*)vt_lo, ao, ao_lo, S, Sp,
+                               m->heads, nqb);
+                }
+                se = SplitEpi<T>{};
+                se.bias = L.proj_b; se.inv_wscale = inv_ws; se.x = x; se.gamma = L.ls1;
+                DTK_LAUNCH("vit_gemm_proj_split", (gemm_split_kernel<T, SEPI_RESID>), dim3(gemm_split_grid(D, rows)), dim3(256), 0, st,
+                           (const T*)ao, (const T*)ao_lo, proj_w, proj_wl, rows, D, D, se);
+                DTK_LAUNCH("vit_layernorm_split", layernorm_split_kernel<T>, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x,
+                           (const T*)nullptr, L.ln2_w, L.ln2_b, xn, xn_lo, rows, D, m->ln_eps, ovf);
+                se = SplitEpi<T>{};
+                se.bias = L.fc1_b; se.inv_wscale = inv_ws; se.out_hi = hid; se.out_lo = hid_lo; se.ovf = epi_ovf;
+                DTK_LAUNCH("vit_gemm_fc1_split", (gemm_split_kernel<T, SEPI_GELU>), dim3(gemm_split_grid(4 * D, rows)), dim3(256), 0, st,
+                           (const T*)xn, (const T*)xn_lo, fc1_w, fc1_wl, rows, 4 * D, D, se);
+                se = SplitEpi<T>{};
+                se.bias = L.fc2_b; se.inv_wscale = inv_ws; se.x = x; se.gamma = L.ls2;
+                DTK_LAUNCH("vit_gemm_fc2_split", (gemm_split_kernel<T, SEPI_RESID>), dim3(gemm_split_grid(D, rows)), dim3(256), 0, st,
+                           (const T*)hid, (const T*)hid_lo, fc2_w, fc2_wl, rows, D, 4 * D, se);
+                continue;
+            }
             GemmEpi<T> e{};
             DTK_LAUNCH("vit_layernorm", layernorm_kernel<T>, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x,
-                       l ? delta : (const T*)nullptr, L.ln1_w, L.ln1_b, xn, rows, D, m->ln_eps, ovf);
+                       pending ? (const T*)delta : (const T*)nullptr, L.ln1_w, L.ln1_b, xn, rows, D, m->ln_eps, ovf);
+            pending = true;
             if (qkv_out && l == m->depth - 1) {  // the qkv hook of the reference (models/extractor.py:107-118), fp32 out
                 e.bias = L.qkv_b; e.out_f32 = qkv_out + (size_t)f0 * S * 3 * D;
                 DTK_LAUNCH("vit_gemm_qkv_facet", (gemm_tiled_kernel<T, EPI_F32>), dim3(gemm_grid(3 * D, rows)), dim3(256), 0, st,
@@ -1381,14 +1454,14 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                            fc2_w, rows, D, 4 * D, e);
             }
         }
-        if (m->depth > 0 && (tokens_out || feat_out)) {
+        if (pending && (tokens_out || feat_out)) {
             // the last MLP's residual update, written straight to the outputs (x itself is dead after the last block)
             const long long t4 = rows * (D / 4);
             DTK_LAUNCH("vit_final_update", final_update_kernel<T>, dim3(dtk_cdiv(t4, 256)), dim3(256), 0, st, x, (const T*)delta,
                        tokens_out ? tokens_out + (size_t)f0 * S * D : (float*)nullptr,
                        feat_out ? feat_out + (size_t)f0 * HW * D : (float*)nullptr, S, D, t4, ovf);
-        } else {   // depth 0 (embedding + position encoding only): no pending update
-            if (m->depth > 0)   // (qkv_out only: keep the residual-update check of the last block)
+        } else {   // depth 0 (embedding + position encoding only) or a split last block: no pending update
+            if (pending)   // (qkv_out only: keep the residual-update check of the last block)
                 DTK_LAUNCH("vit_layernorm", layernorm_kernel<T>, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x, (const T*)delta,
                            (const float*)nullptr, (const float*)nullptr, (T*)nullptr, rows, D, m->ln_eps, ovf);
             if (tokens_out)
@@ -1455,4 +1528,26 @@ extern "C" int dtk_vit_attention(const void* q, const void* k, const void* vt, v
     return Att<_Float16>::launch(reinterpret_cast<const _Float16*>(q), reinterpret_cast<const _Float16*>(k),
                                  reinterpret_cast<const _Float16*>(vt), reinterpret_cast<_Float16*>(out), S, Sp, heads,
                                  heads * 64, frames * heads, variant, dtk_stream(stream));
+}
+
+// The same stage on split operands (vit_split.h: the escalated precision): hi / lo planes of every operand and of the output.
+extern "C" int dtk_vit_attention_split(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
+                                       const void* vt_lo, void* out_hi, void* out_lo, int frames, int heads, int S, int Sp,
+                                       int operand_type, void* stream) {
+    DTK_REQUIRE(q_hi && q_lo && k_hi && k_lo && vt_hi && vt_lo && out_hi && out_lo, "dtk_vit_attention_split: null pointer");
+    DTK_REQUIRE(frames > 0 && heads > 0 && S > 0 && Sp >= S && Sp % 64 == 0, "dtk_vit_attention_split: bad sizes (Sp %% 64 == 0, Sp >= S)");
+    DTK_REQUIRE(operand_type == DTK_OPERAND_F16 || operand_type == DTK_OPERAND_BF16, "dtk_vit_attention_split: operand_type");
+    hipStream_t st = dtk_stream(stream);
+    const int nqb = dtk_cdiv(Sp, 128);
+    const unsigned grid = (unsigned)(frames * heads * nqb);
+    if (operand_type == DTK_OPERAND_BF16) {
+        typedef __bf16 T;
+        DTK_LAUNCH("vit_attention_split", attention_split_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)q_hi, (const T*)q_lo,
+                   (const T*)k_hi, (const T*)k_lo, (const T*)vt_hi, (const T*)vt_lo, (T*)out_hi, (T*)out_lo, S, Sp, heads, nqb);
+    } else {
+        typedef _Float16 T;
+        DTK_LAUNCH("vit_attention_split", attention_split_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)q_hi, (const T*)q_lo,
+                   (const T*)k_hi, (const T*)k_lo, (const T*)vt_hi, (const T*)vt_lo, (T*)out_hi, (T*)out_lo, S, Sp, heads, nqb);
+    }
+    return DTK_OK;
 }

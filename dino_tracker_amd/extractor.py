@@ -13,12 +13,24 @@ Facets: `tokens` (block outputs, models/extractor.py:137-150) is the hot path.  
 attention-map facet and the key self-similarity are small torch expressions over it (not on the hot path).
 
 Operand type of the matrix units: IEEE fp16 by default (`operand_dtype="fp16"`; the residual stream, the statistics and
-every accumulation are fp32) -- the same MFMA rate as bf16 with 8x less operand rounding.  fp16 ends at 65504: activations
-beyond that SATURATE on the device and set an overflow word -- for every value of every frame (residual updates in the
-LayerNorm that applies them; Q / K / V and the MLP hidden inside the epilogues of the GEMMs that store them).  What happens
-then is `on_overflow`: "bf16" (default) re-encodes the call with bf16 operands (fp32's range, 8 mantissa bits), counts it in
-`range_fallbacks`, warns once, and keeps the extractor on bf16 from then on (the out-of-range activations of a trained ViT
-are systematic: the same few channels in every image); "raise" turns the word into a RuntimeError as rounds 3-4 did.
+every accumulation are fp32) -- the same MFMA rate as bf16 with 8x less operand rounding.
+
+Precision (round 6).  `precision="fast"` (default) rounds every matrix operand to ONE 16-bit number: the features are
+1.3e-4 (benchmark weights) .. 2.1e-3 (DINOv2-like outlier statistics) from the fp32 reference, relative.  `precision="split"`
+runs every product of every block on split operands (x = hi + lo, three MFMAs per product, csrc/vit_split.h): fp32-grade
+features (2e-7 .. 4e-6 relative, what the fp32 reference itself is from float64) at ~3x the matrix work.  A list of block
+indices escalates those blocks only.  `precision="auto"` MEASURES which one is needed: the first frames of the first call
+are encoded both ways and the extractor stays on split operands if the fast features differ by more than `auto_tol`
+(relative, default 2.5e-4: the level below which the end-to-end positions were measured within 1e-3 px); the measurement is
+kept in `calibration`.  `precision_report()` returns what the last call ran on.
+
+fp16 ends at 65504: activations beyond that SATURATE on the device and set an overflow word -- for every value of every frame
+(residual updates in the LayerNorm that applies them; Q / K / V and the MLP hidden inside the epilogues of the GEMMs that store
+them).  What happens then is `on_overflow`: "split-bf16" (default since round 6) re-encodes the call on SPLIT bf16 operands --
+fp32's range AND 16 significant bits, i.e. closer to the reference than the plain fp16 pass it replaces --, counts it in
+`range_fallbacks`, warns once and stays there (the out-of-range activations of a trained ViT are systematic: the same few
+channels in every image); "bf16" is the round-5 behaviour (plain bf16 operands: 8 significant bits, the fast kernels; opt-in
+because it is 7-10x further from the reference than fp16); "raise" turns the word into a RuntimeError.
 """
 from __future__ import annotations
 
@@ -45,20 +57,24 @@ class VitExtractor(nn.Module):
 
     def __init__(self, model_name, stride, device, state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  random_seed: Optional[int] = None, operand_dtype: str = "fp16", check_range: bool = False,
-                 on_overflow: str = "bf16"):
+                 on_overflow: str = "split-bf16", precision="fast", auto_tol: float = 2.5e-4, calibration_frames: int = 2):
         super().__init__()
         if operand_dtype not in ("fp16", "bf16"):
             raise ValueError(f"operand_dtype {operand_dtype!r}: 'fp16' or 'bf16'")
-        if on_overflow not in ("bf16", "raise"):
-            raise ValueError(f"on_overflow {on_overflow!r}: 'bf16' (re-encode with bf16 operands) or 'raise'")
+        if on_overflow not in ("split-bf16", "bf16", "raise"):
+            raise ValueError(f"on_overflow {on_overflow!r}: 'split-bf16' (re-encode on split bf16 operands), 'bf16' (plain bf16 "
+                             "operands) or 'raise'")
         self.operand_dtype = operand_dtype
         self.on_overflow = on_overflow
-        self.range_fallbacks = 0        # encode() calls that left the fp16 range and were re-run with bf16 operands
+        self.range_fallbacks = 0        # encode() calls that left the fp16 range and were re-run on (split) bf16 operands
         self.last_overflow = 0          # overflow word of the most recent check (bit 1 residual update, 2 Q/K/V, 4 MLP hidden)
+        self._deferred_pending = 0      # encode(defer_check=True) calls whose overflow bits have not been read yet
         # What is checked for fp16 saturation (include/dtk.h: dtk_vit_model.overflow): every residual update of every token,
         # and every Q / K / V / MLP-hidden value of every frame (inside the GEMM epilogues) -- always.  check_range=True adds a
         # scan of the stored tensors (one extra pass per block): the cross-check of the tests.
         self.check_range = check_range
+        self.auto_tol, self.calibration_frames = float(auto_tol), int(calibration_frames)
+        self.calibration = None         # precision="auto": {"frames", "layer", "rel_fast_vs_split", "tol", "chosen"} once measured
         self.attention_v2 = False       # the round-2/3 attention kernel instead of the one-wave-per-SIMD one (cross-check)
         self.gemm_ws_v1 = False         # the round 1-3 form of the K = 384 weight-stationary GEMMs (A / B measurement)
         self.frame_batch = 0            # frames per pass of the encoder; 0 = the library's default
@@ -78,14 +94,45 @@ class VitExtractor(nn.Module):
         self._sd = {k: v.detach().to(device=device, dtype=torch.float32).contiguous() for k, v in state_dict.items()
                     if k.startswith(("cls_token", "pos_embed", "patch_embed.", "blocks."))}
         self._keep = []      # device tensors referenced by the C structs
-        self._layers_of = {}  # operand type -> ctypes array of dtk_vit_layer (bf16 built on first need)
+        self._wcache = {}    # 16-bit weight tensors / split planes by (name, operand type[, "split"])
+        self._layers_of = {}  # (operand type, split blocks) -> ctypes array of dtk_vit_layer (built on first need)
         self._pos_cache = {}
-        self._layers = self._build_layers(self.operand_dtype)
+        self.set_precision(precision)
+        self._layers = self._build_layers(self.operand_dtype, self.split_blocks)
+
+    def set_precision(self, precision):
+        """"fast" | "split" | "auto" | an iterable of block indices that run on split operands (see the module docstring)."""
+        depth = VIT_CONFIGS[self.model_name]["depth"]
+        if isinstance(precision, str):
+            if precision not in ("fast", "split", "auto"):
+                raise ValueError(f"precision {precision!r}: 'fast', 'split', 'auto' or a list of block indices")
+            self.precision = precision
+            self.split_blocks = frozenset(range(depth)) if precision == "split" else frozenset()
+        else:
+            blocks = frozenset(int(b) for b in precision)
+            if any(not 0 <= b < depth for b in blocks):
+                raise ValueError(f"precision: block indices must be in [0, {depth})")
+            self.precision, self.split_blocks = "blocks", blocks
+        if self.precision != "auto":
+            self.calibration = None
+
+    def precision_report(self):
+        """What the most recent encode() ran on, for callers that must know the feature-error class of their results:
+        relative feature error vs the fp32 reference, measured on this repo's weights (docs/PARITY.md): split fp16 2e-7 .. 4e-6,
+        split bf16 ~2e-5, fp16 1.3e-4 .. 2.1e-3, bf16 1e-3 .. 1.9e-2."""
+        depth = self.cfg["depth"]
+        full = len(self.split_blocks) == depth
+        cls = {("fp16", True): "fp32-grade (<= 4e-6)", ("bf16", True): "2^-16 (~2e-5)", ("fp16", False): "2^-12 (1.3e-4 .. 2.1e-3)",
+               ("bf16", False): "2^-9 (1e-3 .. 1.9e-2)"}[(self.operand_dtype, full)]
+        return {"operand_dtype": self.operand_dtype, "precision": self.precision, "split_blocks": sorted(self.split_blocks),
+                "range_fallbacks": self.range_fallbacks, "last_overflow": self.last_overflow, "calibration": self.calibration,
+                "feature_error_class": cls if (full or not self.split_blocks) else f"mixed ({len(self.split_blocks)}/{depth} blocks split)"}
 
     # ---- weights -> C structs -----------------------------------------------------------------------------------
-    def _build_layers(self, operand_dtype):
-        if operand_dtype in self._layers_of:
-            return self._layers_of[operand_dtype]
+    def _build_layers(self, operand_dtype, split_blocks=frozenset()):
+        key = (operand_dtype, frozenset(split_blocks))
+        if key in self._layers_of:
+            return self._layers_of[key]
         depth = self.cfg["depth"]
         arr = (VitLayer * depth)()
         sd = self._sd
@@ -98,25 +145,57 @@ class VitExtractor(nn.Module):
         wdt = torch.float16 if operand_dtype == "fp16" else torch.bfloat16
 
         def b16(name):  # matrix weights in the operand type of the MFMA kernels
-            w = sd[name]
-            if wdt == torch.float16 and float(w.abs().max()) >= 65504.0:
-                raise RuntimeError(f"{name}: |w| reaches the fp16 limit; use operand_dtype='bf16'")
-            t = w.to(wdt).contiguous()
-            self._keep.append(t)
-            return t.data_ptr()
+            ck = (name, operand_dtype)
+            if ck not in self._wcache:
+                w = sd[name]
+                if wdt == torch.float16 and float(w.abs().max()) >= 65504.0:
+                    raise RuntimeError(f"{name}: |w| reaches the fp16 limit; use operand_dtype='bf16'")
+                self._wcache[ck] = w.to(wdt).contiguous()
+            return self._wcache[ck].data_ptr()
+
+        def split16(names):
+            """hi / lo planes of scale * W for the four matrices of a split block (include/dtk.h: dtk_vit_layer.qkv_w_lo).  One
+            power-of-two scale per block: 2^8 for fp16 (the lo halves of |w| ~ 1e-2 stay normal numbers), less if a weight
+            would leave the range; 1 for bf16."""
+            ck = (names[0], operand_dtype, "split")
+            if ck not in self._wcache:
+                scale = 1.0
+                if wdt == torch.float16:
+                    amax = max(float(sd[n].abs().max()) for n in names)
+                    scale = 256.0
+                    while scale > 1.0 and amax * scale >= 32768.0:
+                        scale /= 2.0
+                    if amax * scale >= 65504.0:
+                        raise RuntimeError(f"{names[0]}: |w| reaches the fp16 limit; use operand_dtype='bf16'")
+                planes = []
+                for n in names:
+                    w = sd[n] * scale
+                    hi = w.to(wdt)
+                    lo = (w - hi.float()).to(wdt)
+                    planes.append((hi.contiguous(), lo.contiguous()))
+                self._wcache[ck] = (scale, planes)
+            return self._wcache[ck]
 
         for i in range(depth):
             p = f"blocks.{i}."
             L = arr[i]
             L.ln1_w, L.ln1_b = f32(p + "norm1.weight"), f32(p + "norm1.bias")
-            L.qkv_w, L.qkv_b = b16(p + "attn.qkv.weight"), f32(p + "attn.qkv.bias")
-            L.proj_w, L.proj_b = b16(p + "attn.proj.weight"), f32(p + "attn.proj.bias")
+            L.qkv_b, L.proj_b = f32(p + "attn.qkv.bias"), f32(p + "attn.proj.bias")
             L.ls1 = f32(p + "ls1.gamma")
             L.ln2_w, L.ln2_b = f32(p + "norm2.weight"), f32(p + "norm2.bias")
-            L.fc1_w, L.fc1_b = b16(p + "mlp.fc1.weight"), f32(p + "mlp.fc1.bias")
-            L.fc2_w, L.fc2_b = b16(p + "mlp.fc2.weight"), f32(p + "mlp.fc2.bias")
+            L.fc1_b, L.fc2_b = f32(p + "mlp.fc1.bias"), f32(p + "mlp.fc2.bias")
             L.ls2 = f32(p + "ls2.gamma")
-        self._layers_of[operand_dtype] = arr
+            names = [p + "attn.qkv.weight", p + "attn.proj.weight", p + "mlp.fc1.weight", p + "mlp.fc2.weight"]
+            if i in split_blocks:
+                scale, planes = split16(names)
+                (L.qkv_w, L.qkv_w_lo), (L.proj_w, L.proj_w_lo), (L.fc1_w, L.fc1_w_lo), (L.fc2_w, L.fc2_w_lo) = \
+                    [(h.data_ptr(), l.data_ptr()) for h, l in planes]
+                L.w_scale = scale
+            else:
+                L.qkv_w, L.proj_w, L.fc1_w, L.fc2_w = [b16(n) for n in names]
+                L.qkv_w_lo = L.proj_w_lo = L.fc1_w_lo = L.fc2_w_lo = None
+                L.w_scale = 1.0
+        self._layers_of[key] = arr
         return arr
 
     def _pos_embed(self, ph: int, pw: int):
@@ -163,15 +242,15 @@ class VitExtractor(nn.Module):
         if want not in ("tokens", "feat", "qkv"):
             raise ValueError(want)
 
-        def run(operand_dtype):
+        def run(operand_dtype, split_blocks, frames=frames, n=n):
             flags = (VIT_TILED_GEMMS if self.tiled_gemms else 0) | (VIT_BF16 if operand_dtype == "bf16" else 0) | \
                 (VIT_CHECK_RANGE if self.check_range else 0) | (VIT_ATTENTION_V2 if self.attention_v2 else 0) | \
                 (VIT_GEMM_WS_V1 if self.gemm_ws_v1 else 0)
             m = VitModel(D, self.cfg["heads"], layer + 1, patch, self.stride, 1e-6, flags,
                          self._sd["patch_embed.proj.weight"].data_ptr(),
                          self._sd["patch_embed.proj.bias"].data_ptr(), cls_pos.data_ptr(), pos.data_ptr(), ms.data_ptr(),
-                         ctypes.cast(self._build_layers(operand_dtype), ctypes.POINTER(VitLayer)), int(self.frame_batch),
-                         overflow.data_ptr())
+                         ctypes.cast(self._build_layers(operand_dtype, split_blocks), ctypes.POINTER(VitLayer)),
+                         int(self.frame_batch), overflow.data_ptr())
             ws_bytes = int(lib().dtk_vit_workspace_bytes(m, H, W, n))
             # the workspace (2.6 GB for 30 frames of 854 x 476) is kept between calls: handing it back to the caching allocator
             # and asking again costs a device allocation (~25 ms) whenever the block has been split or released in between
@@ -186,37 +265,70 @@ class VitExtractor(nn.Module):
             # (`ms`, `ws`, the position encoding and the overflow word are members: they outlive the launches)
             return {"tokens": tokens, "feat": feat, "qkv": qkv}[want]
 
-        out = run(self.operand_dtype)
-        if not defer_check and self.check_overflow(heal=True):
-            out = run(self.operand_dtype)          # the fp16 pass saturated: the same call on bf16 operands (sticky, see check_overflow)
+        if self.precision == "auto" and self.calibration is None and layer >= 0:
+            # measure what the fast operands cost on THIS network and THESE frames: the first frames both ways (a split pass of two
+            # 854 x 476 frames is ~15 ms), fast-vs-split relative difference = the fast path's distance from fp32-grade features
+            if self._deferred_pending:
+                raise RuntimeError("VitExtractor(precision='auto'): the calibrating call cannot follow un-checked deferred calls")
+            k = min(n, max(1, self.calibration_frames))
+            depth_all = frozenset(range(self.cfg["depth"]))
+            ref = run(self.operand_dtype, depth_all, frames[:k].contiguous(), k)
+            if self.check_overflow(heal=True):     # even the calibration pass saturated: now on split bf16 / bf16 (sticky)
+                ref = run(self.operand_dtype, depth_all if self.on_overflow == "split-bf16" else self.split_blocks,
+                          frames[:k].contiguous(), k)
+                self.check_overflow()
+            fast = run(self.operand_dtype, frozenset(), frames[:k].contiguous(), k)
+            fast_overflow = int(self._overflow.item()) if self.operand_dtype == "fp16" else 0
+            if fast_overflow:
+                self._overflow.zero_()
+            rel = float(((fast.double() - ref.double()).norm() / ref.double().norm()).item()) if not fast_overflow else float("inf")
+            chosen = "split" if not (rel <= self.auto_tol) else "fast"
+            self.calibration = {"frames": k, "layer": layer, "rel_fast_vs_split": rel, "tol": self.auto_tol, "chosen": chosen,
+                                "fast_pass_saturated": bool(fast_overflow)}
+            if chosen == "split" or len(self.split_blocks):   # (a range fallback above already put every block on split operands)
+                self.split_blocks = depth_all
+
+        out = run(self.operand_dtype, self.split_blocks)
+        if defer_check:
+            self._deferred_pending += 1
+        elif self.check_overflow(heal=True):
+            out = run(self.operand_dtype, self.split_blocks)   # the fp16 pass saturated: the same call on (split) bf16 operands (sticky)
             self.check_overflow()                  # (bf16 sets no bits; a non-finite residual update would still raise)
         return out
 
     def check_overflow(self, heal: bool = False) -> bool:
         """Reads (one stream synchronisation) and clears the overflow word of the encode() calls since the last check.
-        A non-zero word means those calls' features are not trustworthy.  With on_overflow="bf16" and fp16 operands the
-        extractor switches to bf16 operands for the rest of its life and counts the event; `heal=True` (encode's own call)
-        then returns True so that the caller re-runs the pass.  Otherwise -- "raise", a deferred check whose features were
-        already handed on, or bf16 operands (only non-finite values can set the word there) -- RuntimeError."""
+        A non-zero word means those calls' features are not trustworthy.  With fp16 operands and on_overflow="split-bf16" /
+        "bf16" the extractor switches to split bf16 / plain bf16 operands for the rest of its life and counts the event;
+        `heal=True` (encode's own call) then returns True so that the caller re-runs the pass.  Otherwise -- "raise", a deferred
+        check whose features were already handed on (also when encode's own check finds bits while deferred calls are still
+        un-checked: the bits cannot be attributed), or bf16 operands (only non-finite values can set the word
+        there) -- RuntimeError."""
         if not hasattr(self, "_overflow"):
             return False
         self.last_overflow = int(self._overflow.item())
+        pending, self._deferred_pending = self._deferred_pending, 0
         if not self.last_overflow:
             return False
         self._overflow.zero_()
         what = " and ".join(n for b, n in ((1, "a residual update"), (2, "Q / K / V"), (4, "the MLP hidden")) if self.last_overflow & b)
-        if self.operand_dtype == "fp16" and self.on_overflow == "bf16":
+        if self.operand_dtype == "fp16" and self.on_overflow in ("split-bf16", "bf16"):
             self.operand_dtype = "bf16"
+            to = "bf16"
+            if self.on_overflow == "split-bf16":
+                self.split_blocks = frozenset(range(self.cfg["depth"]))
+                to = "SPLIT bf16 (hi + lo: 16 significant bits, fp32's range)"
             self.range_fallbacks += 1
             import warnings
-            warnings.warn(f"VitExtractor: {what} left the fp16 range (saturated at 65504); this extractor now runs on bf16 "
-                          "operands (range_fallbacks counts the re-encoded calls)", RuntimeWarning, stacklevel=3)
-            if heal:
+            warnings.warn(f"VitExtractor: {what} left the fp16 range (saturated at 65504); this extractor now runs on {to} "
+                          "operands (range_fallbacks counts the re-encoded calls; precision_report() describes the result)",
+                          RuntimeWarning, stacklevel=3)
+            if heal and not pending:
                 return True
             raise RuntimeError(f"dtk_vit_forward: {what} left the fp16 range in a call whose check was deferred: its features "
                                "are saturated and must be discarded -- encode the video again (this extractor is on bf16 now)")
         raise RuntimeError(f"dtk_vit_forward: {what} left the fp16 range (saturated at 65504) or is not finite; "
-                           "construct the extractor with operand_dtype='bf16'")
+                           "construct the extractor with operand_dtype='bf16' (precision='split' keeps 16 significant bits there)")
 
     def release_workspace(self):
         """Frees the encoder's activation workspace (2.6 GB for 30 frames of 854 x 476): preprocessing is done."""

@@ -149,3 +149,22 @@ def make_vit_weights(model_name: str, seed: int = 2, pos_grid: int = 37, patch: 
     return sd
 
 
+def make_outlier_vit_weights(scale_fc2: float = 300.0, model_name: str = "dinov2_vits14") -> Dict[str, torch.Tensor]:
+    """ViT-S weights with the features of a TRAINED DINOv2 that the seeded initialisation lacks (used by
+    tests/test_gpu_p1.py and scripts/e2e_error.py): 'massive activations' (a few tokens whose residual stream carries 1e3-scale
+    values in a few channels, planted through the position encoding of 5 grid cells and the CLS token), LayerNorm gains up to
+    8, LayerScale up to 3, a block with sharper attention, and one block whose MLP output is large (fc2 x scale_fc2)."""
+    sd = {k: v.clone() for k, v in make_vit_weights(model_name, seed=12, layerscale=0.5).items()}
+    g = torch.Generator().manual_seed(13)
+    d = VIT_CONFIGS[model_name]["dim"]
+    pe = sd["pos_embed"]  # [1, 1 + 37*37, d]
+    for cell in (0, 1, 400, 401 + 37, 1369):
+        ch = torch.randint(0, d, (3,), generator=g)
+        pe[0, cell, ch] += torch.tensor([1500.0, -900.0, 600.0])
+    for i in range(VIT_CONFIGS[model_name]["depth"]):
+        sd[f"blocks.{i}.norm1.weight"] *= 1.0 + 7.0 * torch.rand(d, generator=g) ** 4
+        sd[f"blocks.{i}.ls2.gamma"] *= 1.0 + 5.0 * torch.rand(d, generator=g) ** 4
+    sd["blocks.2.attn.qkv.weight"][:2 * d] *= 1.5   # sharper attention in one block (scores to +-100 binades)
+    sd["blocks.3.mlp.fc2.weight"] *= scale_fc2
+    return sd
+

@@ -85,6 +85,13 @@ typedef struct dtk_vit_layer {
     const void* fc2_w;            /* mlp.fc2.weight 16-bit [D][4D] */
     const float* fc2_b;
     const float* ls2;             /* ls2.gamma */
+    /* Round 6 -- the ESCALATED precision of a block (csrc/vit_split.h): when qkv_w_lo is not NULL, this block runs every matrix
+     * product on split operands (x = hi + lo, three MFMAs per product, fp32-grade results at ~3x the matrix work): the four
+     * `*_w` pointers above are then the HI planes and these the LO planes of  w_scale * W  (lo = T(w_scale W - hi); w_scale a
+     * power of two -- 2^8 for fp16 so that the lo halves stay normal numbers, 1 for bf16), all four or none.  Blocks can be
+     * escalated individually; a model whose operand type is bf16 keeps 16 significant bits this way at fp32's range. */
+    const void *qkv_w_lo, *proj_w_lo, *fc1_w_lo, *fc2_w_lo;
+    float w_scale;
 } dtk_vit_layer;
 
 typedef struct dtk_vit_model {
@@ -146,6 +153,12 @@ int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int nframes, in
  * Sp = S rounded up to a multiple of 64 (dtk_vit_forward uses 128). */
 int dtk_vit_attention(const void* q, const void* k, const void* vt, void* out, int frames, int heads, int S, int Sp,
                       int operand_type, void* stream);
+/* The same stage on SPLIT operands (the escalated precision of a block, dtk_vit_layer.qkv_w_lo): every tensor as hi / lo planes
+ * of `operand_type` in the layouts above (x = hi + lo); scores, probabilities and both products carry ~22 (fp16) / ~16 (bf16)
+ * significant bits. */
+int dtk_vit_attention_split(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* vt_hi,
+                            const void* vt_lo, void* out_hi, void* out_lo, int frames, int heads, int S, int Sp, int operand_type,
+                            void* stream);
 
 /* ---- P2: Delta-DINO refinement (models/tracker.py:113-135; models/networks/delta_dino.py:53-61;
  *      models/utils.py:7-45), fp32-grade on the fp16 MFMA (operands split into hi + lo halves, 3 products) ----------

@@ -2,7 +2,10 @@
 same video (oracle ViT -> oracle refine -> oracle infer).  north_star's 1e-3 px is stated on identical inputs; the
 P3 / P2 tests hold it on identical FEATURES, this script measures what the 16-bit operands of P1 add on top (fp16 by
 default since round 3; `bf16` as fifth argument gives the round-2 arithmetic for comparison).
-Writes gpurun_out/e2e_error_*.json (copied to profiles/ by hand).  Usage: python scripts/e2e_error.py [H W T nq [fp16|bf16 [split,fp16 [cpu|cuda]]]]   (Delta-DINO operand modes, one run each; where the oracle runs)"""
+Writes gpurun_out/e2e_error_*.json (copied to profiles/ by hand).
+Usage: python scripts/e2e_error.py [H W T nq [fp16|bf16 [split,fp16 [cpu|cuda [bench|ls1|outlier [fast,split,auto,...]]]]]]
+  (5: ViT operand type; 6: Delta-DINO operand modes, one run each; 7: where the oracle runs; 8: the ViT weights -- round 6:
+  `outlier` = synth.make_outlier_vit_weights, DINOv2-like statistics; 9: VitExtractor precision modes, one run each)"""
 import json
 import os
 import sys
@@ -55,13 +58,21 @@ def argmax_margins(refined, queries, H, W, radius=35.0, stride=7):
 _ORACLE_CACHE = {}
 
 
-def _oracle(H, W, T, nq, layerscale, seed, od="cpu"):
+def vit_weights(weights, layerscale=0.1):
+    """bench: the benchmark's seeded ViT-S (LayerScale `layerscale`); ls1: the same with LayerScale 1.0 (the hub models'
+    init_values); outlier: synth.make_outlier_vit_weights (massive activations, gains to 8, a sharp block, a 300 x MLP)."""
+    if weights == "outlier":
+        return synth.make_outlier_vit_weights(300.0)
+    return synth.make_vit_weights("dinov2_vits14", seed=2, layerscale=1.0 if weights == "ls1" else layerscale)
+
+
+def _oracle(H, W, T, nq, layerscale, seed, od="cpu", weights="bench"):
     """The fp32 oracle's side of the comparison (minutes on CPU, seconds with od = "cuda": the restatement takes its device from
     its inputs), cached so that several device configurations share it."""
-    key = (H, W, T, nq, layerscale, seed, od)
+    key = (H, W, T, nq, layerscale, seed, od, weights)
     if key not in _ORACLE_CACHE:
         name = "dinov2_vits14"
-        sd_cpu = synth.make_vit_weights(name, seed=2, layerscale=layerscale)
+        sd_cpu = vit_weights(weights, layerscale)
         video_cpu = synth.synth_video(T, H, W, seed=seed)
         head_cpu = synth.synth_head_weights(3)
         delta_cpu = synth.synth_delta_dino_weights(384, seed=4)
@@ -98,16 +109,22 @@ def arbitrate(o, dev_refined, traj, H, W, flagged):
     return out
 
 
-def run(H, W, T, nq, layerscale=0.1, seed=2000, operand_dtype="fp16", p2_operands=None, oracle_device="cpu"):
+def run(H, W, T, nq, layerscale=0.1, seed=2000, operand_dtype="fp16", p2_operands=None, oracle_device="cpu", weights="bench",
+        precision="fast", on_overflow="split-bf16"):
     """oracle_device: "cpu" (the form pinned on the reference; minutes at T = 16) or "cuda" (the same restatement on device
     tensors in fp32 -- what makes T = 90 / 1024 queries affordable; pinned against the CPU form in tests/test_gpu_fullsize.py)."""
     dev = "cuda:0"
     od = oracle_device
-    o = _oracle(H, W, T, nq, layerscale, seed, od)
+    o = _oracle(H, W, T, nq, layerscale, seed, od, weights)
     name, sd, video, head, delta, queries = o["name"], o["sd"], o["video"], o["head"], o["delta"], o["queries"]
     dino, refined, rt, ro, rcs = o["dino"], o["refined"], o["rt"], o["ro"], o["rcs"]
-    ex = VitExtractor(name, stride=7, device=dev, state_dict=sd, operand_dtype=operand_dtype)
+    ex = VitExtractor(name, stride=7, device=dev, state_dict=sd, operand_dtype=operand_dtype, precision=precision,
+                      on_overflow=on_overflow)
+    torch.cuda.synchronize()
+    t0 = time.time()
     feat = ex.encode(video.to(dev))
+    torch.cuda.synchronize()
+    encode_seconds = time.time() - t0
     trk = Tracker(video=video.to(dev), dino_features=feat, dino_patch_size=14, stride=7, device=dev)
     trk.tracker_head.load_state_dict(o["head_cpu"])
     trk.delta_dino.load_state_dict(delta)
@@ -158,8 +175,11 @@ def run(H, W, T, nq, layerscale=0.1, seed=2000, operand_dtype="fp16", p2_operand
                                     "frac_le_1e-3": (dec <= 1e-3).float().mean().item()},
         "points_beyond_1e-3px": len(flagged), "arbitrated": arb,
         "arbitration_failures": sum(0 if a["ok"] else 1 for a in arb),
-        "config": f"{W}x{H}x{T}, {nq * nq} queries, ViT-S/14 random weights (LayerScale {layerscale}), seed {seed}, "
-                  f"{operand_dtype} ViT operands, Delta-DINO convolution operands {p2_operands or 'default'}, oracle on {od}",
+        "config": f"{W}x{H}x{T}, {nq * nq} queries, ViT-S/14 {weights} weights (LayerScale {layerscale if weights == 'bench' else '-'}), "
+                  f"seed {seed}, {operand_dtype} ViT operands, precision {precision}, Delta-DINO convolution operands "
+                  f"{p2_operands or 'default'}, oracle on {od}",
+        "weights": weights, "precision": precision, "precision_report": ex.precision_report(), "encode_seconds": encode_seconds,
+        "arbitrated_rate": len(flagged) / max(1, int(err.numel())),
         "feature_rel_err_P1": rel, "feature_rel_err_refined": rel_refined,
         "px_err_vs_oracle_on_same_video": {"p50": err.quantile(q[0]).item(), "p90": err.quantile(q[1]).item(),
                                            "p99": err.quantile(q[2]).item(), "max": err.max().item(),
@@ -180,9 +200,21 @@ if __name__ == "__main__":
     a = [int(x) for x in sys.argv[1:5]] if len(sys.argv) >= 5 else [238, 322, 6, 4]
     dt = sys.argv[5] if len(sys.argv) > 5 else "fp16"
     modes = sys.argv[6].split(",") if len(sys.argv) > 6 else [None]
+    modes = [None if m in ("default", "None") else m for m in modes]
     od = sys.argv[7] if len(sys.argv) > 7 else "cpu"
-    out = [run(*a, operand_dtype=dt, p2_operands=m, oracle_device=od) for m in modes]
+    weights = sys.argv[8] if len(sys.argv) > 8 else "bench"
+    precisions = sys.argv[9].split(",") if len(sys.argv) > 9 else ["fast"]
+    out = []
+    for pr in precisions:
+        # "bf16" as a precision name: plain bf16 operands (the round-5 heal target), for the three-way table of docs/PARITY.md
+        kw = dict(operand_dtype="bf16", precision="fast") if pr == "bf16" else dict(operand_dtype=dt, precision=pr)
+        out += [run(*a, p2_operands=m, oracle_device=od, weights=weights, **kw) for m in modes]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"e2e_error_{a[0]}x{a[1]}x{a[2]}_{dt}.json"), "w") as fh:
+    tag = f"{a[0]}x{a[1]}x{a[2]}_{dt}" + ("" if weights == "bench" and precisions == ["fast"] else f"_{weights}_{'-'.join(precisions)}")
+    with open(os.path.join(ROOT, "gpurun_out", f"e2e_error_{tag}.json"), "w") as fh:
         json.dump(out, fh, indent=1)
-    print(json.dumps(out, indent=1))
+    # the arbitrated lists are long under outlier weights: print the summary only
+    for r in out:
+        print(json.dumps({k: r[k] for k in ("config", "feature_rel_err_P1", "feature_rel_err_refined", "px_err_vs_oracle_on_same_video",
+                                            "points_beyond_1e-3px", "arbitration_failures", "arbitrated_rate", "occ_mismatch_same_video",
+                                            "occ_mismatch_same_video_queries_without_a_tie", "encode_seconds", "precision_report")}, indent=1))

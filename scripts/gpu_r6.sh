@@ -1,0 +1,63 @@
+#!/bin/bash
+# Round-6 GPU work, one gpurun call per invocation: scripts/gpu_r6.sh <step> [<step> ...]; outputs under gpurun_out/.
+#   precision     the round-6 precision tests (split operands, range escalation, auto calibration, e2e under outlier weights) + P1 suite
+#   e2e_outlier   scripts/e2e_error.py from the video under outlier / ls1 / bench weights, fast / split / bf16 -> gpurun_out/e2e_error_*
+#   tests         the whole -m gpu suite;   tests:<expr>  pytest -k <expr>;   files:<paths>
+#   bench         bench.py with the driver's flags (--steps 20 --warmup 5);  bench_quick  --steps 5 --warmup 2 --no-cpu-baseline
+#   profile       scripts/gpu_profile.sh r06: kernel trace + stats, PMC traffic passes, SQ pass -> gpurun_out/r06_*
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+for WHAT in "$@"; do
+  echo "=== $WHAT"
+  case $WHAT in
+    precision)
+      timeout 2400 python -m pytest -m gpu -x -q -s tests/test_gpu_precision.py 2>&1 | tail -60 | tee gpurun_out/precision_tests.log
+      timeout 1500 python -m pytest -m gpu -x -q tests/test_gpu_p1.py 2>&1 | tail -15 | tee gpurun_out/p1_tests.log ;;
+    e2e_outlier)
+      timeout 1500 python scripts/e2e_error.py 476 854 16 16 fp16 default cuda outlier fast,split,bf16 > gpurun_out/e2e_outlier.log 2>&1; tail -80 gpurun_out/e2e_outlier.log
+      timeout 1200 python scripts/e2e_error.py 476 854 16 16 fp16 default cuda ls1 fast,split > gpurun_out/e2e_ls1.log 2>&1; tail -50 gpurun_out/e2e_ls1.log ;;
+    e2e_full)
+      timeout 2400 python scripts/e2e_error.py 476 854 90 32 fp16 default cuda ${E2E_WEIGHTS:-outlier} ${E2E_PREC:-fast,split} > gpurun_out/e2e_full.log 2>&1; tail -80 gpurun_out/e2e_full.log ;;
+    tests)
+      timeout 3000 python -m pytest -m gpu -x -q tests 2>&1 | tail -25 | tee gpurun_out/tests.log ;;
+    tests:*)
+      timeout 2400 python -m pytest -m gpu -x -q -s tests -k "${WHAT#tests:}" 2>&1 | tail -40 | tee gpurun_out/tests_k.log ;;
+    files:*)
+      timeout 2400 python -m pytest -m gpu -x -q -s ${WHAT#files:} 2>&1 | tail -40 | tee gpurun_out/tests_files.log ;;
+    bench)
+      timeout 1500 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err ;;
+    bench_quick)
+      timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-videos30 > gpurun_out/bench_quick.json 2> gpurun_out/bench_quick.err; cat gpurun_out/bench_quick.json; tail -5 gpurun_out/bench_quick.err ;;
+    bench_fast)   # kernel times only: no oracle legs
+      timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-clock-power --no-videos30 --parity-queries 0 > gpurun_out/bench_fast.json 2> gpurun_out/bench_fast.err; cat gpurun_out/bench_fast.json; tail -5 gpurun_out/bench_fast.err ;;
+    bench_split)
+      timeout 900 python bench.py --precision split --steps 3 --warmup 1 --no-cpu-baseline --no-clock-power --no-videos30 > gpurun_out/bench_split.json 2> gpurun_out/bench_split.err; cat gpurun_out/bench_split.json; tail -5 gpurun_out/bench_split.err ;;
+    bench_w1024)
+      timeout 900 python bench.py --width 1024 --steps 2 --warmup 1 --no-cpu-baseline --no-clock-power --no-videos30 > gpurun_out/bench_w1024.json 2> gpurun_out/bench_w1024.err; cat gpurun_out/bench_w1024.json; tail -5 gpurun_out/bench_w1024.err ;;
+    bench_ab)   # same-box A / B of the whole step: the tree's library, then scripts/ubench/libdtk_prev.so (a copy of the previous build), then the tree's again
+      F="--steps 5 --warmup 2 --no-cpu-baseline --no-clock-power --no-videos30 --parity-queries 0"
+      L=dino_tracker_amd/csrc/libdtk.so
+      timeout 600 python bench.py $F > gpurun_out/bench_ab_new1.json 2> gpurun_out/bench_ab.err
+      cp $L /tmp/libdtk_new.so && cp scripts/ubench/libdtk_prev.so $L
+      timeout 600 python bench.py $F > gpurun_out/bench_ab_prev.json 2>> gpurun_out/bench_ab.err
+      cp /tmp/libdtk_new.so $L
+      timeout 600 python bench.py $F > gpurun_out/bench_ab_new2.json 2>> gpurun_out/bench_ab.err
+      python - <<'PY'
+import json
+r = {k: json.load(open(f"gpurun_out/bench_ab_{k}.json")) for k in ("new1", "prev", "new2")}
+print("ms per step:", {k: v["ms_per_step"] for k, v in r.items()})
+keys = sorted(set().union(*[v["roofline"]["kernel_ms"] for v in r.values()]))
+for kk in keys:
+    print(f"  {kk:18s}", "  ".join(f"{k} {r[k]['roofline']['kernel_ms'].get(kk, float('nan')):8.3f}" for k in r))
+PY
+      ;;
+    attn_ab)
+      timeout 600 python scripts/attn_ab.py scripts/ubench/libdtk_prev.so dino_tracker_amd/csrc/libdtk.so 2>&1 | tee gpurun_out/attn_ab.log ;;
+    profile)
+      bash scripts/gpu_profile.sh r06 ;;
+    cmd:*)
+      timeout 2400 bash -c "${WHAT#cmd:}" 2>&1 | tail -60 | tee gpurun_out/cmd.log ;;
+    *) echo "unknown step $WHAT" ;;
+  esac
+done

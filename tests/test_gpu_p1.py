@@ -297,22 +297,9 @@ def test_bf16_operands_on_request(vits):
 
 
 def _outlier_weights(scale_fc2=1.0):
-    """ViT-S weights with the features of a trained DINOv2 the seeded initialisation lacks: 'massive activations' (a few
-    tokens whose residual stream carries 1e3-scale values in a few channels, here planted through the position
-    encoding of 5 grid cells and the CLS token), LayerNorm gains up to 8, LayerScale up to 3, and one block whose MLP
-    output is large (fc2 x scale_fc2)."""
-    sd = {k: v.clone() for k, v in synth.make_vit_weights("dinov2_vits14", seed=12, layerscale=0.5).items()}
-    g = torch.Generator().manual_seed(13)
-    pe = sd["pos_embed"]  # [1, 1 + 37*37, 384]
-    for cell in (0, 1, 400, 401 + 37, 1369):
-        ch = torch.randint(0, 384, (3,), generator=g)
-        pe[0, cell, ch] += torch.tensor([1500.0, -900.0, 600.0])
-    for i in range(12):
-        sd[f"blocks.{i}.norm1.weight"] *= 1.0 + 7.0 * torch.rand(384, generator=g) ** 4
-        sd[f"blocks.{i}.ls2.gamma"] *= 1.0 + 5.0 * torch.rand(384, generator=g) ** 4
-    sd["blocks.2.attn.qkv.weight"][:768] *= 1.5   # sharper attention in one block (scores to +-100 binades)
-    sd["blocks.3.mlp.fc2.weight"] *= scale_fc2
-    return sd
+    """ViT-S weights with DINOv2-like statistics (massive activations, large gains, a sharp block, a large MLP output):
+    dino_tracker_amd.synth.make_outlier_vit_weights (bit-identical to the generator that lived here in rounds 3-5)."""
+    return synth.make_outlier_vit_weights(scale_fc2)
 
 
 def test_outlier_tokens_stay_in_fp16_range():
@@ -343,9 +330,10 @@ def test_outlier_tokens_stay_in_fp16_range():
 
 def test_fp16_saturation_is_reported_and_bf16_is_the_way_out():
     """An MLP output beyond 65504 cannot be an fp16 residual update: the device saturates it (no inf / NaN downstream) and
-    sets the overflow word.  on_overflow="raise": `encode` raises naming operand_dtype='bf16'.  Default (round 5): the call
-    is re-encoded on bf16 operands -- bit-identical to an extractor built with operand_dtype="bf16" --, counted, and the
-    extractor stays on bf16."""
+    sets the overflow word.  on_overflow="raise": `encode` raises naming operand_dtype='bf16'.  on_overflow="bf16" (round 5's
+    default, opt-in since round 6): the call is re-encoded on plain bf16 operands -- bit-identical to an extractor built with
+    operand_dtype="bf16" --, counted, and the extractor stays on bf16.  The round-6 default (split bf16) is in
+    tests/test_gpu_precision.py."""
     sd = _outlier_weights(scale_fc2=3.0e5)
     video = synth.synth_video(1, 140, 210, seed=81)
     ex = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd, on_overflow="raise")
@@ -357,18 +345,27 @@ def test_fp16_saturation_is_reported_and_bf16_is_the_way_out():
     ref = A.vit_tokens(video, sd, "dinov2_vits14", layer=4).permute(1, 2, 0).reshape(-1, 384)
     assert torch.isfinite(feat).all()
     _check(feat[0], ref, **BF16_TOL)
-    exh = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd)
+    exh = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd, on_overflow="bf16")
     with pytest.warns(RuntimeWarning, match="bf16"):
         healed = exh.encode(video, layer=4).cpu()
     assert exh.range_fallbacks == 1 and exh.operand_dtype == "bf16" and exh.last_overflow == 0
     assert torch.equal(healed, feat)
     assert torch.equal(exh.encode(video, layer=4).cpu(), feat) and exh.range_fallbacks == 1   # sticky: no second fp16 attempt
     # a deferred check cannot heal (the features were handed on): it raises, and the extractor is on bf16 afterwards
-    exd = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd)
+    exd = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd, on_overflow="bf16")
     exd.encode(video, layer=4, defer_check=True)
     with pytest.warns(RuntimeWarning), pytest.raises(RuntimeError, match="deferred"):
         exd.check_overflow()
     assert exd.operand_dtype == "bf16" and torch.equal(exd.encode(video, layer=4).cpu(), feat)
+    # a deferred saturating call FOLLOWED by a non-deferred call -- the word's bits cannot be attributed to the
+    # current call, so encode's own check must not "heal" (re-run only the current call and hand the earlier saturated
+    # features on silently): it raises the deferred error
+    exq = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd, on_overflow="bf16")
+    exq.encode(video, layer=4, defer_check=True)
+    with pytest.warns(RuntimeWarning), pytest.raises(RuntimeError, match="deferred"):
+        exq.encode(video, layer=4)
+    assert exq.operand_dtype == "bf16" and exq.last_overflow & 1
+    assert torch.equal(exq.encode(video, layer=4).cpu(), feat)   # afterwards: a clean bf16 extractor
 
 
 def _late_frame_saturation_case(which):
@@ -418,7 +415,8 @@ def _late_frame_saturation_case(which):
 def test_saturation_in_a_late_frame_is_caught_and_healed(which, bit):
     """Q / K / V and the MLP hidden are range-checked for EVERY frame inside the GEMM epilogues (no extra
     pass) -- a clip whose frame 37 alone saturates is reported (on_overflow="raise"), agrees with the explicit scan
-    (check_range=True), and by default is re-encoded on bf16 operands."""
+    (check_range=True), and with on_overflow="bf16" is re-encoded on bf16 operands (the round-6 default, split bf16:
+    tests/test_gpu_precision.py)."""
     sd, video = _late_frame_saturation_case(which)
     ex = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd, on_overflow="raise")
     ex.encode(video[:37], layer=1)                          # the dark frames alone: in range
@@ -435,7 +433,7 @@ def test_saturation_in_a_late_frame_is_caught_and_healed(which, bit):
     with pytest.raises(RuntimeError):
         ext.encode(video, layer=1)
     assert ext.last_overflow & bit
-    exh = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd)
+    exh = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd, on_overflow="bf16")
     with pytest.warns(RuntimeWarning):
         healed = exh.encode(video, layer=1).cpu()
     exb = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd, operand_dtype="bf16")
