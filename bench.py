@@ -57,7 +57,8 @@ def parse():
     ap.add_argument("--no-videos30", action="store_true", help="skip the second timed phase (north_star's 30-video batch, strong scaling)")
     ap.add_argument("--ab", default="", help="comma-separated A / B switches: attention_v2 (round 2-3 attention kernel), "
                                              "gemm_ws_v1 (round 1-3 weight-stationary GEMMs)")
-    ap.add_argument("--cpu-threads", type=int, default=8, help="host threads of the oracle's infer leg (fixed: comparable across rounds)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="host threads of ALL THREE oracle legs (infer, ViT, Delta-DINO); 0 = the fastest of the thread sweep on this box")
     ap.add_argument("--cpu-queries", type=int, default=4, help="queries of the TIMED CPU sample (SURVEY 8d: K = 4, full T)")
     ap.add_argument("--parity-queries", type=int, default=1024,
                     help="queries of parity_sample: HIP infer vs the oracle run ON THE GPU in fp32, on the step's own refined volume "
@@ -70,6 +71,12 @@ def parse():
     ap.add_argument("--cpu-vit-frames", type=int, default=2,
                     help="frames the oracle's ViT / Delta-DINO legs are timed on (also the from-the-video parity leg)")
     ap.add_argument("--operands", default="fp16", choices=["fp16", "bf16"], help="operand type of the ViT's matrix units")
+    ap.add_argument("--precision", default="fast", choices=["fast", "split", "auto"],
+                    help="VitExtractor precision: fast (one 16-bit number per operand: the headline), split (hi + lo operands in every "
+                         "block: fp32-grade features at ~3x the matrix work), auto (calibrated on the first frames)")
+    ap.add_argument("--video-lengths", default="",
+                    help="with --videos V: comma list of frame counts (cycled over the V videos; e.g. DAVIS-like 25..104) -- the batch is "
+                         "then scheduled longest-first over the ranks (sharding.lpt_assignment) instead of v = r (mod world)")
     ap.add_argument("--vit-frame-batch", type=int, default=0, help="frames per pass of the ViT encoder (0 = library default)")
     ap.add_argument("--track-round", type=int, default=0, help="sources per round of dtk_track (0 = library default, 4194304)")
     return ap.parse_args()
@@ -158,7 +165,7 @@ def main():
     # no DINOv2 checkpoint exists offline: seeded random weights of the named architecture; LayerScale mean 0.1 keeps
     # the untrained encoder from collapsing all tokens onto one vector (synth.make_vit_weights)
     vit_sd = synth.make_vit_weights(model_name, seed=2, layerscale=0.1)
-    ex = VitExtractor(model_name, stride=7, device=dev, state_dict=vit_sd, operand_dtype=args.operands)
+    ex = VitExtractor(model_name, stride=7, device=dev, state_dict=vit_sd, operand_dtype=args.operands, precision=args.precision)
     ex.frame_batch = args.vit_frame_batch
     ex.attention_v2 = "attention_v2" in args.ab
     ex.gemm_ws_v1 = "gemm_ws_v1" in args.ab
@@ -281,6 +288,8 @@ def main():
     if prof:
         HW, S = 67 * 121, 67 * 121 + 1
         depth = 12 if C in (384, 768) else 24
+        from dino_tracker_amd import delta_dino as _ddm
+        dd_div = 3.0 if _ddm.conv_operand_mode(None) == 0 else 1.0
         # ALGORITHMIC flops of one video per kernel, and the peak that bounds it (TFLOP/s, dense)
         algo = {
             "vit_attention": (4.0 * S * S * C * depth * T, MFMA_F16_PEAK_TF),
@@ -288,11 +297,19 @@ def main():
             "vit_gemm_proj": (2.0 * S * C * C * depth * T, MFMA_F16_PEAK_TF),
             "vit_gemm_fc1": (2.0 * S * C * 4 * C * depth * T, MFMA_F16_PEAK_TF),
             "vit_gemm_fc2": (2.0 * S * C * 4 * C * depth * T, MFMA_F16_PEAK_TF),
-            # split-fp16 kernels: every fp32 MAC costs three fp16 MFMA MACs (hi*hi + hi*lo + lo*hi)
+            # split-fp16 kernels: every fp32 MAC costs three fp16 MFMA MACs (hi*hi + hi*lo + lo*hi), so their peak is a third;
+            # Delta-DINO runs on PLAIN fp16 operands by default since round 4 (delta_dino.conv_operand_mode == 1): full peak then
+            # (the / 3 had stayed behind and would have printed a fraction above 1)
             "vit_patch_embed": (2.0 * HW * 588 * C * T, MFMA_F16_PEAK_TF / 3),
-            "dd_conv1": (2.0 * 406504 * 4800 * T, MFMA_F16_PEAK_TF / 3),
-            "dd_conv23": (2.0 * (101626 * 204800 + 25466 * 819200) * T, MFMA_F16_PEAK_TF / 3),
-            "dd_conv4": (2.0 * 6420 * 6400 * C * T, MFMA_F16_PEAK_TF / 3),
+            "dd_conv1": (2.0 * 406504 * 4800 * T, MFMA_F16_PEAK_TF / dd_div),
+            "dd_conv23": (2.0 * (101626 * 204800 + 25466 * 819200) * T, MFMA_F16_PEAK_TF / dd_div),
+            "dd_conv4": (2.0 * 6420 * 6400 * C * T, MFMA_F16_PEAK_TF / dd_div),
+            # the escalated precision (--precision split): three MFMAs per product by construction
+            "vit_attention_split": (4.0 * S * S * C * depth * T, MFMA_F16_PEAK_TF / 3),
+            "vit_gemm_qkv_split": (2.0 * S * C * 3 * C * depth * T, MFMA_F16_PEAK_TF / 3),
+            "vit_gemm_proj_split": (2.0 * S * C * C * depth * T, MFMA_F16_PEAK_TF / 3),
+            "vit_gemm_fc1_split": (2.0 * S * C * 4 * C * depth * T, MFMA_F16_PEAK_TF / 3),
+            "vit_gemm_fc2_split": (2.0 * S * C * 4 * C * depth * T, MFMA_F16_PEAK_TF / 3),
             "corr_peaks": (2.0 * HW * C * maps, MFMA_F16_PEAK_TF),
             "refine_corr": (2.0 * 225 * C * maps, F32_PEAK_TF),   # (2*RD+5)^2 window cells per map
             "refine_head": (2.0 * (169 + 121) * 144 * maps, F32_PEAK_TF),
@@ -311,7 +328,7 @@ def main():
         # around it) -- read from the newest committed PMC pass of the same command (scripts/pmc_traffic.py)
         # (the committed passes are of the DEFAULT workload: another width / frame count / query count gets no traffic figure)
         default_workload = args.width == 384 and args.frames == 90 and args.queries == 1024 and not args.videos
-        for prof_file in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if default_workload else ():
+        for prof_file in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if default_workload else ():
             try:
                 with open(os.path.join(ROOT, "profiles", prof_file)) as fh:
                     tr = json.load(fh)["kernels"].get(dom)
@@ -327,6 +344,16 @@ def main():
         roofline["kernel_ms"] = {k: round(v[0], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("DTK_BENCH_KERNELS", "12"))]}
         roofline["kernel_tflops"] = {k: round(algo[k][0] / (prof[k][0] * 1e-3) / 1e12, 1) for k in prof
                                      if k in algo and prof[k][0] > 0}
+        roofline["kernel_frac_of_peak"] = {k: round(algo[k][0] / (prof[k][0] * 1e-3) / 1e12 / algo[k][1], 4) for k in prof
+                                           if k in algo and prof[k][0] > 0}
+        # the same fractions against what the matrix pipes deliver at the MEASURED sustained clock of whole steps (the peaks above
+        # assume the 2.4 GHz nameplate; the chip runs these steps at its power budget, ~2.0 GHz): every MFMA-bound kernel, not
+        # only the attention loop
+        sc_steps = ((clock_power or {}).get("steps_repeat", {}).get("sclk_mhz") or {}).get("p50")
+        if sc_steps:
+            roofline["sclk_mhz_over_steps"] = sc_steps
+            roofline["kernel_frac_of_peak_at_measured_clock"] = {
+                k: round(v / (sc_steps / 2400.0), 4) for k, v in roofline["kernel_frac_of_peak"].items() if algo[k][1] != F32_PEAK_TF}
 
     # ---- shader clock and board power DURING the dominant kernel: the stand-alone attention stage on the
     # benchmark's shapes (90 frames x 6 heads, S = 8108, random 16-bit operands), launched back to back for a few hundred ms while a
@@ -386,7 +413,6 @@ def main():
         # threads than on 8).  The infer leg runs on a FIXED thread count (--cpu-threads, default 8) so that the baseline is
         # comparable from round to round; the sweep over thread counts of a slice of the first pass is reported beside it.
         ncore = torch.get_num_threads()
-        best_thr = max(1, min(args.cpu_threads, ncore))
         probe_src = refined_cpu[0].reshape(C, -1).t()[:128].contiguous()
         sweep = {}
         for thr in sorted({ncore, 64, 32, 16, 8}):
@@ -396,6 +422,9 @@ def main():
             c0 = time.perf_counter()
             A.track(probe_src, refined_cpu, torch.zeros(128, dtype=torch.long), head, H, W)
             sweep[str(thr)] = round(time.perf_counter() - c0, 3)
+        # ONE stated thread count for all three legs (infer ran on 8 threads, ViT / Delta-DINO on all):
+        # --cpu-threads N > 0 fixes it; 0 (default) = the sweep's fastest -- the baseline is then the best this host does
+        best_thr = max(1, min(args.cpu_threads, ncore)) if args.cpu_threads > 0 else int(min(sweep, key=lambda k: sweep[k]))
         torch.set_num_threads(best_thr)
         c0 = time.perf_counter()
         rt_t, ro_t, cs_t, _ = A.infer(refined_cpu, q_cpu[timed], head, H, W, return_aux=True)
@@ -408,8 +437,7 @@ def main():
         if rest.numel():
             r2, o2, c2, _ = A.infer(refined_cpu, q_cpu[rest], head, H, W, return_aux=True)
             rt[rest], ro[rest], cs_all[rest] = r2, o2, c2
-        torch.set_num_threads(ncore)
-        nf = max(1, min(T, args.cpu_vit_frames))
+        nf = max(1, min(T, args.cpu_vit_frames))   # (the ViT / Delta-DINO legs stay on best_thr threads: one stated count)
         vcpu = videos[0][:nf].cpu()
         c0 = time.perf_counter()
         dino_cpu = torch.stack([A.vit_tokens(vcpu[i:i + 1], vit_sd, model_name) for i in range(nf)]) if args.features == "vit" else None
@@ -420,14 +448,15 @@ def main():
         c0 = time.perf_counter()
         refined_nf = A.refine_features(vcpu, dino_cpu, delta)
         t_delta = (time.perf_counter() - c0) / nf
+        torch.set_num_threads(ncore)
         total = T * t_vit + T * t_delta + N * t_query
         cpu = {"value": round(N * T / total, 3), "unit": "query-points*frames/s", "cores": best_thr,
                "kind": "port",
                "sample": f"oracle (fp32 torch restatement of the reference; the un-modified reference is not on this box, its "
                          f"literal per-call path is ~T x more expensive: profiles/r03_cpu_reference_literal.json): "
                          f"infer on {nq} of the {N} queries at full T={T} with all their anchors ({a_bar:.1f} per query) "
-                         f"{t_query:.2f} s/query on {best_thr} threads (fixed; sweep of a 128-map slice in thread_sweep_s); ViT {t_vit:.2f} s/frame and "
-                         f"Delta-DINO {t_delta:.2f} s/frame on {nf} frame(s), {ncore} threads; "
+                         f"{t_query:.2f} s/query; ViT {t_vit:.2f} s/frame and Delta-DINO {t_delta:.2f} s/frame on {nf} frame(s); ALL legs on "
+                         f"{best_thr} threads (the fastest of the sweep of a 128-map slice, thread_sweep_s, unless --cpu-threads); "
                          f"N T / (T t_vit + T t_delta + N t_query), SURVEY 8d",
                "t_query_s": round(t_query, 3), "t_vit_s": round(t_vit, 3), "t_delta_s": round(t_delta, 3),
                "anchors_per_query": round(a_bar, 2), "host_threads": ncore, "thread_sweep_s": sweep,
@@ -561,7 +590,7 @@ def main():
                        "stages": stages, "features": args.features, "mode": args.mode if world > 1 else "single",
                        "track_method": "exact" if method == ops.TRACK_EXACT else "mfma",
                        "anchor_pairs": pairs, "correlation_maps_per_video": maps, "anchor_track_tiers": tiers,
-                       "rccl_ranks": rccl_ranks,
+                       "rccl_ranks": rccl_ranks, "vit_precision": ex.precision_report(),
                        "vit_frames_per_rank": ([sharding.split_range(T, r, world)[1] - sharding.split_range(T, r, world)[0]
                                                 for r in range(world)] if qpar else [T] * world),
                        "parallelism": (f"query-parallel x{world} (frames split for P1/P2, queries for P3)" if qpar

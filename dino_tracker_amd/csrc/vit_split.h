@@ -46,8 +46,14 @@ struct SplitEpi {
     int* ovf;              // fp16: OR 2 (Q / K / V) or 4 (hidden) when a stored value reaches the fp16 limit
 };
 
+// hi = T(v), lo = T(v - hi).  `v` is pinned as an fp32 VALUE first: with HIP's default -ffp-contract=fast the compiler otherwise
+// fuses the caller's last multiply into the conversions (v_fma_mixlo_f16: T(a * b) rounded ONCE from the exact product) for the lo
+// half while the stored hi half is T(fp32(a * b)) -- two different hi's wherever a * b sits within fp32 rounding of a 16-bit
+// midpoint (one value in 2^13), and there hi + lo is off by a whole 16-bit ulp.  Found by the stand-alone attention test: median
+// error 1e-7, five outputs of 115 200 off by 2^-13 .. 2^-10.
 template <typename T>
 __device__ __forceinline__ void split2(float v, T& hi, T& lo) {
+    asm volatile("" : "+v"(v));
     hi = (T)v;
     lo = (T)(v - (float)hi);
 }

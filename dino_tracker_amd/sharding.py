@@ -1,6 +1,9 @@
 """Multi-GPU layout of the per-video hot path: videos are independent, so rank r of a
 one-process-per-GPU job takes videos v = r (mod world) and only the results travel -- one gather of the [N, T, 2]
 fp32 trajectories and [N, T] occlusion flags per video to rank 0 over RCCL (xGMI); no collective touches the data path.
+`run_sharded` is the lock-step form (one gather per round of `world` videos); `run_scheduled` (round 6) assigns the videos
+longest-first by frame count, lets every rank run its list back to back and gathers ONCE at the end -- what a batch of ragged
+clips (DAVIS: 25 .. 104 frames) needs.
 Level 2 (one video on several GPUs, for the single-video scaling curve): `query_parallel` splits the FRAMES over the
 ranks for P1 / P2 (each rank encodes and refines T / world frames), all-gathers the refined volume once (T*HW*C fp32 =
 1.1 GB at T = 90, C = 384: ~140 MB per rank over xGMI), splits the QUERIES over the ranks for P3 (every rank needs all
@@ -71,6 +74,79 @@ def run_sharded(n_videos: int, n: int, t: int, device, track_fn, group=None) -> 
                 if item is not None:
                     out[r * world + src] = item
     return out if rank == 0 else None
+
+
+# ---- round 6: a schedule that does not wait per round ------------------------------------------
+# run_sharded gathers once per ROUND, so every round costs its slowest video: sum_rounds max_r t  >=  max_r sum t.  Nothing needs
+# the results before the end of the batch, and real clips are ragged (DAVIS: 25 .. 104 frames; the step is ~linear in T for P1 / P2
+# and ~quadratic for P3, whose anchor count grows with T).  run_scheduled: longest-processing-time-first assignment, every rank
+# runs its list back to back with NO collective in between, ONE gather of everything at the end.  run_sharded stays as the
+# lock-step form (and as the oracle of the tests).
+def video_cost(frames: int) -> float:
+    """Relative cost of one video of `frames` frames at fixed N: P1 + P2 linear in T (2.2 ms per frame at 854 x 476, ViT-S), P3
+    ~ N T (1 + anchors per query) with anchors ~ T (0.78 ms per frame at T = 90) -- measured on the benchmark step, round 5."""
+    return float(frames) * (1.0 + 0.0039 * float(frames))
+
+
+def lpt_assignment(costs: List[float], world: int) -> List[List[int]]:
+    """Longest-processing-time-first: videos by decreasing cost (ties: lower index first), each to the least loaded rank (ties:
+    lower rank).  Deterministic, so every rank computes the same table without communication.  Graham's bound: makespan <=
+    (4/3 - 1/(3 world)) x optimum.  Equal costs reproduce the round-robin counts (30 over 8: 4/4/4/4/4/4/3/3)."""
+    order = sorted(range(len(costs)), key=lambda v: (-costs[v], v))
+    load = [0.0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for v in order:
+        r = min(range(world), key=lambda i: (load[i], i))
+        out[r].append(v)
+        load[r] += costs[v]
+    return out
+
+
+def schedule_costs(costs: List[float], world: int) -> Dict[str, float]:
+    """Makespans (in cost units) of the three schedules of a batch: ideal = max(mean load, largest video); lpt = max_r sum of the
+    rank's list; lockstep = sum over rounds of the round's largest video (v = r mod world, one gather per round)."""
+    a = lpt_assignment(costs, world)
+    lpt = max((sum(costs[v] for v in lst) for lst in a), default=0.0)
+    lock = sum(max(costs[r0:r0 + world]) for r0 in range(0, len(costs), world))
+    ideal = max(sum(costs) / world, max(costs, default=0.0))
+    return {"ideal": ideal, "lpt": lpt, "lockstep": lock}
+
+
+def run_scheduled(lengths: List[int], n: int, device, track_fn, group=None, costs: Optional[List[float]] = None,
+                  ) -> Optional[Dict[int, Tuple[torch.Tensor, torch.Tensor]]]:
+    """A batch of len(lengths) videos (video v has lengths[v] frames, n queries) over the ranks: LPT assignment by `costs`
+    (default video_cost(frames)), `track_fn(v) -> (traj [n, T_v, 2], occ [n, T_v])` for this rank's videos back to back, then
+    ONE gather of a flat payload per rank (padded to the largest rank's payload: the sizes follow from the table every rank
+    holds).  Rank 0 returns {v: (traj, occ)} for all videos, the others None."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    costs = [video_cost(t) for t in lengths] if costs is None else costs
+    table = lpt_assignment(costs, world)
+    sizes = [sum(n * lengths[v] * 3 for v in lst) for lst in table]
+    parts = []
+    for v in table[rank]:
+        traj, occ = track_fn(v)
+        assert traj.shape == (n, lengths[v], 2) and occ.shape == (n, lengths[v]), (v, tuple(traj.shape), tuple(occ.shape))
+        parts.append(pack_result(traj, occ))
+    payload = torch.zeros(max(sizes + [1]), dtype=torch.float32, device=device)
+    if parts:
+        mine = torch.cat(parts)
+        payload[: mine.numel()] = mine
+    if world > 1:
+        bufs = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
+        dist.gather(payload, bufs, dst=0, group=group)
+        if rank != 0:
+            return None
+    else:
+        bufs = [payload]
+    out: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+    for r, lst in enumerate(table):
+        off = 0
+        for v in lst:
+            k = n * lengths[v] * 3
+            out[v] = unpack_result(bufs[r][off: off + k], n, lengths[v])
+            off += k
+    return out
 
 
 def split_range(n: int, rank: int, world: int) -> Tuple[int, int, int]:

@@ -12,7 +12,7 @@ for WHAT in "$@"; do
   echo "=== $WHAT"
   case $WHAT in
     precision)
-      timeout 2400 python -m pytest -m gpu -x -q -s tests/test_gpu_precision.py 2>&1 | tail -60 | tee gpurun_out/precision_tests.log
+      timeout 2400 python -m pytest -m gpu -x -q -s tests/test_gpu_precision.py 2>&1 | tail -150 | tee gpurun_out/precision_tests.log
       timeout 1500 python -m pytest -m gpu -x -q tests/test_gpu_p1.py 2>&1 | tail -15 | tee gpurun_out/p1_tests.log ;;
     e2e_outlier)
       timeout 1500 python scripts/e2e_error.py 476 854 16 16 fp16 default cuda outlier fast,split,bf16 > gpurun_out/e2e_outlier.log 2>&1; tail -80 gpurun_out/e2e_outlier.log
@@ -24,7 +24,7 @@ for WHAT in "$@"; do
     tests:*)
       timeout 2400 python -m pytest -m gpu -x -q -s tests -k "${WHAT#tests:}" 2>&1 | tail -40 | tee gpurun_out/tests_k.log ;;
     files:*)
-      timeout 2400 python -m pytest -m gpu -x -q -s ${WHAT#files:} 2>&1 | tail -40 | tee gpurun_out/tests_files.log ;;
+      timeout 2400 python -m pytest -m gpu -x -q -s ${WHAT#files:} 2>&1 | tail -150 | tee gpurun_out/tests_files.log ;;
     bench)
       timeout 1500 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err ;;
     bench_quick)

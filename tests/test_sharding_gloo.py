@@ -149,3 +149,82 @@ def test_query_parallel_world8_t90():
     port = 34500 + (os.getpid() % 1000)
     mp.spawn(_qp_worker, args=(world, port, t, hw, c, n, ret), nprocs=world, join=True)
     assert dict(ret) == {r: True for r in range(world)}
+
+
+# ---- round 6: the schedule that does not wait per round (sharding.run_scheduled) --------------------------------------------
+DAVIS_LIKE = [50, 80, 43, 90, 66, 104, 25, 75, 70, 82, 40, 69, 100, 60, 84, 59, 90, 34, 50, 96, 72, 52, 78, 33, 68, 91, 45, 63, 80, 71]
+
+
+def test_lpt_assignment_and_makespans():
+    """Equal lengths: LPT = the round-robin counts; ragged (DAVIS-like 25 .. 104 frames): every video exactly once, LPT's
+    makespan within Graham's bound of the ideal and strictly below the lock-step schedule's sum of round maxima."""
+    assert [len(x) for x in sharding.lpt_assignment([1.0] * 30, 8)] == [4, 4, 4, 4, 4, 4, 3, 3]
+    costs = [sharding.video_cost(t) for t in DAVIS_LIKE]
+    for world in (1, 2, 4, 8):
+        a = sharding.lpt_assignment(costs, world)
+        assert sorted(v for lst in a for v in lst) == list(range(30))
+        sc = sharding.schedule_costs(costs, world)
+        assert abs(sc["lpt"] - max(sum(costs[v] for v in lst) for lst in a)) < 1e-9
+        assert sc["ideal"] <= sc["lpt"] <= (4 / 3 - 1 / (3 * world)) * sc["ideal"] + 1e-9
+        assert sc["lpt"] <= sc["lockstep"] + 1e-9
+    sc8 = sharding.schedule_costs(costs, 8)
+    assert sc8["lpt"] < 0.85 * sc8["lockstep"], sc8          # the per-round waits cost > 15 % on this batch
+    assert sc8["lpt"] < 1.05 * sc8["ideal"], sc8
+
+
+def _ragged_track(v, n, t):
+    g = torch.Generator().manual_seed(500 + v)
+    return torch.rand(n, t, 2, generator=g) * 800, torch.rand(n, t, generator=g) > 0.5
+
+
+def _sched_worker(rank, world, port, lengths, n, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls, clock = [], [0.0]
+        costs = [sharding.video_cost(t) for t in lengths]
+
+        def track(v):
+            calls.append(v)
+            clock[0] += costs[v]          # a virtual clock: this rank's busy time
+            return _ragged_track(v, n, lengths[v])
+
+        out = sharding.run_scheduled(lengths, n, "cpu", track)
+        table = sharding.lpt_assignment(costs, world)
+        assert calls == table[rank]                       # this rank's list, back to back, in LPT order
+        if rank == 0:
+            assert sorted(out) == list(range(len(lengths)))
+            for v, t in enumerate(lengths):
+                tr, oc = _ragged_track(v, n, t)
+                assert out[v][0].shape == (n, t, 2) and torch.equal(out[v][0], tr) and torch.equal(out[v][1], oc)
+        else:
+            assert out is None
+        ret[rank] = clock[0]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_run_scheduled_world8_ragged_davis_batch():
+    """30 clips of 25 .. 104 frames on 8 ranks: one gather at the end, results identical to the per-video outputs, and the
+    makespan of the run (the largest virtual busy time of a rank) IS max_r sum t -- not the lock-step sum of round maxima."""
+    world, n = 8, 5
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 35500 + (os.getpid() % 1000)
+    mp.spawn(_sched_worker, args=(world, port, DAVIS_LIKE, n, ret), nprocs=world, join=True)
+    busy = dict(ret)
+    assert sorted(busy) == list(range(world))
+    sc = sharding.schedule_costs([sharding.video_cost(t) for t in DAVIS_LIKE], world)
+    assert abs(max(busy.values()) - sc["lpt"]) < 1e-6 and max(busy.values()) < 0.85 * sc["lockstep"]
+
+
+def test_run_scheduled_world2_fewer_videos_than_ranks_and_single():
+    """World 2 with ONE video (rank 1 has an empty list and still takes part in the gather), and the single-process form."""
+    world, n = 2, 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 36500 + (os.getpid() % 1000)
+    mp.spawn(_sched_worker, args=(world, port, [7], n, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: sharding.video_cost(7), 1: 0.0}
+    out = sharding.run_scheduled([4, 9, 2], n, "cpu", lambda v: _ragged_track(v, n, [4, 9, 2][v]))
+    assert sorted(out) == [0, 1, 2] and out[1][0].shape == (n, 9, 2) and torch.equal(out[2][1], _ragged_track(2, n, 2)[1])
