@@ -182,7 +182,7 @@ def main():
     mi = ModelInference(trk, RangeNormalizer((W, H, T), device=dev), 0.7, 0.6)  # caches refined features once
     stats_acc = {"sources": 0, "whole_map_tier": 0, "exact_tier": 0, "syncs": 0}
 
-    def one_video(video):
+    def one_video(video, trk=trk, mi=mi):
         if "extract" in stages:
             # P1: ViT-S/14 block-11 tokens, stride 7.  The fp16 overflow word of the encoder is read once per video, behind
             # the tracker's own synchronisations, instead of draining the stream between P1 and P2
@@ -198,9 +198,42 @@ def main():
                 raise
         return res
 
+    # ---- ragged batches (round 6): clips of different lengths need their own Tracker (geometry is fixed per object); built
+    # outside every timed region, one per distinct length this rank is assigned
+    ctx = {T: (trk, mi)}
+
+    def ctx_for(L):
+        if L not in ctx:
+            t2 = Tracker(video=videos[0][:L], dino_features=ex.encode(videos[0][:L]), dino_patch_size=14, stride=7, device=dev,
+                         track_method=method)
+            t2.tracker_head.load_state_dict(head)
+            t2.delta_dino.load_state_dict(delta)
+            t2.to(dev).eval()
+            t2.track_round_sources = args.track_round
+            ctx[L] = (t2, ModelInference(t2, RangeNormalizer((W, H, L), device=dev), 0.7, 0.6))
+        return ctx[L]
+
+    def scheduled_batch(lengths):
+        """LPT assignment by frame count, this rank's list back to back, ONE gather at the end (sharding.run_scheduled)."""
+        def run(v):
+            tk, m_ = ctx[lengths[v]]
+            return one_video(videos[(v // world) % n_distinct][:lengths[v]], tk, m_)
+        return sharding.run_scheduled(lengths, N, dev, run)
+
+    batch_lengths = None
+    if args.videos > 0 and args.video_lengths:
+        ll = [int(x) for x in args.video_lengths.split(",") if x]
+        assert all(1 < x <= T for x in ll), "--video-lengths: every length in (1, --frames]"
+        batch_lengths = [ll[v % len(ll)] for v in range(args.videos)]
+        mine_tbl = sharding.lpt_assignment([sharding.video_cost(x) for x in batch_lengths], world)[rank]
+        for v in mine_tbl:
+            ctx_for(batch_lengths[v])
+
     def step():
         if qpar:
             return sharding.query_parallel_step(trk, ex, mi, videos[0], queries, dev, stages)
+        if args.videos > 0 and batch_lengths is not None:
+            return scheduled_batch(batch_lengths)
         if args.videos > 0:
             res = sharding.run_sharded(args.videos, N, T, dev, lambda v: one_video(videos[(v // world) % n_distinct]))
             return res
@@ -255,6 +288,7 @@ def main():
                     "result_gather_ms_rank0": round(g_ms, 4),
                     "note": "wall time of the K timed steps on each rank (value uses the max); the gather is the only collective of a step"}
     videos_per_step = 1 if qpar else (args.videos if args.videos > 0 else world)
+    frames_per_step = sum(batch_lengths) if batch_lengths is not None else videos_per_step * T   # query-points x FRAMES: ragged batches count their own
 
     # ---- north_star's strong-scaling form in the SAME line: a batch of 30 videos sharded v = r (mod world),
     # 4/4/4/4/4/4/3/3 on 8 ranks, one RCCL gather per round; a second timed phase (one step, the kernels are warm) so that the
@@ -262,19 +296,44 @@ def main():
     videos30 = None
     if args.videos == 0 and not qpar and not args.no_videos30 and stages == ["extract", "refine", "track"] and args.features == "vit":
         V30 = 30
-        barrier()
-        c0 = time.perf_counter()
-        sharding.run_sharded(V30, N, T, dev, lambda v: one_video(videos[(v // world) % n_distinct]))
-        barrier()
-        d30 = time.perf_counter() - c0
-        if world > 1:
-            t30 = torch.tensor([d30], device=dev, dtype=torch.float64)
-            dist.all_reduce(t30, op=dist.ReduceOp.MAX)
-            d30 = float(t30.item())
+
+        def timed(fn):
+            barrier()
+            c0 = time.perf_counter()
+            fn()
+            barrier()
+            d = time.perf_counter() - c0
+            if world > 1:
+                tt = torch.tensor([d], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                d = float(tt.item())
+            return d
+
+        def sched_report(lengths):   # makespans in cost units (sharding.video_cost): what the schedule costs against the ideal
+            cs = [sharding.video_cost(x) for x in lengths]
+            rep = {f"world_{w}": {k: round(v, 1) for k, v in sharding.schedule_costs(cs, w).items()} for w in sorted({world, 8})}
+            rep["unit"] = "sharding.video_cost units; ideal = max(mean load, largest video), lpt = max_r sum (run_scheduled), lockstep = sum of round maxima (run_sharded); world_8 is arithmetic, not a run, unless n_gpus = 8"
+            return rep
+
+        # (a) equal lengths, as in rounds 1-5, now through run_scheduled: LPT = the round-robin counts, ONE gather at the end
+        lengths_eq = [T] * V30
+        d30 = timed(lambda: scheduled_batch(lengths_eq))
+        table = sharding.lpt_assignment([sharding.video_cost(x) for x in lengths_eq], world)
         videos30 = {"videos": V30, "value": round(V30 * N * T / d30, 1), "unit": "query-points*frames/s", "seconds": round(d30, 3),
-                    "scaling": "strong", "videos_by_rank": [len(sharding.videos_of_rank(V30, r, world)) for r in range(world)],
-                    "rounds": (V30 + world - 1) // world,
+                    "scaling": "strong", "videos_by_rank": [len(x) for x in table], "gathers": 1, "schedule": "lpt, back to back, one gather",
+                    "makespan": sched_report(lengths_eq),
                     "note": "one untimed-warm step of the 30-video batch (bench.py --videos 30 is the same thing as the line's own metric)"}
+        # (b) ragged lengths (DAVIS clips run 25 .. 104 frames): the same 30-video batch with five lengths cycled, LPT by frame count
+        fr = sorted({max(2, int(round(T * f))) for f in (0.27, 0.45, 0.62, 0.8, 1.0)})
+        lengths_rg = [fr[v % len(fr)] for v in range(V30)]
+        for v in sharding.lpt_assignment([sharding.video_cost(x) for x in lengths_rg], world)[rank]:
+            ctx_for(lengths_rg[v])
+        scheduled_batch(lengths_rg) if world == 1 else None     # (N = 1: one warm pass so that every length's buffers exist)
+        dr = timed(lambda: scheduled_batch(lengths_rg))
+        videos30["ragged"] = {"lengths": fr, "frames_total": sum(lengths_rg), "value": round(N * sum(lengths_rg) / dr, 1),
+                              "seconds": round(dr, 3), "makespan": sched_report(lengths_rg),
+                              "frames_by_rank": [sum(lengths_rg[v] for v in x) for x in
+                                                 sharding.lpt_assignment([sharding.video_cost(x) for x in lengths_rg], world)]}
 
     # ---- per-kernel pass (separate from the timed region): hipEvents around every launch of the library ---------------
     pairs = int(mi.last_counts[0]) if hasattr(mi, "last_counts") else 0
@@ -577,7 +636,7 @@ def main():
         from dino_tracker_amd import delta_dino as _dd
         p2_mode = {0: "split-f16 conv operands (fp32-grade)", 1: "f16 conv operands"}[_dd.conv_operand_mode(None)]
         out = {
-            "metric": "query-points*frames/s", "value": round(videos_per_step * N * T * args.steps / dt, 1),
+            "metric": "query-points*frames/s", "value": round(frames_per_step * N * args.steps / dt, 1),
             "unit": "query-points*frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if (qpar or args.videos > 0) else "weak",

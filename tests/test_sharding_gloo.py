@@ -165,7 +165,7 @@ def test_lpt_assignment_and_makespans():
         assert sorted(v for lst in a for v in lst) == list(range(30))
         sc = sharding.schedule_costs(costs, world)
         assert abs(sc["lpt"] - max(sum(costs[v] for v in lst) for lst in a)) < 1e-9
-        assert sc["ideal"] <= sc["lpt"] <= (4 / 3 - 1 / (3 * world)) * sc["ideal"] + 1e-9
+        assert sc["ideal"] * (1 - 1e-12) <= sc["lpt"] <= (4 / 3 - 1 / (3 * world)) * sc["ideal"] + 1e-9
         assert sc["lpt"] <= sc["lockstep"] + 1e-9
     sc8 = sharding.schedule_costs(costs, 8)
     assert sc8["lpt"] < 0.85 * sc8["lockstep"], sc8          # the per-round waits cost > 15 % on this batch
