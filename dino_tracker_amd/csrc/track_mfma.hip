@@ -88,21 +88,53 @@ __global__ __launch_bounds__(256) void feat16_kernel(const float* __restrict__ f
     }
 }
 
+// widths served by corr_peaks_wide_kernel (K split over wave pairs): the ViT-B / ViT-L feature widths
+__host__ __device__ inline bool peaks_wide_ok(int C) { return C == 768 || C == 1024; }
+
 // ---- split-fp16 copy of the feature volume (C = 384), the streamed operand of refine_corr_dma ---------------------------
 // fs[cell][chunk kc of 32 channels][hi 32 | lo 32]: x * 32 = hi + lo, both fp16 -- exactly the halves the window
 // correlation otherwise makes while it stages fp32 rows into LDS, made ONCE per volume.  A (cell, chunk) is one 128-byte
 // line, so an LDS-DMA request of 8 cells fetches 8 whole lines and a step needs no VALU and no ds_write at all.
-constexpr float RC_SCALE = 32.f;
+// The scale (round 6): 2^5 as long as the volume's largest cell norm allows it, otherwise the largest power of two with
+// scale x max norm <= 2^14 -- chosen once per volume on the device (rcscale_*_kernel) and kept in a slot at the end of the feat_f16
+// buffer, which the window-correlation kernels read.  Rounds 2-5 had the constant 2^5: features with DINOv2-like outlier statistics
+// (token norms ~4 000, components beyond 2 047) left the fp16 range in a few cells -- the window value became fmaxf(NaN, 0) = 0 and 15
+// of 92 160 positions moved by 0.02 .. 1.3 px (profiles/r06_e2e_error_outlier_854x476x90_1024q.json, first run).  A power of two
+// changes no bit of the results where the old scale did not overflow (benign features keep 2^5).
+constexpr float RC_SCALE_MAX = 32.f;
 __host__ __device__ inline size_t split_planes_offset(const dtk_geom* g) {
     return ((size_t)g->T * hw_pad(g->ph, g->pw) * g->C * 2 + 255) / 256 * 256;
 }
 __host__ __device__ inline bool has_split_planes(const dtk_geom* g) {
-    return g->C == 384 && (long long)g->T * g->ph * g->pw * g->C * 4 < (1LL << 32);  // (32-bit offsets in the descriptor)
+    // (32-bit offsets in the descriptor; round 6: also the wide widths -- refine_corr_dma_kernel<24 / 32>)
+    return (g->C == 384 || peaks_wide_ok(g->C)) && (long long)g->T * g->ph * g->pw * g->C * 4 < (1LL << 32);
+}
+// slot [0]: the scale (float); [1]: bits of the largest cell norm (scratch of the reduction)
+__host__ __device__ inline size_t rc_scale_offset(const dtk_geom* g) {
+    const size_t unit = (size_t)g->T * hw_pad(g->ph, g->pw) * g->C * 2;
+    const size_t end = has_split_planes(g) ? split_planes_offset(g) + (size_t)g->T * g->ph * g->pw * g->C * 4 : unit;
+    return (end + 255) / 256 * 256;
+}
+__global__ __launch_bounds__(256) void rcscale_max_kernel(const float* __restrict__ norms, long long n, unsigned* __restrict__ slot) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = norms[i];
+        m = fmaxf(m, v == v ? v : 3.0e38f);   // (a NaN norm: the smallest scale)
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(slot + 1, __float_as_uint(m));   // norms are >= 0: the bit patterns order like the values
+}
+__global__ void rcscale_final_kernel(unsigned* __restrict__ slot) {
+    const float m = __uint_as_float(slot[1]);
+    float sc = RC_SCALE_MAX;
+    while (sc > 0x1p-40f && m * sc > 16384.f) sc *= 0.5f;
+    reinterpret_cast<float*>(slot)[0] = sc;
 }
 __global__ __launch_bounds__(256) void featsplit_kernel(const float* __restrict__ feat, half_t* __restrict__ fs,
-                                                        long long n8) {
+                                                        long long n8, const float* __restrict__ rc_scale) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // one 8-channel piece
     if (i >= n8) return;
+    const float RC_SCALE = *rc_scale;
     const float4 a = *reinterpret_cast<const float4*>(feat + i * 8), b = *reinterpret_cast<const float4*>(feat + i * 8 + 4);
     const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     h8 hi, lo;
@@ -773,6 +805,234 @@ __global__ __launch_bounds__(256) void corr_peaks_kernel(dtk_geom g, const half_
     }
 }
 
+// ---- corr_peaks for WIDE features (round 6: C = 768 / 1024, the reference's shipped ViT-L configuration) -----------------------
+// At C = 1024 the 64 sources of a wave would need 512 operand registers.  Here the K dimension is split over a PAIR of waves:
+//   workgroup = 4 waves = 2 source groups (sg = w >> 1, 64 sources each) x 2 K halves (kh = w & 1, C / 2 channels each);
+//   a wave keeps ITS K half of its group's 64 sources in the AGPR half of the register file (2 tiles x KSH k-steps x 4 = 256
+//   registers at C = 1024) and reads ITS K half of the cell tile from LDS -- one ds_read_b128 still feeds two MFMAs, as in the
+//   C = 384 kernel, and every wave reads only half of the tile;
+//   the partial sums meet through LDS: of the two accumulators (source tiles t = 0, 1) a wave GIVES the one it does not own
+//   (t = 1 - kh) to its partner and TAKES the partner's partial of the one it owns (t = kh): 4 KB out, 4 KB in per wave and
+//   32-cell tile against 32 KB of fragment reads.  The owner then runs the top-6 list program of corr_peaks_kernel on its 32
+//   sources x 16 cells per lane -- half the list work per MFMA of the C = 384 kernel (128 VALU instructions per 64 MFMA slots).
+// Pipeline per tile n (one wave):  [request tile n+1]  MFMAs of tile n into accN, and between them: partial of tile n-1 out ->
+// barrier B -> partner's partial in -> sums -> list updates of tile n-1;  wait for tile n+1 -> barrier A.
+// The cell tile (32 cells x C x 2 B = 64 KB at C = 1024) sits in a ring of TWO buffers (128 KB) + 16 KB of exchange slots; the
+// LDS image, the DMA requests (8 whole 128-byte lines each), the cell <-> MFMA row checkerboard, the position tags, the candidate
+// band and the record format are those of corr_peaks_kernel, so rescore / refine see no difference.
+constexpr int PKW_SRC = 128;              // sources per workgroup
+constexpr size_t peaks_wide_lds_bytes(int C) { return 2 * (size_t)32 * C * 2 + 4 * 4096 + 64; }
+
+template <int KSH>
+__global__ __launch_bounds__(256) void corr_peaks_wide_kernel(dtk_geom g, const half_t* __restrict__ f16,
+                                                              const half_t* __restrict__ s16, const int32_t* __restrict__ tgt,
+                                                              Rec* __restrict__ rec, int m0, int count, int HWp,
+                                                              const int32_t* __restrict__ row_of, PeaksDone done) {
+    constexpr int C = 32 * KSH;                  // both K halves
+    constexpr int NL = C / 64, NLH = NL / 2;     // 128-byte lines per cell; per K half
+    constexpr int TILE_BYTES = 32 * C * 2;
+    constexpr int TSH = 4;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char cells_dyn[];   // [2][TILE_BYTES] | [4][4096] exchange | s_fr[8]
+    unsigned char* cells = cells_dyn;
+    unsigned char* xch = cells_dyn + 2 * TILE_BYTES;
+    int* s_fr = reinterpret_cast<int*>(cells_dyn + 2 * TILE_BYTES + 4 * 4096);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = w & 1, sg = w >> 1;
+    const int j = lane & 31, h = lane >> 5;
+    const int src0 = blockIdx.x * PKW_SRC + sg * 64;   // first source of this wave's group (index inside the launch)
+    int tf[2];
+    {
+        int lo = INT_MAX, hi = -1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int i = src0 + t * 32 + j;
+            tf[t] = i < count ? min(max(tgt[m0 + i], 0), g.T - 1) : -1;
+            if (tf[t] >= 0) { lo = min(lo, tf[t]); hi = max(hi, tf[t]); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o, WAVE));
+            hi = max(hi, __shfl_xor(hi, o, WAVE));
+        }
+        if (lane == 0) { s_fr[w] = lo; s_fr[4 + w] = hi; }
+    }
+    // the sources: B operand, lane (j, h) holds source j of tile t, channels kh C/2 + 16 ks + 8 h .. + 7 -- straight into AGPRs
+    h8 bs[2][KSH];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int i = src0 + t * 32 + j;
+        const int ic = min(i, count - 1);
+        const half_t* sp = s16 + (size_t)(row_of ? row_of[m0 + ic] : ic) * C + kh * (C / 2) + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < KSH; ++ks)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(bs[t][ks]) : "v"(sp + ks * 16) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KSH; ++ks) asm volatile("" : "+a"(bs[t][ks]));
+    __syncthreads();
+    const int fmin = min(min(s_fr[0], s_fr[1]), min(s_fr[2], s_fr[3]));
+    const int fmax = max(max(s_fr[4], s_fr[5]), max(s_fr[6], s_fr[7]));
+    const int tiles_per_row = pw_pad(g.pw) / 32;
+    const unsigned lds_base = (unsigned)(size_t)cells;
+    const int NT = HWp / 32;
+    const int band = (int)(EPS_PK * (float)(1 << PK_VAL_BITS)) << PK_IDX_BITS;
+    const dtk_u4 srd = dtk_make_srd(f16);
+    unsigned voff_even, voff_odd;
+    {
+        const int pos = 8 * w + (lane >> 3), slot = lane & 7;
+        const int jr = (pos & 16) | ((pos >> 1) & 7) | ((pos & 1) << 3);      // the MFMA row whose cell sits at `pos`
+        const int cell = 8 * (jr >> 3) + 2 * (jr & 3) + ((jr >> 2) & 1);
+        const int piece = slot ^ (jr & 7);
+        voff_even = (unsigned)(cell * C * 2 + piece * 16);
+        voff_odd = (unsigned)((cell ^ 1) * C * 2 + piece * 16);
+    }
+    const unsigned dma_dst = __builtin_amdgcn_readfirstlane(lds_base + w * 1024);
+    unsigned frag_off[4];
+    {
+        const int pi = (j & 16) | ((j & 7) << 1) | ((j >> 3) & 1);
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) frag_off[k4] = (unsigned)(kh * NLH * 4096 + pi * 128 + (((2 * k4 + h) ^ (j & 7)) << 4));
+    }
+    // exchange slots: [wave][quad of accumulator registers][lane] x 16 B; both waves of a pair map lanes to (source, cells) alike
+    unsigned char* x_mine = xch + w * 4096 + lane * 16;
+    const unsigned char* x_partner = xch + (w ^ 1) * 4096 + lane * 16;
+    for (int f = fmin; f <= fmax; ++f) {
+        unsigned next_off = __builtin_amdgcn_readfirstlane((unsigned)f * (unsigned)HWp * (unsigned)(C * 2));   // (volume < 4 GB: host check)
+        int next_in_row = 0, next_odd = 0;
+        auto issue = [&](int buf) {   // the tiles are requested in order: 0, 1, 2, ...
+            const unsigned voff = next_odd ? voff_odd : voff_even;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(dma_dst + (unsigned)buf * (unsigned)TILE_BYTES);
+            peaks_dma<0, NL, NL, C>(srd, next_off, voff, dst);
+            next_off += (unsigned)(32 * C * 2);
+            if (++next_in_row == tiles_per_row) { next_in_row = 0; next_odd ^= 1; }
+        };
+        int v[PK_TOP];
+#pragma unroll
+        for (int k = 0; k < PK_TOP; ++k) v[k] = 0;
+        // partial of the tile this wave does NOT own -> its exchange slot
+        auto give = [&](const f16v (&acc)[2]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<f4*>(x_mine + i * 1024) = f4{acc[1 - kh][4 * i], acc[1 - kh][4 * i + 1], acc[1 - kh][4 * i + 2], acc[1 - kh][4 * i + 3]};
+        };
+        // one step: the MFMAs of the tile in `buf` into accN; between them the exchange and the list updates of the previous tile
+        // (accP, step index np).  `more`: a further tile exists and is requested into the other buffer first.
+        auto step = [&](int buf, f16v (&accN)[2], const f16v (&accP)[2], bool have_prev, int np, bool more) {
+            if (more) issue(buf ^ 1);
+            const unsigned char* base = cells + (size_t)buf * TILE_BYTES;
+            auto frag = [&](int ks) { return *reinterpret_cast<const h8*>(base + frag_off[ks & 3] + (ks >> 2) * 4096); };
+            const int ib = np << TSH;
+            const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int key = 0;
+            f4 xr[4];
+            float val[16];
+            h8 a[3];
+            a[0] = frag(0);
+            a[1] = frag(1);
+            constexpr int NSLOT = 2 * KSH, L0 = 8, NINS = 16 * 8;   // list instructions run in slots L0 .. NSLOT-1
+            peaks_static_for<0, NSLOT>([&](auto qc) {
+                constexpr int q = decltype(qc)::value, ks = q / 2, t = q % 2;
+                if (t == 0 && ks + 2 < KSH) a[(ks + 2) % 3] = frag(ks + 2);
+                accN[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks % 3], bs[t][ks], ks == 0 ? zero16 : accN[t], 0, 0, 0);
+                if (have_prev) {
+                    if constexpr (q == 1) give(accP);
+                    if constexpr (q == 2) __syncthreads();   // barrier B: every partial of the previous tile is in its slot
+                    if constexpr (q == 3) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) xr[i] = *reinterpret_cast<const f4*>(x_partner + i * 1024);
+                    }
+                    if constexpr (q == 6) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) val[r] = accP[kh][r] + xr[r >> 2][r & 3];
+                    }
+                    if constexpr (q >= L0) {
+                        peaks_static_for<(q - L0) * NINS / (NSLOT - L0), (q - L0 + 1) * NINS / (NSLOT - L0)>([&](auto ic) {
+                            constexpr int i = decltype(ic)::value, e = i >> 3;
+                            top_push_op<(i & 7)>(v, val[e], ib | e, key);
+                        });
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            glds_wait<0>();      // the next tile has landed (this wave's requests; the barrier covers the others')
+            __syncthreads();     // barrier A: the tile is published, `buf` and the exchange slots are free
+        };
+        // the last tile's partials: no MFMAs to hide under
+        auto finish = [&](const f16v (&acc)[2], int np) {
+            give(acc);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f4 x = *reinterpret_cast<const f4*>(x_partner + i * 1024);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) top_push_value(v, acc[kh][4 * i + c] + x[c], (np << TSH) | (4 * i + c));
+            }
+        };
+        f16v accA[2], accB[2];
+        issue(0);
+        glds_wait<0>();
+        __syncthreads();
+        int n = 0;
+        for (; n + 1 < NT; n += 2) {
+            step(0, accA, accB, n > 0, n - 1, true);
+            step(1, accB, accA, true, n, n + 2 < NT);
+        }
+        if (n < NT) {   // NT odd: one more tile
+            step(0, accA, accB, n > 0, n - 1, false);
+            finish(accA, n);
+        } else {
+            finish(accB, n - 1);
+        }
+        __syncthreads();   // every wave is done with the buffers and the slots before the next frame restages them
+        // merge the two lane halves of each source of the OWNED tile and write its record (as corr_peaks_kernel)
+        {
+            const int t = kh;
+            int o[PK_TOP];
+#pragma unroll
+            for (int k = 0; k < PK_TOP; ++k) o[k] = __shfl(v[k], lane ^ 32, WAVE);
+            const int i = src0 + t * 32 + j;
+            if (h == 0 && tf[t] == f) {
+                const int amax_i = max(v[0], o[0]);
+                const int thr = amax_i - band;
+                int nc = 0, c0 = 0;
+                Rec* rr = rec + i;
+                const int PWP = pw_pad(g.pw);
+#pragma unroll
+                for (int k = 0; k < 2 * PK_TOP; ++k) {
+                    const int xi = k < PK_TOP ? v[k] : o[k - PK_TOP];
+                    if (xi >= thr) {
+                        const int tag = xi & ((1 << PK_IDX_BITS) - 1);
+                        const int r = tag & 15, st = tag >> TSH;
+                        const int pc = st * 32 + 8 * (r >> 2) + 2 * (r & 3) + ((k < PK_TOP ? 0 : 1) ^ ((st / tiles_per_row) & 1));
+                        const int row = pc / PWP, col = pc - row * PWP;
+                        const int cellc = row * g.pw + min(col, g.pw - 1);
+                        if (nc < KC) rr->cand[nc] = cellc;
+                        if (nc == 0) c0 = cellc;
+                        ++nc;
+                    }
+                }
+                if (v[PK_TOP - 1] >= thr || o[PK_TOP - 1] >= thr || thr <= 0) nc = KC + 1;
+                const float amax = (float)(amax_i >> PK_IDX_BITS) * (1.f / (float)(1 << PK_VAL_BITS));
+                rr->amax = amax;
+                rr->zmax = 0.f;
+                rr->Z = -1.f;
+                if (done.kstar != nullptr && nc == 1 && amax > 2.f * EPS_C) {
+                    rr->ncand = -1;   // finished: rescore_kernel skips it
+                    done.kstar[i] = c0;
+                    done.snorm[i] = done.rown[row_of[m0 + i]];
+                    atomicAdd(&done.hist[(size_t)f * done.HWk + cell_key(c0, g.pw)], 1);
+                } else {
+                    rr->ncand = nc;
+                }
+            }
+        }
+    }
+}
+
 // head16_kernel: one workgroup per map.  The map sits in LDS as fp16 with a zero border; besides the approximate maximum
 // and the candidate cells, the whole refiner runs on the matrix cores without ever staging the hidden activations:
 //   conv1 as GEMM1 (MFMA 16x16x16 f16):  h^T[16 ch][16 px] = W1[16 ch][K = 3 rows x (3 taps + pad) | bias] . X[K][16 px]
@@ -1215,7 +1475,9 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(dtk_geom g, const floa
                                                           const float* __restrict__ snorm,
                                                           const int32_t* __restrict__ perm,
                                                           const int32_t* __restrict__ nvalid,
-                                                          float* __restrict__ xwin, int m0, int ntiles, int dbg) {
+                                                          float* __restrict__ xwin, int m0, int ntiles, int dbg,
+                                                          const float* __restrict__ rc_scale) {
+    const float RC_SCALE = *rc_scale;
     __shared__ float s_sn[RC_SRC];
     __shared__ int s_row[RC_SRC], s_f[RC_SRC], s_k[RC_SRC], s_m[RC_SRC], s_grp[RC_SRC], s_box[RC_SRC * 4], s_first[RC_SRC],
         s_last[RC_SRC], s_ng;
@@ -1402,7 +1664,7 @@ __device__ __forceinline__ void vm_wait_n(int n) {
 // (no branch, so the count is static); the norms of the box come from LDS (a compiler-managed global load here would be
 // waited for with vmcnt(0) and drain the ring).
 template <int NKC, int NS, int NBM, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void refine_corr_dma_kernel(dtk_geom g, const half_t* __restrict__ fs,
+__global__ __launch_bounds__(64 * NW, (NW == 8 || NKC > 12) ? (NKC > 24 ? 1 : 2) : 3) void refine_corr_dma_kernel(dtk_geom g, const half_t* __restrict__ fs,
                                                               const float* __restrict__ norms,
                                                               const float* __restrict__ emb,
                                                               const int32_t* __restrict__ src_row,
@@ -1412,7 +1674,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void refine_corr_dma_kern
                                                               const int32_t* __restrict__ perm,
                                                               const int32_t* __restrict__ nvalid,
                                                               float* __restrict__ xwin, unsigned xwin_bytes, int m0,
-                                                              int ntiles) {
+                                                              int ntiles, const float* __restrict__ rc_scale) {
+    const float RC_SCALE = *rc_scale;   // (a scalar load, before the ring starts: the vmcnt bookkeeping below never sees it)
     // NS = stages of the LDS ring, NBM = largest union box (cells) correlated as one group
     constexpr int STAGE = 64 * 128;    // bytes: 64 cells x (32 hi + 32 lo) halves
     static_assert(NKC % NS == 0 && NKC >= NS, "the stage of a step is chosen at compile time");
@@ -1882,7 +2145,8 @@ extern "C" int dtk_debug_counters(unsigned long long* out4) {
 extern "C" size_t dtk_feat_f16_bytes(const dtk_geom* g) {
     if (!g || g->T <= 0 || g->C <= 0) return 0;
     const size_t unit = (size_t)g->T * hw_pad(g->ph, g->pw) * g->C * 2;
-    return has_split_planes(g) ? split_planes_offset(g) + (size_t)g->T * g->ph * g->pw * g->C * 4 : unit;
+    (void)unit;
+    return rc_scale_offset(g) + 256;   // unit-norm copy [+ split planes] + the scale slot of the window correlations
 }
 
 extern "C" int dtk_make_feat_f16(const dtk_geom* g, const float* feat, const float* norms, void* feat_f16, void* stream) {
@@ -1892,10 +2156,20 @@ extern "C" int dtk_make_feat_f16(const dtk_geom* g, const float* feat, const flo
     const long long cells = (long long)g->T * HWp;
     DTK_LAUNCH("feat16", feat16_kernel, dim3(dtk_cdiv(cells, 4)), dim3(256), 0, dtk_stream(stream), feat, norms,
                reinterpret_cast<half_t*>(feat_f16), g->T, g->ph, g->pw, pw_pad(g->pw), g->C);
+    // the scale of the window correlations' fp16 halves: from the largest cell norm of THIS volume (see RC_SCALE_MAX)
+    unsigned* slot = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(feat_f16) + rc_scale_offset(g));
+    DTK_HIP(hipMemsetAsync(slot, 0, 256, dtk_stream(stream)));
+    {
+        const long long nn = (long long)g->T * g->ph * g->pw;
+        const int blocks = (int)(dtk_cdiv(nn, 256) < 512 ? dtk_cdiv(nn, 256) : 512);
+        DTK_LAUNCH("rcscale", rcscale_max_kernel, dim3(blocks), dim3(256), 0, dtk_stream(stream), norms, nn, slot);
+        DTK_LAUNCH("rcscale", rcscale_final_kernel, dim3(1), dim3(1), 0, dtk_stream(stream), slot);
+    }
     if (has_split_planes(g)) {
         const long long n8 = (long long)g->T * g->ph * g->pw * g->C / 8;
         DTK_LAUNCH("featsplit", featsplit_kernel, dim3(dtk_cdiv(n8, 256)), dim3(256), 0, dtk_stream(stream), feat,
-                   reinterpret_cast<half_t*>(reinterpret_cast<unsigned char*>(feat_f16) + split_planes_offset(g)), n8);
+                   reinterpret_cast<half_t*>(reinterpret_cast<unsigned char*>(feat_f16) + split_planes_offset(g)), n8,
+                   reinterpret_cast<const float*>(slot));
     }
     return DTK_OK;
 }
@@ -1934,9 +2208,12 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
         const int scnt = (int)((M - s0) < L.super ? (M - s0) : L.super);
         // source-stationary fused correlation + selection (C = 384, position tags of 13 bits)
         const int pk_cb = DTK_DBG(dbg, 65536) ? 2 : PK_CB, pk_cells = 32 * pk_cb;
-        const bool peaks = fast && g->C == 384 && L.HWp / pk_cells <= (1 << (PK_IDX_BITS - (pk_cb > 1 ? 5 : 4))) &&
-                           L.HWp % pk_cells == 0 && pw_pad(g->pw) % pk_cells == 0 && !DTK_DBG(dbg, 2048) &&
-                           (long long)g->T * L.HWp * g->C * 2 < (1LL << 32);   // (32-bit tile offsets of the LDS-DMA descriptor)
+        const bool peaks_shape = L.HWp / pk_cells <= (1 << (PK_IDX_BITS - (pk_cb > 1 ? 5 : 4))) &&
+                                 L.HWp % pk_cells == 0 && pw_pad(g->pw) % pk_cells == 0 && !DTK_DBG(dbg, 2048) &&
+                                 (long long)g->T * L.HWp * g->C * 2 < (1LL << 32);   // (32-bit tile offsets of the LDS-DMA descriptor)
+        // round 6: C = 768 / 1024 on the K-split form (corr_peaks_wide_kernel: wave pairs share 64 sources, one K half each)
+        const bool peaks_wide = fast && peaks_wide_ok(g->C) && pk_cb == 1 && peaks_shape;
+        const bool peaks = (fast && g->C == 384 && peaks_shape) || peaks_wide;
         // (histogram and cursors of the round's counting sort: zeroed in front of corr_peaks, whose epilogue already counts)
         DTK_HIP(hipMemsetAsync(ws + L.hist, 0, L.cursor + (size_t)L.nkeys * 4 - L.hist, st));
         if (peaks) {
@@ -1944,7 +2221,7 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
             if (!row_of)
                 DTK_LAUNCH("src16", src16_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, emb, in.src_row, s16, (int)s0, scnt, M,
                            nodm, g->C, PK_SRC_SCALE, (float*)nullptr);
-            const dim3 pgrid(dtk_cdiv(scnt, PK_SRC));
+            const dim3 pgrid(dtk_cdiv(scnt, peaks_wide ? PKW_SRC : PK_SRC));
             // single-candidate sources are finished in corr_peaks' epilogue when the row table (and its norms) exist
             const bool fuse_done = row_table && arg_cell == nullptr && !DTK_DBG(dbg, 2);
             const PeaksDone pdone = fuse_done ? PeaksDone{kstar, snorm, hist, reinterpret_cast<const float*>(ws + L.rown), L.HWk}
@@ -1958,6 +2235,19 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
         DTK_LAUNCH("corr_peaks", (corr_peaks_kernel<24, V, CBV>), pgrid, dim3(256), peaks_lds_bytes(CBV), st, *g, f16, s16,  \
                    in.tgt, rec, (int)s0, scnt, L.HWp, row_of, pdone);                                                        \
     } while (0)
+#define DTK_PEAKS_WIDE(KSHV)                                                                                                  \
+    do {                                                                                                                     \
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_peaks_wide_kernel<KSHV>),   \
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize,                      \
+                                                            (int)peaks_wide_lds_bytes(32 * KSHV));                           \
+        DTK_HIP(attr_);                                                                                                      \
+        DTK_LAUNCH("corr_peaks", (corr_peaks_wide_kernel<KSHV>), pgrid, dim3(256), peaks_wide_lds_bytes(32 * KSHV), st, *g,  \
+                   f16, s16, in.tgt, rec, (int)s0, scnt, L.HWp, row_of, pdone);                                              \
+    } while (0)
+            if (peaks_wide) {
+                if (g->C == 1024) DTK_PEAKS_WIDE(32);
+                else DTK_PEAKS_WIDE(24);
+            } else
 #ifdef DTK_DEV
             if (pk_cb == 2) {
                 switch ((dbg >> 13) & 7) {
@@ -1983,6 +2273,7 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
             DTK_PEAKS(0, PK_CB);
 #endif
 #undef DTK_PEAKS
+#undef DTK_PEAKS_WIDE
         }
         for (long long m0 = s0; m0 < s0 + scnt && !peaks; m0 += L.chunk) {
             const int cnt = (int)((s0 + scnt - m0) < L.chunk ? (s0 + scnt - m0) : L.chunk);
@@ -2018,17 +2309,23 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
                    perm, L.HWk, (int)s0, scnt);
         {
             const int rtiles = dtk_cdiv(scnt, RC_SRC);
+            const float* rc_scale = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(f16) + rc_scale_offset(g));
             if (has_split_planes(g) && !DTK_DBG(dbg, 131072) && (size_t)L.super * WX * WX * 4 < (1ull << 32)) {
                 const int dtiles = dtk_cdiv(scnt, 16 * RCD_NW);
-                DTK_LAUNCH("refine_corr", (refine_corr_dma_kernel<12, RCD_NS, RCD_NBM, RCD_NW>), dim3(8 * dtk_cdiv(dtiles, 8)),
-                           dim3(64 * RCD_NW), 0, st, *g,
-                           reinterpret_cast<const half_t*>(reinterpret_cast<const unsigned char*>(f16) + split_planes_offset(g)),
-                           norms, emb, in.src_row, in.tgt, kstar, snorm, perm, nvalid, xwin, (unsigned)((size_t)scnt * WX * WX * 4),
-                           (int)s0, dtiles);
+#define DTK_RCD(NKCV)                                                                                                          \
+    DTK_LAUNCH("refine_corr", (refine_corr_dma_kernel<NKCV, RCD_NS, RCD_NBM, RCD_NW>), dim3(8 * dtk_cdiv(dtiles, 8)),              \
+               dim3(64 * RCD_NW), 0, st, *g,                                                                                       \
+               reinterpret_cast<const half_t*>(reinterpret_cast<const unsigned char*>(f16) + split_planes_offset(g)), norms, emb,   \
+               in.src_row, in.tgt, kstar, snorm, perm, nvalid, xwin, (unsigned)((size_t)scnt * WX * WX * 4), (int)s0, dtiles, \
+               rc_scale)
+                if (g->C == 1024) DTK_RCD(32);
+                else if (g->C == 768) DTK_RCD(24);
+                else DTK_RCD(12);
+#undef DTK_RCD
             }
             else
                 DTK_LAUNCH("refine_corr", refine_corr_kernel, dim3(8 * dtk_cdiv(rtiles, 8)), dim3(256), 0, st, *g, feat, norms,
-                           emb, in.src_row, in.tgt, kstar, snorm, perm, nvalid, xwin, (int)s0, rtiles, dbg);
+                           emb, in.src_row, in.tgt, kstar, snorm, perm, nvalid, xwin, (int)s0, rtiles, dbg, rc_scale);
         }
         DTK_LAUNCH("refine_head", refine_head_kernel, dim3(dtk_cdiv(scnt, 4)), dim3(256), 0, st, *g, head, in.src_row, in.tgt,
                    in.out_idx, out_xy, rec, kstar, xwin, reinterpret_cast<const float*>(wpk) + 152, redo, uncert,
@@ -2090,8 +2387,8 @@ int dtk_track_mfma(const dtk_geom* g, const float* feat, const float* norms, con
     // Sources that are rows of a small matrix (the anchor stage: N T rows for N T (T + 1) sources): convert the ROWS to fp16 unit
     // vectors once per call instead of every round's sources in order (2.9 ms per benchmark step, 0.4 GB of copies per round);
     // corr_peaks then gathers its 64 sources per wave through src_row.  Needs the row count from the caller (opts->emb_rows).
-    const bool row_table = fast_ok && src_row != nullptr && opts->emb_rows > 0 && opts->emb_rows <= L.super && g->C == 384 &&
-                           !DTK_DBG(dbg, 262144);
+    const bool row_table = fast_ok && src_row != nullptr && opts->emb_rows > 0 && opts->emb_rows <= L.super &&
+                           (g->C == 384 || peaks_wide_ok(g->C)) && !DTK_DBG(dbg, 262144);
     if (row_table)
         DTK_LAUNCH("src16", src16_kernel, dim3(dtk_cdiv(opts->emb_rows, 4)), dim3(256), 0, st, emb, (const int32_t*)nullptr,
                    reinterpret_cast<half_t*>(ws + L.s16), 0, opts->emb_rows, opts->emb_rows, (const int32_t*)nullptr, g->C,

@@ -339,7 +339,9 @@ __device__ __forceinline__ float amax2(float m, float a, float b) { return fmaxf
 template <typename T, int EPI>
 __device__ __forceinline__ void amax_report(float amax, int* ovf) {
     if (IsF16<T>::value && (EPI == EPI_QKV || EPI == EPI_GELU) && ovf) {
-        if (__any(amax >= 65504.f) && (threadIdx.x & 63) == 0) atomicOr(ovf, EPI == EPI_QKV ? 2 : 4);
+        // (65488 = the midpoint below 65504: an fp32 value from there on is STORED as 65504, which the explicit scan of the tensor
+        //  -- DTK_VIT_CHECK_RANGE -- reports)
+        if (__any(amax >= 65488.f) && (threadIdx.x & 63) == 0) atomicOr(ovf, EPI == EPI_QKV ? 2 : 4);
     }
 }
 
@@ -354,7 +356,10 @@ __device__ __forceinline__ void gemm_store_tile(const f4& a, long long mb, int n
                                                 const GemmEpi<T>& e, float& amax) {
     if (IsF16<T>::value && (EPI == EPI_QKV || EPI == EPI_GELU)) {   // rows past M hold the repeated last row: harmless
         const float sc = (EPI == EPI_QKV && n < e.D) ? e.qscale : 1.f;
-        amax = amax2(amax2(amax, (a[0] + bias) * sc, (a[1] + bias) * sc), (a[2] + bias) * sc, (a[3] + bias) * sc);
+        // what is STORED: Q already scaled; for the MLP hidden GELU(v) -- v for large positive v, ~0 for negative ones (ADVICE r5:
+        // the pre-activation's |v| flagged a harmless v <= -65504): the positive part
+        if (EPI == EPI_GELU) amax = fmaxf(fmaxf(fmaxf(amax, a[0] + bias), fmaxf(a[1] + bias, a[2] + bias)), a[3] + bias);
+        else amax = amax2(amax2(amax, (a[0] + bias) * sc, (a[1] + bias) * sc), (a[2] + bias) * sc, (a[3] + bias) * sc);
     }
     if (EPI == EPI_QKV) {
         const int which = n / e.D, rem = n - which * e.D;
@@ -590,7 +595,7 @@ __device__ __forceinline__ void gemm_store_tile_t(const f4& a, long long m, int 
             *reinterpret_cast<T4*>(dst) = T4{(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
         }
     } else if (EPI == EPI_GELU) {
-        if (IsF16<T>::value) amax = amax2(amax2(amax, v[0], v[1]), v[2], v[3]);
+        if (IsF16<T>::value) amax = fmaxf(fmaxf(fmaxf(amax, v[0]), fmaxf(v[1], v[2])), v[3]);   // GELU(v) = v where it is large: the positive part
         if (m >= M) return;
         // (the packed polynomial GELU of the weight-stationary kernels: |error| < 6e-5, below the 16-bit rounding of the result;
         //  libm's erff costs ~10 x the instructions, and this epilogue runs for 4096 features of every token in fc1)
@@ -937,7 +942,10 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const T* __restrict__ A, c
         const bool ok = m_ep < M && nb < N && !DTK_DBG(e.no_store, 3);
         if (IsF16<T>::value && (EPI == EPI_QKV || EPI == EPI_GELU)) {   // the fp16 range, every value of every frame (GemmEpi::ovf)
 #pragma unroll
-            for (int r = 0; r < 8; r += 2) amax = amax2(amax, v[r] * qsc, v[r + 1] * qsc);
+            for (int r = 0; r < 8; r += 2) {
+                if (EPI == EPI_GELU) amax = fmaxf(fmaxf(amax, v[r]), v[r + 1]);   // the stored GELU(v): the positive part of v
+                else amax = amax2(amax, v[r] * qsc, v[r + 1] * qsc);
+            }
         }
         if (EPI == EPI_GELU) {
             T8 o;

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const T* __restrict_
             split_store_tile<T, EPI>(acc[mi][ni], m0 + wr * 64 + mi * 16 + fj, nb, M, N, e, amax);
     }
     if (IsF16<T>::value && (EPI == SEPI_QKV || EPI == SEPI_GELU) && e.ovf) {
-        if (__any(amax >= 65504.f) && lane == 0) atomicOr(e.ovf, EPI == SEPI_QKV ? 2 : 4);
+        if (__any(amax >= 65488.f) && lane == 0) atomicOr(e.ovf, EPI == SEPI_QKV ? 2 : 4);
     }
 #undef SP_FETCH
 #undef SP_STASH

@@ -109,8 +109,8 @@ typedef struct dtk_vit_model {
     int32_t frame_batch;          /* frames per pass of the encoder (workspace grows with it: 87 MB per frame at 854 x 476, ViT-S); 0 = the library's default (90) */
     int32_t* overflow;            /* DEVICE word or NULL; OR-ed with 1 when a residual update (projection / MLP output) reached
                                    * the fp16 limit 65504 or is not finite (every token of every frame: the LayerNorm that
-                                   * applies the update checks it), with 2 / 4 when a value the QKV / fc1 GEMM stores (Q, K, V /
-                                   * the MLP hidden) did: tracked inside those GEMMs' epilogues for every value of every
+                                   * applies the update checks it), with 2 / 4 when a value the QKV / fc1 GEMM STORES (Q after
+                                   * its scale, K, V / the MLP hidden AFTER the GELU) did: tracked inside those GEMMs' epilogues for every value of every
                                    * frame (round 5; DTK_VIT_CHECK_RANGE adds a scan of the stored tensors, the tests'
                                    * cross-check).  The caller zeroes it.  fp16 activations
                                    * SATURATE (FP16_OVFL mode) instead of becoming inf; a non-zero word means the features
@@ -360,9 +360,12 @@ int dtk_bb_nms(const dtk_geom* g, const float* feat, const float* norms, const f
 /* 16-bit copies of the feature volume consumed by DTK_TRACK_MFMA (C % 32 == 0), one buffer of dtk_feat_f16_bytes(g):
  *   - f16[t][row][col][c] = 32 F/|F|, every map row padded with zero cells to a multiple of 128 columns (an N-tile of the
  *     candidate GEMM is one map row);
- *   - at C = 384, behind it (256-byte aligned): the split planes of the window correlation, [t][cell][chunk of 32
- *     channels][hi 32 | lo 32] with 32 F = hi + lo (fp16 both) -- T*ph*pw*C*4 more bytes, made once per volume instead of
- *     once per staged element of every window box. */
+ *   - at C = 384 / 768 / 1024, behind it (256-byte aligned): the split planes of the window correlation, [t][cell][chunk of 32
+ *     channels][hi 32 | lo 32] with s F = hi + lo (fp16 both) -- T*ph*pw*C*4 more bytes, made once per volume instead of
+ *     once per staged element of every window box;
+ *   - behind that (256-byte aligned), a 256-byte slot whose first float is s: 2^5, or the largest power of two with
+ *     s * (largest cell norm of the volume) <= 2^14 when the features are large (round 6: DINOv2-like outlier statistics put
+ *     components beyond 2047 = 65504 / 32) -- chosen on the device by dtk_make_feat_f16, read by the window-correlation kernels. */
 size_t dtk_feat_f16_bytes(const dtk_geom* g);
 int dtk_make_feat_f16(const dtk_geom* g, const float* feat, const float* norms, void* feat_f16, void* stream);
 

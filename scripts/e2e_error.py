@@ -5,7 +5,8 @@ default since round 3; `bf16` as fifth argument gives the round-2 arithmetic for
 Writes gpurun_out/e2e_error_*.json (copied to profiles/ by hand).
 Usage: python scripts/e2e_error.py [H W T nq [fp16|bf16 [split,fp16 [cpu|cuda [bench|ls1|outlier [fast,split,auto,...]]]]]]
   (5: ViT operand type; 6: Delta-DINO operand modes, one run each; 7: where the oracle runs; 8: the ViT weights -- round 6:
-  `outlier` = synth.make_outlier_vit_weights, DINOv2-like statistics; 9: VitExtractor precision modes, one run each)"""
+  `outlier` = synth.make_outlier_vit_weights, DINOv2-like statistics; 9: VitExtractor precision modes, one run each; 10: the model,
+  dinov2_vitl14 = the reference's shipped configuration, block 15, C = 1024)"""
 import json
 import os
 import sys
@@ -58,29 +59,32 @@ def argmax_margins(refined, queries, H, W, radius=35.0, stride=7):
 _ORACLE_CACHE = {}
 
 
-def vit_weights(weights, layerscale=0.1):
-    """bench: the benchmark's seeded ViT-S (LayerScale `layerscale`); ls1: the same with LayerScale 1.0 (the hub models'
+def vit_weights(weights, layerscale=0.1, model="dinov2_vits14"):
+    """bench: the benchmark's seeded ViT (LayerScale `layerscale`); ls1: the same with LayerScale 1.0 (the hub models'
     init_values); outlier: synth.make_outlier_vit_weights (massive activations, gains to 8, a sharp block, a 300 x MLP)."""
     if weights == "outlier":
-        return synth.make_outlier_vit_weights(300.0)
-    return synth.make_vit_weights("dinov2_vits14", seed=2, layerscale=1.0 if weights == "ls1" else layerscale)
+        return synth.make_outlier_vit_weights(300.0, model)
+    return synth.make_vit_weights(model, seed=2 if model == "dinov2_vits14" else 6, layerscale=1.0 if weights == "ls1" else layerscale)
 
 
-def _oracle(H, W, T, nq, layerscale, seed, od="cpu", weights="bench"):
+MODEL_LAYER = {"dinov2_vits14": None, "dinov2_vitb14": None, "dinov2_vitl14": 15}   # config/preprocessing.yaml:9-12: ViT-L, block 15
+
+
+def _oracle(H, W, T, nq, layerscale, seed, od="cpu", weights="bench", model="dinov2_vits14"):
     """The fp32 oracle's side of the comparison (minutes on CPU, seconds with od = "cuda": the restatement takes its device from
     its inputs), cached so that several device configurations share it."""
-    key = (H, W, T, nq, layerscale, seed, od, weights)
+    key = (H, W, T, nq, layerscale, seed, od, weights, model)
     if key not in _ORACLE_CACHE:
-        name = "dinov2_vits14"
-        sd_cpu = vit_weights(weights, layerscale)
+        name = model
+        sd_cpu = vit_weights(weights, layerscale, model)
         video_cpu = synth.synth_video(T, H, W, seed=seed)
         head_cpu = synth.synth_head_weights(3)
-        delta_cpu = synth.synth_delta_dino_weights(384, seed=4)
+        delta_cpu = synth.synth_delta_dino_weights(synth.VIT_CONFIGS[model]["dim"], seed=4)
         queries_cpu = synth.grid_queries(nq, nq, H, W, 0, margin=min(60.0, H / 6))
         to = lambda d: {k: v.to(od) for k, v in d.items()}  # noqa: E731
         sd, head, delta, video, queries = to(sd_cpu), to(head_cpu), to(delta_cpu), video_cpu.to(od), queries_cpu.to(od)
         t0 = time.time()
-        dino = torch.stack([A.vit_tokens(video[t:t + 1], sd, name) for t in range(T)])
+        dino = torch.stack([A.vit_tokens(video[t:t + 1], sd, name, layer=MODEL_LAYER[model]) for t in range(T)])
         refined = A.refine_features(video, dino, delta)
         rt, ro, rcs, _ = A.infer(refined, queries, head, H, W, return_aux=True)
         if od != "cpu":
@@ -110,19 +114,19 @@ def arbitrate(o, dev_refined, traj, H, W, flagged):
 
 
 def run(H, W, T, nq, layerscale=0.1, seed=2000, operand_dtype="fp16", p2_operands=None, oracle_device="cpu", weights="bench",
-        precision="fast", on_overflow="split-bf16"):
+        precision="fast", on_overflow="split-bf16", model="dinov2_vits14"):
     """oracle_device: "cpu" (the form pinned on the reference; minutes at T = 16) or "cuda" (the same restatement on device
     tensors in fp32 -- what makes T = 90 / 1024 queries affordable; pinned against the CPU form in tests/test_gpu_fullsize.py)."""
     dev = "cuda:0"
     od = oracle_device
-    o = _oracle(H, W, T, nq, layerscale, seed, od, weights)
+    o = _oracle(H, W, T, nq, layerscale, seed, od, weights, model)
     name, sd, video, head, delta, queries = o["name"], o["sd"], o["video"], o["head"], o["delta"], o["queries"]
     dino, refined, rt, ro, rcs = o["dino"], o["refined"], o["rt"], o["ro"], o["rcs"]
     ex = VitExtractor(name, stride=7, device=dev, state_dict=sd, operand_dtype=operand_dtype, precision=precision,
                       on_overflow=on_overflow)
     torch.cuda.synchronize()
     t0 = time.time()
-    feat = ex.encode(video.to(dev))
+    feat = ex.encode(video.to(dev), layer=MODEL_LAYER[model])
     torch.cuda.synchronize()
     encode_seconds = time.time() - t0
     trk = Tracker(video=video.to(dev), dino_features=feat, dino_patch_size=14, stride=7, device=dev)
@@ -175,10 +179,10 @@ def run(H, W, T, nq, layerscale=0.1, seed=2000, operand_dtype="fp16", p2_operand
                                     "frac_le_1e-3": (dec <= 1e-3).float().mean().item()},
         "points_beyond_1e-3px": len(flagged), "arbitrated": arb,
         "arbitration_failures": sum(0 if a["ok"] else 1 for a in arb),
-        "config": f"{W}x{H}x{T}, {nq * nq} queries, ViT-S/14 {weights} weights (LayerScale {layerscale if weights == 'bench' else '-'}), "
+        "config": f"{W}x{H}x{T}, {nq * nq} queries, {model} {weights} weights (LayerScale {layerscale if weights == 'bench' else '-'}), "
                   f"seed {seed}, {operand_dtype} ViT operands, precision {precision}, Delta-DINO convolution operands "
                   f"{p2_operands or 'default'}, oracle on {od}",
-        "weights": weights, "precision": precision, "precision_report": ex.precision_report(), "encode_seconds": encode_seconds,
+        "weights": weights, "model": model, "track_tiers": dict(trk.last_track_stats) if trk.last_track_stats else None, "precision": precision, "precision_report": ex.precision_report(), "encode_seconds": encode_seconds,
         "arbitrated_rate": len(flagged) / max(1, int(err.numel())),
         "feature_rel_err_P1": rel, "feature_rel_err_refined": rel_refined,
         "px_err_vs_oracle_on_same_video": {"p50": err.quantile(q[0]).item(), "p90": err.quantile(q[1]).item(),
@@ -204,13 +208,15 @@ if __name__ == "__main__":
     od = sys.argv[7] if len(sys.argv) > 7 else "cpu"
     weights = sys.argv[8] if len(sys.argv) > 8 else "bench"
     precisions = sys.argv[9].split(",") if len(sys.argv) > 9 else ["fast"]
+    model = sys.argv[10] if len(sys.argv) > 10 else "dinov2_vits14"
     out = []
     for pr in precisions:
         # "bf16" as a precision name: plain bf16 operands (the round-5 heal target), for the three-way table of docs/PARITY.md
         kw = dict(operand_dtype="bf16", precision="fast") if pr == "bf16" else dict(operand_dtype=dt, precision=pr)
-        out += [run(*a, p2_operands=m, oracle_device=od, weights=weights, **kw) for m in modes]
+        out += [run(*a, p2_operands=m, oracle_device=od, weights=weights, model=model, **kw) for m in modes]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    tag = f"{a[0]}x{a[1]}x{a[2]}_{dt}" + ("" if weights == "bench" and precisions == ["fast"] else f"_{weights}_{'-'.join(precisions)}")
+    tag = f"{a[0]}x{a[1]}x{a[2]}_{dt}" + ("" if weights == "bench" and precisions == ["fast"] else f"_{weights}_{'-'.join(precisions)}") + \
+        ("" if model == "dinov2_vits14" else "_" + model[-5:])
     with open(os.path.join(ROOT, "gpurun_out", f"e2e_error_{tag}.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     # the arbitrated lists are long under outlier weights: print the summary only

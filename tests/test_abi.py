@@ -61,7 +61,8 @@ def test_hot_path_refuses_cpu_tensors():
 
 def test_struct_layouts_match_header():
     """The ctypes mirrors of the option / statistics structs have the size include/dtk.h's declarations imply (round 4 added
-    dtk_track_opts.emb_rows), and the feat_f16 buffer grows by the split planes exactly at C = 384 (no device needed)."""
+    dtk_track_opts.emb_rows), and the feat_f16 buffer grows by the split planes exactly at C = 384 / 768 / 1024 and by the scale slot
+    (no device needed)."""
     import re
     text = open(entry.os.path.join(entry.ROOT, "include", "dtk.h")).read()
     body = re.search(r"typedef struct dtk_track_opts \{(.*?)\} dtk_track_opts;", text, flags=re.S).group(1)
@@ -70,12 +71,14 @@ def test_struct_layouts_match_header():
     assert fields == [name for name, _ in _lib.TrackOpts._fields_]
     assert ctypes.sizeof(_lib.TrackOpts) == 4 * len(fields)
     handle = _lib.lib()
-    for C, extra in ((384, True), (256, False)):
+    for C, extra in ((384, True), (256, False), (768, True), (1024, True)):   # (round 6: split planes at the ViT-B / ViT-L widths too)
         g = _lib.make_geom(3, C, 140, 210)
         unit = 3 * g.ph * ((g.pw + 127) // 128 * 128) * C * 2
         total = handle.dtk_feat_f16_bytes(g)
         planes = 3 * g.ph * g.pw * C * 4
-        assert total == ((unit + 255) // 256 * 256 + planes if extra else unit), (C, total, unit, planes)
+        body_bytes = (unit + 255) // 256 * 256 + planes if extra else unit
+        # + the 256-byte slot of the window correlations' scale (round 6), behind the 256-byte-aligned body
+        assert total == (body_bytes + 255) // 256 * 256 + 256, (C, total, unit, planes)
     assert handle.dtk_contrastive_workspace_bytes(16, 256, 384, 8107) > 16 * 256 * 8108 * 4 * 2
 
 

@@ -162,8 +162,8 @@ def test_feature_handoff_and_set_video(full384):
 
 
 def test_infer_at_c1024():
-    """The reference's own configuration is ViT-L (C = 1024, config/preprocessing.yaml:10-13): the tracker takes the tiled
-    correlation kernels there.  Both methods vs the oracle at 67 x 121."""
+    """The reference's own configuration is ViT-L (C = 1024, config/preprocessing.yaml:10-13): the tracker takes the K-split
+    correlation kernel there since round 6 (the tiled kernels before).  Both methods vs the oracle at 67 x 121."""
     from gpu_util import make_inference
     T, C = 4, 1024
     feats = synth.synth_features(T, C, 67, 121, seed=64)
@@ -176,6 +176,36 @@ def test_infer_at_c1024():
         traj, occ = mi.infer(queries.cuda())
         assert (traj.cpu() - rt).abs().max() < PX_TOL, method
         assert torch.equal(occ.cpu(), ro), method
+
+
+@pytest.mark.parametrize("C", [768, 1024])
+def test_wide_peaks_path(C):
+    """Round 6: the ViT-B / ViT-L feature widths on their own fast path -- corr_peaks_wide_kernel (the K dimension split over
+    wave pairs, partial sums exchanged through LDS) + refine_corr_dma_kernel<24 / 32> on the split planes -- instead of the
+    generic tiled correlation.  1 900 sources against random target frames at 67 x 121, in one round and in rounds of 512 (the last
+    one ragged: 364 sources = 2 full workgroups of 128 + 108), vs the oracle <= 1e-3 px; the tiers are reported, and nearly every
+    source must finish on the fast tier (the generic path sent 46 k of 8.3 M to the exact tier at C = 1024)."""
+    T = 3
+    feats = synth.synth_features(T, C, 67, 121, seed=60 + C // 256)
+    head = synth.synth_head_weights(3)
+    M = 1900
+    src, tgt = _sources(feats, M, 9, T)
+    ref = A.track(src, feats, tgt, head, H, W)
+    trk = _tracker(feats, head)
+    assert ops.feat_f16_bytes(make_geom(T, C, H, W)) > 2 * T * 67 * 128 * C          # unit-norm copy + split planes
+    outs = {}
+    for rounds in (0, 512):
+        trk.track_round_sources = rounds
+        trk._workspace = None
+        out = torch.full((M, 2), float("nan"), device="cuda")
+        trk.track_sources(trk.features(), src.cuda().contiguous(), None, tgt.int().cuda(), None, out, M)
+        st = trk.last_track_stats
+        outs[rounds] = out.cpu()
+        err = (outs[rounds] - ref).abs().max(dim=1).values
+        print(f"C = {C}, rounds of {rounds or 'all'}: max err {err.max().item():.2e} px, tiers {st}")
+        assert st["sources"] == M and st["exact_tier"] <= M // 20 and st["whole_map_tier"] <= M // 20, st
+        assert torch.isfinite(outs[rounds]).all() and err.max() < PX_TOL, (rounds, int(err.argmax()), err.max())
+    assert torch.equal(outs[0], outs[512])
 
 
 # ---- the reference's per-call API ------------------------------------------------------------------------------------
