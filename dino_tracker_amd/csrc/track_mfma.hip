@@ -106,8 +106,10 @@ __host__ __device__ inline size_t split_planes_offset(const dtk_geom* g) {
     return ((size_t)g->T * hw_pad(g->ph, g->pw) * g->C * 2 + 255) / 256 * 256;
 }
 __host__ __device__ inline bool has_split_planes(const dtk_geom* g) {
-    // (32-bit offsets in the descriptor; round 6: also the wide widths -- refine_corr_dma_kernel<24 / 32>)
-    return (g->C == 384 || peaks_wide_ok(g->C)) && (long long)g->T * g->ph * g->pw * g->C * 4 < (1LL << 32);
+    // (32-bit offsets in the descriptor.  Round 6 measured the wide widths on this form too -- refine_corr_dma_kernel<32> at C = 1024:
+    // 256 registers of stationary sources leave one workgroup per CU, 44.0 ms per benchmark step with a ring of 4 stages, 44.6 with 8,
+    // against 37.3 ms for the generic refine_corr_kernel -- so C = 768 / 1024 stay on the generic kernel and carry no split planes)
+    return g->C == 384 && (long long)g->T * g->ph * g->pw * g->C * 4 < (1LL << 32);
 }
 // slot [0]: the scale (float); [1]: bits of the largest cell norm (scratch of the reduction)
 __host__ __device__ inline size_t rc_scale_offset(const dtk_geom* g) {
@@ -1664,7 +1666,7 @@ __device__ __forceinline__ void vm_wait_n(int n) {
 // (no branch, so the count is static); the norms of the box come from LDS (a compiler-managed global load here would be
 // waited for with vmcnt(0) and drain the ring).
 template <int NKC, int NS, int NBM, int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 8 || NKC > 12) ? (NKC > 24 ? 1 : 2) : 3) void refine_corr_dma_kernel(dtk_geom g, const half_t* __restrict__ fs,
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void refine_corr_dma_kernel(dtk_geom g, const half_t* __restrict__ fs,
                                                               const float* __restrict__ norms,
                                                               const float* __restrict__ emb,
                                                               const int32_t* __restrict__ src_row,
@@ -2318,9 +2320,7 @@ int mfma_phase(const dtk_geom* g, const MfmaLayout& L, unsigned char* ws, const 
                reinterpret_cast<const half_t*>(reinterpret_cast<const unsigned char*>(f16) + split_planes_offset(g)), norms, emb,   \
                in.src_row, in.tgt, kstar, snorm, perm, nvalid, xwin, (unsigned)((size_t)scnt * WX * WX * 4), (int)s0, dtiles, \
                rc_scale)
-                if (g->C == 1024) DTK_RCD(32);
-                else if (g->C == 768) DTK_RCD(24);
-                else DTK_RCD(12);
+                DTK_RCD(12);
 #undef DTK_RCD
             }
             else

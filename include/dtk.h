@@ -360,7 +360,7 @@ int dtk_bb_nms(const dtk_geom* g, const float* feat, const float* norms, const f
 /* 16-bit copies of the feature volume consumed by DTK_TRACK_MFMA (C % 32 == 0), one buffer of dtk_feat_f16_bytes(g):
  *   - f16[t][row][col][c] = 32 F/|F|, every map row padded with zero cells to a multiple of 128 columns (an N-tile of the
  *     candidate GEMM is one map row);
- *   - at C = 384 / 768 / 1024, behind it (256-byte aligned): the split planes of the window correlation, [t][cell][chunk of 32
+ *   - at C = 384, behind it (256-byte aligned): the split planes of the window correlation, [t][cell][chunk of 32
  *     channels][hi 32 | lo 32] with s F = hi + lo (fp16 both) -- T*ph*pw*C*4 more bytes, made once per volume instead of
  *     once per staged element of every window box;
  *   - behind that (256-byte aligned), a 256-byte slot whose first float is s: 2^5, or the largest power of two with

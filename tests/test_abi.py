@@ -61,7 +61,7 @@ def test_hot_path_refuses_cpu_tensors():
 
 def test_struct_layouts_match_header():
     """The ctypes mirrors of the option / statistics structs have the size include/dtk.h's declarations imply (round 4 added
-    dtk_track_opts.emb_rows), and the feat_f16 buffer grows by the split planes exactly at C = 384 / 768 / 1024 and by the scale slot
+    dtk_track_opts.emb_rows), and the feat_f16 buffer grows by the split planes exactly at C = 384 and by the scale slot
     (no device needed)."""
     import re
     text = open(entry.os.path.join(entry.ROOT, "include", "dtk.h")).read()
@@ -71,7 +71,7 @@ def test_struct_layouts_match_header():
     assert fields == [name for name, _ in _lib.TrackOpts._fields_]
     assert ctypes.sizeof(_lib.TrackOpts) == 4 * len(fields)
     handle = _lib.lib()
-    for C, extra in ((384, True), (256, False), (768, True), (1024, True)):   # (round 6: split planes at the ViT-B / ViT-L widths too)
+    for C, extra in ((384, True), (256, False), (1024, False)):
         g = _lib.make_geom(3, C, 140, 210)
         unit = 3 * g.ph * ((g.pw + 127) // 128 * 128) * C * 2
         total = handle.dtk_feat_f16_bytes(g)
