@@ -44,7 +44,8 @@ class VitModel(ctypes.Structure):
                 ("stride", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("flags", ctypes.c_int32),
                 ("patch_w", c_void_p), ("patch_b", c_void_p),
                 ("cls_pos", c_void_p), ("pos", c_void_p), ("mean_std", c_void_p), ("layers", ctypes.POINTER(VitLayer)),
-                ("frame_batch", ctypes.c_int32), ("overflow", c_void_p)]
+                ("frame_batch", ctypes.c_int32), ("overflow", c_void_p),
+                ("tap_out", c_void_p), ("tap_mask", ctypes.c_uint64), ("tap_scale", ctypes.c_float)]
 
 
 VIT_TILED_GEMMS, VIT_BF16, VIT_CHECK_RANGE, VIT_ATTENTION_V2, VIT_GEMM_WS_V1 = 1, 2, 4, 8, 16  # dtk_vit_model.flags

@@ -1119,6 +1119,23 @@ __global__ __launch_bounds__(256) void final_update_kernel(const float* __restri
     if (IsF16<T>::value && overflow && __any(sat) && (threadIdx.x & 63) == 0) atomicOr(overflow, 1);
 }
 
+// tap of the residual stream after a block (dtk_vit_model.tap_out): out += scale * (x + pending update)
+template <typename T>
+__global__ __launch_bounds__(256) void tap_kernel(const float* __restrict__ x, const T* __restrict__ delta, float* __restrict__ out,
+                                                  float scale, long long total4) {
+    typedef typename Vec<T>::t4 T4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    if (delta) {
+        const T4 d = reinterpret_cast<const T4*>(delta)[i];
+        v.x += (float)d[0]; v.y += (float)d[1]; v.z += (float)d[2]; v.w += (float)d[3];
+    }
+    float4 o = reinterpret_cast<float4*>(out)[i];
+    o.x += scale * v.x; o.y += scale * v.y; o.z += scale * v.z; o.w += scale * v.w;
+    reinterpret_cast<float4*>(out)[i] = o;
+}
+
 // fp32 tokens [F][S][D] (CLS first) -> token-major features [F][HW][D] (drop CLS)
 __global__ __launch_bounds__(256) void drop_cls_kernel(const float* __restrict__ x, float* __restrict__ out, int S, int D,
                                                        long long total4) {
@@ -1328,6 +1345,13 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
         // GEMMs of widths without a weight-stationary form: the 256 x 256 DMA kernel when the shape allows, else 128 x 128
         const bool wide_ok = !(m->flags & DTK_VIT_TILED_GEMMS) && D % W2_N == 0;
         bool pending = false;   // `delta` holds a residual update that the next LayerNorm (or the final update) has to apply
+        auto tap = [&](int l, bool with_delta) -> int {   // dtk_vit_model.tap_out: the block output of layer l joins the mean
+            if (!m->tap_out || !((m->tap_mask >> l) & 1)) return DTK_OK;
+            const long long t4 = rows * (D / 4);
+            DTK_LAUNCH("vit_tap", tap_kernel<T>, dim3(dtk_cdiv(t4, 256)), dim3(256), 0, st, x, with_delta ? (const T*)delta : (const T*)nullptr,
+                       m->tap_out + (size_t)f0 * S * D, m->tap_scale, t4);
+            return DTK_OK;
+        };
         for (int l = 0; l < m->depth; ++l) {
             const dtk_vit_layer& L = m->layers[l];
             const T* qkv_w = reinterpret_cast<const T*>(L.qkv_w);
@@ -1376,6 +1400,7 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                 se.bias = L.fc2_b; se.inv_wscale = inv_ws; se.x = x; se.gamma = L.ls2;
                 DTK_LAUNCH("vit_gemm_fc2_split", (gemm_split_kernel<T, SEPI_RESID>), dim3(gemm_split_grid(D, rows)), dim3(256), 0, st,
                            (const T*)hid, (const T*)hid_lo, fc2_w, fc2_wl, rows, D, 4 * D, se);
+                if (tap(l, false)) return DTK_E_HIP;
                 continue;
             }
             GemmEpi<T> e{};
@@ -1461,6 +1486,7 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                 DTK_LAUNCH("vit_gemm_fc2", (gemm_tiled_kernel<T, EPI_DELTA>), dim3(gemm_grid(D, rows)), dim3(256), 0, st, hid,
                            fc2_w, rows, D, 4 * D, e);
             }
+            if (tap(l, true)) return DTK_E_HIP;
         }
         if (pending && (tokens_out || feat_out)) {
             // the last MLP's residual update, written straight to the outputs (x itself is dead after the last block)
@@ -1496,7 +1522,7 @@ extern "C" size_t dtk_vit_workspace_bytes(const dtk_vit_model* m, int video_h, i
 extern "C" int dtk_vit_forward(const dtk_vit_model* m, const float* frames, int nframes, int video_h, int video_w,
                                float* tokens_out, float* feat_out, float* qkv_out, void* workspace,
                                size_t workspace_bytes, void* stream) {
-    DTK_REQUIRE(m && frames && workspace && (tokens_out || feat_out || qkv_out), "dtk_vit_forward: null pointer");
+    DTK_REQUIRE(m && frames && workspace && (tokens_out || feat_out || qkv_out || m->tap_out), "dtk_vit_forward: null pointer");
     DTK_REQUIRE(!qkv_out || m->depth > 0, "dtk_vit_forward: qkv_out needs at least one block");
     DTK_REQUIRE(m->D > 0 && m->heads > 0 && m->D == m->heads * 64, "dtk_vit_forward: d_head must be 64 (D=%d heads=%d)",
                 m->D, m->heads);

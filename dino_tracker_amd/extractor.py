@@ -218,7 +218,7 @@ class VitExtractor(nn.Module):
     # ---- forward ------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def encode(self, frames: torch.Tensor, layer: Optional[int] = None, normalize: bool = True, want: str = "feat",
-               defer_check: bool = False):
+               defer_check: bool = False, taps: Optional[List[int]] = None):
         """frames [n,3,H,W] fp32 -> `feat`: token-major [n, ph*pw, D] (CLS dropped) or `tokens`: [n, 1+ph*pw, D].
         normalize=True applies the ImageNet mean/std inside the patch-embedding kernel (utils.py:46,55).
         A saturated fp16 activation (see __init__) raises RuntimeError -- here, behind one stream synchronisation, or, with
@@ -239,8 +239,11 @@ class VitExtractor(nn.Module):
         ms, overflow = self._ms[bool(normalize)], self._overflow
         D = self.cfg["dim"]
         S = ph * pw + 1
-        if want not in ("tokens", "feat", "qkv"):
+        if want not in ("tokens", "feat", "qkv", "taps"):
             raise ValueError(want)
+        if want == "taps":   # the mean of the block outputs of `taps` in ONE pass (dtk_vit_model.tap_out); layer = the deepest of them
+            taps = sorted({range(self.n_layers)[int(t)] for t in taps})
+            layer = taps[-1]
 
         def run(operand_dtype, split_blocks, frames=frames, n=n):
             flags = (VIT_TILED_GEMMS if self.tiled_gemms else 0) | (VIT_BF16 if operand_dtype == "bf16" else 0) | \
@@ -250,7 +253,11 @@ class VitExtractor(nn.Module):
                          self._sd["patch_embed.proj.weight"].data_ptr(),
                          self._sd["patch_embed.proj.bias"].data_ptr(), cls_pos.data_ptr(), pos.data_ptr(), ms.data_ptr(),
                          ctypes.cast(self._build_layers(operand_dtype, split_blocks), ctypes.POINTER(VitLayer)),
-                         int(self.frame_batch), overflow.data_ptr())
+                         int(self.frame_batch), overflow.data_ptr(), None, 0, 0.0)
+            tap_out = None
+            if want == "taps":
+                tap_out = torch.zeros((n, S, D), dtype=torch.float32, device=self.device)
+                m.tap_out, m.tap_mask, m.tap_scale = tap_out.data_ptr(), sum(1 << t for t in taps), 1.0 / len(taps)
             ws_bytes = int(lib().dtk_vit_workspace_bytes(m, H, W, n))
             # the workspace (2.6 GB for 30 frames of 854 x 476) is kept between calls: handing it back to the caching allocator
             # and asking again costs a device allocation (~25 ms) whenever the block has been split or released in between
@@ -263,7 +270,7 @@ class VitExtractor(nn.Module):
             check(lib().dtk_vit_forward(m, ops._p(frames), n, H, W, ops._p(tokens), ops._p(feat), ops._p(qkv), ops._p(ws),
                                         ws_bytes, ops._stream()))
             # (`ms`, `ws`, the position encoding and the overflow word are members: they outlive the launches)
-            return {"tokens": tokens, "feat": feat, "qkv": qkv}[want]
+            return {"tokens": tokens, "feat": feat, "qkv": qkv, "taps": tap_out}[want]
 
         if self.precision == "auto" and self.calibration is None and layer >= 0:
             # measure what the fast operands cost on THIS network and THESE frames: the first frames both ways (a split pass of two
@@ -338,6 +345,10 @@ class VitExtractor(nn.Module):
     def get_feature_from_input(self, input_img, layers: List[int]):  # models/extractor.py:137-150
         """input_img [B,3,H,W] ALREADY ImageNet-normalised (as the reference's caller does) -> mean over `layers` of
         the block outputs, [B, 1+ph*pw, D]."""
+        if len(set(layers)) == len(layers) and len(layers) > 1:
+            # ONE pass up to the deepest requested block, the outputs of the requested blocks averaged on the way (round 6; rounds 1-5
+            # re-ran blocks 0..l once per requested layer: O(L^2) for the reference's multi-layer mean)
+            return self.encode(input_img, normalize=False, want="taps", taps=list(layers))
         outs = [self.encode(input_img, layer=l, normalize=False, want="tokens") for l in layers]
         return torch.stack(outs).mean(dim=0)
 

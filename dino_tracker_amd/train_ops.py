@@ -819,12 +819,23 @@ def fused_adam_step(optimizer) -> None:
     groups = optimizer.param_groups
     if len(groups) > ADAM_MAX_GROUPS:
         raise NotImplementedError(f"fused Adam: {len(groups)} parameter groups (max {ADAM_MAX_GROUPS})")
+    # validate EVERYTHING before any state is touched (a NotImplementedError raised half-way through the walk below left
+    # the step counters of the tensors already visited advanced with no update applied)
+    live = [p for grp in groups for p in grp["params"] if p.grad is not None]
+    if len(live) > ADAM_MAX_TENSORS:
+        raise NotImplementedError(f"fused Adam: more than {ADAM_MAX_TENSORS} parameter tensors")
+    for grp in groups:
+        if grp.get("weight_decay", 0) != 0 or grp.get("amsgrad", False) or grp.get("maximize", False):
+            raise NotImplementedError("fused Adam: weight_decay / amsgrad / maximize are not implemented")
+        if (float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"])) != (float(groups[0]["betas"][0]), float(groups[0]["betas"][1]), float(groups[0]["eps"])):
+            raise NotImplementedError("fused Adam: per-group betas / eps")
+    for p in live:
+        if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.dtype == torch.float32):
+            raise NotImplementedError("fused Adam: contiguous fp32 device parameters only")
     a = AdamArgs()
     n = 0
     keep = []
     for gi, grp in enumerate(groups):
-        if grp.get("weight_decay", 0) != 0 or grp.get("amsgrad", False) or grp.get("maximize", False):
-            raise NotImplementedError("fused Adam: weight_decay / amsgrad / maximize are not implemented")
         if gi == 0:
             a.beta1, a.beta2, a.eps = float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"])
         elif (float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"])) != (float(groups[0]["betas"][0]), float(groups[0]["betas"][1]), float(groups[0]["eps"])):
@@ -866,7 +877,14 @@ def install_fused_adam(optimizer):
     if any(g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False) or g.get("capturable", False)
            for g in optimizer.param_groups):
         return optimizer
-    if any(not p.is_cuda for g in optimizer.param_groups for p in g["params"]):
+    from ._lib import ADAM_MAX_GROUPS, ADAM_MAX_TENSORS
+    params = [p for g in optimizer.param_groups for p in g["params"]]
+    # what the kernel cannot take keeps torch's own step (checked here, once, instead of failing at the first optimizer.step())
+    if any(not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()) for p in params) or len(params) > ADAM_MAX_TENSORS or \
+            len(optimizer.param_groups) > ADAM_MAX_GROUPS:
+        return optimizer
+    g0 = optimizer.param_groups[0]
+    if any((g["betas"], g["eps"]) != (g0["betas"], g0["eps"]) for g in optimizer.param_groups):
         return optimizer
 
     def step(closure=None):

@@ -115,6 +115,12 @@ typedef struct dtk_vit_model {
                                    * cross-check).  The caller zeroes it.  fp16 activations
                                    * SATURATE (FP16_OVFL mode) instead of becoming inf; a non-zero word means the features
                                    * are not trustworthy and the model should be run with DTK_VIT_BF16. */
+    /* Round 6 -- the multi-layer form of get_feature_from_input (models/extractor.py:142-149: the MEAN over the requested layers of
+     * the block outputs) in ONE pass: after every block l with bit l of tap_mask set, tap_out [n][1 + ph*pw][D] += tap_scale x (the
+     * residual stream after block l).  The caller zeroes tap_out and sets tap_scale = 1 / #layers.  NULL / 0: off. */
+    float* tap_out;
+    uint64_t tap_mask;
+    float tap_scale;
 } dtk_vit_model;
 
 #define DTK_VIT_TILED_GEMMS 1   /* run the K = 384 GEMMs on the tiled kernel too (cross-check in the tests) */

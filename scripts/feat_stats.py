@@ -19,7 +19,7 @@ for ls in (1.0, 0.3, 0.1, 0.03):
     trk = Tracker(video=video, dino_features=f, device="cuda:0", track_method=ops.TRACK_MFMA)
     trk.tracker_head.load_state_dict(synth.synth_head_weights(3)); trk.to("cuda:0").eval()
     trk.refined_features = None
-    trk._refined, trk._refined_norms = trk._dino, trk._dino_norms
+    trk._refined, trk._refined_norms = trk._packed_dino()   # (the raw volume's norms are made on demand since round 5: ADVICE r5)
     mi = ModelInference(trk, RangeNormalizer((W, H, T), device="cuda:0"), 0.7, 0.6)
     q = synth.grid_queries(8, 8, H, W, 0).cuda()
     ops.profile_enable(True)
@@ -27,4 +27,4 @@ for ls in (1.0, 0.3, 0.1, 0.03):
     prof = ops.profile_collect(); ops.profile_enable(False)
     err = (traj[:, :, 0] - (q[:, None, 0] - 4.2 * torch.arange(T, device="cuda")[None])).abs().median().item()
     print(f"layerscale {ls}: cos(random pairs) mean {cs.mean():.3f} max {cs.max():.3f}; cos(neighbours) {nb.mean():.3f}; anchors/query {int(mi.last_counts[0])/64:.1f}; "
-          f"median |x err| vs true motion {err:.2f}px; occ {occ.float().mean():.2f}; head_exact ms {prof.get('head_exact',(0,0))[0]:.1f} head16 ms {prof['head16'][0]:.1f}")
+          f"median |x err| vs true motion {err:.2f}px; occ {occ.float().mean():.2f}; head_exact ms {prof.get('head_exact',(0,0))[0]:.1f} head16 ms {prof.get('head16', (0, 0))[0]:.1f}")

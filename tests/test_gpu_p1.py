@@ -173,6 +173,13 @@ def test_cls_row_and_layer_mean_match_reference_golden():
     _check(tok[0], gold[0])
     cls_err = (tok[0, 0] - gold[0, 0]).norm() / gold[0, 0].norm()
     assert cls_err < 1e-3, cls_err  # the CLS token itself, not just "finite"
+    # round 6: the multi-layer mean comes out of ONE pass (dtk_vit_model.tap_out) -- the same numbers as one pass per layer, for
+    # fast blocks (the pending 16-bit update joins the tap), split blocks, and a mix of both
+    for pr in ("fast", "split", [0, 3, 5]):
+        e2 = VitExtractor(MG.P1_CASE["model"], stride=7, device="cuda:0", state_dict=MG.p1_weights(1.0), precision=pr)
+        one = e2.get_feature_from_input(x, layers=[2, 5, 3])
+        per = torch.stack([e2.encode(x, layer=l, normalize=False, want="tokens") for l in (2, 5, 3)]).mean(dim=0)
+        assert (one - per).abs().max() <= 2e-6 * per.abs().max(), (pr, (one - per).abs().max().item())
 
 
 def test_qkv_facets_match_reference_golden():
