@@ -57,7 +57,7 @@ class VitExtractor(nn.Module):
 
     def __init__(self, model_name, stride, device, state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  random_seed: Optional[int] = None, operand_dtype: str = "fp16", check_range: bool = False,
-                 on_overflow: str = "split-bf16", precision="fast", auto_tol: float = 2.5e-4, calibration_frames: int = 2):
+                 on_overflow: str = "split-bf16", precision=None, auto_tol: float = 2.5e-4, calibration_frames: int = 2):
         super().__init__()
         if operand_dtype not in ("fp16", "bf16"):
             raise ValueError(f"operand_dtype {operand_dtype!r}: 'fp16' or 'bf16'")
@@ -97,7 +97,9 @@ class VitExtractor(nn.Module):
         self._wcache = {}    # 16-bit weight tensors / split planes by (name, operand type[, "split"])
         self._layers_of = {}  # (operand type, split blocks) -> ctypes array of dtk_vit_layer (built on first need)
         self._pos_cache = {}
-        self.set_precision(precision)
+        # (precision=None: $DTK_VIT_PRECISION -- how the reference's UN-MODIFIED preprocessing/save_dino_embed_video.py, which
+        #  passes no such argument, is run on split operands -- or "fast")
+        self.set_precision(precision if precision is not None else os.environ.get("DTK_VIT_PRECISION", "fast"))
         self._layers = self._build_layers(self.operand_dtype, self.split_blocks)
 
     def set_precision(self, precision):

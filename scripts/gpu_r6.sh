@@ -56,6 +56,10 @@ PY
       timeout 600 python scripts/attn_ab.py scripts/ubench/libdtk_prev.so dino_tracker_amd/csrc/libdtk.so 2>&1 | tee gpurun_out/attn_ab.log ;;
     profile)
       bash scripts/gpu_profile.sh r06 ;;
+    sq)   # the SQ-counter pass alone (scripts/pmc_sq.py: rows per template instantiation since round 6)
+      R=$PWD; rm -rf /tmp/prof_sq; ( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES \
+          -d /tmp/prof_sq -o sq -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-clock-power --no-videos30 --parity-queries 0 > /dev/null 2> $R/gpurun_out/r06_sq.err )
+      python scripts/pmc_sq.py $(find /tmp/prof_sq -name "*.db" | head -1) > gpurun_out/r06_pmc_sq.md 2>> gpurun_out/r06_sq.err; head -30 gpurun_out/r06_pmc_sq.md ;;
     cmd:*)
       timeout 2400 bash -c "${WHAT#cmd:}" 2>&1 | tail -60 | tee gpurun_out/cmd.log ;;
     *) echo "unknown step $WHAT" ;;
