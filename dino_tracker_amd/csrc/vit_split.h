@@ -377,7 +377,9 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const T* __rest
             for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[u][r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float mnew = fmaxf(mrun, tmax);
-        const float alpha = exp2f(mrun - mnew);   // first tile: exp2(-inf) = 0
+        // (raw v_exp_f32: its only difference from exp2f -- results below 2^-126 flush to zero -- is irrelevant for weights of a sum
+        //  whose largest term is 2^10; exp2f's subnormal-range fix-up was three more VALU instructions per score)
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);   // first tile: exp2(-inf) = 0
         mrun = mnew;
         const float mref = mnew - AS_PSHIFT;
         float lsum = 0.f;
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const T* __rest
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(sacc[u][r] - mref);
+                const float p = __builtin_amdgcn_exp2f(sacc[u][r] - mref);
                 lsum += p;
                 T x0, x1;
                 split2<T>(p, x0, x1);
@@ -394,10 +396,12 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const T* __rest
                 p_l[u][r >> 3][r & 7] = x1;
             }
         lrun = lrun * alpha + lsum;
+        if (!__all(alpha == 1.f)) {   // (after the first tiles the running maximum rarely moves: skip the 32 multiplies then)
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        }
         // ---- O^T += V^T P
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
