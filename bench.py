@@ -169,7 +169,6 @@ def main():
     ex.frame_batch = args.vit_frame_batch
     ex.attention_v2 = "attention_v2" in args.ab
     ex.gemm_ws_v1 = "gemm_ws_v1" in args.ab
-    ex.gemm_wide_v1 = "gemm_wide_v1" in args.ab
     if args.features == "vit":
         feats0 = ex.encode(videos[0])
     else:

@@ -821,112 +821,6 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const T* __restrict__
     amax_report<T, EPI>(amax, e.ovf);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Round 6: the same 256 x 256 tile and LDS-DMA ring on FOUR waves, one per SIMD, each with a 128 x 128 wave tile (64 MFMA 16x16x32
-// tiles = 256 accumulator registers).  Why: gemm_wide_kernel's 8 waves read 12 fragments (12 KB per wave) per 32 MFMAs -- 96 KB of
-// LDS reads per 32-wide k-step and CU against 1024 cycles of matrix work per SIMD: 94 B per clock of the LDS's 128, which is what
-// holds the wide models' GEMMs at 0.29-0.43 of peak.  A 128 x 128 wave tile reads 16 fragments per 64 MFMAs: 64 KB per k-step
-// and CU, 62 B per clock.  The fragments of k-step ks+1 are read while the MFMAs of ks run (two register sets), so a lone wave
-// never waits for LDS at the head of a step.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int W4_REQ = (W2_M + W2_N) / 16 / 4;  // 8 DMA requests per wave and stage
-
-template <typename T, int EPI>
-__global__ __launch_bounds__(256, 1) void gemm_wide4_kernel(const T* __restrict__ A, const T* __restrict__ Wt,
-                                                            long long M, int N, int K, GemmEpi<T> e) {
-    typedef typename Vec<T>::t8 T8;
-    typedef typename Vec<T>::t4 T4;
-    (void)sizeof(T8); (void)sizeof(T4);
-    operand_mode<T>();
-    __shared__ __attribute__((aligned(1024))) unsigned char stages[W2_STAGES * W2_STAGE_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ncol = N / W2_N;
-    const long long nrow = (M + W2_M - 1) / W2_M;
-    const long long kb = blockIdx.x >> 3;
-    const long long row_blk = (kb / ncol) * 8 + (blockIdx.x & 7);
-    if (row_blk >= nrow) return;
-    const long long m0 = row_blk * W2_M;
-    const int n0 = (int)(kb % ncol) * W2_N;
-    const int wr = w >> 1, wc = w & 1;  // wave tile: rows wr*128.., columns wc*128..
-    const int fj = lane & 15, fg = lane >> 4;
-    const T* src[W4_REQ];
-    unsigned dst[W4_REQ];
-#pragma unroll
-    for (int i = 0; i < W4_REQ; ++i) {
-        const int q = w * W4_REQ + i;  // 0..15: A rows 16q.., 16..31: Wt rows n0 + 16(q-16)..
-        const bool isA = q < W2_M / 16;
-        const int row = (isA ? q : q - W2_M / 16) * 16 + (lane >> 2);
-        const int piece = (lane & 3) ^ ((0x1230 >> (((row >> 2) & 3) * 4)) & 3);
-        const long long grow = isA ? min(m0 + row, M - 1) : (long long)(n0 + row);
-        src[i] = (isA ? A : Wt) + grow * K + piece * 8;
-        dst[i] = (isA ? 0 : W2_M * 64) + (isA ? q : q - W2_M / 16) * 1024;
-    }
-    const unsigned lds0 = (unsigned)(size_t)&stages[0];
-    const int nk = K / GK;
-    auto issue = [&](int ks, int buf) {
-        const int kk = min(ks, nk - 1);
-#pragma unroll
-        for (int i = 0; i < W4_REQ; ++i)
-            ws_glds16(src[i] + (size_t)kk * GK, __builtin_amdgcn_readfirstlane(lds0 + buf * W2_STAGE_BYTES + dst[i]));
-    };
-    f4 acc[8][8];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = f4{0.f, 0.f, 0.f, 0.f};
-    const int fsw = (0x1230 >> (((fj >> 2) & 3) * 4)) & 3;
-    const unsigned a_off = ((wr * 128 + fj) * 4 + (fg ^ fsw)) * 16;
-    const unsigned b_off = W2_M * 64 + ((wc * 128 + fj) * 4 + (fg ^ fsw)) * 16;
-    T8 afA[8], bfA[8], afB[8], bfB[8];
-    auto load = [&](T8 (&af)[8], T8 (&bf)[8], int buf) {
-        const unsigned char* sb = stages + buf * W2_STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            af[i] = *reinterpret_cast<const T8*>(sb + a_off + i * 1024);
-            bf[i] = *reinterpret_cast<const T8*>(sb + b_off + i * 1024);
-        }
-    };
-    auto mul = [&](const T8 (&af)[8], const T8 (&bf)[8]) {
-#pragma unroll
-        for (int ni = 0; ni < 8; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) acc[mi][ni] = mfma16(bf[ni], af[mi], acc[mi][ni]);   // (W tile) x (token tile)^T: D transposed
-    };
-    issue(0, 0);
-    issue(1, 1);
-    issue(2, 2);
-    ws_wait<2 * W4_REQ>();  // stage 0 landed
-    __syncthreads();
-    load(afA, bfA, 0);
-    // iteration ks: stage ks+1 is published, stage ks+3 requested into the slot of ks-1, the fragments of ks+1 are read into the
-    // other register set while the MFMAs of ks run
-    int ks = 0;
-    for (; ks + 1 < nk; ks += 2) {
-        ws_wait<W4_REQ>();  // stage ks+1 landed (ks+2 may still fly)
-        __syncthreads();
-        issue(ks + 3, (ks + 3) & 3);
-        load(afB, bfB, (ks + 1) & 3);
-        mul(afA, bfA);
-        ws_wait<W4_REQ>();  // stage ks+2
-        __syncthreads();
-        issue(ks + 4, (ks + 4) & 3);
-        load(afA, bfA, (ks + 2) & 3);   // (past the end: a clamped repeat of the last stage, never multiplied)
-        mul(afB, bfB);
-    }
-    if (ks < nk) mul(afA, bfA);   // nk odd
-    ws_wait<0>();
-    float amax = 0.f;
-#pragma unroll
-    for (int ni = 0; ni < 8; ++ni) {
-        const int nb = n0 + wc * 128 + ni * 16 + fg * 4;
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
-            gemm_store_tile_t<T, EPI>(acc[mi][ni], m0 + wr * 128 + mi * 16 + fj, nb, M, N, e, amax);
-    }
-    amax_report<T, EPI>(amax, e.ovf);
-}
-
 // V2M (round 4, default 3): bit 0 = weights in AGPRs (loaded there by asm; the builtin MFMA takes them from there as they are)
 // and zero accumulators through the MFMA's C operand; bit 1 = token tiles by LDS-DMA through a buffer descriptor (scalar tile
 // offset + constant per-lane offset: 3 issue slots per request instead of ~13).  V2M = 0 is the round 1-3 form, kept for the
@@ -1450,7 +1344,6 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
         };
         // GEMMs of widths without a weight-stationary form: the 256 x 256 DMA kernel when the shape allows, else 128 x 128
         const bool wide_ok = !(m->flags & DTK_VIT_TILED_GEMMS) && D % W2_N == 0;
-        const bool wide_v1 = (m->flags & DTK_VIT_GEMM_WIDE_V1) != 0;   // the 8-wave form of rounds 2-5 (A / B measurement)
         bool pending = false;   // `delta` holds a residual update that the next LayerNorm (or the final update) has to apply
         auto tap = [&](int l, bool with_delta) -> int {   // dtk_vit_model.tap_out: the block output of layer l joins the mean
             if (!m->tap_out || !((m->tap_mask >> l) & 1)) return DTK_OK;
@@ -1534,11 +1427,7 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                                gr.second);
                 }
             } else if (wide_ok) {
-                if (wide_v1) {
-                    DTK_LAUNCH("vit_gemm_qkv", (gemm_wide_kernel<T, EPI_QKV>), dim3(gemm_wide_grid(3 * D, rows)), dim3(512), 0, st, xn, qkv_w, rows, 3 * D, D, e);
-                } else {
-                    DTK_LAUNCH("vit_gemm_qkv", (gemm_wide4_kernel<T, EPI_QKV>), dim3(gemm_wide_grid(3 * D, rows)), dim3(256), 0, st, xn, qkv_w, rows, 3 * D, D, e);
-                }
+                DTK_LAUNCH("vit_gemm_qkv", (gemm_wide_kernel<T, EPI_QKV>), dim3(gemm_wide_grid(3 * D, rows)), dim3(512), 0, st, xn, qkv_w, rows, 3 * D, D, e);
             } else {
                 DTK_LAUNCH("vit_gemm_qkv", (gemm_tiled_kernel<T, EPI_QKV>), dim3(gemm_grid(3 * D, rows)), dim3(256), 0, st, xn,
                            qkv_w, rows, 3 * D, D, e);
@@ -1557,13 +1446,8 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                                gr.second);
                 }
             } else if (wide_ok) {
-                if (wide_v1) {
-                    DTK_LAUNCH("vit_gemm_proj", (gemm_wide_kernel<T, EPI_DELTA>), dim3(gemm_wide_grid(D, rows)), dim3(512), 0, st, ao,
+                DTK_LAUNCH("vit_gemm_proj", (gemm_wide_kernel<T, EPI_DELTA>), dim3(gemm_wide_grid(D, rows)), dim3(512), 0, st, ao,
                            proj_w, rows, D, D, e);
-                } else {
-                    DTK_LAUNCH("vit_gemm_proj", (gemm_wide4_kernel<T, EPI_DELTA>), dim3(gemm_wide_grid(D, rows)), dim3(256), 0, st, ao,
-                           proj_w, rows, D, D, e);
-                }
             } else {
                 DTK_LAUNCH("vit_gemm_proj", (gemm_tiled_kernel<T, EPI_DELTA>), dim3(gemm_grid(D, rows)), dim3(256), 0, st, ao,
                            proj_w, rows, D, D, e);
@@ -1582,11 +1466,7 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                                gr.second);
                 }
             } else if (wide_ok) {
-                if (wide_v1) {
-                    DTK_LAUNCH("vit_gemm_fc1", (gemm_wide_kernel<T, EPI_GELU>), dim3(gemm_wide_grid(4 * D, rows)), dim3(512), 0, st, xn, fc1_w, rows, 4 * D, D, e);
-                } else {
-                    DTK_LAUNCH("vit_gemm_fc1", (gemm_wide4_kernel<T, EPI_GELU>), dim3(gemm_wide_grid(4 * D, rows)), dim3(256), 0, st, xn, fc1_w, rows, 4 * D, D, e);
-                }
+                DTK_LAUNCH("vit_gemm_fc1", (gemm_wide_kernel<T, EPI_GELU>), dim3(gemm_wide_grid(4 * D, rows)), dim3(512), 0, st, xn, fc1_w, rows, 4 * D, D, e);
             } else {
                 DTK_LAUNCH("vit_gemm_fc1", (gemm_tiled_kernel<T, EPI_GELU>), dim3(gemm_grid(4 * D, rows)), dim3(256), 0, st, xn,
                            fc1_w, rows, 4 * D, D, e);
@@ -1598,13 +1478,8 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                 DTK_LAUNCH("vit_gemm_fc2", gemm_wide_delta_kernel<T>, dim3(dtk_cdiv(rows, WD_M)), dim3(512), 0, st, hid, fc2_w,
                            rows, 4 * D, e);
             } else if (wide_ok) {
-                if (wide_v1) {
-                    DTK_LAUNCH("vit_gemm_fc2", (gemm_wide_kernel<T, EPI_DELTA>), dim3(gemm_wide_grid(D, rows)), dim3(512), 0, st, hid,
+                DTK_LAUNCH("vit_gemm_fc2", (gemm_wide_kernel<T, EPI_DELTA>), dim3(gemm_wide_grid(D, rows)), dim3(512), 0, st, hid,
                            fc2_w, rows, D, 4 * D, e);
-                } else {
-                    DTK_LAUNCH("vit_gemm_fc2", (gemm_wide4_kernel<T, EPI_DELTA>), dim3(gemm_wide_grid(D, rows)), dim3(256), 0, st, hid,
-                           fc2_w, rows, D, 4 * D, e);
-                }
             } else {
                 DTK_LAUNCH("vit_gemm_fc2", (gemm_tiled_kernel<T, EPI_DELTA>), dim3(gemm_grid(D, rows)), dim3(256), 0, st, hid,
                            fc2_w, rows, D, 4 * D, e);

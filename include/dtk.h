@@ -129,7 +129,6 @@ typedef struct dtk_vit_model {
 #define DTK_VIT_ATTENTION_V2 8  /* attention on the round-2/3 kernel (16 waves per CU x 32 queries) instead of the one-wave-per-SIMD
                                  * kernel of round 4: the cross-check path of the tests */
 #define DTK_VIT_GEMM_WS_V1 16   /* the K = 384 weight-stationary GEMMs in their round 1-3 form (A / B measurement, cross-check) */
-#define DTK_VIT_GEMM_WIDE_V1 32 /* the wide models' 256 x 256 GEMMs on the 8-wave kernel of rounds 2-5 instead of round 6's 4 waves x (128 x 128) */
 #define DTK_OPERAND_F16 0
 #define DTK_OPERAND_BF16 1
 #define DTK_OPERAND_ATTENTION_V2 0x100  /* OR-ed into dtk_vit_attention's operand_type: the same selection for the stand-alone stage */
