@@ -71,9 +71,11 @@ def parse():
     ap.add_argument("--cpu-vit-frames", type=int, default=2,
                     help="frames the oracle's ViT / Delta-DINO legs are timed on (also the from-the-video parity leg)")
     ap.add_argument("--operands", default="fp16", choices=["fp16", "bf16"], help="operand type of the ViT's matrix units")
-    ap.add_argument("--precision", default="fast", choices=["fast", "split", "auto"],
-                    help="VitExtractor precision: fast (one 16-bit number per operand: the headline), split (hi + lo operands in every "
-                         "block: fp32-grade features at ~3x the matrix work), auto (calibrated on the first frames)")
+    ap.add_argument("--precision", default="auto", choices=["fast", "split", "auto"],
+                    help="VitExtractor precision: auto (default: the extractor MEASURES fast-vs-split on the first two frames of its first "
+                         "call -- outside the timed region -- and keeps the fast operands only if they are within 2.5e-4 of the split ones; "
+                         "on the benchmark's weights it measures 1.3e-4 and runs fast: config.vit_precision.calibration), fast (one 16-bit "
+                         "number per operand, no check), split (hi + lo operands in every block: fp32-grade features, ~2x the step)")
     ap.add_argument("--video-lengths", default="",
                     help="with --videos V: comma list of frame counts (cycled over the V videos; e.g. DAVIS-like 25..104) -- the batch is "
                          "then scheduled longest-first over the ranks (sharding.lpt_assignment) instead of v = r (mod world)")
@@ -640,7 +642,7 @@ def main():
             "unit": "query-points*frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if (qpar or args.videos > 0) else "weak",
-            "vs_baseline": None, "dtype": (f"mixed: {args.operands} ViT operands, {p2_mode} in Delta-DINO, " + ("f32 tracker" if method == ops.TRACK_EXACT
+            "vs_baseline": None, "dtype": (f"mixed: {ex.operand_dtype} ViT operands ({'hi + lo split in ' + str(len(ex.split_blocks)) + ' blocks' if ex.split_blocks else 'one per value'}), {p2_mode} in Delta-DINO, " + ("f32 tracker" if method == ops.TRACK_EXACT
                                                                        else "f16 candidates + f32 deciders in the tracker")
                       + "; f32 accumulate"),
             "data": "synthetic",
