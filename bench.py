@@ -54,6 +54,7 @@ def parse():
                          "feature-level generator with dense anchors (worst case for the tracker stage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-power", action="store_true", help="skip the shader-clock / board-power sampling legs")
+    ap.add_argument("--no-live-traffic", action="store_true", help="skip the two rocprofv3 PMC child passes that measure roofline.traffic live")
     ap.add_argument("--no-videos30", action="store_true", help="skip the second timed phase (north_star's 30-video batch, strong scaling)")
     ap.add_argument("--ab", default="", help="comma-separated A / B switches: attention_v2 (round 2-3 attention kernel), "
                                              "gemm_ws_v1 (round 1-3 weight-stationary GEMMs)")
@@ -400,6 +401,39 @@ def main():
                     break
             except (OSError, ValueError, KeyError):
                 pass
+        # LIVE traffic of the dominant kernel when it is the attention (the figure above is a committed
+        # constant): the stand-alone stage on operands of the step's shape under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
+        # (two child processes, separate passes as MI355X_MICROARCH.md prescribes; FETCH_SIZE x 2 on gfx950, KiB -> bytes).  Any
+        # failure (no rocprofv3, a refused counter, a timeout) leaves the committed figure in place and says so.
+        if default_workload and dom == "vit_attention" and world == 1 and not args.no_live_traffic:
+            import glob
+            import shutil
+            import tempfile
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            try:
+                import pmc_traffic
+                vals = {}
+                for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                    td = tempfile.mkdtemp(prefix="dtk_traffic_", dir="/tmp")
+                    try:
+                        cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", td, "-o", "t", "--", sys.executable,
+                               os.path.join(ROOT, "scripts", "attn_traffic_child.py"), str(T), str(C // 64), str(S), args.operands]
+                        subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=240, check=True,
+                                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                        dbs = glob.glob(os.path.join(td, "**", "*.db"), recursive=True)
+                        pk = pmc_traffic.per_kernel(dbs[0], counter)
+                        n_, v_ = pk["attention4_kernel"]
+                        vals[counter] = (2.0 if counter == "FETCH_SIZE" else 1.0) * v_ * 1024.0 / n_
+                    finally:
+                        shutil.rmtree(td, ignore_errors=True)
+                roofline["traffic_committed_file"] = roofline.get("traffic")
+                roofline["traffic"] = round(vals["FETCH_SIZE"] + vals["WRITE_SIZE"])
+                roofline["traffic_source"] = ("THIS run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate child passes) of the stand-alone "
+                                              "attention stage on random operands of the step's shape (scripts/attn_traffic_child.py)")
+                roofline["traffic_fetch_write"] = [round(vals["FETCH_SIZE"]), round(vals["WRITE_SIZE"])]
+                roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / (4.0 * T * (C // 64) * S * 64 * 2), 4)
+            except Exception as ex_:   # noqa: BLE001
+                roofline["traffic_live_error"] = f"{type(ex_).__name__}: {str(ex_)[:200]}"
         roofline["avg_launch_ms"] = round(ms / max(launches, 1), 4)
         roofline["launches"] = launches
         roofline["kernel_ms"] = {k: round(v[0], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("DTK_BENCH_KERNELS", "12"))]}

@@ -30,7 +30,7 @@ for WHAT in "$@"; do
     bench_quick)
       timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-videos30 > gpurun_out/bench_quick.json 2> gpurun_out/bench_quick.err; cat gpurun_out/bench_quick.json; tail -5 gpurun_out/bench_quick.err ;;
     bench_fast)   # kernel times only: no oracle legs
-      timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-clock-power --no-videos30 --parity-queries 0 > gpurun_out/bench_fast.json 2> gpurun_out/bench_fast.err; cat gpurun_out/bench_fast.json; tail -5 gpurun_out/bench_fast.err ;;
+      timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-clock-power --no-live-traffic --no-videos30 --parity-queries 0 > gpurun_out/bench_fast.json 2> gpurun_out/bench_fast.err; cat gpurun_out/bench_fast.json; tail -5 gpurun_out/bench_fast.err ;;
     bench_split)
       timeout 900 python bench.py --precision split --steps 3 --warmup 1 --no-cpu-baseline --no-clock-power --no-videos30 > gpurun_out/bench_split.json 2> gpurun_out/bench_split.err; cat gpurun_out/bench_split.json; tail -5 gpurun_out/bench_split.err ;;
     bench_w1024)
@@ -58,7 +58,7 @@ PY
       bash scripts/gpu_profile.sh r06 ;;
     sq)   # the SQ-counter pass alone (scripts/pmc_sq.py: rows per template instantiation since round 6)
       R=$PWD; rm -rf /tmp/prof_sq; ( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES \
-          -d /tmp/prof_sq -o sq -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-clock-power --no-videos30 --parity-queries 0 > /dev/null 2> $R/gpurun_out/r06_sq.err )
+          -d /tmp/prof_sq -o sq -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-clock-power --no-live-traffic --no-videos30 --parity-queries 0 > /dev/null 2> $R/gpurun_out/r06_sq.err )
       python scripts/pmc_sq.py $(find /tmp/prof_sq -name "*.db" | head -1) > gpurun_out/r06_pmc_sq.md 2>> gpurun_out/r06_sq.err; head -30 gpurun_out/r06_pmc_sq.md ;;
     cmd:*)
       timeout 2400 bash -c "${WHAT#cmd:}" 2>&1 | tail -60 | tee gpurun_out/cmd.log ;;

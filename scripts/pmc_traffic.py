@@ -44,19 +44,20 @@ def per_kernel(path, counter):
         c[0] += n; c[1] += v
     return out
 
-rd, wr = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-res = {}
-names = NAMES
-what = "`python bench.py --steps 1 --warmup 0 --no-cpu-baseline`"
-if len(sys.argv) > 3:  # third argument: comma-separated kernel functions of another command (fourth: its description)
-    names = {k: k for k in sys.argv[3].split(",")}
-    what = sys.argv[4] if len(sys.argv) > 4 else "the given command"
-for fn, launch in names.items():
-    if fn in rd and fn in wr:
-        fetch = 2.0 * rd[fn][1] * 1024.0 / rd[fn][0]
-        write = wr[fn][1] * 1024.0 / wr[fn][0]
-        res[launch] = {"kernel": fn, "launches_sampled": rd[fn][0], "fetch_bytes_per_launch": round(fetch),
-                       "write_bytes_per_launch": round(write), "bytes_per_launch": round(fetch + write)}
-print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of "
-                            + what + "; FETCH_SIZE x 2 (gfx950), KiB -> bytes",
-                  "kernels": res}, indent=1))
+if __name__ == "__main__":
+    rd, wr = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+    res = {}
+    names = NAMES
+    what = "`python bench.py --steps 1 --warmup 0 --no-cpu-baseline`"
+    if len(sys.argv) > 3:  # third argument: comma-separated kernel functions of another command (fourth: its description)
+        names = {k: k for k in sys.argv[3].split(",")}
+        what = sys.argv[4] if len(sys.argv) > 4 else "the given command"
+    for fn, launch in names.items():
+        if fn in rd and fn in wr:
+            fetch = 2.0 * rd[fn][1] * 1024.0 / rd[fn][0]
+            write = wr[fn][1] * 1024.0 / wr[fn][0]
+            res[launch] = {"kernel": fn, "launches_sampled": rd[fn][0], "fetch_bytes_per_launch": round(fetch),
+                           "write_bytes_per_launch": round(write), "bytes_per_launch": round(fetch + write)}
+    print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of "
+                                + what + "; FETCH_SIZE x 2 (gfx950), KiB -> bytes",
+                      "kernels": res}, indent=1))
