@@ -331,7 +331,8 @@ def main():
         lengths_rg = [fr[v % len(fr)] for v in range(V30)]
         for v in sharding.lpt_assignment([sharding.video_cost(x) for x in lengths_rg], world)[rank]:
             ctx_for(lengths_rg[v])
-        scheduled_batch(lengths_rg) if world == 1 else None     # (N = 1: one warm pass so that every length's buffers exist)
+        if world == 1:
+            scheduled_batch(lengths_rg)     # (one warm pass so that every length's buffers exist before the timed one)
         dr = timed(lambda: scheduled_batch(lengths_rg))
         videos30["ragged"] = {"lengths": fr, "frames_total": sum(lengths_rg), "value": round(N * sum(lengths_rg) / dr, 1),
                               "seconds": round(dr, 3), "makespan": sched_report(lengths_rg),
