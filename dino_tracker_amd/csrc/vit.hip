@@ -1365,21 +1365,30 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                 const T* fc1_wl = reinterpret_cast<const T*>(L.fc1_w_lo);
                 const T* fc2_wl = reinterpret_cast<const T*>(L.fc2_w_lo);
                 const float inv_ws = 1.f / (L.w_scale > 0.f ? L.w_scale : 1.f);
+                // the LDS-DMA form of the split GEMM (256 x 128 tiles; round 6: fc2 38.3 -> 34.5, qkv 41.4 -> 39.3 ms per step, ViT-L
+                // 1613 -> 1461 ms) unless DTK_VIT_TILED_GEMMS asks for the register-staged 128 x 128 kernel (the tests' cross-check)
+                const bool split_dma = !(m->flags & DTK_VIT_TILED_GEMMS);
                 DTK_LAUNCH("vit_layernorm_split", layernorm_split_kernel<T>, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x,
                            pending ? (const T*)delta : (const T*)nullptr, L.ln1_w, L.ln1_b, xn, xn_lo, rows, D, m->ln_eps, ovf);
                 pending = false;
                 SplitEpi<T> se{};
                 if (qkv_out && l == m->depth - 1) {
                     se.bias = L.qkv_b; se.inv_wscale = inv_ws; se.out_f32 = qkv_out + (size_t)f0 * S * 3 * D;
-                    DTK_LAUNCH("vit_gemm_qkv_facet", (gemm_split_kernel<T, SEPI_F32>), dim3(gemm_split_grid(3 * D, rows)), dim3(256),
-                               0, st, xn, xn_lo, qkv_w, qkv_wl, rows, 3 * D, D, se);
+                    if (split_dma && (3 * D) % SD_N == 0) {
+                    DTK_LAUNCH("vit_gemm_qkv_facet", (gemm_split_dma_kernel<T, SEPI_F32>), dim3(gemm_split_dma_grid(3 * D, rows)), dim3(512), 0, st, xn, xn_lo, qkv_w, qkv_wl, rows, 3 * D, D, se);
+                } else {
+                    DTK_LAUNCH("vit_gemm_qkv_facet", (gemm_split_kernel<T, SEPI_F32>), dim3(gemm_split_grid(3 * D, rows)), dim3(256), 0, st, xn, xn_lo, qkv_w, qkv_wl, rows, 3 * D, D, se);
+                }
                     se = SplitEpi<T>{};
                 }
                 se.bias = L.qkv_b; se.inv_wscale = inv_ws; se.q_hi = q; se.q_lo = q_lo; se.k_hi = k; se.k_lo = k_lo; se.vt_hi = vt;
                 se.vt_lo = vt_lo; se.S = S; se.Sp = Sp; se.heads = m->heads; se.D = D; se.qscale = 0.125f * 1.4426950408889634f;
                 se.ovf = epi_ovf;
-                DTK_LAUNCH("vit_gemm_qkv_split", (gemm_split_kernel<T, SEPI_QKV>), dim3(gemm_split_grid(3 * D, rows)), dim3(256), 0, st,
-                           xn, xn_lo, qkv_w, qkv_wl, rows, 3 * D, D, se);
+                if (split_dma && (3 * D) % SD_N == 0) {
+                    DTK_LAUNCH("vit_gemm_qkv_split", (gemm_split_dma_kernel<T, SEPI_QKV>), dim3(gemm_split_dma_grid(3 * D, rows)), dim3(512), 0, st, xn, xn_lo, qkv_w, qkv_wl, rows, 3 * D, D, se);
+                } else {
+                    DTK_LAUNCH("vit_gemm_qkv_split", (gemm_split_kernel<T, SEPI_QKV>), dim3(gemm_split_grid(3 * D, rows)), dim3(256), 0, st, xn, xn_lo, qkv_w, qkv_wl, rows, 3 * D, D, se);
+                }
                 {
                     const int nqb = dtk_cdiv(Sp, 128);
                     DTK_LAUNCH("vit_attention_split", attention_split_kernel<T>, dim3((unsigned)(nf * m->heads * nqb)), dim3(256), 0, st,
@@ -1388,18 +1397,27 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                 }
                 se = SplitEpi<T>{};
                 se.bias = L.proj_b; se.inv_wscale = inv_ws; se.x = x; se.gamma = L.ls1;
-                DTK_LAUNCH("vit_gemm_proj_split", (gemm_split_kernel<T, SEPI_RESID>), dim3(gemm_split_grid(D, rows)), dim3(256), 0, st,
-                           (const T*)ao, (const T*)ao_lo, proj_w, proj_wl, rows, D, D, se);
+                if (split_dma && (D) % SD_N == 0) {
+                    DTK_LAUNCH("vit_gemm_proj_split", (gemm_split_dma_kernel<T, SEPI_RESID>), dim3(gemm_split_dma_grid(D, rows)), dim3(512), 0, st, (const T*)ao, (const T*)ao_lo, proj_w, proj_wl, rows, D, D, se);
+                } else {
+                    DTK_LAUNCH("vit_gemm_proj_split", (gemm_split_kernel<T, SEPI_RESID>), dim3(gemm_split_grid(D, rows)), dim3(256), 0, st, (const T*)ao, (const T*)ao_lo, proj_w, proj_wl, rows, D, D, se);
+                }
                 DTK_LAUNCH("vit_layernorm_split", layernorm_split_kernel<T>, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x,
                            (const T*)nullptr, L.ln2_w, L.ln2_b, xn, xn_lo, rows, D, m->ln_eps, ovf);
                 se = SplitEpi<T>{};
                 se.bias = L.fc1_b; se.inv_wscale = inv_ws; se.out_hi = hid; se.out_lo = hid_lo; se.ovf = epi_ovf;
-                DTK_LAUNCH("vit_gemm_fc1_split", (gemm_split_kernel<T, SEPI_GELU>), dim3(gemm_split_grid(4 * D, rows)), dim3(256), 0, st,
-                           (const T*)xn, (const T*)xn_lo, fc1_w, fc1_wl, rows, 4 * D, D, se);
+                if (split_dma && (4 * D) % SD_N == 0) {
+                    DTK_LAUNCH("vit_gemm_fc1_split", (gemm_split_dma_kernel<T, SEPI_GELU>), dim3(gemm_split_dma_grid(4 * D, rows)), dim3(512), 0, st, (const T*)xn, (const T*)xn_lo, fc1_w, fc1_wl, rows, 4 * D, D, se);
+                } else {
+                    DTK_LAUNCH("vit_gemm_fc1_split", (gemm_split_kernel<T, SEPI_GELU>), dim3(gemm_split_grid(4 * D, rows)), dim3(256), 0, st, (const T*)xn, (const T*)xn_lo, fc1_w, fc1_wl, rows, 4 * D, D, se);
+                }
                 se = SplitEpi<T>{};
                 se.bias = L.fc2_b; se.inv_wscale = inv_ws; se.x = x; se.gamma = L.ls2;
-                DTK_LAUNCH("vit_gemm_fc2_split", (gemm_split_kernel<T, SEPI_RESID>), dim3(gemm_split_grid(D, rows)), dim3(256), 0, st,
-                           (const T*)hid, (const T*)hid_lo, fc2_w, fc2_wl, rows, D, 4 * D, se);
+                if (split_dma && (D) % SD_N == 0) {
+                    DTK_LAUNCH("vit_gemm_fc2_split", (gemm_split_dma_kernel<T, SEPI_RESID>), dim3(gemm_split_dma_grid(D, rows)), dim3(512), 0, st, (const T*)hid, (const T*)hid_lo, fc2_w, fc2_wl, rows, D, 4 * D, se);
+                } else {
+                    DTK_LAUNCH("vit_gemm_fc2_split", (gemm_split_kernel<T, SEPI_RESID>), dim3(gemm_split_grid(D, rows)), dim3(256), 0, st, (const T*)hid, (const T*)hid_lo, fc2_w, fc2_wl, rows, D, 4 * D, se);
+                }
                 if (tap(l, false)) return DTK_E_HIP;
                 continue;
             }

@@ -10,14 +10,15 @@
 //   x = hi + lo,  hi = T(x),  lo = T(x - hi)        (T = _Float16: exact to max(2^-22 |x|, 2^-25); T = __bf16: 2^-16 |x|, fp32's range)
 //   a . b  ~  a_hi b_hi + a_hi b_lo + a_lo b_hi     (three MFMAs, fp32 accumulate; the dropped lo.lo term is 2^-22 / 2^-16 relative)
 // on LN output x W_qkv, Q K^T, P V, attention output x W_proj, LN output x W_fc1, GELU hidden x W_fc2; the residual updates are
-// added to the fp32 stream inside the GEMM epilogue (no 16-bit pending update); GELU is erff in fp32.  The same emulation with
+// added to the fp32 stream inside the GEMM epilogue (no 16-bit pending update); GELU in fp32 through erfc (4.7e-7 absolute).  The same emulation with
 // hi + lo operands lands on 3.6e-6 (outlier weights) / 2.1e-7 (benchmark weights) relative -- what the fp32 ORACLE itself is from
 // float64 (3.0e-6 / 4.8e-7).  T = __bf16 is the range escalation: a value beyond 65504 needs fp32's exponent, and bf16 hi + lo keeps
 // 16 significant bits there (plain bf16 operands: 8).
 //
 // Kernels (simple, LDS-tiled, ~3x the matrix work of the fast path by construction; this is the strict mode, not the headline):
 //   layernorm_split_kernel   LayerNorm (+ a pending 16-bit update of a preceding FAST block) -> hi / lo planes
-//   gemm_split_kernel        128 x 128 x 32 tiles, register-prefetched, hi / lo planes of A and W in LDS, MFMA 16x16x32 as
+//   gemm_split_dma_kernel    256 x 128 x 32 tiles by LDS-DMA (ring of three 48 KB stages), the production form;
+//   gemm_split_kernel        128 x 128 x 32 tiles, register-prefetched (cross-check, DTK_VIT_TILED_GEMMS): hi / lo planes of A and W in LDS, MFMA 16x16x32 as
 //                            (W tile) x (token tile)^T so that a lane owns 4 consecutive features of one token (8-byte / 16-byte
 //                            stores); epilogues: Q / K / V^T planes, GELU planes, fp32 residual add, fp32 out (the qkv facet)
 //   attention_split_kernel   flash attention, d_head 64: S^T = K Q^T and O^T = V^T P^T on MFMA 32x32x16 (per-query statistics are
@@ -56,6 +57,23 @@ __device__ __forceinline__ void split2(float v, T& hi, T& lo) {
     asm volatile("" : "+v"(v));
     hi = (T)v;
     lo = (T)(v - (float)hi);
+}
+
+// GELU(x) = x Phi(x) through erfc(|z|) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2), t = 1 / (1 + p |z|), z = x / sqrt 2
+// (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7): x >= 0: x - (x / 2) erfc(z); x < 0: (x / 2) erfc(|z|) -- no cancellation in the
+// negative tail.  Measured against float64 over [-12, 12]: |error| <= 4.7e-7 absolute, <= 2.9e-7 |x| (torch's fp32 gelu: 1.2e-6);
+// 14 VALU instructions, two of them transcendental, where libm's erff is ~50 with its two branches taken by different lanes -- the
+// erff epilogue was 40 % of the split fc1 GEMM (58.8 ms per step against fc2's 34.5 for the same matrix work).
+__device__ __forceinline__ float gelu_erfc(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float c = p * t * __builtin_amdgcn_exp2f(-(z * z) * 1.4426950408889634f);   // erfc(|z|)
+    const float h = 0.5f * x * c;
+    return x >= 0.f ? x - h : h;
 }
 
 // ---- LayerNorm -> hi / lo planes ------------------------------------------------------------------------------------------
@@ -151,7 +169,7 @@ __device__ __forceinline__ void split_store_tile(const f4& a, long long m, int n
         T4 h, l;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float g = 0.5f * v[r] * (1.f + erff(v[r] * 0.70710678118654752f));
+            const float g = gelu_erfc(v[r]);
             if (IsF16<T>::value) amax = fmaxf(amax, fabsf(g));
             T x0, x1;
             split2<T>(g, x0, x1);
@@ -264,6 +282,112 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const T* __restrict_
     }
 #undef SP_FETCH
 #undef SP_STASH
+}
+
+// ---- the same product on the LDS-DMA pipeline of gemm_wide_delta_kernel (round 6, second form) -----------------------------------
+// 256 tokens x 128 features per workgroup of 8 waves (4 x 2, wave tile 64 x 64), 32-wide k-steps; a stage = A_hi | A_lo (256 rows x
+// 64 B each) | W_hi | W_lo (128 rows x 64 B each) = 48 KB arrives by global_load_lds_dwordx4 (no staging registers, no ds_write),
+// ring of three stages, two in flight.  LDS image and swizzle are gemm_tiled_kernel's (four 16-byte pieces per row, gswz), produced
+// by giving every DMA lane the matching source address.  Used when N % 128 == 0 (every GEMM of the ViT-S / B / L blocks).
+constexpr int SD_M = 256, SD_N = 128, SD_STAGES = 3;
+constexpr int SD_STAGE_BYTES = (2 * SD_M + 2 * SD_N) * 64;   // 49152
+constexpr int SD_REQ = (2 * SD_M + 2 * SD_N) / 16 / 8;       // DMA requests per wave and stage: 6
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_split_dma_kernel(const T* __restrict__ Ah, const T* __restrict__ Al,
+                                                                const T* __restrict__ Wh, const T* __restrict__ Wl, long long M, int N,
+                                                                int K, SplitEpi<T> e) {
+    typedef typename Vec<T>::t8 T8;
+    operand_mode<T>();
+    __shared__ __attribute__((aligned(1024))) unsigned char stages[SD_STAGES * SD_STAGE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ncol = N / SD_N;
+    const long long nrow = (M + SD_M - 1) / SD_M;
+    const long long kb = blockIdx.x >> 3;
+    const long long row_blk = (kb / ncol) * 8 + (blockIdx.x & 7);   // the column tiles of a row block back to back on one XCD
+    if (row_blk >= nrow) return;
+    const long long m0 = row_blk * SD_M;
+    const int n0 = (int)(kb % ncol) * SD_N;
+    const int wr = w >> 1, wc = w & 1;
+    const int fj = lane & 15, fg = lane >> 4;
+    // request q = 6 w + i: 0..15 A_hi rows 16 q.., 16..31 A_lo, 32..39 W_hi rows n0 + 16 (q - 32).., 40..47 W_lo
+    const T* src[SD_REQ];
+    unsigned dst[SD_REQ];
+#pragma unroll
+    for (int i = 0; i < SD_REQ; ++i) {
+        const int q = w * SD_REQ + i;
+        const bool isA = q < 32;
+        const int blk = isA ? (q & 15) : ((q - 32) & 7);
+        const bool lo = isA ? q >= 16 : q >= 40;
+        const int row = blk * 16 + (lane >> 2);
+        const int piece = (lane & 3) ^ ((0x1230 >> (((row >> 2) & 3) * 4)) & 3);
+        const long long grow = isA ? min(m0 + row, M - 1) : (long long)(n0 + row);
+        src[i] = (isA ? (lo ? Al : Ah) : (lo ? Wl : Wh)) + grow * K + piece * 8;
+        dst[i] = (isA ? (lo ? SD_M * 64 : 0) : 2 * SD_M * 64 + (lo ? SD_N * 64 : 0)) + blk * 1024;
+    }
+    const unsigned lds0 = (unsigned)(size_t)&stages[0];
+    const int nk = K / SP_K;
+    auto issue = [&](int ks, int buf) {
+        const int kk = min(ks, nk - 1);   // past the end: a harmless repeat keeps the request count per stage uniform
+#pragma unroll
+        for (int i = 0; i < SD_REQ; ++i)
+            ws_glds16(src[i] + (size_t)kk * SP_K, __builtin_amdgcn_readfirstlane(lds0 + buf * SD_STAGE_BYTES + dst[i]));
+    };
+    f4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f4{0.f, 0.f, 0.f, 0.f};
+    const int fsw = (0x1230 >> (((fj >> 2) & 3) * 4)) & 3;
+    const unsigned a_off = ((wr * 64 + fj) * 4 + (fg ^ fsw)) * 16;
+    const unsigned b_off = 2 * SD_M * 64 + ((wc * 64 + fj) * 4 + (fg ^ fsw)) * 16;
+    issue(0, 0);
+    issue(1, 1);
+    ws_wait<SD_REQ>();   // stage 0 landed (stage 1 may still fly)
+    __syncthreads();
+    int buf = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        issue(ks + 2, buf == 0 ? 2 : buf - 1);   // (buf + 2) % 3: the stage consumed in the previous iteration
+        const unsigned char* sb = stages + buf * SD_STAGE_BYTES;
+        T8 ah[4], al[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            ah[mi] = *reinterpret_cast<const T8*>(sb + a_off + mi * 1024);
+            al[mi] = *reinterpret_cast<const T8*>(sb + SD_M * 64 + a_off + mi * 1024);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const T8 bh = *reinterpret_cast<const T8*>(sb + b_off + ni * 1024);
+            const T8 bl = *reinterpret_cast<const T8*>(sb + SD_N * 64 + b_off + ni * 1024);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {   // (W tile) x (token tile)^T: D transposed -- the small terms first
+                acc[mi][ni] = mfma16(bl, ah[mi], acc[mi][ni]);
+                acc[mi][ni] = mfma16(bh, al[mi], acc[mi][ni]);
+                acc[mi][ni] = mfma16(bh, ah[mi], acc[mi][ni]);
+            }
+        }
+        ws_wait<SD_REQ>();   // stage ks + 1 landed; the requests of ks + 2 stay in flight
+        __syncthreads();
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    ws_wait<0>();
+    float amax = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int nb = n0 + wc * 64 + ni * 16 + fg * 4;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+            split_store_tile<T, EPI>(acc[mi][ni], m0 + wr * 64 + mi * 16 + fj, nb, M, N, e, amax);
+    }
+    if (IsF16<T>::value && (EPI == SEPI_QKV || EPI == SEPI_GELU) && e.ovf) {
+        if (__any(amax >= 65488.f) && lane == 0) atomicOr(e.ovf, EPI == SEPI_QKV ? 2 : 4);
+    }
+}
+
+inline unsigned gemm_split_dma_grid(int N, long long rows) {
+    const long long ncol = N / SD_N, nrow = dtk_cdiv(rows, SD_M);
+    return (unsigned)(dtk_cdiv(nrow, 8) * 8 * ncol);
 }
 
 inline unsigned gemm_split_grid(int N, long long rows) {

@@ -114,6 +114,11 @@ def test_split_precision_is_fp32_grade(weights):
     assert r_split < r_fast / 50
     rep = exs.precision_report()
     assert rep["feature_error_class"].startswith("fp32-grade") and rep["split_blocks"] == list(range(12))
+    # the two forms of the split GEMM (LDS-DMA 256 x 128 tiles in production, register-staged 128 x 128 tiles with tiled_gemms) agree
+    # to fp32 summation order
+    ext = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd, precision="split")
+    ext.tiled_gemms = True
+    assert _rel(ext.encode(video, layer=layer), strict) < 2e-6
     # tokens (CLS kept) and the qkv facet come out of the same split pass
     tok = exs.encode(video[:1], layer=layer, want="tokens")
     assert torch.equal(tok[0, 1:], strict[0])
