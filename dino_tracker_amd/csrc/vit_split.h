@@ -468,19 +468,35 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const T* __rest
         AS_PUT(0, s0, s1); AS_PUT(1, s2, s3); AS_PUT(2, s4, s5); AS_PUT(3, s6, s7);
         __syncthreads();
         if (kt + 1 < nkt) AS_FETCH(kt + 1);
-        // ---- S^T = K Q^T, two 32-key sub-tiles
+        // ---- S^T = K Q^T, two 32-key sub-tiles.  The two accumulators take turns (a chain of dependent MFMAs on ONE accumulator
+        // leaves the matrix pipe idle between links) and the fragments of d-step ks + 1 are requested before the MFMAs of ks (the
+        // first form read two fragments, waited for them, issued three MFMAs: the LDS latency sat in front of every group)
         f16v sacc[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[u][r] = 0.f;
+        {
+            T8 kh_[2][2], kl_[2][2];   // [ping-pong][u]
+            auto kload = [&](int ks, int pp) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int o = k_off + u * 32 * AS_PITCH + ks * 32;
+                    kh_[pp][u] = *reinterpret_cast<const T8*>(lds + o);
+                    kl_[pp][u] = *reinterpret_cast<const T8*>(lds + AS_PLANE + o);
+                }
+            };
+            kload(0, 0);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int o = k_off + u * 32 * AS_PITCH + ks * 32;
-                const T8 a_h = *reinterpret_cast<const T8*>(lds + o), a_l = *reinterpret_cast<const T8*>(lds + AS_PLANE + o);
-                sacc[u] = mfma32(a_l, qh[ks], sacc[u]);
-                sacc[u] = mfma32(a_h, ql[ks], sacc[u]);
-                sacc[u] = mfma32(a_h, qh[ks], sacc[u]);
+                const int pp = ks & 1;
+                if (ks + 1 < 4) kload(ks + 1, pp ^ 1);
+                sacc[0] = mfma32(kl_[pp][0], qh[ks], sacc[0]);
+                sacc[1] = mfma32(kl_[pp][1], qh[ks], sacc[1]);
+                sacc[0] = mfma32(kh_[pp][0], ql[ks], sacc[0]);
+                sacc[1] = mfma32(kh_[pp][1], ql[ks], sacc[1]);
+                sacc[0] = mfma32(kh_[pp][0], qh[ks], sacc[0]);
+                sacc[1] = mfma32(kh_[pp][1], qh[ks], sacc[1]);
             }
         }
         // keys past S (the zero padding rows of the last tile) take no part
@@ -526,19 +542,30 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(const T* __rest
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
         }
-        // ---- O^T += V^T P
+        // ---- O^T += V^T P: the two d blocks take turns, the V^T fragments of the next 16-key group are requested ahead
+        {
+            T8 vh_[2][2], vl_[2][2];   // [ping-pong][dt]
+            auto vload = [&](int g, int pp) {   // g = 2 u + s: the 16-key group
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int o = 2 * AS_PLANE + v_off + dt * 32 * AS_PITCH + (u * 32 + s * 16) * 2;
-                    const T8 a_h = *reinterpret_cast<const T8*>(lds + o), a_l = *reinterpret_cast<const T8*>(lds + AS_PLANE + o);
-                    oacc[dt] = mfma32(a_l, p_h[u][s], oacc[dt]);
-                    oacc[dt] = mfma32(a_h, p_l[u][s], oacc[dt]);
-                    oacc[dt] = mfma32(a_h, p_h[u][s], oacc[dt]);
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int o = 2 * AS_PLANE + v_off + dt * 32 * AS_PITCH + g * 32;
+                    vh_[pp][dt] = *reinterpret_cast<const T8*>(lds + o);
+                    vl_[pp][dt] = *reinterpret_cast<const T8*>(lds + AS_PLANE + o);
                 }
+            };
+            vload(0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int pp = g & 1, u = g >> 1, sg = g & 1;
+                if (g + 1 < 4) vload(g + 1, pp ^ 1);
+                oacc[0] = mfma32(vl_[pp][0], p_h[u][sg], oacc[0]);
+                oacc[1] = mfma32(vl_[pp][1], p_h[u][sg], oacc[1]);
+                oacc[0] = mfma32(vh_[pp][0], p_l[u][sg], oacc[0]);
+                oacc[1] = mfma32(vh_[pp][1], p_l[u][sg], oacc[1]);
+                oacc[0] = mfma32(vh_[pp][0], p_h[u][sg], oacc[0]);
+                oacc[1] = mfma32(vh_[pp][1], p_h[u][sg], oacc[1]);
+            }
+        }
     }
     const float ltot = lrun + __shfl_xor(lrun, 32);
     const float inv = 1.f / ltot;
