@@ -129,6 +129,22 @@ __device__ __forceinline__ dtk_u4 dtk_make_srd(const void* p) {
     return r;
 }
 
+// Zero `bytes` (a multiple of 4, `p` 4-byte aligned) with a KERNEL.  For launches that may be captured into a graph (the training
+// iteration, trainer.GraphedIteration): a hipMemsetAsync captured as a memset node was observed NOT to clear its range on replays
+// on this stack (round 6: the contrastive backward's |G| maximum started from the previous replay's bits -- gradients of 1e28 --
+// and ATen's multi-block top-k, which memsets its semaphores the same way, faulted on its second replay).
+static __global__ void dtk_zero_words_kernel(unsigned* __restrict__ p, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline hipError_t dtk_zero_async(void* p, size_t bytes, hipStream_t st) {
+    const size_t words = (bytes + 3) / 4;
+    if (words == 0) return hipSuccess;
+    const size_t blocks = (words + 1023) / 1024;
+    hipLaunchKernelGGL(dtk_zero_words_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st,
+                       reinterpret_cast<unsigned*>(p), words);
+    return hipGetLastError();
+}
+
 // effective source count: min(M, *dM) when a device-side count is supplied
 __device__ __forceinline__ int dtk_active(int M, const int32_t* dM) {
     if (dM == nullptr) return M;

@@ -2160,7 +2160,7 @@ extern "C" int dtk_make_feat_f16(const dtk_geom* g, const float* feat, const flo
                reinterpret_cast<half_t*>(feat_f16), g->T, g->ph, g->pw, pw_pad(g->pw), g->C);
     // the scale of the window correlations' fp16 halves: from the largest cell norm of THIS volume (see RC_SCALE_MAX)
     unsigned* slot = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(feat_f16) + rc_scale_offset(g));
-    DTK_HIP(hipMemsetAsync(slot, 0, 256, dtk_stream(stream)));
+    DTK_HIP(dtk_zero_async(slot, 256, dtk_stream(stream)));   // (dtk_make_feat_f16 runs inside the captured training iteration: common.h)
     {
         const long long nn = (long long)g->T * g->ph * g->pw;
         const int blocks = (int)(dtk_cdiv(nn, 256) < 512 ? dtk_cdiv(nn, 256) : 512);

@@ -1207,7 +1207,7 @@ extern "C" int dtk_emb_reg_forward(const float* x, const float* raw, int F, int 
     DTK_REQUIRE(x && raw && cell_sums && out2 && F > 0 && C > 0 && n > 0, "dtk_emb_reg_forward: bad arguments");
     const long long cells = (long long)F * n;
     hipStream_t st = dtk_stream(stream);
-    DTK_HIP(hipMemsetAsync(out2, 0, 2 * sizeof(float), st));
+    DTK_HIP(dtk_zero_async(out2, 2 * sizeof(float), st));   // (a kernel, not a memset node: common.h)
     DTK_LAUNCH("train_emb_reg", emb_reg_forward_kernel, dim3(dtk_cdiv(cells, 256)), dim3(256), 0, st, x, raw, cell_sums, out2, C,
                (long long)n, cells);
     return DTK_OK;
@@ -1386,8 +1386,8 @@ extern "C" int dtk_contrastive_backward(const float* fe, const float* a, const i
     float* csum = reinterpret_cast<float*>(w); w += cl_al((size_t)Q * n * 4);
     unsigned* gmax = reinterpret_cast<unsigned*>(w);
     float* scale = reinterpret_cast<float*>(w + 256);
-    DTK_HIP(hipMemsetAsync(rsum, 0, cl_al((size_t)Q * B * 4) + cl_al((size_t)Q * n * 4) + 512, st));   // rsum, csum, gmax, scale
-    DTK_HIP(hipMemsetAsync(dfe, 0, (size_t)F * C * n * 4, st));
+    DTK_HIP(dtk_zero_async(rsum, cl_al((size_t)Q * B * 4) + cl_al((size_t)Q * n * 4) + 512, st));   // rsum, csum, gmax, scale
+    DTK_HIP(dtk_zero_async(dfe, (size_t)F * C * n * 4, st));
     DTK_LAUNCH("train_cl_grad", cl_grad_tile_kernel, dim3(dtk_cdiv(np, 64), dtk_cdiv(B, 64), Q), dim3(256), 0, st, S, lse, g, na, nf, fidx,
                G1, G1T, rsum, csum, gmax, B, n, np, 1.f / temp);
     DTK_LAUNCH("train_cl_scale", cl_scale_kernel, dim3(1), dim3(1), 0, st, gmax, scale);
@@ -1408,6 +1408,44 @@ extern "C" int dtk_contrastive_backward(const float* fe, const float* a, const i
 }
 
 
+// ---- operand scale of a gradient tensor (include/dtk.h: dtk_pow2_scale) ---------------------------------------------------------------
+// out[0] = 2^e with max |x| * 2^e in [2^9, 2^10] (max |x| clamped below at 1e-30), what train_ops._pow2_scale computed with a library
+// reduction: torch.exp2(torch.floor(10 - torch.log2(vector_norm(x, inf).clamp_min(1e-30)))).  Why a kernel of its own (round 6): the
+// library's multi-block reduction zeroes its semaphores with a memset, and a memset captured into a graph does not hold its place in
+// the stream on this stack (common.h: dtk_zero_async) -- inside the captured training iteration the norm came back as 0 and every data
+// gradient behind it as NaN.  scratch: one 32-bit word.  NaN inputs propagate (a NaN maximum gives a NaN scale, as before).
+namespace {
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ bits) {
+    float m = 0.f;
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = fabsf(x[i]);
+        bad |= v != v;
+        m = fmaxf(m, v);
+    }
+    unsigned u = bad ? 0x7fc00000u : __float_as_uint(m);      // (non-negative floats and the quiet NaN above them order as integers)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o, 64));
+    if ((threadIdx.x & 63) == 0 && u != 0u) atomicMax(bits, u);
+}
+__global__ void pow2_scale_kernel(const unsigned* __restrict__ bits, float* __restrict__ out) {
+    const float amax = fmaxf(__uint_as_float(*bits), 1e-30f);   // (fmaxf drops a NaN: restored below)
+    out[0] = (*bits > 0x7f800000u) ? __uint_as_float(0x7fc00000u) : exp2f(floorf(10.f - log2f(amax)));
+}
+}  // namespace
+
+extern "C" int dtk_pow2_scale(const float* x, int64_t n, float* out, void* scratch, void* stream) {
+    DTK_REQUIRE(x && out && scratch && n > 0, "dtk_pow2_scale: null pointer or empty tensor");
+    hipStream_t st = dtk_stream(stream);
+    unsigned* bits = reinterpret_cast<unsigned*>(scratch);
+    DTK_HIP(dtk_zero_async(bits, 4, st));
+    const long long blocks = (n + 256 * 8 - 1) / (256 * 8);
+    DTK_LAUNCH("train_absmax", absmax_bits_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, x, (long long)n, bits);
+    DTK_LAUNCH("train_pow2_scale", pow2_scale_kernel, dim3(1), dim3(1), 0, st, bits, out);
+    return DTK_OK;
+}
+
+
 // ---- fused Adam (round 5; include/dtk.h: dtk_adam_step) ------------------------------------------------------------------------
 // One launch over every parameter tensor of the training step.  Block b works on chunk b of the concatenation of the tensors in
 // chunks of ADAM_CHUNK elements (a tensor's last chunk is short); it finds its tensor by walking the <= 32 sizes in the argument block.
@@ -1415,7 +1453,11 @@ namespace {
 constexpr int ADAM_CHUNK = 4096;   // elements per block (256 threads x 4 float4 ... tails handled per element)
 struct AdamScalars { float step_size[DTK_ADAM_MAX_TENSORS]; float inv_bc2_sqrt[DTK_ADAM_MAX_TENSORS]; float omb1, beta2, omb2, eps; };
 
-__global__ __launch_bounds__(256) void adam_multi_kernel(dtk_adam_args a, AdamScalars sc) {
+// DEV: the two per-tensor scalars come from device memory (dev[t] = step size, dev[DTK_ADAM_MAX_TENSORS + t] = 1 / sqrt(bias
+// correction 2)) instead of the argument block -- the form a captured graph replays: pointers and sizes are baked into the launch,
+// the learning rate and the step count change every iteration.
+template <bool DEV>
+__global__ __launch_bounds__(256) void adam_multi_kernel(dtk_adam_args a, AdamScalars sc, const float* __restrict__ dev) {
     long long chunk = blockIdx.x;
     int t = 0;
     for (; t < a.n_tensors; ++t) {
@@ -1429,7 +1471,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(dtk_adam_args a, AdamSc
     float* __restrict__ m = a.exp_avg[t];
     float* __restrict__ v = a.exp_avg_sq[t];
     const long long n = a.numel[t], base = chunk * ADAM_CHUNK;
-    const float step_size = sc.step_size[t], inv_bc2_sqrt = sc.inv_bc2_sqrt[t];
+    const float step_size = DEV ? dev[t] : sc.step_size[t], inv_bc2_sqrt = DEV ? dev[DTK_ADAM_MAX_TENSORS + t] : sc.inv_bc2_sqrt[t];
     for (long long i = base + threadIdx.x; i < n && i < base + ADAM_CHUNK; i += 256) {
         const float gi = g[i];
         const float mi = m[i] + sc.omb1 * (gi - m[i]);                   // exp_avg.lerp_(grad, 1 - beta1)
@@ -1442,26 +1484,65 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(dtk_adam_args a, AdamSc
 }
 }  // namespace
 
-extern "C" int dtk_adam_step(const dtk_adam_args* a, void* stream) {
+static int adam_check(const dtk_adam_args* a, long long* chunks_out, bool need_tensors = true) {
     DTK_REQUIRE(a && a->n_tensors > 0 && a->n_tensors <= DTK_ADAM_MAX_TENSORS, "dtk_adam_step: bad arguments");
     DTK_REQUIRE(a->beta1 >= 0. && a->beta1 < 1. && a->beta2 >= 0. && a->beta2 < 1. && a->eps >= 0., "dtk_adam_step: bad betas / eps");
     long long chunks = 0;
     for (int t = 0; t < a->n_tensors; ++t) {
-        DTK_REQUIRE(a->param[t] && a->grad[t] && a->exp_avg[t] && a->exp_avg_sq[t] && a->numel[t] > 0 && a->group[t] >= 0 &&
-                        a->group[t] < DTK_ADAM_MAX_GROUPS && a->step[t] >= 1,
+        DTK_REQUIRE((!need_tensors || (a->param[t] && a->grad[t] && a->exp_avg[t] && a->exp_avg_sq[t] && a->numel[t] > 0)) &&
+                        a->group[t] >= 0 && a->group[t] < DTK_ADAM_MAX_GROUPS && a->step[t] >= 1,
                     "dtk_adam_step: tensor %d: null pointer, empty tensor, bad group or step < 1", t);
         chunks += (a->numel[t] + ADAM_CHUNK - 1) / ADAM_CHUNK;
     }
-    AdamScalars sc;
+    *chunks_out = chunks;
+    return DTK_OK;
+}
+
+static void adam_scalars(const dtk_adam_args* a, AdamScalars* sc) {
     for (int t = 0; t < DTK_ADAM_MAX_TENSORS; ++t) {
         const int st_ = t < a->n_tensors ? a->step[t] : 1;
         const double bc1 = 1.0 - pow(a->beta1, (double)st_), bc2 = 1.0 - pow(a->beta2, (double)st_);
-        sc.step_size[t] = t < a->n_tensors ? (float)(a->lr[a->group[t]] / bc1) : 0.f;
-        sc.inv_bc2_sqrt[t] = (float)(1.0 / sqrt(bc2));
+        sc->step_size[t] = t < a->n_tensors ? (float)(a->lr[a->group[t]] / bc1) : 0.f;
+        sc->inv_bc2_sqrt[t] = (float)(1.0 / sqrt(bc2));
     }
     // torch forms its scalar coefficients in double and rounds them to fp32 once (1 - 0.999 = 0.001 there; 1.f - 0.999f = 0.00100004673)
-    sc.omb1 = (float)(1.0 - a->beta1); sc.beta2 = (float)a->beta2; sc.omb2 = (float)(1.0 - a->beta2); sc.eps = (float)a->eps;
+    sc->omb1 = (float)(1.0 - a->beta1); sc->beta2 = (float)a->beta2; sc->omb2 = (float)(1.0 - a->beta2); sc->eps = (float)a->eps;
+}
+
+extern "C" int dtk_adam_step(const dtk_adam_args* a, void* stream) {
+    long long chunks = 0;
+    if (int rc = adam_check(a, &chunks)) return rc;
+    AdamScalars sc;
+    adam_scalars(a, &sc);
     hipStream_t st = dtk_stream(stream);
-    DTK_LAUNCH("adam_step", adam_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, st, *a, sc);
+    DTK_LAUNCH("adam_step", adam_multi_kernel<false>, dim3((unsigned)chunks), dim3(256), 0, st, *a, sc, (const float*)nullptr);
+    return DTK_OK;
+}
+
+// The per-tensor scalars of dtk_adam_step (step[] and lr[] of `a`), as that call forms them: out_host[t] = lr[group[t]] / (1 -
+// beta1^step[t]), out_host[DTK_ADAM_MAX_TENSORS + t] = 1 / sqrt(1 - beta2^step[t]).  Host arithmetic only.
+extern "C" int dtk_adam_scalars(const dtk_adam_args* a, float* out_host) {
+    long long chunks = 0;
+    if (int rc = adam_check(a, &chunks, false)) return rc;   // (only n_tensors, betas, eps, group[], step[] and lr[] are read)
+    DTK_REQUIRE(out_host != nullptr, "dtk_adam_scalars: null output");
+    AdamScalars sc;
+    adam_scalars(a, &sc);
+    for (int t = 0; t < DTK_ADAM_MAX_TENSORS; ++t) {
+        out_host[t] = sc.step_size[t];
+        out_host[DTK_ADAM_MAX_TENSORS + t] = sc.inv_bc2_sqrt[t];
+    }
+    return DTK_OK;
+}
+
+// dtk_adam_step with the per-tensor scalars read from DEVICE memory (2 * DTK_ADAM_MAX_TENSORS floats in dtk_adam_scalars' layout;
+// step[] / lr[] of `a` are only validated): the launch a captured iteration replays while the host refreshes the scalars.
+extern "C" int dtk_adam_step_dev(const dtk_adam_args* a, const float* scalars_dev, void* stream) {
+    long long chunks = 0;
+    if (int rc = adam_check(a, &chunks)) return rc;
+    DTK_REQUIRE(scalars_dev != nullptr, "dtk_adam_step_dev: null scalars");
+    AdamScalars sc;
+    adam_scalars(a, &sc);
+    hipStream_t st = dtk_stream(stream);
+    DTK_LAUNCH("adam_step", adam_multi_kernel<true>, dim3((unsigned)chunks), dim3(256), 0, st, *a, sc, scalars_dev);
     return DTK_OK;
 }

@@ -144,8 +144,9 @@ class LongRangeSampler(torch.nn.Module):
         eligible = can_f.sum(dim=1) >= 2
         keys = torch.where(eligible, torch.rand(can_f.shape[0], device=dev), torch.full((), -1.0, device=dev))
         k = min(batch_size, can_f.shape[0])
-        top = torch.topk(keys, k)
-        rows, ok = top.indices, top.values >= 0
+        from .train_ops import topk_rows      # (torch.topk, on a path that survives graph capture however many trajectories there are)
+        top_v, top_i = topk_rows(keys[None], k)
+        rows, ok = top_i[0], top_v[0] >= 0
         # two distinct tracked frames per row, uniformly (what multinomial(2, replacement=False) over the 0 / 1 validity row
         # draws) -- as the two largest of one uniform key per tracked frame: torch.multinomial validates its input with two host
         # reads per call
@@ -212,17 +213,27 @@ class DinoTrackerSampler(LongRangeSampler):
         batches.  A frame set with fewer than two eligible trajectories is redrawn, as in the reference (dataset.py:175-179) --
         on the HOST, against a host copy of the (static) per-frame validity of the trajectories, so the redraw costs no
         device read.  Extra keys: "valid" [B] bool and "frames_set_t_host" (list of int)."""
-        assert self.num_frames is not None, "num_frames must be specified"
+        host, union = self.draw_frame_sets(generator)
         dev = self.fg_valid_trajectories.device
-        n_fg = self.get_fg_batch_size()
+        staged = stage_to_device(host, dev)                                                        # one small async copy
+        frames_set_t = stage_to_device(torch.tensor(union, dtype=torch.int32), dev)
+        return self.batch_from_frame_sets(staged, frames_set_t, union)
+
+    def draw_frame_sets(self, generator=None):
+        """The HOST part of forward_device: the two drawn frame sets and their positions in the sorted union, as one [4, num_frames]
+        int64 host tensor (rows: foreground set, background set, foreground positions, background positions) + the union (list)."""
+        assert self.num_frames is not None, "num_frames must be specified"
         t = self.vid_len
         sets = [self._draw_frame_set(name, t, generator) for name in ("fg", "bg")]               # host draws
         s0, s1 = sets[0].tolist(), sets[1].tolist()
         union = sorted(set(s0) | set(s1))
         pos = {f: i for i, f in enumerate(union)}
-        host = torch.tensor([s0, s1, [pos[f] for f in s0], [pos[f] for f in s1]], dtype=torch.long)
-        staged = stage_to_device(host, dev)                                                        # one small async copy
-        frames_set_t = stage_to_device(torch.tensor(union, dtype=torch.int32), dev)
+        return torch.tensor([s0, s1, [pos[f] for f in s0], [pos[f] for f in s1]], dtype=torch.long), union
+
+    def batch_from_frame_sets(self, staged, frames_set_t, union=None):
+        """The DEVICE part of forward_device: `staged` = draw_frame_sets' table on the device, `frames_set_t` [n] int32 the union.
+        Nothing here reads the host: the call can be captured in a graph whose replays see new contents of the two tensors."""
+        n_fg = self.get_fg_batch_size()
         parts = []
         for j, (name, bs) in enumerate((("fg", n_fg), ("bg", self.batch_size - n_fg))):
             p1, p2, l1, l2, ok = self.sample_rows_on_device(getattr(self, f"{name}_valid_trajectories"),

@@ -409,10 +409,11 @@ class Tracker(nn.Module):
         fg = (fg_masks[src_t.to(fg_masks.device)] > 0).reshape(k, h * w).to(dev)
         keys = torch.rand(k, h * w, device=dev)
         neg = torch.full_like(keys, -1.0)
-        pick_fg = torch.topk(torch.where(fg, keys, neg), min(n_fg, h * w), dim=1)
-        pick_bg = torch.topk(torch.where(fg, neg, keys), min(n_bg, h * w), dim=1)
-        cells = torch.cat([pick_fg.indices, pick_bg.indices], dim=1)                  # [k, n_fg + n_bg]
-        valid = torch.cat([pick_fg.values, pick_bg.values], dim=1) >= 0
+        from .train_ops import topk_rows                                               # (torch.topk, graph-safe for rows this long)
+        pick_fg = topk_rows(torch.where(fg, keys, neg), min(n_fg, h * w))
+        pick_bg = topk_rows(torch.where(fg, neg, keys), min(n_bg, h * w))
+        cells = torch.cat([pick_fg[1], pick_bg[1]], dim=1)                            # [k, n_fg + n_bg]
+        valid = torch.cat([pick_fg[0], pick_bg[0]], dim=1) >= 0
         t_col = src_t[:, None].expand_as(cells)
         pts = torch.stack([(cells % w).float(), torch.div(cells, w, rounding_mode="floor").float(), t_col.float()], dim=2)
         src_idx = source_selector[:, None].expand_as(cells)

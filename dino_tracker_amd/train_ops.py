@@ -62,6 +62,10 @@ def blurpool(x: torch.Tensor, filt: torch.Tensor, stride: int = 2) -> torch.Tens
 
 
 _WORKSPACE = {}
+# A captured iteration (trainer.GraphedIteration) has the addresses of these buffers baked into its launches: once a graph exists a
+# buffer that is outgrown (a batch with more frames) is kept alive next to its replacement instead of being freed.
+RETAIN_REPLACED_WORKSPACES = False
+_RETIRED = []
 
 
 def _workspace(name: str, numel: int, like: torch.Tensor) -> torch.Tensor:
@@ -71,6 +75,8 @@ def _workspace(name: str, numel: int, like: torch.Tensor) -> torch.Tensor:
     key = (name, like.device, like.dtype)
     buf = _WORKSPACE.get(key)
     if buf is None or buf.numel() < numel:
+        if buf is not None and RETAIN_REPLACED_WORKSPACES:
+            _RETIRED.append(buf)
         _WORKSPACE[key] = buf = torch.empty(numel, dtype=like.dtype, device=like.device)
     return buf[:numel]
 
@@ -78,6 +84,7 @@ def _workspace(name: str, numel: int, like: torch.Tensor) -> torch.Tensor:
 def release_scratch() -> None:
     """Drop the persistent scratch (Tracker.eval() calls this: inference needs none of it)."""
     _WORKSPACE.clear()
+    _RETIRED.clear()
     _PACKED.clear()
 
 
@@ -144,6 +151,14 @@ W_SCALE = 256.0  # weights carry 2^8 into the fp16 split (their lo halves stay n
 def _pow2_scale(t: torch.Tensor) -> torch.Tensor:
     """Device scalar 2^e with max |t| * 2^e in [2^9, 2^10]: the operand scale of a gradient tensor for the fp16 split (its
     entries down to 2^-24 of the largest keep normal halves).  No host synchronisation."""
+    if t.is_cuda and t.dtype == torch.float32 and t.numel() > 0:
+        # csrc/train.hip dtk_pow2_scale: the library's multi-block reduction is not safe inside a captured graph on this stack
+        from . import ops
+        from ._lib import check, lib
+        t = t.contiguous()
+        out = torch.empty(2, dtype=torch.float32, device=t.device)      # [scale, scratch word]
+        check(lib().dtk_pow2_scale(t.data_ptr(), t.numel(), out.data_ptr(), out.data_ptr() + 4, ops._stream()))
+        return out[:1]
     amax = torch.linalg.vector_norm(t, ord=float("inf")).clamp_min(1e-30)  # one reduction pass, no |t| temporary
     return torch.exp2(torch.floor(10.0 - torch.log2(amax))).reshape(1)
 
@@ -806,7 +821,95 @@ def head_forward(head, cost: torch.Tensor) -> torch.Tensor:
     return 2.0 * xy / scale - 1.0
 
 
+# ---- the k largest per row, for long rows --------------------------------------------------------------------------------------------
+TOPK_CHUNK, TOPK_DIRECT, TOPK_SLICES = 2048, 2500, 192
+
+
+def _topk_one_block(x: torch.Tensor, k: int):
+    """torch.topk(x, k, dim=1) kept on its one-block-per-slice kernel: rows no longer than TOPK_DIRECT, at most TOPK_SLICES rows per call
+    (ATen picks the multi-block path from (slices, slice length): <= 200 slices of < 5000 elements never take it)."""
+    if x.shape[0] <= TOPK_SLICES:
+        return torch.topk(x, k, dim=1)
+    parts = [torch.topk(p, k, dim=1) for p in x.split(TOPK_SLICES)]
+    return torch.cat([p.values for p in parts]), torch.cat([p.indices for p in parts])
+
+
+def topk_rows(x: torch.Tensor, k: int):
+    """torch.topk(x, k, dim=1) (values, indices) for a 2-D tensor whose rows may be long.  Few long rows send torch.topk to its
+    multi-block radix path, which does not survive a captured graph on this stack (its second replay reads state the first one left
+    behind: a memory fault in trainer.GraphedIteration, found by bisection with scripts/dev/graph_bisect.py).  Long rows go in
+    levels instead -- the k largest of every TOPK_CHUNK-wide piece, then the k largest of those candidates: the same set, every level on
+    the one-block-per-slice kernel.  Ties between equal values may resolve to a different index than torch.topk's (the callers' values
+    are continuous random keys)."""
+    rows, n = x.shape
+    if n <= TOPK_DIRECT:
+        return _topk_one_block(x, k)
+    if 2 * k > TOPK_CHUNK:      # (every level must at least halve the row)
+        return torch.topk(x, k, dim=1)
+    groups = (n + TOPK_CHUNK - 1) // TOPK_CHUNK
+    pad = groups * TOPK_CHUNK - n
+    if pad:
+        x = torch.cat([x, torch.full((rows, pad), float("-inf"), dtype=x.dtype, device=x.device)], dim=1)
+    first = _topk_one_block(x.view(rows * groups, TOPK_CHUNK), k)
+    cand_val = first[0].view(rows, groups * k)
+    base = (torch.arange(groups, device=x.device) * TOPK_CHUNK)[None, :, None]
+    cand_idx = (first[1].view(rows, groups, k) + base).view(rows, groups * k)
+    second = topk_rows(cand_val, k)
+    return second[0], cand_idx.gather(1, second[1])
+
+
 # ---- fused Adam (round 5; csrc/train.hip: dtk_adam_step) ----------------------------------------------------------------------------
+def _adam_args(optimizer, advance: bool = True):
+    """The argument block of dtk_adam_step for the optimizer's current state (-> (AdamArgs, tensors to keep alive) or (None, [])
+    when no parameter has a gradient).  `advance`: count this call as a step (torch.optim.Adam's lazy state initialisation and
+    `state["step"] += 1`).  Raises for options the kernel does not implement -- BEFORE any state is touched (a
+    NotImplementedError raised half-way through the walk left the step counters of the tensors already visited advanced with no
+    update applied)."""
+    from ._lib import ADAM_MAX_GROUPS, ADAM_MAX_TENSORS, AdamArgs
+    groups = optimizer.param_groups
+    if len(groups) > ADAM_MAX_GROUPS:
+        raise NotImplementedError(f"fused Adam: {len(groups)} parameter groups (max {ADAM_MAX_GROUPS})")
+    live = [p for grp in groups for p in grp["params"] if p.grad is not None]
+    if len(live) > ADAM_MAX_TENSORS:
+        raise NotImplementedError(f"fused Adam: more than {ADAM_MAX_TENSORS} parameter tensors")
+    g0 = (float(groups[0]["betas"][0]), float(groups[0]["betas"][1]), float(groups[0]["eps"]))
+    for grp in groups:
+        if grp.get("weight_decay", 0) != 0 or grp.get("amsgrad", False) or grp.get("maximize", False):
+            raise NotImplementedError("fused Adam: weight_decay / amsgrad / maximize are not implemented")
+        if (float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"])) != g0:
+            raise NotImplementedError("fused Adam: per-group betas / eps")
+    for p in live:
+        if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.dtype == torch.float32):
+            raise NotImplementedError("fused Adam: contiguous fp32 device parameters only")
+    a = AdamArgs()
+    a.beta1, a.beta2, a.eps = g0
+    n = 0
+    keep = []
+    for gi, grp in enumerate(groups):
+        a.lr[gi] = float(grp["lr"])
+        for p in grp["params"]:
+            if p.grad is None:
+                continue
+            st = optimizer.state[p]
+            if len(st) == 0:   # torch.optim.Adam's lazy state initialisation
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if advance:
+                st["step"] += 1
+            s_now = int(st["step"].item()) if torch.is_tensor(st["step"]) else int(st["step"])
+            g = p.grad.contiguous()
+            keep.append(g)
+            a.param[n], a.grad[n] = p.data_ptr(), g.data_ptr()
+            a.exp_avg[n], a.exp_avg_sq[n] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            a.numel[n], a.group[n], a.step[n] = p.numel(), gi, max(s_now, 1)
+            n += 1
+    if n == 0:
+        return None, []
+    a.n_tensors = n
+    return a, keep
+
+
 def fused_adam_step(optimizer) -> None:
     """One step of a torch.optim.Adam instance (dino_tracker.py:110-115: default betas / eps, no weight decay, no amsgrad, two
     parameter groups whose learning rates the LambdaLR of optimization/schedulers.py:4-8 rewrites) as ONE kernel launch over all
@@ -814,58 +917,72 @@ def fused_adam_step(optimizer) -> None:
     checkpoints and the scheduler work unchanged.  Raises for options the kernel does not implement."""
     import ctypes
 
-    from ._lib import ADAM_MAX_GROUPS, ADAM_MAX_TENSORS, AdamArgs, check, lib
+    from ._lib import check, lib
     from . import ops
-    groups = optimizer.param_groups
-    if len(groups) > ADAM_MAX_GROUPS:
-        raise NotImplementedError(f"fused Adam: {len(groups)} parameter groups (max {ADAM_MAX_GROUPS})")
-    # validate EVERYTHING before any state is touched (ADVICE r5: a NotImplementedError raised half-way through the walk below left
-    # the step counters of the tensors already visited advanced with no update applied)
-    live = [p for grp in groups for p in grp["params"] if p.grad is not None]
-    if len(live) > ADAM_MAX_TENSORS:
-        raise NotImplementedError(f"fused Adam: more than {ADAM_MAX_TENSORS} parameter tensors")
-    for grp in groups:
-        if grp.get("weight_decay", 0) != 0 or grp.get("amsgrad", False) or grp.get("maximize", False):
-            raise NotImplementedError("fused Adam: weight_decay / amsgrad / maximize are not implemented")
-        if (float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"])) != (float(groups[0]["betas"][0]), float(groups[0]["betas"][1]), float(groups[0]["eps"])):
-            raise NotImplementedError("fused Adam: per-group betas / eps")
-    for p in live:
-        if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.dtype == torch.float32):
-            raise NotImplementedError("fused Adam: contiguous fp32 device parameters only")
-    a = AdamArgs()
-    n = 0
-    keep = []
-    for gi, grp in enumerate(groups):
-        if gi == 0:
-            a.beta1, a.beta2, a.eps = float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"])
-        elif (float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"])) != (float(groups[0]["betas"][0]), float(groups[0]["betas"][1]), float(groups[0]["eps"])):
-            raise NotImplementedError("fused Adam: per-group betas / eps")
-        a.lr[gi] = float(grp["lr"])
-        for p in grp["params"]:
-            if p.grad is None:
-                continue
-            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.dtype == torch.float32):
-                raise NotImplementedError("fused Adam: contiguous fp32 device parameters only")
-            st = optimizer.state[p]
-            if len(st) == 0:   # torch.optim.Adam's lazy state initialisation
-                st["step"] = torch.tensor(0.0)
-                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            st["step"] += 1
-            s_now = int(st["step"].item()) if torch.is_tensor(st["step"]) else int(st["step"])
-            if n >= ADAM_MAX_TENSORS:
-                raise NotImplementedError(f"fused Adam: more than {ADAM_MAX_TENSORS} parameter tensors")
-            g = p.grad.contiguous()
-            keep.append(g)
-            a.param[n], a.grad[n] = p.data_ptr(), g.data_ptr()
-            a.exp_avg[n], a.exp_avg_sq[n] = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-            a.numel[n], a.group[n], a.step[n] = p.numel(), gi, s_now
-            n += 1
-    if n == 0:
+    a, _keep = _adam_args(optimizer)
+    if a is None:
         return
-    a.n_tensors = n
     with torch.no_grad():
         check(lib().dtk_adam_step(ctypes.byref(a), ops._stream()))
+
+
+class GraphAdam:
+    """The fused Adam step of a CAPTURED iteration (trainer.GraphedIteration).  A launch baked into a graph reads its two per-tensor
+    scalars (step size, 1 / sqrt(bias correction 2)) from `self.scalars` on the device; `refresh(params)` advances the step counts of
+    the tensors that launch updates, forms the scalars from the optimizer's CURRENT learning rates exactly as dtk_adam_step does
+    (dtk_adam_scalars: the arithmetic lives in one place) and queues their upload on the current stream -- call it before every
+    replay.  The optimizer object and its state dict stay torch's."""
+
+    def __init__(self, optimizer, device):
+        from ._lib import ADAM_MAX_TENSORS
+        self.optimizer = optimizer
+        self.scalars = torch.zeros(2 * ADAM_MAX_TENSORS, dtype=torch.float32, device=device)
+        self._host = [torch.zeros(2 * ADAM_MAX_TENSORS, dtype=torch.float32).pin_memory() for _ in range(4)]
+        self._events = [None] * 4
+        self._next = 0
+
+    def launch(self):
+        """Inside a capture, after backward: the launch.  Returns (parameters it updates, in its order; their gradient tensors --
+        the addresses are baked into the launch, so the caller keeps them alive as long as the graph)."""
+        import ctypes
+
+        from ._lib import check, lib
+        from . import ops
+        a, keep = _adam_args(self.optimizer, advance=False)
+        if a is None:
+            raise RuntimeError("GraphAdam: no parameter has a gradient")
+        params = [p for grp in self.optimizer.param_groups for p in grp["params"] if p.grad is not None]
+        with torch.no_grad():
+            check(lib().dtk_adam_step_dev(ctypes.byref(a), ctypes.c_void_p(self.scalars.data_ptr()), ops._stream()))
+        return params, keep
+
+    def refresh(self, params):
+        import ctypes
+
+        from ._lib import AdamArgs, check, lib
+        opt = self.optimizer
+        a = AdamArgs()
+        g0 = opt.param_groups[0]
+        a.beta1, a.beta2, a.eps = float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"])
+        group_of = {id(p): gi for gi, grp in enumerate(opt.param_groups) for p in grp["params"]}
+        for gi, grp in enumerate(opt.param_groups):
+            a.lr[gi] = float(grp["lr"])
+        for n, p in enumerate(params):
+            st = opt.state[p]
+            st["step"] += 1
+            a.group[n] = group_of[id(p)]
+            a.step[n] = int(st["step"].item()) if torch.is_tensor(st["step"]) else int(st["step"])
+        a.n_tensors = len(params)
+        i = self._next
+        self._next = (i + 1) % len(self._host)
+        if self._events[i] is not None:
+            self._events[i].synchronize()
+        host = self._host[i]
+        check(lib().dtk_adam_scalars(ctypes.byref(a), ctypes.cast(host.data_ptr(), ctypes.POINTER(ctypes.c_float))))
+        self.scalars.copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._events[i] = ev
 
 
 def install_fused_adam(optimizer):

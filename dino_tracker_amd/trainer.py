@@ -158,15 +158,16 @@ def foreground_at(mask: torch.Tensor, coords: torch.Tensor, resw: int, resh: int
 def pick_subsets(member_sets, counts, generator=None):
     """member_sets: list of bool [P, L] masks over the same L slots; counts: how many to draw from each.  One uniform key per
     slot; per set the `count` largest keys among its members.  Returns (slot indices [P, sum(counts)], ok [P, sum(counts)])."""
+    from .train_ops import topk_rows
     P, L = member_sets[0].shape
     dev = member_sets[0].device
     keys = torch.rand(P, L, device=dev, generator=generator)
     neg = torch.full((), -1.0, device=dev)
     idx, ok = [], []
     for members, k in zip(member_sets, counts):
-        top = torch.topk(torch.where(members, keys, neg), min(k, L), dim=1)
-        idx.append(top.indices)
-        ok.append(top.values >= 0)
+        top = topk_rows(torch.where(members, keys, neg), min(k, L))
+        idx.append(top[1])
+        ok.append(top[0] >= 0)
     return torch.cat(idx, dim=1), torch.cat(ok, dim=1)
 
 
@@ -228,29 +229,175 @@ class BestBuddyTable:
 
 # ---- mutual nearest neighbours of the refined features ------------------------------------------------------------------
 @torch.no_grad()
-def mutual_argmax(frame_embeddings: torch.Tensor, s_sel: torch.Tensor, t_sel: torch.Tensor, geom=None):
-    """dino_tracker.py:262-283: for P frame pairs (indices into frame_embeddings [F, C, h, w]) the arg-max over the TARGET
-    cells of every source cell's cosine, and over the SOURCE cells of every target cell's -> (nn_st [P, n], nn_ts [P, n]).
-    On the device: dtk_argmax_cells (fp16 MFMA candidate search + exact fp32 decision, the N4 kernel path; first maximum on
-    ties) -- the n x n affinity matrix is never written.  On a host tensor: the affinity matrix and two arg-maxes."""
+def mutual_argmax_prepare(frame_embeddings: torch.Tensor, s_sel: torch.Tensor, t_sel: torch.Tensor, geom=None):
+    """Everything of `mutual_argmax` in front of the search itself (device tensors only): the token-major copy, its 16-bit planes
+    and the (source row, target frame) lists of both directions.  No host read -- the part a captured iteration keeps in its first
+    graph (the search reads one counter back, so it runs between the two graphs)."""
+    from . import ops
     Fn, C, h, w = frame_embeddings.shape
     n = h * w
     P = s_sel.shape[0]
+    feat, norms = ops.pack_features(frame_embeddings.contiguous())
+    method = ops.TRACK_MFMA if C % 32 == 0 else ops.TRACK_EXACT
+    f16 = ops.make_feat_f16(geom, feat, norms) if method == ops.TRACK_MFMA else None
+    ar = torch.arange(n, device=feat.device)
+    rows = torch.cat([s_sel[:, None] * n + ar[None, :], t_sel[:, None] * n + ar[None, :]]).reshape(-1).to(torch.int32)
+    tgt = torch.cat([t_sel[:, None].expand(P, n), s_sel[:, None].expand(P, n)]).reshape(-1).to(torch.int32)
+    return dict(geom=geom, feat=feat, norms=norms, f16=f16, rows=rows.contiguous(), tgt=tgt.contiguous(), method=method,
+                P=P, n=n, Fn=Fn, C=C)
+
+
+@torch.no_grad()
+def mutual_argmax_search(pre) -> torch.Tensor:
+    """dtk_argmax_cells over the lists of mutual_argmax_prepare -> cell [2 P n] int32 (fp16 MFMA candidate search + exact fp32
+    decision, the N4 kernel path; first maximum on ties; one counter read on the host)."""
+    from . import ops
+    cell, _ = ops.argmax_cells(pre["geom"], pre["feat"], pre["norms"], pre["f16"], pre["feat"].reshape(pre["Fn"] * pre["n"], pre["C"]),
+                               pre["rows"], pre["tgt"], pre["method"])
+    return cell
+
+
+@torch.no_grad()
+def mutual_argmax(frame_embeddings: torch.Tensor, s_sel: torch.Tensor, t_sel: torch.Tensor, geom=None):
+    """dino_tracker.py:262-283: for P frame pairs (indices into frame_embeddings [F, C, h, w]) the arg-max over the TARGET
+    cells of every source cell's cosine, and over the SOURCE cells of every target cell's -> (nn_st [P, n], nn_ts [P, n]).
+    On the device: dtk_argmax_cells (mutual_argmax_prepare / _search) -- the n x n affinity matrix is never written.  On a host
+    tensor: the affinity matrix and two arg-maxes."""
     if frame_embeddings.is_cuda:
-        from . import ops
-        feat, norms = ops.pack_features(frame_embeddings.contiguous())
-        method = ops.TRACK_MFMA if C % 32 == 0 else ops.TRACK_EXACT
-        f16 = ops.make_feat_f16(geom, feat, norms) if method == ops.TRACK_MFMA else None
-        ar = torch.arange(n, device=feat.device)
-        rows = torch.cat([s_sel[:, None] * n + ar[None, :], t_sel[:, None] * n + ar[None, :]]).reshape(-1).to(torch.int32)
-        tgt = torch.cat([t_sel[:, None].expand(P, n), s_sel[:, None].expand(P, n)]).reshape(-1).to(torch.int32)
-        cell, _ = ops.argmax_cells(geom, feat, norms, f16, feat.reshape(Fn * n, C), rows.contiguous(), tgt.contiguous(), method)
-        cell = cell.long().view(2, P, n)
+        pre = mutual_argmax_prepare(frame_embeddings, s_sel, t_sel, geom)
+        cell = mutual_argmax_search(pre).long().view(2, pre["P"], pre["n"])
         return cell[0], cell[1]
     ff = frame_embeddings.flatten(2).transpose(1, 2)
     sf, tf = ff[s_sel], ff[t_sel]
     aff = torch.bmm(sf, tf.transpose(1, 2)) / torch.clamp(sf.norm(dim=2)[:, :, None] * tf.norm(dim=2)[:, None, :], min=EPS)
     return aff.argmax(dim=2), aff.argmax(dim=1)
+
+
+# ---- one iteration, eager or as two captured graphs ----------------------------------------------------------------------------
+def graphs_enabled(device) -> bool:
+    """DTK_TRAIN_GRAPH: "1" (default on a GPU) replays captured iterations, "0" runs every iteration eagerly."""
+    return torch.device(device).type == "cuda" and os.environ.get("DTK_TRAIN_GRAPH", "1") != "0"
+
+
+class GraphedIteration:
+    """One iteration of the device-side trainer -- batch, forward, the loss terms, backward, the Adam step -- either eagerly or as TWO
+    captured graphs (hipGraph through torch.cuda.CUDAGraph) around the one step that reads the device on the host:
+
+        host    the batch's two frame sets (DinoTrackerSampler.draw_frame_sets), copied into the graphs' input tensors; the Adam
+                scalars of this step (train_ops.GraphAdam.refresh: step counts and the scheduler's current learning rates)
+        graph A the sampler's device part, the forward pass, the tracking and cycle terms, the random parts of both contrastive
+                selections, the operands of the mutual-nearest-neighbour search            (trainer.iteration_front)
+        eager   dtk_argmax_cells: its undecidable rows take the exact path, their count is read back (one synchronisation)
+        graph B the contrastive terms on the search's result, the regularisers, the total, BACKWARD through both halves, the fused
+                Adam step on device-resident scalars                                      (trainer.iteration_back)
+
+    Why: the iteration is ~1 100 launches of which ~1 000 are small library kernels of the selections and loss arithmetic; issued one
+    by one they keep the host as busy as the device (docs/TRAINING.md, round 4: per-iteration times jitter 0.03-0.14 s with host
+    stalls).  A replay is two launches.
+
+    A graph is specific to (frames in the batch, cycle term on, refiner term on): the union of the two drawn frame sets has 6-8
+    frames at config/train.yaml's sizes, and the terms switch on at apply_*_after.  The FIRST iteration of a key runs eagerly (every
+    lazily created table and scratch buffer of that shape then exists with real contents), the second is captured, later ones replay.
+    All graphs share one memory pool: an iteration leaves nothing in it that the next one reads (parameters, optimizer state,
+    BatchNorm statistics and the inputs live outside), so keys may replay in any order.  train_ops' persistent scratch keeps outgrown
+    buffers alive once a graph exists (their addresses are baked into the launches).
+
+    Random numbers: the device draws inside a capture go through torch's graph-safe Philox state (fresh offsets every replay); the
+    host draws are the sampler's.  `values` of run(): the seven loss values (a fresh device vector)."""
+
+    def __init__(self, trainer, model, optimizer, sampler, enabled=None):
+        self.trainer, self.model, self.optimizer, self.sampler = trainer, model, optimizer, sampler
+        self.device = next(model.parameters()).device
+        self.enabled = graphs_enabled(self.device) if enabled is None else bool(enabled)
+        self.entries, self.seen = {}, set()
+        self.counts = {"eager": 0, "captured": 0, "replayed": 0}
+        if self.enabled and not getattr(optimizer, "_dtk_fused", False):
+            self.enabled = False    # torch's own Adam step (DTK_TRAIN_ADAM=torch, options the kernel lacks): its scalars live on the host
+        if self.enabled:
+            from .train_ops import GraphAdam
+            self.pool = torch.cuda.graph_pool_handle()
+            self.stream = torch.cuda.Stream(device=self.device)
+            self.adam = GraphAdam(optimizer, self.device)
+
+    def invalidate(self):
+        """Drop every captured graph (a tensor whose address they read was replaced, e.g. DinoTrackerSampler.load_next_batch)."""
+        self.entries, self.seen = {}, set()
+
+    def key(self, union, i):
+        cfg = self.trainer.config
+        return (len(union), i >= cfg.get("apply_cyc_after", 0), i >= cfg.get("apply_cl_ref_after", 0))
+
+    # -- eager ------------------------------------------------------------------------------------------------------------
+    def run_eager(self, host, union, i):
+        from .dataset import stage_to_device
+        tr, model = self.trainer, self.model
+        self.optimizer.zero_grad(set_to_none=True)
+        if self.entries:    # (the last capture's autograd graph and its AccumulateGrad nodes belong to the capture stream: see capture())
+            model.frame_embeddings = model.raw_embeddings = model.residual_embeddings = None
+        staged = stage_to_device(host, self.device)
+        frames_set_t = stage_to_device(torch.tensor(union, dtype=torch.int32), self.device)
+        inputs, labels, valid = tr._batch(self.sampler.batch_from_frame_sets(staged, frames_set_t, union))
+        loss, values = tr.iteration_losses(model, inputs, labels, valid, i)
+        loss.backward()
+        self.optimizer.step()
+        self.counts["eager"] += 1
+        return values
+
+    # -- capture ----------------------------------------------------------------------------------------------------------
+    def capture(self, key, host, union, i):
+        from . import train_ops
+        tr, model = self.trainer, self.model
+        train_ops.RETAIN_REPLACED_WORKSPACES = True
+        e = {"staged": torch.zeros(host.shape, dtype=torch.long, device=self.device),
+             "frames_set_t": torch.zeros(len(union), dtype=torch.int32, device=self.device)}
+        self.optimizer.zero_grad(set_to_none=True)
+        # The previous (eager) iteration's autograd graph is still alive through the tensors the model keeps for the loss terms; it
+        # holds the parameters' AccumulateGrad nodes, which belong to the stream they were created on -- gradients accumulated there
+        # would leave the capturing stream.  Without that graph the capture creates its own nodes.
+        model.frame_embeddings = model.raw_embeddings = model.residual_embeddings = None
+        train_ops._PACKED.clear()
+        torch.cuda.synchronize(self.device)
+        gA, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gA, pool=self.pool, stream=self.stream):
+            inputs, labels, valid = tr._batch(self.sampler.batch_from_frame_sets(e["staged"], e["frames_set_t"], None))
+            st = tr.iteration_front(model, inputs, labels, valid, i)
+        pre = st["prepared"][2] if st["prepared"] is not None else None
+        e["found"] = torch.zeros(2 * pre["P"] * pre["n"], dtype=torch.int32, device=self.device) if pre is not None else None
+        with torch.cuda.graph(gB, pool=self.pool, stream=self.stream):
+            loss, values = tr.iteration_back(model, st, e["found"], i)
+            loss.backward()
+            e["params"], e["grads"] = self.adam.launch()
+        e.update(gA=gA, gB=gB, st=st, values=values)
+        self.entries[key] = e
+        self.counts["captured"] += 1
+        return e
+
+    # -- replay -----------------------------------------------------------------------------------------------------------
+    def replay(self, e, host, union):
+        from .dataset import stage_to_device
+        e["staged"].copy_(stage_to_device(host, self.device))
+        e["frames_set_t"].copy_(stage_to_device(torch.tensor(union, dtype=torch.int32), self.device))
+        self.adam.refresh(e["params"])
+        e["gA"].replay()
+        if e["found"] is not None:
+            e["found"].copy_(self.trainer.refined_bb_search(self.model, e["st"]["prepared"]))
+        e["gB"].replay()
+        self.optimizer._opt_called = True
+        self.counts["replayed"] += 1
+        return e["values"].clone()
+
+    def run(self, i):
+        host, union = self.sampler.draw_frame_sets()
+        if not self.enabled:
+            return self.run_eager(host, union, i)
+        key = self.key(union, i)
+        e = self.entries.get(key)
+        if e is None:
+            if key not in self.seen:
+                self.seen.add(key)
+                return self.run_eager(host, union, i)
+            e = self.capture(key, host, union, i)       # (a capture records, it does not execute: the replay below is the iteration)
+        return self.replay(e, host, union)
 
 
 # ---- the trainer ----------------------------------------------------------------------------------------------------------
@@ -280,11 +427,14 @@ def make_trainer(base):
             return torch.stack([xx.reshape(-1), yy.reshape(-1)], dim=-1)
 
         # -- batch -------------------------------------------------------------------------------------------------------
-        def get_inputs_and_labels_device(self, sampler):
-            sample = sampler.forward_device()
+        @staticmethod
+        def _batch(sample):
             labels = sample["t2_points_normalized"][:, :-1]
             inputs = (sample["t1_points"], sample["source_frame_indices"], sample["target_frame_indices"], sample["frames_set_t"])
             return inputs, labels, sample["valid"]
+
+        def get_inputs_and_labels_device(self, sampler):
+            return self._batch(sampler.forward_device())
 
         # -- loss terms --------------------------------------------------------------------------------------------------
         def split_counts(self, per_pair, fg_ratio):
@@ -330,24 +480,49 @@ def make_trainer(base):
             div = self.config["cl_div_dino_bb"]
             return ((l_st * w / div).sum() + (l_ts * w / div).sum()) / 2
 
-        def refined_bb_selection(self, model, frames_set_t):
-            """Random part of dino_tracker.py:245-305: cl_n_frames index pairs (source == target allowed, as there), the
-            mutual nearest neighbours of the current refined features, and up to cl_points_per_pair of them per pair split
-            foreground / background by the source frame's mask at the cell centres."""
+        def refined_bb_prepare(self, model, frames_set_t):
+            """Random part of dino_tracker.py:245-305, first half: cl_n_frames index pairs (source == target allowed, as there)
+            and the operands of the mutual-nearest-neighbour search over the current refined features (no host read)."""
             fe = model.frame_embeddings
             n = frames_set_t.shape[0]
             dev = fe.device
             P = self.config["cl_n_frames"]
             s_sel = torch.randint(n, (P,), device=dev)
             t_sel = torch.randint(n, (P,), device=dev)
-            geom = model.tracker_head.geom(fe.shape[0], fe.shape[1]) if fe.is_cuda else None
-            nn_st, nn_ts = mutual_argmax(fe.detach(), s_sel, t_sel, geom)
-            cells = torch.arange(nn_st.shape[1], device=dev)
+            pre = None
+            if fe.is_cuda:
+                pre = mutual_argmax_prepare(fe.detach(), s_sel, t_sel, model.tracker_head.geom(fe.shape[0], fe.shape[1]))
+            return s_sel, t_sel, pre
+
+        def refined_bb_search(self, model, prepared):
+            """The search between the two halves -> (nn_st [P, n], nn_ts [P, n]) or, on the device, the flat int32 cell list."""
+            s_sel, t_sel, pre = prepared
+            if pre is not None:
+                return mutual_argmax_search(pre)
+            return mutual_argmax(model.frame_embeddings.detach(), s_sel, t_sel)
+
+        def refined_bb_finish(self, frames_set_t, prepared, found):
+            """Second half: the mutual pairs and up to cl_points_per_pair of them per frame pair, split foreground / background
+            by the source frame's mask at the cell centres."""
+            s_sel, t_sel, pre = prepared
+            if pre is not None:
+                cell = found.long().view(2, pre["P"], pre["n"])
+                nn_st, nn_ts = cell[0], cell[1]
+            else:
+                nn_st, nn_ts = found
+            cells = torch.arange(nn_st.shape[1], device=nn_st.device)
             mutual = nn_ts.gather(1, nn_st) == cells[None, :]
             fg = self._cell_fg[frames_set_t[s_sel].long()]
             n_fg, n_bg = self.split_counts(self.config["cl_points_per_pair"], self.config["cl_fg_points_ratio"])
             src_cells, ok = pick_subsets([mutual & fg, mutual & ~fg], [n_fg, n_bg])
             return s_sel, t_sel, src_cells, nn_st.gather(1, src_cells), ok
+
+        def refined_bb_selection(self, model, frames_set_t):
+            """Random part of dino_tracker.py:245-305: cl_n_frames index pairs (source == target allowed, as there), the
+            mutual nearest neighbours of the current refined features, and up to cl_points_per_pair of them per pair split
+            foreground / background by the source frame's mask at the cell centres."""
+            prepared = self.refined_bb_prepare(model, frames_set_t)
+            return self.refined_bb_finish(frames_set_t, prepared, self.refined_bb_search(model, prepared))
 
         def refined_bb_terms(self, model, s_sel, t_sel, src_cells, tgt_cells, ok):
             """Deterministic part of dino_tracker.py:245-325 for explicit selections (cells of the token grid)."""
@@ -421,28 +596,46 @@ def make_trainer(base):
             ts = wgt[:, None] * huber(c["target_source_coords"], c["source_coords"][:, :2])
             return (weighted_mean(st, c["keep"]) + weighted_mean(ts, c["keep"])) / 2
 
-        def iteration_losses(self, model, inputs, labels, valid, i):
-            """The seven loss values of one iteration as a device vector in LOSS_NAMES order (dino_tracker.py:407-426)."""
+        def iteration_front(self, model, inputs, labels, valid, i):
+            """The iteration up to the mutual-nearest-neighbour search (dino_tracker.py:407-417 and the draws of :159-212 / the
+            first half of :245-305): forward pass, tracking term, cycle term, both selections' random parts.  No host read."""
             cfg = self.config
             frames_set_t = inputs[-1]
             coords = model(inputs)
             zero = coords.new_zeros(())
-            tracking = weighted_mean(huber(coords, labels), valid)
-            loss = tracking
-            cyc = cl_ref = zero
+            st = dict(frames_set_t=frames_set_t, tracking=weighted_mean(huber(coords, labels), valid), cyc=zero, prepared=None)
             if i >= cfg.get("apply_cyc_after", 0):
-                cyc = self.cycle_terms(model, frames_set_t)
-                loss = loss + cfg["lambda_cyc"] * cyc
+                st["cyc"] = self.cycle_terms(model, frames_set_t)
+            st["bb_sel"] = self.dino_bb_selection(frames_set_t)
             if i >= cfg.get("apply_cl_ref_after", 0):
-                cl_bb, cl_ref = self.contrastive_losses(model, self.dino_bb_selection(frames_set_t),
-                                                        self.refined_bb_selection(model, frames_set_t))
+                st["prepared"] = self.refined_bb_prepare(model, frames_set_t)
+            return st
+
+        def iteration_back(self, model, st, found, i):
+            """The rest (dino_tracker.py:418-426): contrastive terms on the search's result `found`, regularisers, the total ->
+            (loss, the seven loss values as a device vector in LOSS_NAMES order)."""
+            cfg = self.config
+            tracking, cyc = st["tracking"], st["cyc"]
+            loss = tracking
+            cl_ref = tracking.new_zeros(())
+            if i >= cfg.get("apply_cyc_after", 0):
+                loss = loss + cfg["lambda_cyc"] * cyc
+            if st["prepared"] is not None:
+                ref_sel = self.refined_bb_finish(st["frames_set_t"], st["prepared"], found)
+                cl_bb, cl_ref = self.contrastive_losses(model, st["bb_sel"], ref_sel)
                 loss = loss + cfg["lambda_cl_ref_bb"] * cl_ref
             else:
-                cl_bb = self.dino_bb_terms(model, *self.dino_bb_selection(frames_set_t))
+                cl_bb = self.dino_bb_terms(model, *st["bb_sel"])
             norm_reg, angle_reg = emb_regularization_terms(model.frame_embeddings, model.raw_embeddings)
             loss = loss + cfg["lambda_cl_dino_bb"] * cl_bb + cfg["lambda_emb_norm"] * norm_reg + cfg["lambda_angle"] * angle_reg
             return loss, torch.stack([loss.detach(), tracking.detach(), cl_bb.detach(), cl_ref.detach(), norm_reg.detach(),
                                       angle_reg.detach(), cyc.detach()])
+
+        def iteration_losses(self, model, inputs, labels, valid, i):
+            """The seven loss values of one iteration as a device vector in LOSS_NAMES order (dino_tracker.py:407-426)."""
+            st = self.iteration_front(model, inputs, labels, valid, i)
+            found = self.refined_bb_search(model, st["prepared"]) if st["prepared"] is not None else None
+            return self.iteration_back(model, st, found, i)
 
         # -- the loop (dino_tracker.py:392-448) ---------------------------------------------------------------------------
         def train(self):
@@ -464,12 +657,9 @@ def make_trainer(base):
             self.set_model_train(model)
             self.init_losses()
             self.prepare_tables(model)
+            step = GraphedIteration(self, model, optimizer, train_sampler)
             for i in tqdm(range(self.init_iter, total_iterations)):
-                optimizer.zero_grad(set_to_none=True)
-                inputs, labels, valid = self.get_inputs_and_labels_device(train_sampler)
-                loss, values = self.iteration_losses(model, inputs, labels, valid, i)
-                loss.backward()
-                optimizer.step()
+                values = step.run(i)
                 scheduler.step()
                 self.update_losses(*values.unbind())          # device scalars: read when log_losses formats them
                 if i % 100 == 0:
@@ -479,6 +669,7 @@ def make_trainer(base):
                 if i % sampler_batch_iterations == 0 and i > 0:
                     print("Loading next batch", flush=True)
                     train_sampler.load_next_batch()
+                    step.invalidate()                         # (the trajectory tables are new tensors: graphs read the old ones)
             model.save_weights(total_iterations)
 
     DINOTracker.__qualname__ = "DINOTracker"

@@ -477,6 +477,11 @@ int dtk_resample2d_forward(const float* src, float* dst, int64_t planes, int32_t
 int dtk_resample2d_backward(const float* ddst, float* dsrc, int64_t planes, int32_t hs, int32_t ws, int32_t hd, int32_t wd,
                             const int32_t* yranges, const float* ywhi, const int32_t* xranges, const float* xwhi, void* stream);
 
+/* Operand scale of a gradient tensor for the fp16 split of the training convolutions: out[0] = 2^e with max |x| * 2^e in [2^9, 2^10]
+ * (max |x| clamped below at 1e-30; a NaN in x gives NaN).  x: n floats on the device; scratch: 4 bytes on the device.  Three small
+ * launches, no memset -- safe inside a captured graph (a library reduction is not, on this stack: csrc/common.h, dtk_zero_async). */
+int dtk_pow2_scale(const float* x, int64_t n, float* out, void* scratch, void* stream);
+
 /* ---- N1: the optimiser step of test-time training (dino_tracker.py:110-115: torch.optim.Adam over two parameter groups, default
  * betas / eps, no weight decay, no amsgrad; optimization/schedulers.py:4-8 scales the groups' learning rates) ---------------------
  * ONE launch updates every parameter tensor of the step: the tensors travel BY VALUE in the argument block (their gradients are
@@ -500,6 +505,13 @@ typedef struct dtk_adam_args {
     double beta1, beta2, eps;
 } dtk_adam_args;
 int dtk_adam_step(const dtk_adam_args* a, void* stream);
+/* The same update for a CAPTURED iteration (hipGraph): pointers and sizes are baked into the launch, the two per-tensor scalars --
+ * step size lr[group] / (1 - beta1^step) and 1 / sqrt(1 - beta2^step) -- are read from device memory that the host refreshes before
+ * every replay.  dtk_adam_scalars forms them on the host exactly as dtk_adam_step does (out_host: 2 * DTK_ADAM_MAX_TENSORS floats,
+ * step sizes first; it reads n_tensors, betas, eps, group[], step[] and lr[] only -- the tensor pointers may be null);
+ * dtk_adam_step_dev launches with `scalars_dev` in that layout. */
+int dtk_adam_scalars(const dtk_adam_args* a, float* out_host);
+int dtk_adam_step_dev(const dtk_adam_args* a, const float* scalars_dev, void* stream);
 
 #ifdef __cplusplus
 }

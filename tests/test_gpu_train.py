@@ -836,3 +836,88 @@ def test_fused_adam_matches_torch_adam():
         assert (sa_["exp_avg_sq"] - sb_["exp_avg_sq"]).abs().max() <= 1e-6 * sa_["exp_avg_sq"].abs().max()
     assert float(ob.state[pb[-1]]["step"]) == float(oa.state[pa[-1]]["step"]) == 6   # skipped once: its own bias corrections
     assert [gr["lr"] for gr in oa.param_groups] == [gr["lr"] for gr in ob.param_groups]
+
+
+def _standalone(tmp_path, overrides=None, cfg=None, width=None):
+    """The device-side trainer over dino_tracker_amd.train's restated control plane on the rebuilt-anywhere synthetic inputs."""
+    import argparse
+    import train_data as TD
+    from dino_tracker_amd import train as TR
+    c = dict(TD.CFG, **(cfg or {}))
+    if width:
+        c["C"] = width
+    d, yml = TD.build(str(tmp_path / "train"), None, c, overrides=overrides, synthetic_video=True)
+    TR.fix_random_seeds(2)
+    tr = TR.standalone_trainer(argparse.Namespace(config=yml, data_path=d, device="cuda:0"))
+    tr.load_fg_masks()
+    tr.load_dino_best_buddies()
+    sampler = tr.get_sampler()
+    model, opt, sched = tr.train_setup()
+    from dino_tracker_amd.train_ops import install_fused_adam
+    install_fused_adam(opt)
+    tr.set_model_train(model)
+    tr.init_losses()
+    tr.prepare_tables(model)
+    return tr, sampler, model, opt, sched
+
+
+def test_graphed_iteration_equals_eager_iteration(tmp_path):
+    """trainer.GraphedIteration: a REPLAYED iteration (two captured graphs around the mutual-nearest-neighbour search, Adam on
+    device-resident scalars) against the same iteration run eagerly from the same state -- parameters, Adam moments, BatchNorm
+    statistics, the generators of host and device.  The device draws inside a capture go through torch's graph-safe Philox state
+    with the generator's current offset, so both see the same random selections; what differs is the order of the atomic sums
+    of three backward kernels.  Also: the first iteration of a key runs eagerly, the second is captured, the schedule's decayed
+    learning rate reaches the captured Adam launch, step counts advance once per iteration."""
+    import copy
+    from dino_tracker_amd import trainer as T
+    tr, sampler, model, opt, sched = _standalone(tmp_path, cfg=dict(C=384))
+    fixed = sampler.draw_frame_sets()
+    sampler.draw_frame_sets = lambda generator=None: (fixed[0].clone(), list(fixed[1]))     # one key
+    step = T.GraphedIteration(tr, model, opt, sampler, enabled=True)
+    vals = []
+    for i in range(1, 4):
+        vals.append(step.run(i))
+        sched.step()
+    assert step.counts == {"eager": 1, "captured": 1, "replayed": 2}, step.counts
+    assert all(bool(torch.isfinite(v).all()) for v in vals)
+    steps = {float(opt.state[p]["step"]) for g in opt.param_groups for p in g["params"]}
+    assert steps == {3.0}, steps
+
+    def snapshot():
+        return (copy.deepcopy(model.state_dict()), copy.deepcopy(opt.state_dict()), copy.deepcopy(sched.state_dict()),
+                torch.get_rng_state(), torch.cuda.get_rng_state())
+
+    def restore(s):
+        model.load_state_dict(s[0])
+        opt.load_state_dict(copy.deepcopy(s[1]))
+        sched.load_state_dict(s[2])
+        torch.set_rng_state(s[3])
+        torch.cuda.set_rng_state(s[4])
+
+    # a decayed learning rate for the head group that the captured launch cannot have baked in
+    for g in opt.param_groups:
+        g["lr"] = g["lr"] * 0.37
+    s0 = snapshot()
+    v_graph = step.run(4)
+    torch.cuda.synchronize()
+    p_graph = {k: v.clone() for k, v in model.state_dict().items()}
+    m_graph = [opt.state[p]["exp_avg"].clone() for g in opt.param_groups for p in g["params"]]
+    restore(s0)
+    # (load_state_dict re-creates the moment tensors: the captured launch has the OLD addresses baked in -- from here on eager only)
+    step.enabled = False
+    v_eager = step.run(4)
+    torch.cuda.synchronize()
+    assert step.counts["replayed"] == 3 and step.counts["eager"] == 2
+    rel = ((v_graph - v_eager).abs() / v_eager.abs().clamp(min=1e-12)).max().item()
+    print("graph vs eager loss values", v_graph.tolist(), v_eager.tolist(), "max rel", rel)
+    assert rel < 1e-4, rel
+    worst = 0.0
+    for k, v in model.state_dict().items():
+        if v.dtype.is_floating_point:
+            d = (p_graph[k] - v).abs().max().item() / max(v.abs().max().item(), 1e-12)
+            worst = max(worst, d)
+            assert d < 2e-4, (k, d)
+    for a, p in zip(m_graph, [p for g in opt.param_groups for p in g["params"]]):
+        b = opt.state[p]["exp_avg"]
+        assert (a - b).abs().max().item() <= 2e-4 * max(b.abs().max().item(), 1e-20)
+    print("graph vs eager: worst relative parameter difference", worst)
