@@ -82,6 +82,9 @@ def parse():
                          "then scheduled longest-first over the ranks (sharding.lpt_assignment) instead of v = r (mod world)")
     ap.add_argument("--vit-frame-batch", type=int, default=0, help="frames per pass of the ViT encoder (0 = library default)")
     ap.add_argument("--track-round", type=int, default=0, help="sources per round of dtk_track (0 = library default, 4194304)")
+    ap.add_argument("--no-train", action="store_true", help="skip the test-time-training leg (BASELINE config 5; extra key `train`)")
+    ap.add_argument("--train-widths", default="384", help="feature widths of the training leg, comma-separated (384 = north star, 1024 = the reference's own)")
+    ap.add_argument("--train-iters", type=int, default=30, help="timed iterations of the training leg per width and mode")
     return ap.parse_args()
 
 
@@ -109,6 +112,26 @@ def literal_over_port(C):
     except Exception:
         pass
     return None
+
+
+def train_leg(args):
+    """BASELINE.json config 5 next to the headline: per-video test-time training at 854 x 476 x T, config/train.yaml's batch sizes, every
+    loss term on -- seconds per iteration of the device-side trainer with the iteration replayed from captured graphs and
+    eagerly, kernel time per iteration by origin.  A child process per width (scripts/train_iter_bench.py: its own allocator and
+    generators); the inference model of this process is idle meanwhile.  Not part of `value`."""
+    res = {"config": f"854x476x{args.frames}, config/train.yaml batch sizes (512 pairs, 4 + 4 frames, 4 x 256 cycle points, 4 x 256 contrastive "
+                     "points), all loss terms on; dino_tracker_amd.train control plane, trainer.GraphedIteration",
+           "unit": "s per iteration", "data": "synthetic"}
+    for width in [int(x) for x in args.train_widths.split(",") if x]:
+        cmd = [sys.executable, os.path.join(ROOT, "scripts", "train_iter_bench.py"), "--width", str(width), "--frames", str(args.frames),
+               "--iters", str(args.train_iters), "--modes", "graph,eager", "--kernel-share"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            res[f"C={width}"] = json.loads(line[-1]) if (r.returncode == 0 and line) else {"error": (r.stderr or r.stdout)[-400:]}
+        except Exception as ex:  # noqa: BLE001
+            res[f"C={width}"] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
+    return res
 
 
 def main():
@@ -693,6 +716,8 @@ def main():
                                        else f"video-parallel x{world}")},
             "videos30": videos30, "per_rank": per_rank, "roofline": roofline, "clock_power": clock_power, "cpu_baseline": cpu, "parity_sample": parity,
         }
+        if world == 1 and not args.no_train:
+            out["train"] = train_leg(args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -276,6 +276,7 @@ class _ConvMfma(torch.autograd.Function):
         return dx, dw, None, None, None
 
 
+PAD_THIN_INPUTS = os.environ.get("DTK_TRAIN_LAYER1", "implicit") == "implicit"   # "im2col": round 3's form of the first layer
 USE_MFMA_CONVS = True  # device tensors: csrc/train.hip (_ConvMfma); False: round 2's unfold + library GEMM (_ConvGemm)
 
 
@@ -289,6 +290,15 @@ def conv2d_gemm(x: torch.Tensor, weight: torch.Tensor, bias, padding: int, dilat
         kh = weight.shape[-1]
         same = weight.shape[-2] == kh and 2 * padding == dilation * (kh - 1) and padding_mode in ("reflect", "zeros")
         fn = _ConvMfma if (USE_MFMA_CONVS and same and weight.shape[0] % 4 == 0) else _ConvGemm
+        if (fn is _ConvMfma and PAD_THIN_INPUTS and USE_IMPLICIT_CONVS and kh == 5 and weight.shape[1] < 16 and weight.shape[0] % 16 == 0
+                and dilation in (1, 2) and min(x.shape[-2:]) > 4 * dilation + 1 and not x.requires_grad):
+            # Layer 1 (3 -> 64 channels, the full-resolution frames): the implicit-GEMM kernels take input channels in sixteens, so the
+            # frames and the weights are padded with zero channels -- forward and weight gradient then run on conv5x5_split /
+            # conv_wgrad_split like layers 2-4 instead of im2col (1.25 GB of unfolded pixels written and read twice per iteration) + a
+            # GEMM with K = 75.  The padded channels multiply zeros; the weight gradient's slice is F.pad's backward.
+            extra = 16 - weight.shape[1]
+            x = F.pad(x, (0, 0, 0, 0, 0, extra))
+            weight = F.pad(weight, (0, 0, 0, 0, 0, extra))
         y = fn.apply(x, weight, padding, dilation, padding_mode)
         return y if bias is None else y + bias[None, :, None, None]
     n, cin, h, w = x.shape

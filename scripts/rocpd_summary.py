@@ -8,8 +8,17 @@ db = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in db.execute("pragma table_info(rocpd_kernel_dispatch)")]
 sym_cols = [r[1] for r in db.execute("pragma table_info(rocpd_info_kernel_symbol)")]
 name_col = "kernel_name" if "kernel_name" in sym_cols else ("display_name" if "display_name" in sym_cols else sym_cols[-1])
+where = ""
+if "--window" in sys.argv:  # --window KERNEL FIRST LAST: only the dispatches from the FIRST-th to the LAST-th launch of KERNEL (0-based)
+    i = sys.argv.index("--window")
+    key, first, last = sys.argv[i + 1], int(sys.argv[i + 2]), int(sys.argv[i + 3])
+    marks = [r[0] for r in db.execute(f"""select d.start from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id
+                                          where s.{name_col} like ? order by d.start""", (f"%{key}%",))]
+    where = f"where d.start >= {marks[first]} and d.start < {marks[last]}"
+    print(f"(window: between launches {first} and {last} of `{key}`: {(marks[last] - marks[first]) / 1e6:.2f} ms, "
+          f"{(marks[last] - marks[first]) / 1e6 / (last - first):.3f} ms per occurrence)\n")
 rows = db.execute(f"""select s.{name_col}, count(*), sum(d.end - d.start), min(d.end - d.start), max(d.end - d.start)
-                      from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id
+                      from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id {where}
                       group by s.{name_col} order by 3 desc""").fetchall()
 total = sum(r[2] for r in rows)
 print("| kernel | calls | total ms | avg us | min us | max us | % |")

@@ -560,7 +560,8 @@ def test_batchnorm_train_kernels(shape, relu):
     assert pre.grad.abs().max() <= 1e-3 * cot.abs().sum(dim=(0, 2, 3)).max()
 
 
-@pytest.mark.parametrize("shape", [(2, 5, 63, 427), (1, 3, 4, 4), (3, 2, 5, 6), (2, 4, 238, 427), (1, 2, 119, 214), (1, 1, 7, 4)])
+@pytest.mark.parametrize("shape", [(2, 5, 63, 427), (1, 3, 4, 4), (3, 2, 5, 6), (2, 4, 238, 427), (1, 2, 119, 214), (1, 1, 7, 4),
+                                   (2, 3, 126, 854), (1, 2, 64, 40), (1, 1, 17, 18), (1, 2, 23, 16)])   # (the last four: the 2 x 4-block backward of round 6)
 def test_blurpool_kernels(shape):
     """csrc/train.hip blur-pool and its adjoint against the depthwise-convolution statement of antialiased_cnns.BlurPool
     (reflect pad (1, 2, 1, 2), outer([1,3,3,1]) / 64, stride 2) in float64 on the host, odd and even plane sizes."""
@@ -626,6 +627,38 @@ def test_conv_mfma_forward_and_gradients_match_float64(case):
     y2 = train_ops._ConvGemm.apply(xd2, wd2, pad, dil, mode)
     y2.backward(dy.cuda())
     assert rel(y2.detach(), y64.detach()) < 1e-5
+
+
+def test_first_layer_on_the_implicit_kernels_matches_float64():
+    """Round 6: Delta-DINO's first layer (3 -> 64 channels, reflect padding; delta_dino.py:29) through train_ops.conv2d_gemm takes
+    the implicit-GEMM kernels with its frames and weights padded to 16 zero channels (round 3-5: im2col + a K = 75 GEMM): output and
+    weight gradient vs torch's convolution in float64; the frames carry no gradient (the padded channels' weight gradient is cut off
+    by F.pad's backward), and the im2col form (DTK_TRAIN_LAYER1=im2col's switch) still agrees."""
+    import torch.nn.functional as F
+    from dino_tracker_amd import train_ops
+    g = torch.Generator().manual_seed(5)
+    n, cin, cout, h, w, pad = 3, 3, 64, 61, 90, 2
+    x = torch.rand(n, cin, h, w, generator=g)
+    wt = (torch.randn(cout, cin, 5, 5, generator=g) * 0.1)
+    b = torch.randn(cout, generator=g) * 0.1
+    dy = torch.randn(n, cout, h, w, generator=g) * 1e-5
+    w64 = wt.double().requires_grad_(True)
+    y64 = F.conv2d(F.pad(x.double(), (pad,) * 4, mode="reflect"), w64, b.double())
+    y64.backward(dy.double())
+    res = {}
+    for flag in (True, False):
+        train_ops.PAD_THIN_INPUTS = flag
+        try:
+            wd = wt.cuda().requires_grad_(True)
+            y = train_ops.conv2d_gemm(x.cuda(), wd, b.cuda(), pad, 1, "reflect")
+            y.backward(dy.cuda())
+        finally:
+            train_ops.PAD_THIN_INPUTS = True
+        assert wd.grad.shape == wt.shape
+        res[flag] = (float((y.detach().cpu().double() - y64.detach()).abs().max() / y64.detach().abs().max()),
+                     float((wd.grad.cpu().double() - w64.grad).abs().max() / w64.grad.abs().max()))
+    print("first layer: (rel err y, rel err dw) implicit", res[True], "im2col", res[False])
+    assert max(res[True]) < 3e-6 and max(res[False]) < 1e-5, res
 
 
 @pytest.mark.parametrize("hw,stride", [((476, 854), 7), ((224, 308), 7), ((126, 140), 14)])
