@@ -363,27 +363,21 @@ __global__ __launch_bounds__(256) void blurpool_bwd2_kernel(const float* __restr
     blur_bwd_block(dy + (long long)blockIdx.z * Ho * Wo, dx + (long long)blockIdx.z * H * W, mx, my, H, W, Ho, Wo, vec);
 }
 
-// Round 6: a thread owns 2 x 4 such blocks (inputs 4 j .. 4 j + 3 of rows 8 i .. 8 i + 7).  Away from the borders the six rows of dy
-// it needs are combined along x once -- four values per row, (even, odd) of both blocks -- and every row of dx is a two-term
-// combination of two neighbouring row results: 24 loads and 16 8-byte stores for 32 outputs where the per-block form issues 72 and 16
-// (the one-block kernel ran at a fifth of its traffic: 0.98 ms for the 1.04 GB of the first layer's gradient).  Tiles that touch a
-// border fall back to the per-block routine.  Needs W even (8-byte aligned row pairs: `vec` of the caller).
+// Round 6: a thread owns 2 x 4 such blocks (inputs 4 j .. 4 j + 3 of rows 8 i .. 8 i + 7), INTERIOR tiles only (j in [jlo, jhi), i in
+// [ilo, ihi): every block of the tile is away from the borders).  The six rows of dy it needs are combined along x once -- four values
+// per row, (even, odd) of both blocks -- and every row of dx is a two-term combination of two neighbouring row results: 24 loads and
+// 16 8-byte stores for 32 outputs where the per-block form issues 72 and 16 (the one-block kernel ran at a fifth of its traffic: 0.98
+// ms for the 1.04 GB of the first layer's gradient).  The blocks outside the interior rectangle go to blurpool_bwd_border_kernel (the
+// per-block routine over the four border strips): with both in one kernel the lane that owns a border tile held its whole wave for
+// eight slow blocks (measured: 2.6 ms).  Needs W even (8-byte aligned row pairs: `vec` of the caller).
+template <bool VEC>   // VEC: W and H W even, every row pair starts 8-byte aligned; otherwise 4-byte stores
 __global__ __launch_bounds__(256) void blurpool_bwd8_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W,
-                                                            int Ho, int Wo) {
-    const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
+                                                            int Ho, int Wo, int jlo, int jhi, int ilo, int ihi) {
+    const int j = jlo + blockIdx.x * 64 + (threadIdx.x & 63), i = ilo + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (j >= jhi || i >= ihi) return;
     const int mx0 = 2 * j, my0 = 4 * i;
-    if (2 * mx0 >= W || 2 * my0 >= H) return;
     const float* gp = dy + (long long)blockIdx.z * Ho * Wo;
     float* dp = dx + (long long)blockIdx.z * H * W;
-    const bool interior = mx0 >= 1 && 2 * (mx0 + 1) + 1 <= W - 4 && my0 >= 1 && 2 * (my0 + 3) + 1 <= H - 4;
-    if (!interior) {
-#pragma unroll 1
-        for (int b = 0; b < 4; ++b) {
-            blur_bwd_block(gp, dp, mx0, my0 + b, H, W, Ho, Wo, 1);
-            blur_bwd_block(gp, dp, mx0 + 1, my0 + b, H, W, Ho, Wo, 1);
-        }
-        return;
-    }
     float4 prev, cur, nxt;   // x-combined rows my - 1, my, my + 1: (even, odd) of block mx0, (even, odd) of block mx0 + 1
     auto xrow = [&](int a) {
         const float* row = gp + (long long)a * Wo + mx0 - 1;
@@ -396,13 +390,37 @@ __global__ __launch_bounds__(256) void blurpool_bwd8_kernel(const float* __restr
     for (int b = 0; b < 4; ++b) {
         nxt = xrow(my0 + b + 1);
         float* r0 = dp + (long long)(2 * (my0 + b)) * W + 4 * j;
-        *reinterpret_cast<float2*>(r0) = float2{fmaf(0.375f, cur.x, 0.125f * prev.x), fmaf(0.375f, cur.y, 0.125f * prev.y)};
-        *reinterpret_cast<float2*>(r0 + 2) = float2{fmaf(0.375f, cur.z, 0.125f * prev.z), fmaf(0.375f, cur.w, 0.125f * prev.w)};
-        *reinterpret_cast<float2*>(r0 + W) = float2{fmaf(0.125f, nxt.x, 0.375f * cur.x), fmaf(0.125f, nxt.y, 0.375f * cur.y)};
-        *reinterpret_cast<float2*>(r0 + W + 2) = float2{fmaf(0.125f, nxt.z, 0.375f * cur.z), fmaf(0.125f, nxt.w, 0.375f * cur.w)};
+        const float4 e = {fmaf(0.375f, cur.x, 0.125f * prev.x), fmaf(0.375f, cur.y, 0.125f * prev.y), fmaf(0.375f, cur.z, 0.125f * prev.z),
+                          fmaf(0.375f, cur.w, 0.125f * prev.w)};
+        const float4 o = {fmaf(0.125f, nxt.x, 0.375f * cur.x), fmaf(0.125f, nxt.y, 0.375f * cur.y), fmaf(0.125f, nxt.z, 0.375f * cur.z),
+                          fmaf(0.125f, nxt.w, 0.375f * cur.w)};
+        if (VEC) {
+            *reinterpret_cast<float2*>(r0) = float2{e.x, e.y};
+            *reinterpret_cast<float2*>(r0 + 2) = float2{e.z, e.w};
+            *reinterpret_cast<float2*>(r0 + W) = float2{o.x, o.y};
+            *reinterpret_cast<float2*>(r0 + W + 2) = float2{o.z, o.w};
+        } else {
+            r0[0] = e.x; r0[1] = e.y; r0[2] = e.z; r0[3] = e.w;
+            r0[W] = o.x; r0[W + 1] = o.y; r0[W + 2] = o.z; r0[W + 3] = o.w;
+        }
         prev = cur;
         cur = nxt;
     }
+}
+
+// the 2 x 2 blocks OUTSIDE the rectangle mx in [x0, x1), my in [y0, y1) of an nbx x nby grid of blocks: left strip, right strip, then the
+// top and bottom strips between them; one thread per block
+__global__ __launch_bounds__(256) void blurpool_bwd_border_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W,
+                                                                  int Ho, int Wo, int nbx, int nby, int x0, int x1, int y0, int y1, int vec) {
+    int t = blockIdx.x * 256 + threadIdx.x;
+    const int nl = x0 * nby, nr = (nbx - x1) * nby, nt = (x1 - x0) * y0, nb = (x1 - x0) * (nby - y1);
+    int mx, my;
+    if (t < nl) { mx = t % x0; my = t / x0; }
+    else if ((t -= nl) < nr) { mx = x1 + t % (nbx - x1); my = t / (nbx - x1); }
+    else if ((t -= nr) < nt) { mx = x0 + t % (x1 - x0); my = t / (x1 - x0); }
+    else if ((t -= nt) < nb) { mx = x0 + t % (x1 - x0); my = y1 + t / (x1 - x0); }
+    else return;
+    blur_bwd_block(dy + (long long)blockIdx.z * Ho * Wo, dx + (long long)blockIdx.z * H * W, mx, my, H, W, Ho, Wo, vec);
 }
 
 int slices(int N, int C, int HW) {
@@ -470,9 +488,16 @@ extern "C" int dtk_blurpool_backward(const float* dy, float* dx, int64_t planes,
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     if (planes <= 65535) {
         const int vec = (((long long)H * W) % 2 == 0 && W % 2 == 0) ? 1 : 0;  // every row pair starts 8-byte aligned
-        if (vec && H >= 16 && W >= 16) {
-            DTK_LAUNCH("blurpool_bwd", blurpool_bwd8_kernel, dim3(dtk_cdiv((W + 3) / 4, 64), dtk_cdiv((H + 7) / 8, 4), (unsigned)planes),
-                       dim3(256), 0, dtk_stream(stream), dy, dx, H, W, Ho, Wo);
+        const int jhi = (W - 7) / 4 + 1, ihi = (H - 11) / 8 + 1;   // interior tiles: j in [1, jhi), i in [1, ihi)
+        if (jhi > 1 && ihi > 1) {
+            const int nbx = (W + 1) / 2, nby = (H + 1) / 2;
+            const dim3 grid(dtk_cdiv(jhi - 1, 64), dtk_cdiv(ihi - 1, 4), (unsigned)planes);
+            if (vec) DTK_LAUNCH("blurpool_bwd", blurpool_bwd8_kernel<true>, grid, dim3(256), 0, dtk_stream(stream), dy, dx, H, W, Ho, Wo, 1, jhi, 1, ihi);
+            else DTK_LAUNCH("blurpool_bwd", blurpool_bwd8_kernel<false>, grid, dim3(256), 0, dtk_stream(stream), dy, dx, H, W, Ho, Wo, 1, jhi, 1, ihi);
+            const int x0 = 2, x1 = 2 * jhi, y0 = 4, y1 = 4 * ihi;
+            const int nborder = x0 * nby + (nbx - x1) * nby + (x1 - x0) * y0 + (x1 - x0) * (nby - y1);
+            DTK_LAUNCH("blurpool_bwd_border", blurpool_bwd_border_kernel, dim3(dtk_cdiv(nborder, 256), 1, (unsigned)planes), dim3(256), 0,
+                       dtk_stream(stream), dy, dx, H, W, Ho, Wo, nbx, nby, x0, x1, y0, y1, vec);
             return DTK_OK;
         }
         DTK_LAUNCH("blurpool_bwd", blurpool_bwd2_kernel, dim3(dtk_cdiv((W + 1) / 2, 64), dtk_cdiv((H + 1) / 2, 4), (unsigned)planes),
@@ -1471,13 +1496,19 @@ __global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restric
     bool bad = false;
     const long long n4 = (((size_t)x & 15) == 0) ? n / 4 : 0;          // 16-byte pieces (torch allocations are aligned), then the tail
     const float4* x4 = reinterpret_cast<const float4*>(x);
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        const float4 v = x4[i];
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    auto take = [&](const float4 v) {
         const float a = fabsf(v.x), b = fabsf(v.y), c = fabsf(v.z), d = fabsf(v.w);
         bad |= (a != a) | (b != b) | (c != c) | (d != d);
         m = fmaxf(fmaxf(m, fmaxf(a, b)), fmaxf(c, d));
+    };
+    for (; i + 3 * stride < n4; i += 4 * stride) {      // four 16-byte loads in flight per lane
+        const float4 v0 = x4[i], v1 = x4[i + stride], v2 = x4[i + 2 * stride], v3 = x4[i + 3 * stride];
+        take(v0); take(v1); take(v2); take(v3);
     }
-    for (long long i = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    for (; i < n4; i += stride) take(x4[i]);
+    for (i = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const float v = fabsf(x[i]);
         bad |= v != v;
         m = fmaxf(m, v);
