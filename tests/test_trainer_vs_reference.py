@@ -328,3 +328,24 @@ def test_cells_at_equals_gather_of_frame_cells_and_lse_identity():
     bb = (a * b).sum(2) / torch.clamp(a.norm(dim=2) * b.norm(dim=2), min=T.EPS)
     assert torch.allclose(l_st, torch.logsumexp(cos(a, fb) / 0.1, dim=2) - bb / 0.1, rtol=1e-12, atol=1e-12)
     assert not T.fused_contrastive(fe)                      # a host tensor never takes the kernel path
+
+
+def test_topk_rows_is_topk_for_long_rows():
+    """train_ops.topk_rows (the k largest per row in levels of 2048-wide pieces, so that no call takes ATen's multi-block radix path --
+    its memset-initialised semaphores do not survive a captured graph on the target stack): values and index consistency against
+    torch.topk for rows up to 4e5 elements, more rows than one call takes, and the direct / fallback branches."""
+    import torch
+    from dino_tracker_amd.train_ops import topk_rows
+    torch.manual_seed(0)
+    for rows, n, k in [(2, 107604, 16), (4, 406504, 179), (3, 5000, 7), (2, 4097, 2048), (1, 100, 10), (2, 9000, 1024), (300, 2400, 5)]:
+        x = torch.rand(rows, n)
+        a = torch.topk(x, k, dim=1)
+        v, i = topk_rows(x, k)
+        assert torch.equal(a.values, v), (rows, n, k)
+        assert torch.equal(x.gather(1, i), v)
+        assert all(len(set(r.tolist())) == k for r in i)
+    # members at -1 (the trainer's "key per element, non-members at -1" subsets): fewer members than k leaves -1 values at the end
+    keys = torch.full((2, 50000), -1.0)
+    keys[0, [5, 40000, 49999]] = torch.tensor([0.3, 0.9, 0.1])
+    v, i = topk_rows(keys, 8)
+    assert i[0, :3].tolist() == [40000, 5, 49999] and bool((v[0, 3:] == -1).all()) and bool((v[1] == -1).all())
