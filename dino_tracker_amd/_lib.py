@@ -132,6 +132,8 @@ SIGNATURES = {
     "dtk_contrastive_backward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_float, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dtk_emb_reg_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dtk_sample_bilinear_forward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_void_p]),
+    "dtk_sample_bilinear_backward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_void_p]),
     "dtk_pow2_scale": (c_int, [c_void_p, ctypes.c_int64, c_void_p, c_void_p, c_void_p]),
     "dtk_adam_step": (c_int, [ctypes.POINTER(AdamArgs), c_void_p]),
     "dtk_adam_scalars": (c_int, [ctypes.POINTER(AdamArgs), ctypes.POINTER(ctypes.c_float)]),

@@ -251,14 +251,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 __device__ __forceinline__ int refl(int p, int n) { return p < 0 ? -p : (p >= n ? 2 * n - 2 - p : p); }
 __device__ __forceinline__ float blur_tap(int i) { return (i == 0 || i == 3) ? 0.125f : 0.375f; }
 
-__global__ __launch_bounds__(256) void blurpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long planes,
-                                                           int H, int W, int Ho, int Wo) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= planes * Ho * Wo) return;
-    const int ox = (int)(idx % Wo);
-    const long long t = idx / Wo;
-    const int oy = (int)(t % Ho);
-    const float* xp = x + (t / Ho) * (long long)H * W;
+__device__ __forceinline__ float blur_fwd_one(const float* __restrict__ xp, int oy, int ox, int H, int W) {
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -268,7 +261,53 @@ __global__ __launch_bounds__(256) void blurpool_fwd_kernel(const float* __restri
         for (int j = 0; j < 4; ++j) r = fmaf(blur_tap(j), row[refl(2 * ox + j - 1, W)], r);
         acc = fmaf(blur_tap(i), r, acc);
     }
-    y[idx] = acc;
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void blurpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long planes,
+                                                           int H, int W, int Ho, int Wo) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= planes * Ho * Wo) return;
+    const int ox = (int)(idx % Wo);
+    const long long t = idx / Wo;
+    const int oy = (int)(t % Ho);
+    y[idx] = blur_fwd_one(x + (t / Ho) * (long long)H * W, oy, ox, H, W);
+}
+
+// Round 6: a thread owns output column ox of four consecutive output rows 4 i .. 4 i + 3, INTERIOR tiles only (no reflected tap): the
+// ten input rows are combined along x once (four loads each) and every output is a four-term combination of four of those row values
+// -- 10 loads per output where the per-output form issues 16 behind two 64-bit divisions (it ran at 2.0 TB/s: 0.51 ms for the first
+// layer).  Same products and the same order of additions as blur_fwd_one.  The outputs outside the interior rectangle go to
+// blurpool_fwd_border_kernel.
+__global__ __launch_bounds__(256) void blurpool_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int Ho, int Wo,
+                                                            int oxhi, int ihi) {
+    const int ox = 1 + blockIdx.x * 64 + (threadIdx.x & 63), i = 1 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ox >= oxhi || i >= ihi) return;
+    const float* xp = x + (long long)blockIdx.z * H * W + 2 * ox - 1;
+    float* yp = y + (long long)blockIdx.z * Ho * Wo + ox;
+    float r[10];
+#pragma unroll
+    for (int a = 0; a < 10; ++a) {
+        const float* row = xp + (long long)(8 * i - 1 + a) * W;
+        r[a] = fmaf(0.125f, row[3], fmaf(0.375f, row[2], fmaf(0.375f, row[1], 0.125f * row[0])));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        yp[(long long)(4 * i + k) * Wo] = fmaf(0.125f, r[2 * k + 3], fmaf(0.375f, r[2 * k + 2], fmaf(0.375f, r[2 * k + 1], 0.125f * r[2 * k])));
+}
+
+// the outputs OUTSIDE the rectangle ox in [x0, x1), oy in [y0, y1): left strip, right strip, then top and bottom between them
+__global__ __launch_bounds__(256) void blurpool_fwd_border_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int Ho,
+                                                                  int Wo, int x0, int x1, int y0, int y1) {
+    int t = blockIdx.x * 256 + threadIdx.x;
+    const int nl = x0 * Ho, nr = (Wo - x1) * Ho, nt = (x1 - x0) * y0, nb = (x1 - x0) * (Ho - y1);
+    int ox, oy;
+    if (t < nl) { ox = t % x0; oy = t / x0; }
+    else if ((t -= nl) < nr) { ox = x1 + t % (Wo - x1); oy = t / (Wo - x1); }
+    else if ((t -= nr) < nt) { ox = x0 + t % (x1 - x0); oy = t / (x1 - x0); }
+    else if ((t -= nt) < nb) { ox = x0 + t % (x1 - x0); oy = y1 + t / (x1 - x0); }
+    else return;
+    y[(long long)blockIdx.z * Ho * Wo + (long long)oy * Wo + ox] = blur_fwd_one(x + (long long)blockIdx.z * H * W, oy, ox, H, W);
 }
 
 // the outputs o and weights through which input position p (of n, output length no) is read: at most 6 entries
@@ -477,6 +516,16 @@ extern "C" int dtk_blurpool_forward(const float* x, float* y, int64_t planes, in
     DTK_REQUIRE(planes > 0 && H >= 4 && W >= 4, "dtk_blurpool_forward: bad shape %lld x %d x %d (reflection needs >= 4)", (long long)planes, H, W);
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long long total = (long long)planes * Ho * Wo;
+    const int oxhi = (W - 3) / 2 + 1, ihi = (H - 9) / 8 + 1;   // interior: ox in [1, oxhi), row groups i in [1, ihi) (rows 4 i .. 4 i + 3)
+    if (planes <= 65535 && oxhi > 1 && ihi > 1) {
+        DTK_LAUNCH("blurpool_fwd", blurpool_fwd4_kernel, dim3(dtk_cdiv(oxhi - 1, 64), dtk_cdiv(ihi - 1, 4), (unsigned)planes), dim3(256), 0,
+                   dtk_stream(stream), x, y, H, W, Ho, Wo, oxhi, ihi);
+        const int x0 = 1, x1 = oxhi, y0 = 4, y1 = 4 * ihi;
+        const int nborder = x0 * Ho + (Wo - x1) * Ho + (x1 - x0) * y0 + (x1 - x0) * (Ho - y1);
+        DTK_LAUNCH("blurpool_fwd_border", blurpool_fwd_border_kernel, dim3(dtk_cdiv(nborder, 256), 1, (unsigned)planes), dim3(256), 0,
+                   dtk_stream(stream), x, y, H, W, Ho, Wo, x0, x1, y0, y1);
+        return DTK_OK;
+    }
     DTK_LAUNCH("blurpool_fwd", blurpool_fwd_kernel, dim3(dtk_cdiv(total, 256)), dim3(256), 0, dtk_stream(stream), x, y,
                (long long)planes, H, W, Ho, Wo);
     return DTK_OK;
@@ -1480,6 +1529,70 @@ extern "C" int dtk_contrastive_backward(const float* fe, const float* a, const i
                                  nullptr, fidx, stream);
     if (rc != DTK_OK) return rc;
     DTK_LAUNCH("train_cl_dfe", cl_dfe_fix_kernel, dim3(dtk_cdiv((long long)F * n, 256)), dim3(256), 0, st, dfe, fe, csum, nf, fidx, Q, C, n, F);
+    return DTK_OK;
+}
+
+
+// ---- bilinear reads of the batch's frame embeddings, both ways (include/dtk.h: dtk_sample_bilinear_forward / _backward) -------------
+// Tracker.sample_embeddings of the training step (tracker.py:96-111 -> utils.py:65-109 with t an exact frame index): out[b] = the four
+// cells around (x, y) of frame t, weighted -- align_corners, border clamp -- read from the token-major copy [n][h w][C] the tracker
+// passes keep anyway.  The traced form (train_ops._bilinear_corners / _bilinear_read) is ~45 small library launches forward and ~20
+// backward, four times per iteration; here one launch each way.  Same arithmetic, same order: fx = clamp((x + 1) / 2 (w - 1), 0, w - 1),
+// x0 = floor(fx), wx = fx - x0, x1 = min(x0 + 1, w - 1); corners in the order (y0, x0), (y0, x1), (y1, x0), (y1, x1).
+namespace {
+struct BilinearTaps { long long cell[4]; float wgt[4]; };
+__device__ __forceinline__ BilinearTaps bilinear_taps(const float* __restrict__ p, int n, int h, int w) {
+    const float fx = fminf(fmaxf((p[0] + 1.f) * 0.5f * (float)(w - 1), 0.f), (float)(w - 1));
+    const float fy = fminf(fmaxf((p[1] + 1.f) * 0.5f * (float)(h - 1), 0.f), (float)(h - 1));
+    const int t = min(max((int)rintf(p[2]), 0), n - 1);
+    const float x0f = fminf(floorf(fx), (float)(w - 1)), y0f = fminf(floorf(fy), (float)(h - 1));
+    const float wx = fx - x0f, wy = fy - y0f;
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = min(x0 + 1, w - 1), y1 = min(y0 + 1, h - 1);
+    BilinearTaps r;
+    const long long base = (long long)t * h * w;
+    r.cell[0] = base + (long long)y0 * w + x0; r.wgt[0] = (1.f - wx) * (1.f - wy);
+    r.cell[1] = base + (long long)y0 * w + x1; r.wgt[1] = wx * (1.f - wy);
+    r.cell[2] = base + (long long)y1 * w + x0; r.wgt[2] = (1.f - wx) * wy;
+    r.cell[3] = base + (long long)y1 * w + x1; r.wgt[3] = wx * wy;
+    return r;
+}
+__global__ __launch_bounds__(128) void sample_bilinear_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ pts,
+                                                                  float* __restrict__ out, int n, int h, int w, int C) {
+    const BilinearTaps tp = bilinear_taps(pts + (long long)blockIdx.x * 3, n, h, w);
+    for (int c = threadIdx.x; c < C; c += 128) {
+        float acc = feat[tp.cell[0] * C + c] * tp.wgt[0];
+        acc = acc + feat[tp.cell[1] * C + c] * tp.wgt[1];
+        acc = acc + feat[tp.cell[2] * C + c] * tp.wgt[2];
+        acc = acc + feat[tp.cell[3] * C + c] * tp.wgt[3];
+        out[(long long)blockIdx.x * C + c] = acc;
+    }
+}
+__global__ __launch_bounds__(128) void sample_bilinear_bwd_kernel(const float* __restrict__ g, const float* __restrict__ pts,
+                                                                  float* __restrict__ dfeat, int n, int h, int w, int C) {
+    const BilinearTaps tp = bilinear_taps(pts + (long long)blockIdx.x * 3, n, h, w);
+    for (int c = threadIdx.x; c < C; c += 128) {
+        const float gv = g[(long long)blockIdx.x * C + c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(&dfeat[tp.cell[k] * C + c], gv * tp.wgt[k]);
+    }
+}
+}  // namespace
+
+extern "C" int dtk_sample_bilinear_forward(const float* feat, const float* pts, float* out, int32_t B, int32_t n, int32_t h, int32_t w,
+                                           int32_t C, void* stream) {
+    DTK_REQUIRE(feat && pts && out, "dtk_sample_bilinear_forward: null pointer");
+    DTK_REQUIRE(B >= 0 && n > 0 && h > 0 && w > 0 && C > 0, "dtk_sample_bilinear_forward: bad sizes");
+    if (B == 0) return DTK_OK;
+    DTK_LAUNCH("train_sample_fwd", sample_bilinear_fwd_kernel, dim3((unsigned)B), dim3(128), 0, dtk_stream(stream), feat, pts, out, n, h, w, C);
+    return DTK_OK;
+}
+
+extern "C" int dtk_sample_bilinear_backward(const float* g, const float* pts, float* dfeat, int32_t B, int32_t n, int32_t h, int32_t w,
+                                            int32_t C, void* stream) {
+    DTK_REQUIRE(g && pts && dfeat, "dtk_sample_bilinear_backward: null pointer");
+    DTK_REQUIRE(B >= 0 && n > 0 && h > 0 && w > 0 && C > 0, "dtk_sample_bilinear_backward: bad sizes");
+    if (B == 0) return DTK_OK;
+    DTK_LAUNCH("train_sample_bwd", sample_bilinear_bwd_kernel, dim3((unsigned)B), dim3(128), 0, dtk_stream(stream), g, pts, dfeat, n, h, w, C);
     return DTK_OK;
 }
 

@@ -576,11 +576,49 @@ class _SampleBilinear(torch.autograd.Function):
         return d.view(n, h, w, c).permute(0, 3, 1, 2), None
 
 
+class _SampleBilinearFused(torch.autograd.Function):
+    """_SampleBilinear on two kernels (csrc/train.hip: dtk_sample_bilinear_forward / _backward; round 6): the read goes to the
+    token-major copy of the batch's embeddings that the tracker passes of the iteration share (_packed_frames), the gradient is
+    accumulated straight into the iteration's shared token-major buffer (_GradSink) -- ~65 small library launches per call become 2."""
+
+    @staticmethod
+    def forward(ctx, emb, pts):
+        from . import ops
+        from ._lib import check, lib
+        n, c, h, w = emb.shape
+        feat, _ = _packed_frames(emb)
+        p = pts.detach().to(torch.float32).contiguous()
+        out = torch.empty(p.shape[0], c, dtype=torch.float32, device=emb.device)
+        check(lib().dtk_sample_bilinear_forward(feat.data_ptr(), p.data_ptr(), out.data_ptr(), p.shape[0], n, h, w, c, ops._stream()))
+        ctx.save_for_backward(p)
+        ctx.shape = emb.shape
+        ctx.sink = getattr(emb, "_dtk_sink", None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        from ._lib import check, lib
+        (p,) = ctx.saved_tensors
+        n, c, h, w = ctx.shape
+        g = g.contiguous()
+        d = ctx.sink.get(n, h, w, c, g) if ctx.sink is not None else torch.zeros(n * h * w, c, dtype=g.dtype, device=g.device)
+        check(lib().dtk_sample_bilinear_backward(g.data_ptr(), p.data_ptr(), d.data_ptr(), p.shape[0], n, h, w, c, ops._stream()))
+        if ctx.sink is not None:
+            return None, None    # left in the shared buffer (_GradSink adds it)
+        return ops.unpack_features(d.view(n, h * w, c), h, w), None
+
+
+USE_FUSED_SAMPLE = os.environ.get("DTK_TRAIN_SAMPLE", "fused") == "fused"
+
+
 def sample_bilinear(emb: torch.Tensor, pts: torch.Tensor) -> torch.Tensor:
     """Tracker.sample_embeddings (tracker.py:96-111): emb [n, C, h, w], pts [B, 3] = (x, y in [-1, 1] token-grid
     coordinates, frame index into emb) -> [B, C]; align_corners, border clamp.  Gradient flows to `emb` only (the
     reference detaches the points, utils.py:91)."""
     if emb.requires_grad and torch.is_grad_enabled():
+        if USE_FUSED_SAMPLE and emb.is_cuda and emb.dtype == torch.float32 and pts.shape[0] > 0:
+            return _SampleBilinearFused.apply(emb, pts)
         return _SampleBilinear.apply(emb, pts)
     return _bilinear_read(emb, *_bilinear_corners(emb.shape, pts))
 
@@ -832,12 +870,13 @@ def head_forward(head, cost: torch.Tensor) -> torch.Tensor:
 
 
 # ---- the k largest per row, for long rows --------------------------------------------------------------------------------------------
-TOPK_CHUNK, TOPK_DIRECT, TOPK_SLICES = 2048, 2500, 192
+TOPK_CHUNK, TOPK_DIRECT, TOPK_SLICES = 2048, 2500, 768
 
 
 def _topk_one_block(x: torch.Tensor, k: int):
     """torch.topk(x, k, dim=1) kept on its one-block-per-slice kernel: rows no longer than TOPK_DIRECT, at most TOPK_SLICES rows per call
-    (ATen picks the multi-block path from (slices, slice length): <= 200 slices of < 5000 elements never take it)."""
+    (ATen picks the multi-block path from (slices, slice length): fewer than 800 slices of fewer than 3000 elements never take it; the
+    cycle term's 4 x 406 504 keys are 796 slices of 2048 -- one launch per level)."""
     if x.shape[0] <= TOPK_SLICES:
         return torch.topk(x, k, dim=1)
     parts = [torch.topk(p, k, dim=1) for p in x.split(TOPK_SLICES)]

@@ -477,6 +477,15 @@ int dtk_resample2d_forward(const float* src, float* dst, int64_t planes, int32_t
 int dtk_resample2d_backward(const float* ddst, float* dsrc, int64_t planes, int32_t hs, int32_t ws, int32_t hd, int32_t wd,
                             const int32_t* yranges, const float* ywhi, const int32_t* xranges, const float* xwhi, void* stream);
 
+/* Tracker.sample_embeddings of the training step (models/tracker.py:96-111 -> utils.py:65-109 for an exact frame index): pts [B][3] =
+ * (x, y in [-1, 1] token-grid coordinates, frame index into the batch), feat the token-major batch embeddings [n][h w][C] ->
+ * out [B][C], bilinear over the four surrounding cells, align_corners, border clamp.  The backward ACCUMULATES g [B][C] into dfeat
+ * [n][h w][C] (atomic adds: several points share cells); the points carry no gradient (the reference detaches them, utils.py:91). */
+int dtk_sample_bilinear_forward(const float* feat, const float* pts, float* out, int32_t B, int32_t n, int32_t h, int32_t w, int32_t C,
+                                void* stream);
+int dtk_sample_bilinear_backward(const float* g, const float* pts, float* dfeat, int32_t B, int32_t n, int32_t h, int32_t w, int32_t C,
+                                 void* stream);
+
 /* Operand scale of a gradient tensor for the fp16 split of the training convolutions: out[0] = 2^e with max |x| * 2^e in [2^9, 2^10]
  * (max |x| clamped below at 1e-30; a NaN in x gives NaN).  x: n floats on the device; scratch: 4 bytes on the device.  Three small
  * launches, no memset -- safe inside a captured graph (a library reduction is not, on this stack: csrc/common.h, dtk_zero_async). */

@@ -1002,3 +1002,40 @@ def test_standalone_train_module_end_to_end(tmp_path):
     rel = np.abs(logs["1"] - logs["0"]) / np.maximum(np.abs(logs["0"]), 1e-9)
     print("replayed vs eager loss values over 9 iterations: max rel", rel.max())
     assert rel.max() < 5e-3, rel.max()
+
+
+def test_fused_bilinear_sampling_matches_the_traced_form():
+    """train_ops._SampleBilinearFused (dtk_sample_bilinear_forward / _backward: one launch each way) against the traced four-corner
+    read (_SampleBilinear) and against the same expression in float64: values, and the gradient into the frame embeddings -- with the
+    iteration's shared gradient buffer (attach_grad_sink) and without it.  Points on cell centres, on the borders, outside [-1, 1]
+    (clamped), repeated (their gradients add), fractional frame indices within rounding."""
+    from dino_tracker_amd import train_ops
+    g = torch.Generator().manual_seed(4)
+    n, c, h, w, B = 5, 384, 17, 23, 300
+    emb0 = torch.randn(n, c, h, w, generator=g)
+    pts = torch.rand(B, 3, generator=g) * 2 - 1
+    pts[:, 2] = torch.randint(0, n, (B,), generator=g).float() + (torch.rand(B, generator=g) - 0.5) * 1e-3
+    pts[:8, :2] = torch.tensor([[-1, -1], [1, 1], [-1, 1], [1, -1], [0, 0], [-1.3, 0.2], [0.4, 1.7], [1.0, 0.999999]])
+    pts[8:16] = pts[:8]
+    gout = torch.randn(B, c, generator=g)
+    res = {}
+    for name, fused, sink in (("fused+sink", True, True), ("traced+sink", False, True), ("fused", True, False), ("traced", False, False)):
+        train_ops.USE_FUSED_SAMPLE = fused
+        train_ops._PACKED.clear()
+        try:
+            leaf = emb0.clone().cuda().requires_grad_(True)
+            e = train_ops.attach_grad_sink(leaf * 1.0) if sink else leaf * 1.0
+            out = train_ops.sample_bilinear(e, pts.cuda())
+            out.backward(gout.cuda())
+        finally:
+            train_ops.USE_FUSED_SAMPLE = True
+        res[name] = (out.detach().cpu(), leaf.grad.cpu())
+    leaf64 = emb0.double().requires_grad_(True)
+    out64 = train_ops._bilinear_read(leaf64, *train_ops._bilinear_corners(leaf64.shape, pts.double()))
+    out64.backward(gout.double())
+    for name, (o, gr) in res.items():
+        eo = float((o.double() - out64.detach()).abs().max() / out64.detach().abs().max())
+        eg = float((gr.double() - leaf64.grad).abs().max() / leaf64.grad.abs().max())
+        print(name, "rel err value", eo, "gradient", eg)
+        assert eo < 3e-6 and eg < 3e-6, (name, eo, eg)
+    assert torch.equal(res["fused"][0], res["fused+sink"][0])
