@@ -1629,7 +1629,13 @@ __global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restric
     unsigned u = bad ? 0x7fc00000u : __float_as_uint(m);      // (non-negative floats and the quiet NaN above them order as integers)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, o, 64));
-    if ((threadIdx.x & 63) == 0 && u != 0u) atomicMax(bits, u);
+    __shared__ unsigned part[4];     // one atomic per workgroup: thousands of waves on one address serialise in the L2
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u = max(max(part[0], part[1]), max(part[2], part[3]));
+        if (u != 0u) atomicMax(bits, u);
+    }
 }
 __global__ void pow2_scale_kernel(const unsigned* __restrict__ bits, float* __restrict__ out) {
     const float amax = fmaxf(__uint_as_float(*bits), 1e-30f);   // (fmaxf drops a NaN: restored below)
@@ -1643,7 +1649,7 @@ extern "C" int dtk_pow2_scale(const float* x, int64_t n, float* out, void* scrat
     unsigned* bits = reinterpret_cast<unsigned*>(scratch);
     DTK_HIP(dtk_zero_async(bits, 4, st));
     const long long blocks = (n + 256 * 16 - 1) / (256 * 16);
-    DTK_LAUNCH("train_absmax", absmax_bits_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, x, (long long)n, bits);
+    DTK_LAUNCH("train_absmax", absmax_bits_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, x, (long long)n, bits);
     DTK_LAUNCH("train_pow2_scale", pow2_scale_kernel, dim3(1), dim3(1), 0, st, bits, out);
     return DTK_OK;
 }
