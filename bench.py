@@ -446,7 +446,7 @@ def main():
                                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                         dbs = glob.glob(os.path.join(td, "**", "*.db"), recursive=True)
                         pk = pmc_traffic.per_kernel(dbs[0], counter)
-                        n_, v_ = pk["attention4_kernel"]
+                        n_, v_ = next(v for k_, v in pk.items() if k_.startswith("attention") and k_.endswith("_kernel"))   # (attention6_kernel since round 6)
                         vals[counter] = (2.0 if counter == "FETCH_SIZE" else 1.0) * v_ * 1024.0 / n_
                     finally:
                         shutil.rmtree(td, ignore_errors=True)

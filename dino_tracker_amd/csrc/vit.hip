@@ -29,6 +29,7 @@
 #include "vit_attention2.h"
 #include "vit_attention4.h"
 #include "vit_attention5.h"
+#include "vit_attention6.h"
 #undef ATT2_NS
 #undef ATT2_T
 #undef ATT2_F16
@@ -40,6 +41,7 @@
 #include "vit_attention2.h"
 #include "vit_attention4.h"
 #include "vit_attention5.h"
+#include "vit_attention6.h"
 #undef ATT2_NS
 #undef ATT2_T
 #undef ATT2_F16
@@ -1221,9 +1223,13 @@ template <> struct Att<_Float16> {
                    FH, QB);
             DTK_A5(5, 0) DTK_A5(6, 32) DTK_A5(7, 8 | 64) DTK_A5(8, 8 | 32 | 64) DTK_A5(9, 8 | 128) DTK_A5(10, 8 | 32 | 128)
 #undef DTK_A5
-        } else {
+        } else if (variant == 4) {   // rounds 4-5: 64 queries per wave (DTK_VIT_ATTENTION_V4 / DTK_OPERAND_ATTENTION_V4)
             const unsigned grid = att2_f16::attention4_grid(FH, S, &QB);
             DTK_LAUNCH("vit_attention", (att2_f16::attention4_kernel<0>), dim3(grid), dim3(256), 0, st, q, k, vt, o, S, Sp, heads,
+                       D, FH, QB);
+        } else {
+            const unsigned grid = att2_f16::attention6_grid(FH, S, &QB);
+            DTK_LAUNCH("vit_attention", (att2_f16::attention6_kernel<0>), dim3(grid), dim3(256), 0, st, q, k, vt, o, S, Sp, heads,
                        D, FH, QB);
         }
         return DTK_OK;
@@ -1241,9 +1247,13 @@ template <> struct Att<__bf16> {
             const unsigned grid = att2_bf16::attention5_grid(FH, S, &QB);
             DTK_LAUNCH("vit_attention", (att2_bf16::attention5_kernel<0>), dim3(grid), dim3(512), 0, st, q, k, vt, o, S, Sp, heads,
                        D, FH, QB);
-        } else {
+        } else if (variant == 4) {
             const unsigned grid = att2_bf16::attention4_grid(FH, S, &QB);
             DTK_LAUNCH("vit_attention", (att2_bf16::attention4_kernel<0>), dim3(grid), dim3(256), 0, st, q, k, vt, o, S, Sp,
+                       heads, D, FH, QB);
+        } else {
+            const unsigned grid = att2_bf16::attention6_grid(FH, S, &QB);
+            DTK_LAUNCH("vit_attention", (att2_bf16::attention6_kernel<0>), dim3(grid), dim3(256), 0, st, q, k, vt, o, S, Sp,
                        heads, D, FH, QB);
         }
         return DTK_OK;
@@ -1451,7 +1461,7 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                            qkv_w, rows, 3 * D, D, e);
             }
             if (scan_all && scan_range(q, (long long)(p.ao - p.q) / 2, 2)) return DTK_E_HIP;
-            if (Att<T>::launch(q, k, vt, ao, S, Sp, m->heads, D, nf * m->heads, (m->flags & DTK_VIT_ATTENTION_V2) ? 2 : 0, st)) return DTK_E_HIP;
+            if (Att<T>::launch(q, k, vt, ao, S, Sp, m->heads, D, nf * m->heads, (m->flags & DTK_VIT_ATTENTION_V2) ? 2 : ((m->flags & DTK_VIT_ATTENTION_V4) ? 4 : 0), st)) return DTK_E_HIP;
             e = GemmEpi<T>{};
             e.bias = L.proj_b; e.delta = delta; e.gamma = L.ls1; e.no_store = dbg_ns;
             if (ws_ok) {
@@ -1563,13 +1573,13 @@ extern "C" int dtk_vit_attention(const void* q, const void* k, const void* vt, v
                                  int Sp, int operand_type, void* stream) {
     DTK_REQUIRE(q && k && vt && out, "dtk_vit_attention: null pointer");
     DTK_REQUIRE(frames > 0 && heads > 0 && S > 0 && Sp >= S && Sp % 64 == 0, "dtk_vit_attention: bad sizes (Sp %% 64 == 0, Sp >= S)");
-    int variant = (operand_type & DTK_OPERAND_ATTENTION_V2) ? 2 : 0;
+    int variant = (operand_type & DTK_OPERAND_ATTENTION_V2) ? 2 : ((operand_type & DTK_OPERAND_ATTENTION_V4) ? 4 : 0);
     if (operand_type & DTK_OPERAND_ATTENTION_V5) {   // 5 full, 6 in phase; micro-benchmark ablations (results are garbage): 7 / 8 no vector work, 9 / 10 no matrix work
         const int inph = (operand_type & DTK_OPERAND_ATTENTION_V5_INPHASE) ? 1 : 0;
         variant = 5 + inph + ((operand_type & 0x800) ? 2 : 0) + ((operand_type & 0x1000) ? 4 : 0);
         DTK_REQUIRE(variant <= 10, "dtk_vit_attention: ablation bits 0x800 and 0x1000 exclude each other");
     }
-    operand_type &= ~(DTK_OPERAND_ATTENTION_V2 | DTK_OPERAND_ATTENTION_V5 | DTK_OPERAND_ATTENTION_V5_INPHASE | 0x800 | 0x1000);
+    operand_type &= ~(DTK_OPERAND_ATTENTION_V2 | DTK_OPERAND_ATTENTION_V4 | DTK_OPERAND_ATTENTION_V5 | DTK_OPERAND_ATTENTION_V5_INPHASE | 0x800 | 0x1000);
     DTK_REQUIRE(operand_type == DTK_OPERAND_F16 || operand_type == DTK_OPERAND_BF16, "dtk_vit_attention: operand_type");
     if (operand_type == DTK_OPERAND_BF16)
         return Att<__bf16>::launch(reinterpret_cast<const __bf16*>(q), reinterpret_cast<const __bf16*>(k),

@@ -129,9 +129,12 @@ typedef struct dtk_vit_model {
 #define DTK_VIT_ATTENTION_V2 8  /* attention on the round-2/3 kernel (16 waves per CU x 32 queries) instead of the one-wave-per-SIMD
                                  * kernel of round 4: the cross-check path of the tests */
 #define DTK_VIT_GEMM_WS_V1 16   /* the K = 384 weight-stationary GEMMs in their round 1-3 form (A / B measurement, cross-check) */
+#define DTK_VIT_ATTENTION_V4 32 /* attention on the round-4/5 kernel (one wave per SIMD, 64 queries per wave: csrc/vit_attention4.h) instead of
+                                 * round 6's 128 queries per wave (csrc/vit_attention6.h): A / B measurement, cross-check */
 #define DTK_OPERAND_F16 0
 #define DTK_OPERAND_BF16 1
 #define DTK_OPERAND_ATTENTION_V2 0x100  /* OR-ed into dtk_vit_attention's operand_type: the same selection for the stand-alone stage */
+#define DTK_OPERAND_ATTENTION_V4 0x2000 /* the same selection as DTK_VIT_ATTENTION_V4 for the stand-alone stage */
 #define DTK_OPERAND_ATTENTION_V5 0x200  /* stand-alone stage only: the round-5 EXPERIMENT kernel, two waves per SIMD alternating matrix /
                                          * vector phases (csrc/vit_attention5.h); measured against the library's kernel by
                                          * scripts/attn_ab.py, not used by dtk_vit_forward */

@@ -6,7 +6,7 @@ the 128-byte requests of wide reads at 64 bytes, so it is doubled; WRITE_SIZE is
 import json, re, sqlite3, sys
 
 NAMES = {  # kernel function -> launch name used by bench.py (only kernels with one launch name)
-    "attention_kernel": "vit_attention", "attention2_kernel": "vit_attention", "attention4_kernel": "vit_attention", "corr_peaks_kernel": "corr_peaks", "refine_corr_kernel": "refine_corr_generic", "refine_corr_dma_kernel": "refine_corr",
+    "attention_kernel": "vit_attention", "attention2_kernel": "vit_attention", "attention4_kernel": "vit_attention", "attention6_kernel": "vit_attention", "corr_peaks_kernel": "corr_peaks", "refine_corr_kernel": "refine_corr_generic", "refine_corr_dma_kernel": "refine_corr",
     "refine_head_kernel": "refine_head", "layernorm_kernel": "vit_layernorm", "rescore_kernel": "rescore",
     "patch_embed_split_kernel": "vit_patch_embed", "conv1_split_kernel": "dd_conv1", "gemm_wide_delta_kernel": "vit_gemm_fc2",
 }

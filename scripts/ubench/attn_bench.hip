@@ -23,6 +23,7 @@
 #include "attention3.h"
 #endif
 #include "vit_attention4.h"
+#include "attention6.h"
 #undef ATT2_NS
 #undef ATT2_T
 #undef ATT2_F16
@@ -36,6 +37,7 @@
 #include "attention3.h"
 #endif
 #include "vit_attention4.h"
+#include "attention6.h"
 #undef ATT2_NS
 #undef ATT2_T
 #undef ATT2_F16
@@ -150,7 +152,22 @@ struct Run {
             hipLaunchKernelGGL(kern, dim3(g), dim3(64 * NW), 0, 0, (const T*)q, (const T*)k, (const T*)vt, o2, S, Sp, heads, D, FH, QB); };
         auto v4 = [&](auto kern) { int QB; const unsigned g = att2_f16::attention4_grid(FH, S, &QB);
             hipLaunchKernelGGL(kern, dim3(g), dim3(256), 0, 0, (const T*)q, (const T*)k, (const T*)vt, o2, S, Sp, heads, D, FH, QB); };
+        auto v6 = [&](auto kern, auto nq_tag) { constexpr int NQ = decltype(nq_tag)::value; int QB; const unsigned g = att2_f16::attention6_grid<NQ>(FH, S, &QB);
+            hipLaunchKernelGGL(kern, dim3(g), dim3(256), 0, 0, (const T*)q, (const T*)k, (const T*)vt, o2, S, Sp, heads, D, FH, QB); };
         if constexpr (F16) {
+            if (getenv("ATTN_V6")) {   // round 6: NQ query tiles per wave (attention6.h: no guards -- the stress rows 5 .. 7 of (frame 0, head 0) are expected to fail)
+                timeit("v4 (library form)", [&] { v4(att2_f16::attention4_kernel<0>); });
+                timeit("v4 without guards (ABL 8)", [&] { v4(att2_f16::attention4_kernel<8>); });
+                timeit("v6 NQ = 2 (64 q/wave)", [&] { v6(att2_f16::attention6_kernel<2>, std::integral_constant<int, 2>{}); });
+                timeit("v6 NQ = 3 (96 q/wave)", [&] { v6(att2_f16::attention6_kernel<3>, std::integral_constant<int, 3>{}); });
+                timeit("v6 NQ = 4 (128 q/wave)", [&] { v6(att2_f16::attention6_kernel<4>, std::integral_constant<int, 4>{}); });
+                timeit("v4 (library form), again", [&] { v4(att2_f16::attention4_kernel<0>); });
+                timeit("v6 NQ = 4, again", [&] { v6(att2_f16::attention6_kernel<4>, std::integral_constant<int, 4>{}); });
+                timeit("v6 NQ = 4: no LDS reads", [&] { v6(att2_f16::attention6_kernel<4, 128>, std::integral_constant<int, 4>{}); });
+                timeit("v6 NQ = 4: no exp", [&] { v6(att2_f16::attention6_kernel<4, 1>, std::integral_constant<int, 4>{}); });
+                CK(hipFree(q)); CK(hipFree(k)); CK(hipFree(vt)); CK(hipFree(o2));
+                return;
+            }
             timeit("v4 (1 wave/SIMD, 64 q/wave)", [&] { v4(att2_f16::attention4_kernel<0>); });
             timeit("v4 row sums on the matrix pipe", [&] { v4(att2_f16::attention4_kernel<0, true>); });
             if (abl) {

@@ -227,11 +227,13 @@ def test_full_resolution_all_blocks_bench_weights():
     print(f"full-res 12 blocks, bench weights: min token cos {cos:.6f}, rel Frobenius {rel:.3e}")
 
 
-@pytest.mark.parametrize("kernel", ["v4", "v2", "v5"])
+@pytest.mark.parametrize("kernel", ["v6", "v4", "v2", "v5"])
 @pytest.mark.parametrize("dt", ["fp16", "bf16"])
 def test_attention_guards_and_safe_pass(dt, kernel):
     """dtk_vit_attention alone on crafted 16-bit operands vs an fp64 softmax on the SAME operands, for both operand types and
-    all kernels (v4: the library's one-wave-per-SIMD kernel of round 4, vit_attention4.h -- its reference enters through the
+    all kernels (v6: the library's kernel since round 6, vit_attention6.h -- one wave per SIMD, FOUR query tiles per wave, every
+    matrix instruction an asm statement on AGPR fragments, a tile's rescale deferred to the sub-step that issues its next PV
+    product; v4: the one-wave-per-SIMD kernel of rounds 4-5, vit_attention4.h -- its reference enters through the
     MFMA's C operand and its two query tiles are guarded half a key tile apart; v2: attention2_kernel, the cross-check path;
     v5: the round-5 EXPERIMENT, two waves per SIMD alternating matrix / vector steps, vit_attention5.h -- measured slower and
     not used by dtk_vit_forward, kept correct).
@@ -242,7 +244,7 @@ def test_attention_guards_and_safe_pass(dt, kernel):
     below 0; (8) a row whose large scores all sit in LATE tiles: the estimate is low and the sums jump past POISON_T in one
     step (fp16); and ordinary rows that share their wave with them.  S is not a multiple of the 64-key tile (masked tail)."""
     from dino_tracker_amd import ops
-    from dino_tracker_amd._lib import OPERAND_ATTENTION_V2, OPERAND_ATTENTION_V5, OPERAND_BF16, OPERAND_F16, check, lib
+    from dino_tracker_amd._lib import OPERAND_ATTENTION_V2, OPERAND_ATTENTION_V4, OPERAND_ATTENTION_V5, OPERAND_BF16, OPERAND_F16, check, lib
     tdt = torch.float16 if dt == "fp16" else torch.bfloat16
     g = torch.Generator().manual_seed(11)
     F, Hh, S = 1, 2, 1000
@@ -269,7 +271,7 @@ def test_attention_guards_and_safe_pass(dt, kernel):
     out = torch.empty(F, S, Hh * 64, dtype=tdt, device="cuda")
     qd, kd, vd = qb.cuda().contiguous(), kb.cuda().contiguous(), vt.cuda().contiguous()
     check(lib().dtk_vit_attention(ops._p(qd), ops._p(kd), ops._p(vd), ops._p(out), F, Hh, S, Sp,
-                                  (OPERAND_F16 if dt == "fp16" else OPERAND_BF16) | {"v2": OPERAND_ATTENTION_V2, "v5": OPERAND_ATTENTION_V5}.get(kernel, 0),
+                                  (OPERAND_F16 if dt == "fp16" else OPERAND_BF16) | {"v2": OPERAND_ATTENTION_V2, "v4": OPERAND_ATTENTION_V4, "v5": OPERAND_ATTENTION_V5}.get(kernel, 0),
                                   ops._stream()))
     s = qb.double()[:, :, :S] @ kb.double()[:, :, :S].transpose(2, 3)            # exp2-domain scores
     p = torch.softmax(s * 0.6931471805599453, dim=-1)
