@@ -103,12 +103,6 @@ __global__ __launch_bounds__(256, 1) void attention6_kernel(const op_t* __restri
             for (int ks = 0; ks < 4; ++ks) kq[blk][ks] = *reinterpret_cast<const op8*>(kp + ks * 16);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int qt = 0; qt < NQ; ++qt)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+a"(qf[qt][ks]));
-
     unsigned kvo[2], vvo[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -135,6 +129,14 @@ __global__ __launch_bounds__(256, 1) void attention6_kernel(const op_t* __restri
         issue_one(2, std::integral_constant<int, 2>{}, j);
     }
     static_assert(A4_AHEAD == 3 && A4_NB == 4, "prologue requests tiles 0..2 into a ring of four");
+    // ONE trip to memory for the Q fragments, the estimate's key rows and the first three tiles (the asm loads of Q are invisible to the
+    // compiler's vmcnt bookkeeping: wait, then re-define every loaded register behind the wait, as gemm_ws does for its weights)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int qt = 0; qt < NQ; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+a"(qf[qt][ks]));
+    __syncthreads();   // tiles 0 .. 2 of every wave have landed
 
     // reference estimate (attention2 MODE 1): keys 0..63 and the query tile's own 32 keys, while the first tiles are in flight
     float m_run[NQ], l_run[NQ];
@@ -208,8 +210,6 @@ __global__ __launch_bounds__(256, 1) void attention6_kernel(const op_t* __restri
             va[j] = lds_base + (voff0 ^ (j << 5));
         }
     }
-    vm_wait<0>();  // tiles 0 .. 2 have landed
-    __syncthreads();
 #pragma unroll
     for (int f = 0; f < 8; ++f) {
         if (f & 1) a6_lds_frag<4096>(kf[f], ka[f >> 1]);
@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256, 1) void attention6_kernel(const op_t* __restri
         }
     };
 
+    const int tail_tile = (S & 63) != 0 ? ntiles - 1 : -1;
     int pend[NQ];        // wave-uniform: tile q's guard tripped in its last softmax; handled after its next PV product
     float lsum[NQ];
 #pragma unroll
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void attention6_kernel(const op_t* __restri
         chunk_fin(15, q0e, q1e);
         const float lt = lta + ltb;
         l_run[SQ] += lt;
-        if (t == ntiles - 1 && (S & 63) != 0) mask_tail(sc[SET], t);
+        if (t == tail_tile) mask_tail(sc[SET], t);   // (one scalar compare: the key tile with keys beyond S, or -1)
         if (ABL & 8) return;
         // tile U: its PV product of the previous key tile and its scores of this one are issued -- a pending rescale can run now
         if (pend[U]) {
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256, 1) void attention6_kernel(const op_t* __restri
         }
         // tile SQ: the guard on the row sums just formed (handled after ITS next PV product, i.e. after sub-step SQ of the next key tile)
         lsum[SQ] = lt;
-        pend[SQ] = __builtin_amdgcn_readfirstlane(__any(!(lt < RESC_T)));
+        pend[SQ] = __builtin_amdgcn_ballot_w64(!(lt < RESC_T)) != 0ull;   // (a compare into VCC and one scalar test)
     };
     auto key_tile = [&](auto vb_tag, int t) {
         vm_wait<4>();   // this wave's requests of tile t + 1 have landed (those of tile t + 2 stay in flight)
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256, 1) void attention6_kernel(const op_t* __restri
         }
         l_run[NQ - 1] += lta;
         lsum[NQ - 1] = lta;
-        pend[NQ - 1] = (ABL & 8) ? 0 : __builtin_amdgcn_readfirstlane(__any(!(lta < RESC_T)));
+        pend[NQ - 1] = (ABL & 8) ? 0 : (__builtin_amdgcn_ballot_w64(!(lta < RESC_T)) != 0ull);
         // (the converts above are compiler-scheduled VALU writes of registers an asm MFMA reads next: keep them apart)
         asm volatile("s_nop 4" ::: "memory");
 #pragma unroll
