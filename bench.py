@@ -194,6 +194,7 @@ def main():
     ex = VitExtractor(model_name, stride=7, device=dev, state_dict=vit_sd, operand_dtype=args.operands, precision=args.precision)
     ex.frame_batch = args.vit_frame_batch
     ex.attention_v2 = "attention_v2" in args.ab
+    ex.attention_v4 = ex.attention_v4 or "attention_v4" in args.ab   # rounds 4-5: 64 queries per wave
     ex.gemm_ws_v1 = "gemm_ws_v1" in args.ab
     if args.features == "vit":
         feats0 = ex.encode(videos[0])

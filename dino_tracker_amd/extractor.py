@@ -44,7 +44,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from ._lib import VIT_ATTENTION_V2, VIT_GEMM_WS_V1, VIT_BF16, VIT_CHECK_RANGE, VIT_TILED_GEMMS, VitLayer, VitModel, check, lib
+from ._lib import VIT_ATTENTION_V2, VIT_ATTENTION_V4, VIT_GEMM_WS_V1, VIT_BF16, VIT_CHECK_RANGE, VIT_TILED_GEMMS, VitLayer, VitModel, check, lib
 from .synth import VIT_CONFIGS, make_vit_weights
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
@@ -76,6 +76,7 @@ class VitExtractor(nn.Module):
         self.auto_tol, self.calibration_frames = float(auto_tol), int(calibration_frames)
         self.calibration = None         # precision="auto": {"frames", "layer", "rel_fast_vs_split", "tol", "chosen"} once measured
         self.attention_v2 = False       # the round-2/3 attention kernel instead of the one-wave-per-SIMD one (cross-check)
+        self.attention_v4 = os.environ.get("DTK_VIT_ATTENTION_V4", "0") == "1"   # rounds 4-5: 64 queries per wave (round 6: 128; A / B)
         self.gemm_ws_v1 = False         # the round 1-3 form of the K = 384 weight-stationary GEMMs (A / B measurement)
         self.frame_batch = 0            # frames per pass of the encoder; 0 = the library's default
         if model_name not in VIT_CONFIGS:
@@ -249,7 +250,7 @@ class VitExtractor(nn.Module):
 
         def run(operand_dtype, split_blocks, frames=frames, n=n):
             flags = (VIT_TILED_GEMMS if self.tiled_gemms else 0) | (VIT_BF16 if operand_dtype == "bf16" else 0) | \
-                (VIT_CHECK_RANGE if self.check_range else 0) | (VIT_ATTENTION_V2 if self.attention_v2 else 0) | \
+                (VIT_CHECK_RANGE if self.check_range else 0) | (VIT_ATTENTION_V2 if self.attention_v2 else 0) | (VIT_ATTENTION_V4 if self.attention_v4 else 0) | \
                 (VIT_GEMM_WS_V1 if self.gemm_ws_v1 else 0)
             m = VitModel(D, self.cfg["heads"], layer + 1, patch, self.stride, 1e-6, flags,
                          self._sd["patch_embed.proj.weight"].data_ptr(),

@@ -289,6 +289,25 @@ def test_attention_guards_and_safe_pass(dt, kernel):
     assert s[0, 1, 300, 640:].min() > 30 and s[0, 1, 300, :96].max() < 8
 
 
+def test_encoder_on_the_previous_attention_kernel_agrees(vits):
+    """Round 6 moved dtk_vit_forward's attention to vit_attention6.h (four query tiles per wave); DTK_VIT_ATTENTION_V4 keeps rounds
+    4-5's kernel (two tiles) selectable: both encoders against the fp32 oracle and against each other (the two kernels estimate the
+    same per-query reference and differ in nothing but the order of the row sums), at a token count that is not a multiple of 128."""
+    sd, ex = vits
+    ex4 = VitExtractor("dinov2_vits14", stride=7, device="cuda:0", state_dict=sd)
+    ex4.attention_v4 = True
+    video = synth.synth_video(2, 238, 322, seed=83)     # 33 x 45 + 1 = 1486 tokens
+    a, b = ex.encode(video, layer=5).cpu(), ex4.encode(video, layer=5).cpu()
+    for t in range(2):
+        ref = A.vit_tokens(video[t:t + 1], sd, "dinov2_vits14", layer=5).permute(1, 2, 0).reshape(-1, 384)
+        _, ra = _check(a[t], ref)
+        _, rb = _check(b[t], ref)
+        assert abs(ra - rb) < 0.2 * max(ra, rb), (ra, rb)
+    d = float((a - b).norm() / b.norm())
+    print("attention6 vs attention4 encoders: rel", d)
+    assert d < 2e-4, d
+
+
 # ---- operand types and the fp16 range ---------------------------------------------------------------------------------
 def test_bf16_operands_on_request(vits):
     """operand_dtype='bf16' (DTK_VIT_BF16): the round-2 arithmetic, kept for activations beyond fp16's range."""
