@@ -28,15 +28,15 @@ for WHAT in "$@"; do
     bench)
       timeout 1500 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err ;;
     bench_quick)
-      timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-videos30 > gpurun_out/bench_quick.json 2> gpurun_out/bench_quick.err; cat gpurun_out/bench_quick.json; tail -5 gpurun_out/bench_quick.err ;;
+      timeout 900 python bench.py --steps 5 --warmup 2 --no-train --no-cpu-baseline --no-videos30 > gpurun_out/bench_quick.json 2> gpurun_out/bench_quick.err; cat gpurun_out/bench_quick.json; tail -5 gpurun_out/bench_quick.err ;;
     bench_fast)   # kernel times only: no oracle legs
-      timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-clock-power --no-live-traffic --no-videos30 --parity-queries 0 > gpurun_out/bench_fast.json 2> gpurun_out/bench_fast.err; cat gpurun_out/bench_fast.json; tail -5 gpurun_out/bench_fast.err ;;
+      timeout 600 python bench.py --steps 5 --warmup 2 --no-train --no-cpu-baseline --no-clock-power --no-live-traffic --no-videos30 --parity-queries 0 > gpurun_out/bench_fast.json 2> gpurun_out/bench_fast.err; cat gpurun_out/bench_fast.json; tail -5 gpurun_out/bench_fast.err ;;
     bench_split)
-      timeout 900 python bench.py --precision split --steps 3 --warmup 1 --no-cpu-baseline --no-clock-power --no-videos30 > gpurun_out/bench_split.json 2> gpurun_out/bench_split.err; cat gpurun_out/bench_split.json; tail -5 gpurun_out/bench_split.err ;;
+      timeout 900 python bench.py --precision split --steps 3 --warmup 1 --no-train --no-cpu-baseline --no-clock-power --no-videos30 > gpurun_out/bench_split.json 2> gpurun_out/bench_split.err; cat gpurun_out/bench_split.json; tail -5 gpurun_out/bench_split.err ;;
     bench_w1024)
-      timeout 900 python bench.py --width 1024 --precision fast --steps 2 --warmup 1 --no-cpu-baseline --no-clock-power --no-videos30 > gpurun_out/bench_w1024.json 2> gpurun_out/bench_w1024.err; cat gpurun_out/bench_w1024.json; tail -5 gpurun_out/bench_w1024.err ;;
+      timeout 900 python bench.py --width 1024 --precision fast --steps 2 --warmup 1 --no-train --no-cpu-baseline --no-clock-power --no-videos30 > gpurun_out/bench_w1024.json 2> gpurun_out/bench_w1024.err; cat gpurun_out/bench_w1024.json; tail -5 gpurun_out/bench_w1024.err ;;
     bench_ab)   # same-box A / B of the whole step: the tree's library, then scripts/ubench/libdtk_prev.so (a copy of the previous build), then the tree's again
-      F="--steps 5 --warmup 2 --no-cpu-baseline --no-clock-power --no-videos30 --parity-queries 0"
+      F="--steps 5 --warmup 2 --no-train --no-cpu-baseline --no-clock-power --no-videos30 --parity-queries 0"
       L=dino_tracker_amd/csrc/libdtk.so
       timeout 600 python bench.py $F > gpurun_out/bench_ab_new1.json 2> gpurun_out/bench_ab.err
       cp $L /tmp/libdtk_new.so && cp scripts/ubench/libdtk_prev.so $L
@@ -58,7 +58,7 @@ PY
       bash scripts/gpu_profile.sh r06 ;;
     sq)   # the SQ-counter pass alone (scripts/pmc_sq.py: rows per template instantiation since round 6)
       R=$PWD; rm -rf /tmp/prof_sq; ( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES \
-          -d /tmp/prof_sq -o sq -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-clock-power --no-live-traffic --no-videos30 --parity-queries 0 > /dev/null 2> $R/gpurun_out/r06_sq.err )
+          -d /tmp/prof_sq -o sq -- python $R/bench.py --steps 1 --warmup 0 --no-train --no-cpu-baseline --no-clock-power --no-live-traffic --no-videos30 --parity-queries 0 > /dev/null 2> $R/gpurun_out/r06_sq.err )
       python scripts/pmc_sq.py $(find /tmp/prof_sq -name "*.db" | head -1) > gpurun_out/r06_pmc_sq.md 2>> gpurun_out/r06_sq.err; head -30 gpurun_out/r06_pmc_sq.md ;;
     cmd:*)
       timeout 2400 bash -c "${WHAT#cmd:}" 2>&1 | tail -60 | tee gpurun_out/cmd.log ;;
