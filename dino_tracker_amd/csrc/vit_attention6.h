@@ -278,8 +278,13 @@ __global__ __launch_bounds__(256, 1) void attention6_kernel(const op_t* __restri
         };
         auto chunk_fin = [&](int c, float p0, float p1) {
             const int bj = c >> 2, e = 2 * (c & 3);
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(lta) : "v"(p0));
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(ltb) : "v"(p1));
+            if (c == 0) {   // the chains start from the first chunk's values (no zero-initialised registers, no adds)
+                lta = p0;
+                ltb = p1;
+            } else {
+                asm volatile("v_add_f32 %0, %0, %1" : "+v"(lta) : "v"(p0));
+                asm volatile("v_add_f32 %0, %0, %1" : "+v"(ltb) : "v"(p1));
+            }
             unsigned wv;
             if constexpr (F16) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(wv) : "v"(p0), "v"(p1));
             else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(wv) : "v"(p0), "v"(p1));

@@ -11,8 +11,8 @@ rm -rf /tmp/prof_kt /tmp/prof_rd /tmp/prof_wr
 CMD="python $R/bench.py --steps 2 --warmup 1 --precision fast --no-train --no-cpu-baseline --no-clock-power --no-live-traffic --no-videos30"   # (--precision fast: what auto picks on these weights, without the calibration's extra launches in the trace)
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o bench -- $CMD > $R/gpurun_out/${TAG}_kt_bench.json 2> $R/gpurun_out/${TAG}_kt.err
 db=$(find /tmp/prof_kt -name "*.db" | head -1)
-# idle gaps of the device inside the two timed steps (one patch-embedding launch per step since round 4: occurrences 1 .. 3)
-python $R/scripts/rocpd_summary.py $db --gaps --gaps-window patch_embed 1 3 > $R/gpurun_out/${TAG}_kernel_trace_table.md 2>> $R/gpurun_out/${TAG}_kt.err
+# idle gaps of the device inside the two timed steps (one patch-embedding launch per step since round 4: occurrences 1 .. 2 = one timed step)
+python $R/scripts/rocpd_summary.py $db --gaps --gaps-window patch_embed 1 2 > $R/gpurun_out/${TAG}_kernel_trace_table.md 2>> $R/gpurun_out/${TAG}_kt.err
 CMD1="python $R/bench.py --steps 1 --warmup 0 --precision fast --no-train --no-cpu-baseline --no-clock-power --no-live-traffic --no-videos30"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_rd -o rd -- $CMD1 > /dev/null 2> $R/gpurun_out/${TAG}_rd.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_wr -o wr -- $CMD1 > /dev/null 2> $R/gpurun_out/${TAG}_wr.err
