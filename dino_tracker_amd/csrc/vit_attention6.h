@@ -215,6 +215,9 @@ __global__ __launch_bounds__(256, 1) void attention6_kernel(const op_t* __restri
         if (f & 1) a6_lds_frag<4096>(kf[f], ka[f >> 1]);
         else a6_lds_frag<0>(kf[f], ka[f >> 1]);
     }
+    // (asm reads: nobody but this statement waits for them -- the counted wait that opens a key tile assumes the SIXTEEN reads of a
+    //  preceding last sub-step and would let key tile 0 start on fragments that have not landed)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     auto mask_tail = [&](f16v (&s2)[2], int t) {  // keys beyond S (last tile only)
 #pragma unroll
