@@ -325,7 +325,10 @@ __global__ __launch_bounds__(256, 1) void attention6_kernel(const op_t* __restri
         chunk_fin(15, q0e, q1e);
         const float lt = lta + ltb;
         l_run[SQ] += lt;
-        if (t == tail_tile) mask_tail(sc[SET], t);   // (one scalar compare: the key tile with keys beyond S, or -1)
+        if (t == tail_tile) {   // (one scalar compare: the key tile with keys beyond S, or -1)
+            asm volatile("s_nop 15" ::: "memory");   // the scores were written by asm MFMAs two slots ago: the compiler pads nothing for them
+            mask_tail(sc[SET], t);
+        }
         if (ABL & 8) return;
         // tile U: its PV product of the previous key tile and its scores of this one are issued -- a pending rescale can run now
         if (pend[U]) {
