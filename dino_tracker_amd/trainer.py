@@ -313,6 +313,8 @@ class GraphedIteration:
         self.counts = {"eager": 0, "captured": 0, "replayed": 0}
         if self.enabled and not getattr(optimizer, "_dtk_fused", False):
             self.enabled = False    # torch's own Adam step (DTK_TRAIN_ADAM=torch, options the kernel lacks): its scalars live on the host
+        if self.enabled and not getattr(sampler, "fg_valid_trajectories", torch.empty(0)).is_cuda:
+            self.enabled = False    # keep_traj_in_cpu: the batch is assembled from host tensors -- nothing to capture
         if self.enabled:
             from .train_ops import GraphAdam
             self.pool = torch.cuda.graph_pool_handle()
