@@ -338,6 +338,8 @@ class Tracker(nn.Module):
         """tracker.py:303-325 in training mode: refine the batch's frames with gradients, keep the tensors the loss
         terms of dino_tracker.py read (`frame_embeddings`, `raw_embeddings`, `residual_embeddings`)."""
         frames_set_t = inp[-1]
+        from . import train_ops as _to
+        _to.new_iteration()   # (what the tracker passes of one iteration share starts here)
         if use_raw_features:
             frame_embeddings = raw_embeddings = self.get_dino_embed_video(frames_set_t)
         elif self._refined is not None:  # a cached volume takes precedence, as in the reference (tracker.py:315-317)

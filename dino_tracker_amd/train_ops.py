@@ -839,8 +839,31 @@ def track_points(head, src: torch.Tensor, frames: torch.Tensor, tgt: torch.Tenso
     return head_forward(head, torch.relu(cosine_maps(src, frames, tgt))[:, None])
 
 
+_HEAD_PACKED = {}
+
+
+def new_iteration() -> None:
+    """Drop what the calls of ONE training iteration share (the packed head parameters: three tracker passes use one copy, i.e. one
+    set of ~20 small launches and one gradient edge instead of three).  Tracker._forward_train calls this first."""
+    _HEAD_PACKED.clear()
+
+
 def _head_packed(head, n, c, h, w, like):
-    """(packed normalised head parameters with autograd into the weights, geometry) or None if the kernels do not apply."""
+    """(packed normalised head parameters with autograd into the weights, geometry) or None if the kernels do not apply.  Shared by
+    the tracker passes of an iteration (new_iteration) while the parameters are the same objects at the same versions."""
+    c0, c2 = head.cnn_refiner[0], head.cnn_refiner[2]
+    key = (id(head), n, c, h, w, torch.is_grad_enabled(), c0.weight._version, c2.weight._version,
+           None if c0.bias is None else c0.bias._version, None if c2.bias is None else c2.bias._version)
+    hit = _HEAD_PACKED.get(key)
+    if hit is not None:
+        return hit
+    out = _head_packed_compute(head, n, c, h, w, like)
+    _HEAD_PACKED.clear()
+    _HEAD_PACKED[key] = out
+    return out
+
+
+def _head_packed_compute(head, n, c, h, w, like):
     from ._lib import make_geom
     c0, c2 = head.cnn_refiner[0], head.cnn_refiner[2]
     if c0.out_channels != 16 or c2.in_channels != 16 or float(head.argmax_radius) / float(head.step_h) > 5.0:
@@ -959,6 +982,19 @@ def _adam_args(optimizer, advance: bool = True):
     return a, keep
 
 
+def _bump_versions(optimizer) -> None:
+    """The kernel writes the parameters through raw pointers: tell autograd (and everything keyed on `_version`, e.g. the packed head
+    parameters shared by an iteration's tracker passes) that they changed, as an in-place torch op would."""
+    bump = getattr(torch.autograd.graph, "increment_version", None)
+    for grp in optimizer.param_groups:
+        for p in grp["params"]:
+            if p.grad is not None:
+                if bump is not None:
+                    bump(p)
+                else:
+                    p.data.add_(0)
+
+
 def fused_adam_step(optimizer) -> None:
     """One step of a torch.optim.Adam instance (dino_tracker.py:110-115: default betas / eps, no weight decay, no amsgrad, two
     parameter groups whose learning rates the LambdaLR of optimization/schedulers.py:4-8 rewrites) as ONE kernel launch over all
@@ -973,6 +1009,7 @@ def fused_adam_step(optimizer) -> None:
         return
     with torch.no_grad():
         check(lib().dtk_adam_step(ctypes.byref(a), ops._stream()))
+    _bump_versions(optimizer)
 
 
 class GraphAdam:
@@ -1003,6 +1040,7 @@ class GraphAdam:
         params = [p for grp in self.optimizer.param_groups for p in grp["params"] if p.grad is not None]
         with torch.no_grad():
             check(lib().dtk_adam_step_dev(ctypes.byref(a), ctypes.c_void_p(self.scalars.data_ptr()), ops._stream()))
+        _bump_versions(self.optimizer)
         return params, keep
 
     def refresh(self, params):
