@@ -72,7 +72,7 @@ def parse():
     ap.add_argument("--cpu-vit-frames", type=int, default=2,
                     help="frames the oracle's ViT / Delta-DINO legs are timed on (also the from-the-video parity leg)")
     ap.add_argument("--operands", default="fp16", choices=["fp16", "bf16"], help="operand type of the ViT's matrix units")
-    ap.add_argument("--precision", default="auto", choices=["fast", "split", "auto"],
+    ap.add_argument("--precision", default="auto", choices=["fast", "split", "auto", "auto-blocks"],
                     help="VitExtractor precision: auto (default: the extractor MEASURES fast-vs-split on the first two frames of its first "
                          "call -- outside the timed region -- and keeps the fast operands only if they are within 2.5e-4 of the split ones; "
                          "on the benchmark's weights it measures 1.3e-4 and runs fast: config.vit_precision.calibration), fast (one 16-bit "

@@ -547,6 +547,17 @@ __device__ __forceinline__ void ws_glds16(const void* gsrc, unsigned lds_dst) {
 template <int N>
 __device__ __forceinline__ void ws_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
+// One wave's share of a pipeline stage of the wide GEMMs by DESCRIPTOR LDS-DMA (round 6; common.h dtk_buffer_lds16: three issue
+// slots per request where the global_load_lds form above costs ~13 -- 64-bit address arithmetic on the VALU, m0 saved and restored).
+// Request i of wave w lands at stage + (w REQ + i) KB: the stages of gemm_wide_delta / gemm_wide / gemm_split_dma are laid out so.
+// srd[i] = descriptor over the first row of the request's operand tile, voff[i] = the lane's constant byte offset in it (row, swizzled
+// piece), soff = the k-step's byte offset.  A kernel that calls this must not use ws_glds16 (m0: tests/test_abi.py::test_m0_users).
+template <int REQ, int I = 0>
+__device__ __forceinline__ void wd_issue(const dtk_u4 (&srd)[REQ], const unsigned (&voff)[REQ], unsigned soff, unsigned lds_dst) {
+    dtk_buffer_lds16<I * 1024>(srd[I], soff, voff[I], lds_dst);
+    if constexpr (I + 1 < REQ) wd_issue<REQ, I + 1>(srd, voff, soff, lds_dst);
+}
+
 // GELU(x) = x Phi(x) with erf(s / sqrt 2) ~ s P(s^2) on |s| <= 4.25 (odd minimax polynomial, 9 coefficients, |err| < 2e-5;
 // |GELU error| < 6e-5 everywhere, far below the bf16 rounding of the result); two values per packed fp32 instruction
 __device__ __forceinline__ f2 gelu2(f2 x) {
@@ -644,25 +655,23 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_delta_kernel(const T* __rest
     const int fj = lane & 15, fg = lane >> 4;
     // ---- DMA sources: request q = 5 w + i covers 16 rows (A rows 16q.. for q < 16, Wt rows 16(q-16).. otherwise); lane
     // (row 16q' + lane/4, slot lane%4) fetches the piece that gswz puts in that slot
-    const T* src[WD_REQ];
-    unsigned dst[WD_REQ];
+    dtk_u4 srd[WD_REQ];
+    unsigned voff[WD_REQ];
 #pragma unroll
     for (int i = 0; i < WD_REQ; ++i) {
         const int q = w * WD_REQ + i;
         const bool isA = q < WD_M / 16;
         const int row = (isA ? q : q - WD_M / 16) * 16 + (lane >> 2);
         const int piece = (lane & 3) ^ ((0x1230 >> (((row >> 2) & 3) * 4)) & 3);
-        const long long grow = isA ? min(m0 + row, M - 1) : (long long)row;  // Wt has exactly WD_N rows
-        src[i] = (isA ? A : Wt) + grow * K + piece * 8;
-        dst[i] = (isA ? 0 : WD_A_BYTES) + (isA ? q : q - WD_M / 16) * 1024;
+        const int trow = isA ? (int)(min(m0 + row, M - 1) - m0) : row;  // Wt has exactly WD_N rows; rows past M repeat the last one
+        srd[i] = dtk_make_srd(isA ? A + m0 * K : Wt);
+        voff[i] = (unsigned)(trow * K + piece * 8) * 2u;
     }
-    const unsigned lds0 = (unsigned)(size_t)&stages[0];
+    const unsigned lds0 = (unsigned)(size_t)&stages[0] + (unsigned)w * (WD_REQ * 1024);
     const int nk = K / GK;
     auto issue = [&](int ks, int buf) {
         const int kk = min(ks, nk - 1);  // past the end: a harmless repeat keeps the request count per stage uniform
-#pragma unroll
-        for (int i = 0; i < WD_REQ; ++i)
-            ws_glds16(src[i] + (size_t)kk * GK, __builtin_amdgcn_readfirstlane(lds0 + buf * WD_STAGE_BYTES + dst[i]));
+        wd_issue<WD_REQ>(srd, voff, (unsigned)kk * (GK * 2), __builtin_amdgcn_readfirstlane(lds0 + buf * WD_STAGE_BYTES));
     };
     f4 acc[8][6];
 #pragma unroll
@@ -735,7 +744,7 @@ inline unsigned gemm_wide_grid(int N, long long rows) {
     return (unsigned)(dtk_cdiv(nrow, 8) * 8 * ncol);
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, bool PIPE = true>
 __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const T* __restrict__ A, const T* __restrict__ Wt,
                                                            long long M, int N, int K, GemmEpi<T> e) {
     typedef typename Vec<T>::t8 T8;
@@ -754,25 +763,23 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const T* __restrict__
     const int n0 = (int)(kb % ncol) * W2_N;
     const int wr = w >> 2, wc = w & 3;  // wave tile: rows wr*128.., columns wc*64..
     const int fj = lane & 15, fg = lane >> 4;
-    const T* src[W2_REQ];
-    unsigned dst[W2_REQ];
+    dtk_u4 srd[W2_REQ];
+    unsigned voff[W2_REQ];
 #pragma unroll
     for (int i = 0; i < W2_REQ; ++i) {
         const int q = w * W2_REQ + i;  // 0..15: A rows 16q.., 16..31: Wt rows n0 + 16(q-16)..
         const bool isA = q < W2_M / 16;
         const int row = (isA ? q : q - W2_M / 16) * 16 + (lane >> 2);
         const int piece = (lane & 3) ^ ((0x1230 >> (((row >> 2) & 3) * 4)) & 3);
-        const long long grow = isA ? min(m0 + row, M - 1) : (long long)(n0 + row);
-        src[i] = (isA ? A : Wt) + grow * K + piece * 8;
-        dst[i] = (isA ? 0 : W2_M * 64) + (isA ? q : q - W2_M / 16) * 1024;
+        const int trow = isA ? (int)(min(m0 + row, M - 1) - m0) : row;
+        srd[i] = dtk_make_srd(isA ? A + m0 * K : Wt + (long long)n0 * K);
+        voff[i] = (unsigned)(trow * K + piece * 8) * 2u;
     }
-    const unsigned lds0 = (unsigned)(size_t)&stages[0];
+    const unsigned lds0 = (unsigned)(size_t)&stages[0] + (unsigned)w * (W2_REQ * 1024);
     const int nk = K / GK;
     auto issue = [&](int ks, int buf) {
         const int kk = min(ks, nk - 1);
-#pragma unroll
-        for (int i = 0; i < W2_REQ; ++i)
-            ws_glds16(src[i] + (size_t)kk * GK, __builtin_amdgcn_readfirstlane(lds0 + buf * W2_STAGE_BYTES + dst[i]));
+        wd_issue<W2_REQ>(srd, voff, (unsigned)kk * (GK * 2), __builtin_amdgcn_readfirstlane(lds0 + buf * W2_STAGE_BYTES));
     };
     f4 acc[8][4];
 #pragma unroll
@@ -788,6 +795,57 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const T* __restrict__
     ws_wait<2 * W2_REQ>();  // stage 0 landed
     __syncthreads();
     int buf = 0;
+    if (PIPE) {
+        // Round 6: the fragment reads run ONE HALF-STEP AHEAD of the MFMAs that consume them.  In the form below every wave reads
+        // its eight fragments right behind the barrier -- all eight waves of the CU at once, 64 ds_read_b128 = 256 LDS cycles plus
+        // the latency, with the matrix pipes idle (SQ counters, fc2 of ViT-S on the same loop: waves parked 45 %, pipes 38 % busy).
+        // Here a k-step is two halves of 16 MFMAs (token tiles 0-3 | 4-7 against the four W tiles); the A fragments of the second
+        // half are requested in front of the first half's MFMAs, and A (first half) + W fragments of the NEXT stage behind the
+        // barrier, in front of the second half's MFMAs: two fragment sets (fa / fb, alternating with the k-step: the loop is
+        // unrolled by two so that the set is a compile-time index), 64 fragment registers + 128 accumulators.
+        T8 fa[2][4], fb[2][4], ga[4];
+        {
+            const unsigned char* sb = stages;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[0][i] = *reinterpret_cast<const T8*>(sb + a_off + i * 1024);
+                fb[0][i] = *reinterpret_cast<const T8*>(sb + b_off + i * 1024);
+            }
+        }
+        for (int ks = 0; ks < nk; ks += 2) {   // (nk is even: K % 256 == 0 on this path)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                issue(ks + s + 3, (buf + 3) & 3);  // the stage consumed in the previous step
+                const unsigned char* sb = stages + buf * W2_STAGE_BYTES;
+                const unsigned char* sn = stages + ((buf + 1) & 3) * W2_STAGE_BYTES;
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) ga[mi] = *reinterpret_cast<const T8*>(sb + a_off + (4 + mi) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = mfma16(fb[s][ni], fa[s][mi], acc[mi][ni]);
+                __builtin_amdgcn_sched_barrier(0);
+                // (this wave's reads of the current stage have returned before it passes the barrier: the DMA requests of the next
+                //  step overwrite the stage that was current one step earlier)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                ws_wait<2 * W2_REQ>();  // stage ks + 1 landed; ks + 2 and ks + 3 stay in flight
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {   // (behind the last step: the repeated last stage, harmless)
+                    fa[s ^ 1][i] = *reinterpret_cast<const T8*>(sn + a_off + i * 1024);
+                    fb[s ^ 1][i] = *reinterpret_cast<const T8*>(sn + b_off + i * 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) acc[4 + mi][ni] = mfma16(fb[s][ni], ga[mi], acc[4 + mi][ni]);
+                __builtin_amdgcn_sched_barrier(0);
+                buf = (buf + 1) & 3;
+            }
+        }
+    } else {
     for (int ks = 0; ks < nk; ++ks) {
         issue(ks + 3, (buf + 3) & 3);  // the stage consumed in the previous iteration
         const unsigned char* sb = stages + buf * W2_STAGE_BYTES;
@@ -809,6 +867,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const T* __restrict__
         ws_wait<2 * W2_REQ>();  // stage ks + 1 landed; ks + 2 and ks + 3 stay in flight
         __syncthreads();
         buf = (buf + 1) & 3;
+    }
     }
     ws_wait<0>();
     // D tiles are TRANSPOSED (the MFMAs above multiply (W tile) x (token tile)^T): lane (fg, fj) holds features 4 fg + r of token fj
@@ -1344,6 +1403,15 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
         // DTK_VIT_TILED_GEMMS: every GEMM on the tiled kernel (tests cross-check the weight-stationary one with it)
         const bool ws_ok = D == WS_K && !(m->flags & DTK_VIT_TILED_GEMMS);
         const bool ws_v1 = (m->flags & DTK_VIT_GEMM_WS_V1) != 0;
+        const bool wide_v1 = (m->flags & DTK_VIT_GEMM_WIDE_V1) != 0;   // the 256 x 256 GEMMs without the half-step fragment prefetch (A / B)
+#define DTK_WIDE(NAME, EPI_, N_, ...)                                                                                          \
+    do {                                                                                                                       \
+        if (wide_v1) {                                                                                                         \
+            DTK_LAUNCH(NAME, (gemm_wide_kernel<T, EPI_, false>), dim3(gemm_wide_grid(N_, rows)), dim3(512), 0, st, __VA_ARGS__); \
+        } else {                                                                                                               \
+            DTK_LAUNCH(NAME, (gemm_wide_kernel<T, EPI_, true>), dim3(gemm_wide_grid(N_, rows)), dim3(512), 0, st, __VA_ARGS__);  \
+        }                                                                                                                      \
+    } while (0)
         const int dbg_ns = DTK_DBG(dtk_dev_flags() >> 16, 3);  // DTK_DEV: skip the weight-stationary kernel's stores
         auto ws_grid = [&](int N) {  // one resident round: one workgroup per CU
             const int colwg = dtk_cdiv(N, WS_COLS);
@@ -1455,7 +1523,7 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                                gr.second);
                 }
             } else if (wide_ok) {
-                DTK_LAUNCH("vit_gemm_qkv", (gemm_wide_kernel<T, EPI_QKV>), dim3(gemm_wide_grid(3 * D, rows)), dim3(512), 0, st, xn, qkv_w, rows, 3 * D, D, e);
+                DTK_WIDE("vit_gemm_qkv", EPI_QKV, 3 * D, xn, qkv_w, rows, 3 * D, D, e);
             } else {
                 DTK_LAUNCH("vit_gemm_qkv", (gemm_tiled_kernel<T, EPI_QKV>), dim3(gemm_grid(3 * D, rows)), dim3(256), 0, st, xn,
                            qkv_w, rows, 3 * D, D, e);
@@ -1474,8 +1542,7 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                                gr.second);
                 }
             } else if (wide_ok) {
-                DTK_LAUNCH("vit_gemm_proj", (gemm_wide_kernel<T, EPI_DELTA>), dim3(gemm_wide_grid(D, rows)), dim3(512), 0, st, ao,
-                           proj_w, rows, D, D, e);
+                DTK_WIDE("vit_gemm_proj", EPI_DELTA, D, ao, proj_w, rows, D, D, e);
             } else {
                 DTK_LAUNCH("vit_gemm_proj", (gemm_tiled_kernel<T, EPI_DELTA>), dim3(gemm_grid(D, rows)), dim3(256), 0, st, ao,
                            proj_w, rows, D, D, e);
@@ -1494,7 +1561,7 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                                gr.second);
                 }
             } else if (wide_ok) {
-                DTK_LAUNCH("vit_gemm_fc1", (gemm_wide_kernel<T, EPI_GELU>), dim3(gemm_wide_grid(4 * D, rows)), dim3(512), 0, st, xn, fc1_w, rows, 4 * D, D, e);
+                DTK_WIDE("vit_gemm_fc1", EPI_GELU, 4 * D, xn, fc1_w, rows, 4 * D, D, e);
             } else {
                 DTK_LAUNCH("vit_gemm_fc1", (gemm_tiled_kernel<T, EPI_GELU>), dim3(gemm_grid(4 * D, rows)), dim3(256), 0, st, xn,
                            fc1_w, rows, 4 * D, D, e);
@@ -1506,8 +1573,7 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                 DTK_LAUNCH("vit_gemm_fc2", gemm_wide_delta_kernel<T>, dim3(dtk_cdiv(rows, WD_M)), dim3(512), 0, st, hid, fc2_w,
                            rows, 4 * D, e);
             } else if (wide_ok) {
-                DTK_LAUNCH("vit_gemm_fc2", (gemm_wide_kernel<T, EPI_DELTA>), dim3(gemm_wide_grid(D, rows)), dim3(512), 0, st, hid,
-                           fc2_w, rows, D, 4 * D, e);
+                DTK_WIDE("vit_gemm_fc2", EPI_DELTA, D, hid, fc2_w, rows, D, 4 * D, e);
             } else {
                 DTK_LAUNCH("vit_gemm_fc2", (gemm_tiled_kernel<T, EPI_DELTA>), dim3(gemm_grid(D, rows)), dim3(256), 0, st, hid,
                            fc2_w, rows, D, 4 * D, e);

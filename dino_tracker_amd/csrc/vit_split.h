@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const T* __restrict_
 
 // ---- the same product on the LDS-DMA pipeline of gemm_wide_delta_kernel (round 6, second form) -----------------------------------
 // 256 tokens x 128 features per workgroup of 8 waves (4 x 2, wave tile 64 x 64), 32-wide k-steps; a stage = A_hi | A_lo (256 rows x
-// 64 B each) | W_hi | W_lo (128 rows x 64 B each) = 48 KB arrives by global_load_lds_dwordx4 (no staging registers, no ds_write),
+// 64 B each) | W_hi | W_lo (128 rows x 64 B each) = 48 KB arrives by LDS-DMA (buffer_load_dwordx4 ... lds through descriptors; no staging registers, no ds_write),
 // ring of three stages, two in flight.  LDS image and swizzle are gemm_tiled_kernel's (four 16-byte pieces per row, gswz), produced
 // by giving every DMA lane the matching source address.  Used when N % 128 == 0 (every GEMM of the ViT-S / B / L blocks).
 constexpr int SD_M = 256, SD_N = 128, SD_STAGES = 3;
@@ -312,8 +312,9 @@ __global__ __launch_bounds__(512, 1) void gemm_split_dma_kernel(const T* __restr
     const int wr = w >> 1, wc = w & 1;
     const int fj = lane & 15, fg = lane >> 4;
     // request q = 6 w + i: 0..15 A_hi rows 16 q.., 16..31 A_lo, 32..39 W_hi rows n0 + 16 (q - 32).., 40..47 W_lo
-    const T* src[SD_REQ];
-    unsigned dst[SD_REQ];
+    // (descriptor LDS-DMA, vit.hip wd_issue: the request's LDS slot is q KB into the stage)
+    dtk_u4 srd[SD_REQ];
+    unsigned voff[SD_REQ];
 #pragma unroll
     for (int i = 0; i < SD_REQ; ++i) {
         const int q = w * SD_REQ + i;
@@ -322,17 +323,15 @@ __global__ __launch_bounds__(512, 1) void gemm_split_dma_kernel(const T* __restr
         const bool lo = isA ? q >= 16 : q >= 40;
         const int row = blk * 16 + (lane >> 2);
         const int piece = (lane & 3) ^ ((0x1230 >> (((row >> 2) & 3) * 4)) & 3);
-        const long long grow = isA ? min(m0 + row, M - 1) : (long long)(n0 + row);
-        src[i] = (isA ? (lo ? Al : Ah) : (lo ? Wl : Wh)) + grow * K + piece * 8;
-        dst[i] = (isA ? (lo ? SD_M * 64 : 0) : 2 * SD_M * 64 + (lo ? SD_N * 64 : 0)) + blk * 1024;
+        const int trow = isA ? (int)(min(m0 + row, M - 1) - m0) : row;
+        srd[i] = dtk_make_srd(isA ? (lo ? Al : Ah) + m0 * K : (lo ? Wl : Wh) + (long long)n0 * K);
+        voff[i] = (unsigned)(trow * K + piece * 8) * 2u;
     }
-    const unsigned lds0 = (unsigned)(size_t)&stages[0];
+    const unsigned lds0 = (unsigned)(size_t)&stages[0] + (unsigned)w * (SD_REQ * 1024);
     const int nk = K / SP_K;
     auto issue = [&](int ks, int buf) {
         const int kk = min(ks, nk - 1);   // past the end: a harmless repeat keeps the request count per stage uniform
-#pragma unroll
-        for (int i = 0; i < SD_REQ; ++i)
-            ws_glds16(src[i] + (size_t)kk * SP_K, __builtin_amdgcn_readfirstlane(lds0 + buf * SD_STAGE_BYTES + dst[i]));
+        wd_issue<SD_REQ>(srd, voff, (unsigned)kk * (SP_K * 2), __builtin_amdgcn_readfirstlane(lds0 + buf * SD_STAGE_BYTES));
     };
     f4 acc[4][4];
 #pragma unroll

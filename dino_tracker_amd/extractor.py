@@ -22,7 +22,10 @@ features (2e-7 .. 4e-6 relative, what the fp32 reference itself is from float64)
 indices escalates those blocks only.  `precision="auto"` MEASURES which one is needed: the first frames of the first call
 are encoded both ways and the extractor stays on split operands if the fast features differ by more than `auto_tol`
 (relative, default 2.5e-4: the level below which the end-to-end positions were measured within 1e-3 px); the measurement is
-kept in `calibration`.  `precision_report()` returns what the last call ran on.
+kept in `calibration`.  `precision="auto-blocks"` goes one step further when the fast pass is NOT good enough: it measures what
+each block contributes when it alone runs on single 16-bit operands (one pass of the calibration frames per block, all other
+blocks split), keeps on the fast kernels the largest set of blocks whose contributions -- added in quadrature, then MEASURED
+together -- stay below `block_margin * auto_tol`, and escalates the rest.  `precision_report()` returns what the last call ran on.
 
 fp16 ends at 65504: activations beyond that SATURATE on the device and set an overflow word -- for every value of every frame
 (residual updates in the LayerNorm that applies them; Q / K / V and the MLP hidden inside the epilogues of the GEMMs that store
@@ -44,7 +47,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from ._lib import VIT_ATTENTION_V2, VIT_ATTENTION_V4, VIT_GEMM_WS_V1, VIT_BF16, VIT_CHECK_RANGE, VIT_TILED_GEMMS, VitLayer, VitModel, check, lib
+from ._lib import VIT_ATTENTION_V2, VIT_ATTENTION_V4, VIT_GEMM_WIDE_V1, VIT_GEMM_WS_V1, VIT_BF16, VIT_CHECK_RANGE, VIT_TILED_GEMMS, VitLayer, VitModel, check, lib
 from .synth import VIT_CONFIGS, make_vit_weights
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
@@ -57,7 +60,8 @@ class VitExtractor(nn.Module):
 
     def __init__(self, model_name, stride, device, state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  random_seed: Optional[int] = None, operand_dtype: str = "fp16", check_range: bool = False,
-                 on_overflow: str = "split-bf16", precision=None, auto_tol: float = 2.5e-4, calibration_frames: int = 2):
+                 on_overflow: str = "split-bf16", precision=None, auto_tol: float = 2.5e-4, calibration_frames: int = 2,
+                 block_margin: float = 0.8):
         super().__init__()
         if operand_dtype not in ("fp16", "bf16"):
             raise ValueError(f"operand_dtype {operand_dtype!r}: 'fp16' or 'bf16'")
@@ -74,10 +78,12 @@ class VitExtractor(nn.Module):
         # scan of the stored tensors (one extra pass per block): the cross-check of the tests.
         self.check_range = check_range
         self.auto_tol, self.calibration_frames = float(auto_tol), int(calibration_frames)
+        self.block_margin = float(block_margin)   # precision="auto-blocks": the mixed pass must measure <= block_margin * auto_tol
         self.calibration = None         # precision="auto": {"frames", "layer", "rel_fast_vs_split", "tol", "chosen"} once measured
         self.attention_v2 = False       # the round-2/3 attention kernel instead of the one-wave-per-SIMD one (cross-check)
         self.attention_v4 = os.environ.get("DTK_VIT_ATTENTION_V4", "0") == "1"   # rounds 4-5: 64 queries per wave (round 6: 128; A / B)
         self.gemm_ws_v1 = False         # the round 1-3 form of the K = 384 weight-stationary GEMMs (A / B measurement)
+        self.gemm_wide_v1 = os.environ.get("DTK_VIT_GEMM_WIDE_V1", "0") == "1"   # D = 768 / 1024: the wide GEMMs without the fragment prefetch (A / B)
         self.frame_batch = 0            # frames per pass of the encoder; 0 = the library's default
         if model_name not in VIT_CONFIGS:
             raise NotImplementedError(f"{model_name}: the HIP encoder covers dinov2_vit{{s,b,l}}14 (d_head 64)")
@@ -104,11 +110,11 @@ class VitExtractor(nn.Module):
         self._layers = self._build_layers(self.operand_dtype, self.split_blocks)
 
     def set_precision(self, precision):
-        """"fast" | "split" | "auto" | an iterable of block indices that run on split operands (see the module docstring)."""
+        """"fast" | "split" | "auto" | "auto-blocks" | an iterable of block indices that run on split operands (see the module docstring)."""
         depth = VIT_CONFIGS[self.model_name]["depth"]
         if isinstance(precision, str):
-            if precision not in ("fast", "split", "auto"):
-                raise ValueError(f"precision {precision!r}: 'fast', 'split', 'auto' or a list of block indices")
+            if precision not in ("fast", "split", "auto", "auto-blocks"):
+                raise ValueError(f"precision {precision!r}: 'fast', 'split', 'auto', 'auto-blocks' or a list of block indices")
             self.precision = precision
             self.split_blocks = frozenset(range(depth)) if precision == "split" else frozenset()
         else:
@@ -116,7 +122,7 @@ class VitExtractor(nn.Module):
             if any(not 0 <= b < depth for b in blocks):
                 raise ValueError(f"precision: block indices must be in [0, {depth})")
             self.precision, self.split_blocks = "blocks", blocks
-        if self.precision != "auto":
+        if self.precision not in ("auto", "auto-blocks"):
             self.calibration = None
 
     def precision_report(self):
@@ -251,7 +257,7 @@ class VitExtractor(nn.Module):
         def run(operand_dtype, split_blocks, frames=frames, n=n):
             flags = (VIT_TILED_GEMMS if self.tiled_gemms else 0) | (VIT_BF16 if operand_dtype == "bf16" else 0) | \
                 (VIT_CHECK_RANGE if self.check_range else 0) | (VIT_ATTENTION_V2 if self.attention_v2 else 0) | (VIT_ATTENTION_V4 if self.attention_v4 else 0) | \
-                (VIT_GEMM_WS_V1 if self.gemm_ws_v1 else 0)
+                (VIT_GEMM_WS_V1 if self.gemm_ws_v1 else 0) | (VIT_GEMM_WIDE_V1 if self.gemm_wide_v1 else 0)
             m = VitModel(D, self.cfg["heads"], layer + 1, patch, self.stride, 1e-6, flags,
                          self._sd["patch_embed.proj.weight"].data_ptr(),
                          self._sd["patch_embed.proj.bias"].data_ptr(), cls_pos.data_ptr(), pos.data_ptr(), ms.data_ptr(),
@@ -275,27 +281,38 @@ class VitExtractor(nn.Module):
             # (`ms`, `ws`, the position encoding and the overflow word are members: they outlive the launches)
             return {"tokens": tokens, "feat": feat, "qkv": qkv, "taps": tap_out}[want]
 
-        if self.precision == "auto" and self.calibration is None and layer >= 0:
+        if self.precision in ("auto", "auto-blocks") and self.calibration is None and layer >= 0:
             # measure what the fast operands cost on THIS network and THESE frames: the first frames both ways (a split pass of two
             # 854 x 476 frames is ~15 ms), fast-vs-split relative difference = the fast path's distance from fp32-grade features
             if self._deferred_pending:
-                raise RuntimeError("VitExtractor(precision='auto'): the calibrating call cannot follow un-checked deferred calls")
+                raise RuntimeError(f"VitExtractor(precision={self.precision!r}): the calibrating call cannot follow un-checked deferred calls")
             k = min(n, max(1, self.calibration_frames))
             depth_all = frozenset(range(self.cfg["depth"]))
-            ref = run(self.operand_dtype, depth_all, frames[:k].contiguous(), k)
+            cal = frames[:k].contiguous()
+            ref = run(self.operand_dtype, depth_all, cal, k)
             if self.check_overflow(heal=True):     # even the calibration pass saturated: now on split bf16 / bf16 (sticky)
-                ref = run(self.operand_dtype, depth_all if self.on_overflow == "split-bf16" else self.split_blocks,
-                          frames[:k].contiguous(), k)
+                ref = run(self.operand_dtype, depth_all if self.on_overflow == "split-bf16" else self.split_blocks, cal, k)
                 self.check_overflow()
-            fast = run(self.operand_dtype, frozenset(), frames[:k].contiguous(), k)
-            fast_overflow = int(self._overflow.item()) if self.operand_dtype == "fp16" else 0
-            if fast_overflow:
-                self._overflow.zero_()
-            rel = float(((fast.double() - ref.double()).norm() / ref.double().norm()).item()) if not fast_overflow else float("inf")
+            ref64, ref_norm = ref.double(), ref.double().norm()
+
+            def measure(split_blocks):
+                """relative distance of a pass with `split_blocks` escalated from the all-split pass (inf if it saturates fp16)"""
+                got = run(self.operand_dtype, frozenset(split_blocks), cal, k)
+                ovf = int(self._overflow.item()) if self.operand_dtype == "fp16" else 0
+                if ovf:
+                    self._overflow.zero_()
+                    return float("inf"), True
+                return float(((got.double() - ref64).norm() / ref_norm).item()), False
+
+            rel, fast_overflow = measure(frozenset())
             chosen = "split" if not (rel <= self.auto_tol) else "fast"
             self.calibration = {"frames": k, "layer": layer, "rel_fast_vs_split": rel, "tol": self.auto_tol, "chosen": chosen,
                                 "fast_pass_saturated": bool(fast_overflow)}
-            if chosen == "split" or len(self.split_blocks):   # (a range fallback above already put every block on split operands)
+            if len(self.split_blocks):             # (a range fallback above already put every block on split operands)
+                self.split_blocks = depth_all
+            elif chosen == "split" and self.precision == "auto-blocks":
+                self.split_blocks = self._pick_blocks(measure, layer)
+            elif chosen == "split":
                 self.split_blocks = depth_all
 
         out = run(self.operand_dtype, self.split_blocks)
@@ -305,6 +322,38 @@ class VitExtractor(nn.Module):
             out = run(self.operand_dtype, self.split_blocks)   # the fp16 pass saturated: the same call on (split) bf16 operands (sticky)
             self.check_overflow()                  # (bf16 sets no bits; a non-finite residual update would still raise)
         return out
+
+    def _pick_blocks(self, measure, layer):
+        """precision="auto-blocks" after the all-fast pass measured beyond auto_tol: which blocks stay on single 16-bit operands.
+        e_b = the distance from the all-split features with block b ALONE fast (what b's operand roundings cost at the output,
+        amplification by the later blocks included); roundings of different blocks are independent, so a fast set F is predicted
+        at sqrt(sum e_b^2) -- F grows from the cheapest block while that stays below block_margin * auto_tol, and is then
+        MEASURED as one pass; while the measurement is above the bound the costliest member leaves.  Blocks beyond `layer` do not
+        run and stay un-escalated.  Fills calibration["blocks"]."""
+        used = list(range(layer + 1))
+        bound = self.block_margin * self.auto_tol
+        alone = {}
+        for b in used:
+            alone[b], sat = measure(frozenset(used) - {b})
+        order = sorted(used, key=lambda b: alone[b])
+        fast, acc = [], 0.0
+        for b in order:
+            if not (acc + alone[b] ** 2) ** 0.5 <= bound:
+                break
+            fast.append(b)
+            acc += alone[b] ** 2
+        tried = []
+        while fast:
+            rel, sat = measure(frozenset(used) - frozenset(fast))
+            tried.append({"fast_blocks": sorted(fast), "predicted": sum(alone[b] ** 2 for b in fast) ** 0.5, "measured": rel})
+            if rel <= bound:
+                break
+            fast.pop()                              # the costliest member (fast is in ascending order of e_b)
+        split = frozenset(used) - frozenset(fast)
+        self.calibration.update({"chosen": "blocks" if fast else "split", "blocks": {
+            "bound": bound, "alone": [alone[b] for b in used], "fast_blocks": sorted(fast), "split_blocks": sorted(split),
+            "passes": tried, "measured": tried[-1]["measured"] if fast else 0.0}})
+        return split if fast else frozenset(range(self.cfg["depth"]))
 
     def check_overflow(self, heal: bool = False) -> bool:
         """Reads (one stream synchronisation) and clears the overflow word of the encode() calls since the last check.

@@ -52,6 +52,22 @@ for kk in keys:
     print(f"  {kk:18s}", "  ".join(f"{k} {r[k]['roofline']['kernel_ms'].get(kk, float('nan')):8.3f}" for k in r))
 PY
       ;;
+    wide_ab)   # the 256 x 256 GEMMs with / without the half-step fragment prefetch (DTK_VIT_GEMM_WIDE_V1=1: without), C = 1024 and 768
+      F="--precision fast --steps 2 --warmup 1 --no-train --no-cpu-baseline --no-clock-power --no-live-traffic --no-videos30 --parity-queries 0"
+      for W in 1024 768; do
+        timeout 600 python bench.py --width $W $F > gpurun_out/wide_ab_${W}_new.json 2> gpurun_out/wide_ab.err
+        DTK_VIT_GEMM_WIDE_V1=1 timeout 600 python bench.py --width $W $F > gpurun_out/wide_ab_${W}_v1.json 2>> gpurun_out/wide_ab.err
+      done
+      python - <<'PY'
+import json
+for W in (1024, 768):
+    r = {k: json.load(open(f"gpurun_out/wide_ab_{W}_{k}.json")) for k in ("new", "v1")}
+    print(f"C = {W}: ms per step:", {k: v["ms_per_step"] for k, v in r.items()})
+    keys = sorted(set().union(*[v["roofline"]["kernel_ms"] for v in r.values()]))
+    for kk in keys:
+        print(f"  {kk:18s}", "  ".join(f"{k} {r[k]['roofline']['kernel_ms'].get(kk, float('nan')):9.3f}" for k in r))
+PY
+      ;;
     attn_ab)
       timeout 600 python scripts/attn_ab.py scripts/ubench/libdtk_prev.so dino_tracker_amd/csrc/libdtk.so 2>&1 | tee gpurun_out/attn_ab.log ;;
     profile)

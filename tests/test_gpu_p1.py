@@ -512,3 +512,23 @@ def test_vitl_layer15_full_resolution_and_all_24_blocks():
         r = A.vit_tokens(small[t:t + 1], sd, "dinov2_vitl14").permute(1, 2, 0).reshape(-1, 1024)
         cos, rel = _check(tok[t, 1:], r, rel_max=6e-4)
         print(f"ViT-L 24 blocks, frame {t}: min token cos {cos:.7f}, rel {rel:.2e}")
+
+
+@pytest.mark.parametrize("name,layer", [("dinov2_vitb14", 3), ("dinov2_vitl14", 2)])
+def test_wide_gemm_fragment_prefetch_is_bit_identical(name, layer):
+    """Round 6: gemm_wide_kernel (D = 768 / 1024) reads its fragments one half-step ahead of the MFMAs that consume them and its
+    stages arrive through buffer descriptors; every accumulator still sums its k-steps in the same order, so the features are
+    BIT-identical to the round 4-5 loop (DTK_VIT_GEMM_WIDE_V1), here over a frame whose token count is not a multiple of the 256-row
+    tile (clamped tail rows) and, against the tiled kernel (different tile shape, same k order per accumulator), close (the tiled epilogues differ in their GELU form)."""
+    sd = synth.make_vit_weights(name, seed=9, layerscale=0.1)
+    video = synth.synth_video(2, 154, 238, seed=84)
+    out = {}
+    for form in ("new", "v1", "tiled"):
+        ex = VitExtractor(name, stride=7, device="cuda:0", state_dict=sd)
+        ex.gemm_wide_v1, ex.tiled_gemms = form == "v1", form == "tiled"
+        out[form] = ex.encode(video, layer=layer)
+    assert torch.isfinite(out["new"]).all()
+    assert torch.equal(out["new"], out["v1"])
+    rel = ((out["new"].double() - out["tiled"].double()).norm() / out["tiled"].double().norm()).item()
+    print(f"{name}: wide vs tiled GEMMs rel {rel:.2e}")
+    assert rel < 2e-4

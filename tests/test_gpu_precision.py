@@ -269,3 +269,44 @@ def test_end_to_end_from_the_video_at_vitl_block15():
     assert a["occ_mismatch_same_video_queries_without_a_tie"] == 0, a
     s = a["same_features"]
     assert s["arbitration_failures"] == 0 and s["points_beyond_1e-3px"] <= 4 and a["occ_mismatch_same_features"] <= 0 + 90 * s["points_beyond_1e-3px"], a
+
+
+def test_auto_blocks_escalates_only_what_is_needed_at_vitl():
+    """precision="auto-blocks": where the all-fast pass measures beyond auto_tol (ViT-L block 15: 3.3e-4 against 2.5e-4) the
+    calibration measures every block's lone contribution and keeps on the fast kernels the largest set that MEASURES below
+    block_margin * auto_tol; the rest runs on split operands.  Asserted: some but not all of the 16 blocks are escalated, the
+    features of the whole video are within auto_tol of the float64 oracle, and end to end from the video (854 x 476, T = 16, 256
+    queries, every query) the positions hold the same bar as the all-split pass: p99 <= 1e-3 px, every point beyond 1e-3 px
+    arbitrated in float64, flags identical for the queries without an arbitrated point."""
+    sd = synth.make_vit_weights("dinov2_vitl14", seed=6, layerscale=0.1)
+    video = synth.synth_video(3, 140, 210, seed=83)
+    ref = _ref64(video, sd, "dinov2_vitl14", 15)
+    ex = VitExtractor("dinov2_vitl14", stride=7, device="cuda:0", state_dict=sd, precision="auto-blocks")
+    got = ex.encode(video, layer=15)
+    c = ex.calibration
+    print("auto-blocks, ViT-L block 15:", json.dumps(c))
+    assert c["chosen"] == "blocks" and c["rel_fast_vs_split"] > c["tol"]
+    b = c["blocks"]
+    assert 0 < len(b["fast_blocks"]) < 16 and sorted(b["fast_blocks"] + b["split_blocks"]) == list(range(16))
+    assert b["measured"] <= b["bound"] == 0.8 * c["tol"]
+    assert ex.split_blocks == frozenset(b["split_blocks"]) and ex.precision_report()["feature_error_class"].startswith("mixed")
+    r = _rel(got, ref)
+    print(f"auto-blocks features vs float64: {r:.2e} ({len(b['split_blocks'])} of 16 blocks split)")
+    assert r <= c["tol"]
+    ex.encode(video[:1], layer=15)
+    assert ex.calibration is c                           # calibrated once
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import e2e_error
+    r = e2e_error.run(476, 854, 16, 16, oracle_device="cuda", precision="auto-blocks", model="dinov2_vitl14")
+    a = {k: r[k] for k in ("feature_rel_err_P1", "px_err_vs_oracle_on_same_video", "points_beyond_1e-3px", "arbitration_failures",
+                           "arbitrated_rate", "occ_mismatch_same_video", "occ_mismatch_same_video_queries_without_a_tie",
+                           "encode_seconds", "precision_report")}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "e2e_error_vitl_auto_blocks_476x854x16.json"), "w") as fh:
+        json.dump(a, fh, indent=1)
+    print("end to end at ViT-L block 15, auto-blocks:", json.dumps(a))
+    assert a["precision_report"]["calibration"]["chosen"] == "blocks"
+    assert a["feature_rel_err_P1"] <= 2.5e-4, a
+    assert a["px_err_vs_oracle_on_same_video"]["p99"] <= 1e-3, a
+    assert a["arbitration_failures"] == 0, a
+    assert a["occ_mismatch_same_video_queries_without_a_tie"] == 0, a

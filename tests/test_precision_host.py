@@ -56,6 +56,8 @@ def test_precision_argument_and_report():
     assert ex.precision_report()["feature_error_class"].startswith("mixed")
     ex.set_precision("auto")
     assert ex.calibration is None and not ex.split_blocks
+    ex.set_precision("auto-blocks")
+    assert ex.precision == "auto-blocks" and ex.calibration is None and not ex.split_blocks
     for bad in ("strict", [12], [-1]):
         with pytest.raises(ValueError):
             ex.set_precision(bad)
@@ -70,3 +72,36 @@ def test_precision_from_the_environment(monkeypatch):
     monkeypatch.setenv("DTK_VIT_PRECISION", "split")
     assert len(VitExtractor("dinov2_vits14", stride=7, device="cpu", state_dict=sd).split_blocks) == 12
     assert not VitExtractor("dinov2_vits14", stride=7, device="cpu", state_dict=sd, precision="fast").split_blocks
+
+
+def test_auto_blocks_selection_logic():
+    """precision="auto-blocks" (extractor._pick_blocks) on a synthetic error model: block b alone fast costs e_b, a fast set costs
+    amp * sqrt(sum e_b^2).  The cheapest blocks stay fast while the quadrature sum fits block_margin * auto_tol; a measurement above
+    the bound (amp > 1) evicts the costliest member; a block whose lone pass saturates (inf) is always escalated; blocks beyond
+    `layer` are not touched."""
+    sd = synth.make_vit_weights("dinov2_vits14", seed=2, layerscale=0.1)
+    e = [3e-4, 0.5e-4, 0.6e-4, float("inf"), 0.7e-4, 1.0e-4, 1.2e-4, 0.4e-4]     # blocks 0..7; layer = 7
+
+    def model(amp, calls):
+        def measure(split_blocks):
+            fast = [b for b in range(8) if b not in split_blocks]
+            calls.append(tuple(fast))
+            v = (amp if len(fast) > 1 else 1.0) * sum(e[b] ** 2 for b in fast) ** 0.5
+            return v, v == float("inf")
+        return measure
+
+    ex = VitExtractor("dinov2_vits14", stride=7, device="cpu", state_dict=sd, precision="auto-blocks", auto_tol=2.5e-4, block_margin=0.8)
+    ex.calibration, calls = {}, []
+    split = ex._pick_blocks(model(1.0, calls), layer=7)
+    # ascending: 7 (0.4), 1 (0.5), 2 (0.6), 4 (0.7), 5 (1.0), 6 (1.2): sqrt(.16+.25+.36+.49+1.0) = 1.503e-4 <= 2e-4; + 1.44 -> 1.92e-4 <= 2e-4; + block 0 no
+    assert split == frozenset({0, 3}), split
+    c = ex.calibration
+    assert c["chosen"] == "blocks" and c["blocks"]["fast_blocks"] == [1, 2, 4, 5, 6, 7] and abs(c["blocks"]["measured"] - 1.924e-4) < 1e-6
+    assert calls[:8] == [(b,) for b in range(8)] and len(calls) == 9
+    ex.calibration, calls = {}, []
+    split = ex._pick_blocks(model(1.2, calls), layer=7)                                  # sets measure 1.2 x the quadrature sum: 2.31e-4 -> block 6 leaves -> 1.80e-4
+    assert split == frozenset({0, 3, 6}) and len(ex.calibration["blocks"]["passes"]) == 2, (split, ex.calibration)
+    ex.calibration = {}
+    assert ex._pick_blocks(model(100.0, []), layer=7) == frozenset(range(7)) and ex.calibration["blocks"]["fast_blocks"] == [7]
+    ex.calibration = {}
+    assert ex._pick_blocks(lambda split_blocks: (1e-3, False), layer=7) == frozenset(range(12)) and ex.calibration["chosen"] == "split"
