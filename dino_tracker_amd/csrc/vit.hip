@@ -597,7 +597,7 @@ __device__ __forceinline__ void gemm_store_tile_t(const f4& a, long long m, int 
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= sc;
         if (IsF16<T>::value) amax = amax2(amax2(amax, v[0], v[1]), v[2], v[3]);
-        if (m >= M) return;
+        if (m >= M || DTK_DBG(e.no_store, 4)) return;
         const int f = (int)(m / e.S), sp = (int)(m - (long long)f * e.S);
         if (which == 2) {
             T* vp = e.vt + (((size_t)f * e.heads + head) * 64 + dh) * e.Sp + sp;
@@ -609,18 +609,31 @@ __device__ __forceinline__ void gemm_store_tile_t(const f4& a, long long m, int 
         }
     } else if (EPI == EPI_GELU) {
         if (IsF16<T>::value) amax = fmaxf(fmaxf(fmaxf(amax, v[0]), fmaxf(v[1], v[2])), v[3]);   // GELU(v) = v where it is large: the positive part
-        if (m >= M) return;
+        if (m >= M || DTK_DBG(e.no_store, 4)) return;
         // (the packed polynomial GELU of the weight-stationary kernels: |error| < 6e-5, below the 16-bit rounding of the result;
         //  libm's erff costs ~10 x the instructions, and this epilogue runs for 4096 features of every token in fc1)
         const f2 g0 = gelu2(f2{v[0], v[1]}), g1 = gelu2(f2{v[2], v[3]});
         *reinterpret_cast<T4*>(e.out + m * N + nb) = T4{(T)g0[0], (T)g0[1], (T)g1[0], (T)g1[1]};
     } else {   // EPI_DELTA
-        if (m >= M) return;
+        if (m >= M || DTK_DBG(e.no_store, 4)) return;
         const float4 g4 = *reinterpret_cast<const float4*>(e.gamma + nb);
         *reinterpret_cast<T4*>(e.delta + m * N + nb) = T4{(T)(g4.x * v[0]), (T)(g4.y * v[1]), (T)(g4.z * v[2]), (T)(g4.w * v[3])};
     }
 }
 
+
+// The same tile as a VALUE (EPI_GELU / EPI_DELTA; round 6: gemm_wide_kernel stages its output tile in LDS and writes whole rows)
+template <typename T, int EPI>
+__device__ __forceinline__ typename Vec<T>::t4 gemm_value_tile_t(const f4& a, const float4& b4, const float4& g4, float& amax) {
+    typedef typename Vec<T>::t4 T4;
+    const float v[4] = {a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w};
+    if (EPI == EPI_GELU) {
+        if (IsF16<T>::value) amax = fmaxf(fmaxf(fmaxf(amax, v[0]), fmaxf(v[1], v[2])), v[3]);
+        const f2 g0 = gelu2(f2{v[0], v[1]}), g1 = gelu2(f2{v[2], v[3]});
+        return T4{(T)g0[0], (T)g0[1], (T)g1[0], (T)g1[1]};
+    }
+    return T4{(T)(g4.x * v[0]), (T)(g4.y * v[1]), (T)(g4.z * v[2]), (T)(g4.w * v[3])};
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // wide-tile GEMM for N = 384 and long K (fc2 of ViT-S: K = 1536):  C[M][384] = A[M][K] . Wt[384][K]^T, EPI_DELTA epilogue
@@ -738,6 +751,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_delta_kernel(const T* __rest
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int W2_M = 256, W2_N = 256, W2_STAGES = 4, W2_STAGE_BYTES = (W2_M + W2_N) * 64;
 constexpr int W2_REQ = (W2_M + W2_N) / 16 / 8;  // 4 DMA requests per wave and stage
+constexpr int W2_OPITCH = W2_N * 2 + 8;          // staged output rows: 512 B + 8 (the 8-byte writes of 16 tokens fall on 16 different bank pairs)
+constexpr int W2_LDS_BYTES = W2_STAGES * W2_STAGE_BYTES > W2_M * W2_OPITCH ? W2_STAGES * W2_STAGE_BYTES : W2_M * W2_OPITCH;
 
 inline unsigned gemm_wide_grid(int N, long long rows) {
     const long long ncol = N / W2_N, nrow = dtk_cdiv(rows, W2_M);
@@ -751,7 +766,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const T* __restrict__
     typedef typename Vec<T>::t4 T4;
     (void)sizeof(T8); (void)sizeof(T4);
     operand_mode<T>();
-    __shared__ __attribute__((aligned(1024))) unsigned char stages[W2_STAGES * W2_STAGE_BYTES];
+    __shared__ __attribute__((aligned(1024))) unsigned char stages[W2_LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ncol = N / W2_N;
@@ -776,9 +791,9 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const T* __restrict__
         voff[i] = (unsigned)(trow * K + piece * 8) * 2u;
     }
     const unsigned lds0 = (unsigned)(size_t)&stages[0] + (unsigned)w * (W2_REQ * 1024);
-    const int nk = K / GK;
+    const int nk = DTK_DBG(e.no_store, 8) ? 0 : K / GK;
     auto issue = [&](int ks, int buf) {
-        const int kk = min(ks, nk - 1);
+        const int kk = DTK_DBG(e.no_store, 16 | 8) ? 0 : min(ks, nk - 1);
         wd_issue<W2_REQ>(srd, voff, (unsigned)kk * (GK * 2), __builtin_amdgcn_readfirstlane(lds0 + buf * W2_STAGE_BYTES));
     };
     f4 acc[8][4];
@@ -872,12 +887,73 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const T* __restrict__
     ws_wait<0>();
     // D tiles are TRANSPOSED (the MFMAs above multiply (W tile) x (token tile)^T): lane (fg, fj) holds features 4 fg + r of token fj
     float amax = 0.f;
+    if (PIPE && EPI != EPI_QKV) {
+        // Round 6: the [M][N] epilogues leave through LDS.  A store instruction of the direct form below covers 16 tokens x 32 bytes --
+        // sixteen quarter lines; with everything but the epilogue switched off (DTK_DEV ablation) the stores of fc1 at D = 1024 ran at
+        // 1.5 TB/s and cost a third of the kernel, because a CU holds ONE workgroup of this kernel (128 KB of stages) and nothing
+        // overlaps its epilogue.  The stages are dead here: the 256 x 256 tile is staged as 16-bit values (row pitch 520 B) and leaves
+        // as whole 512-byte rows, 16 bytes per lane, two rows per wave and instruction.
+        __syncthreads();   // every wave's requests have landed (the wait above) and every wave is done with the stages
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int nb = n0 + wc * 64 + ni * 16 + fg * 4;
+        for (int ni = 0; ni < 4; ++ni) {
+            const int cb = wc * 64 + ni * 16 + fg * 4;
+            const float4 b4 = e.bias ? *reinterpret_cast<const float4*>(e.bias + n0 + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 g4 = EPI == EPI_DELTA ? *reinterpret_cast<const float4*>(e.gamma + n0 + cb) : make_float4(1.f, 1.f, 1.f, 1.f);
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
-            gemm_store_tile_t<T, EPI>(acc[mi][ni], m0 + wr * 128 + mi * 16 + fj, nb, M, N, e, amax);
+            for (int mi = 0; mi < 8; ++mi)
+                *reinterpret_cast<T4*>(stages + (wr * 128 + mi * 16 + fj) * W2_OPITCH + cb * 2) =
+                    gemm_value_tile_t<T, EPI>(acc[mi][ni], b4, g4, amax);
+        }
+        __syncthreads();
+        T* const outp = (EPI == EPI_GELU ? e.out : e.delta) + n0 + (tid & 31) * 8;
+#pragma unroll 4
+        for (int it = 0; it < W2_M / 16; ++it) {
+            const int row = it * 16 + (tid >> 5);
+            const unsigned char* sp = stages + row * W2_OPITCH + (tid & 31) * 16;
+            const uint2 lo = *reinterpret_cast<const uint2*>(sp), hi = *reinterpret_cast<const uint2*>(sp + 8);
+            if (m0 + row < M && !DTK_DBG(e.no_store, 4)) *reinterpret_cast<uint4*>(outp + (m0 + row) * N) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+    } else if (PIPE && EPI == EPI_QKV && n0 < 2 * e.D) {
+        // Q and K tiles the same way (a 256-feature tile is four heads of ONE of q / k / v: D is a multiple of 256 on this path): a
+        // token's 64 features of a head are 128 contiguous bytes of q / k [frame][head][position][64].  V^T (tokens contiguous, one
+        // row per feature) keeps the direct form below.
+        __syncthreads();
+        const int which = n0 / e.D, head0 = (n0 - which * e.D) >> 6;
+        const float sc = which == 0 ? e.qscale : 1.f;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int cb = wc * 64 + ni * 16 + fg * 4;
+            const float4 b4 = e.bias ? *reinterpret_cast<const float4*>(e.bias + n0 + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const f4& a = acc[mi][ni];
+                const float v0 = (a[0] + b4.x) * sc, v1 = (a[1] + b4.y) * sc, v2 = (a[2] + b4.z) * sc, v3 = (a[3] + b4.w) * sc;
+                if (IsF16<T>::value) amax = amax2(amax2(amax, v0, v1), v2, v3);
+                *reinterpret_cast<T4*>(stages + (wr * 128 + mi * 16 + fj) * W2_OPITCH + cb * 2) = T4{(T)v0, (T)v1, (T)v2, (T)v3};
+            }
+        }
+        __syncthreads();
+        T* const qk = (which == 0 ? e.q : e.k) + (tid & 7) * 8;
+        const int hh = head0 + ((tid & 31) >> 3);
+#pragma unroll 4
+        for (int it = 0; it < W2_M / 16; ++it) {
+            const int row = it * 16 + (tid >> 5);
+            const unsigned char* sp = stages + row * W2_OPITCH + (tid & 31) * 16;
+            const uint2 lo = *reinterpret_cast<const uint2*>(sp), hi = *reinterpret_cast<const uint2*>(sp + 8);
+            const long long m = m0 + row;
+            if (m < M && !DTK_DBG(e.no_store, 4)) {
+                const unsigned f = (unsigned)m / (unsigned)e.S, pos = (unsigned)m - f * (unsigned)e.S;   // (M < 2^31 tokens)
+                *reinterpret_cast<uint4*>(qk + (((size_t)f * e.heads + hh) * e.Sp + pos) * 64) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int nb = n0 + wc * 64 + ni * 16 + fg * 4;
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+                gemm_store_tile_t<T, EPI>(acc[mi][ni], m0 + wr * 128 + mi * 16 + fj, nb, M, N, e, amax);
+        }
     }
     amax_report<T, EPI>(amax, e.ovf);
 }
@@ -1412,7 +1488,9 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
             DTK_LAUNCH(NAME, (gemm_wide_kernel<T, EPI_, true>), dim3(gemm_wide_grid(N_, rows)), dim3(512), 0, st, __VA_ARGS__);  \
         }                                                                                                                      \
     } while (0)
-        const int dbg_ns = DTK_DBG(dtk_dev_flags() >> 16, 3);  // DTK_DEV: skip the weight-stationary kernel's stores
+        // DTK_DEV: bits 0-1 skip the weight-stationary kernel's stores; gemm_wide_kernel: 4 no stores, 8 no main loop (pipeline fill +
+        // epilogue only), 16 every stage from k = 0 (cache-hot operands)
+        const int dbg_ns = DTK_DBG(dtk_dev_flags() >> 16, 0x7f);
         auto ws_grid = [&](int N) {  // one resident round: one workgroup per CU
             const int colwg = dtk_cdiv(N, WS_COLS);
             const int chunks = 256 / colwg > 0 ? 256 / colwg : 1;
@@ -1568,7 +1646,7 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
             }
             if (scan_all && scan_range(hid, rows * 4 * D, 4)) return DTK_E_HIP;
             e = GemmEpi<T>{};
-            e.bias = L.fc2_b; e.delta = delta; e.gamma = L.ls2;
+            e.bias = L.fc2_b; e.delta = delta; e.gamma = L.ls2; e.no_store = dbg_ns;
             if (ws_ok && D == WD_N) {  // (ws_ok: the fast-path GEMMs are on, dtk_vit_model.flags)
                 DTK_LAUNCH("vit_gemm_fc2", gemm_wide_delta_kernel<T>, dim3(dtk_cdiv(rows, WD_M)), dim3(512), 0, st, hid, fc2_w,
                            rows, 4 * D, e);

@@ -68,6 +68,22 @@ for W in (1024, 768):
         print(f"  {kk:18s}", "  ".join(f"{k} {r[k]['roofline']['kernel_ms'].get(kk, float('nan')):9.3f}" for k in r))
 PY
       ;;
+    wide_time)   # encoder kernels alone, ViT-L and ViT-B, this tree's wide GEMMs vs their round-5 form (same box)
+      : > gpurun_out/wide_time.jsonl
+      for M in dinov2_vitl14 dinov2_vitb14; do
+        timeout 300 python scripts/dev/wide_abl.py $M 30 >> gpurun_out/wide_time.jsonl 2>> gpurun_out/wide_time.err
+        DTK_VIT_GEMM_WIDE_V1=1 timeout 300 python scripts/dev/wide_abl.py $M 30 >> gpurun_out/wide_time.jsonl 2>> gpurun_out/wide_time.err
+      done
+      cat gpurun_out/wide_time.jsonl ;;
+    wide_abl)   # DTK_DEV ablations of gemm_wide_kernel (scripts/ubench/libdtk_dev.so = a `make DEV=1` build): where a 256 x 256 tile's time goes
+      L=dino_tracker_amd/csrc/libdtk.so
+      cp $L /tmp/libdtk_keep.so && cp scripts/ubench/libdtk_dev.so $L
+      : > gpurun_out/wide_abl.jsonl
+      for D in 0 262144 524288 1048576 1310720; do
+        DTK_DEBUG=$D timeout 300 python scripts/dev/wide_abl.py dinov2_vitl14 30 >> gpurun_out/wide_abl.jsonl 2>> gpurun_out/wide_abl.err
+      done
+      cp /tmp/libdtk_keep.so $L
+      cat gpurun_out/wide_abl.jsonl ;;
     attn_ab)
       timeout 600 python scripts/attn_ab.py scripts/ubench/libdtk_prev.so dino_tracker_amd/csrc/libdtk.so 2>&1 | tee gpurun_out/attn_ab.log ;;
     profile)
