@@ -653,7 +653,9 @@ constexpr int WD_M = 256, WD_N = 384, WD_STAGES = 3;
 constexpr int WD_A_BYTES = WD_M * 64, WD_B_BYTES = WD_N * 64, WD_STAGE_BYTES = WD_A_BYTES + WD_B_BYTES;
 constexpr int WD_REQ = (WD_M + WD_N) / 16 / 8;  // DMA requests per wave and stage (16 rows of 64 B each): 5
 
-template <typename T>
+constexpr int WD_OPITCH = WD_N * 2 + 8;   // staged output rows (round 6): 768 B + 8
+
+template <typename T, bool STAGED = true>
 __global__ __launch_bounds__(512, 2) void gemm_wide_delta_kernel(const T* __restrict__ A, const T* __restrict__ Wt,
                                                                  long long M, int K, GemmEpi<T> e) {
     typedef typename Vec<T>::t8 T8;
@@ -727,6 +729,40 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_delta_kernel(const T* __rest
     // D tiles are TRANSPOSED (round 5): lane (fg, fj) holds features 4 fg + r (r = 0..3) of token fj of each 16 x 16 tile -- four
     // consecutive features of one token: ONE 8-byte store per tile and lane (48 per lane and 256 x 384 tile) where the
     // token-major form needed four 2-byte stores (192)
+    if (STAGED) {
+        // Round 6: through LDS (see gemm_wide_kernel's epilogue: a CU holds one workgroup of this kernel, nothing overlaps the epilogue,
+        // and its 8-byte stores -- 16 tokens x 32 B per instruction -- ran at 1.5 TB/s).  The 256 x 384 tile is 192 KB of 16-bit values:
+        // two passes of 128 rows (the waves of row half p stage, everybody writes out: the 128 rows are 96 KB of CONTIGUOUS memory).
+        static_assert(128 * WD_OPITCH <= WD_STAGES * WD_STAGE_BYTES, "staged half tile must fit the stages");
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            __syncthreads();   // p = 0: every wave's requests have landed and the stages are dead; p = 1: pass 0 has been read out
+            if (wr == p) {
+#pragma unroll
+                for (int ni = 0; ni < 6; ++ni) {
+                    const int nb = wc * 96 + ni * 16 + fg * 4;
+                    const float4 b4 = e.bias ? *reinterpret_cast<const float4*>(e.bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 g4 = *reinterpret_cast<const float4*>(e.gamma + nb);
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi) {
+                        const f4& a = acc[mi][ni];
+                        *reinterpret_cast<T4*>(stages + (mi * 16 + fj) * WD_OPITCH + nb * 2) =
+                            T4{(T)(g4.x * (a[0] + b4.x)), (T)(g4.y * (a[1] + b4.y)), (T)(g4.z * (a[2] + b4.z)), (T)(g4.w * (a[3] + b4.w))};
+                    }
+                }
+            }
+            __syncthreads();
+            const long long mb = m0 + p * 128;
+#pragma unroll 4
+            for (int it = 0; it < 128 * (WD_N / 8) / 512; ++it) {   // 6144 16-byte pieces, 12 per thread
+                const int idx = it * 512 + tid, row = idx / (WD_N / 8), piece = idx - row * (WD_N / 8);
+                const unsigned char* sp = stages + row * WD_OPITCH + piece * 16;
+                const uint2 lo = *reinterpret_cast<const uint2*>(sp), hi = *reinterpret_cast<const uint2*>(sp + 8);
+                if (mb + row < M) *reinterpret_cast<uint4*>(e.delta + (mb + row) * WD_N + piece * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int ni = 0; ni < 6; ++ni) {
         const int nb = wc * 96 + ni * 16 + fg * 4;
@@ -1648,8 +1684,13 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
             e = GemmEpi<T>{};
             e.bias = L.fc2_b; e.delta = delta; e.gamma = L.ls2; e.no_store = dbg_ns;
             if (ws_ok && D == WD_N) {  // (ws_ok: the fast-path GEMMs are on, dtk_vit_model.flags)
-                DTK_LAUNCH("vit_gemm_fc2", gemm_wide_delta_kernel<T>, dim3(dtk_cdiv(rows, WD_M)), dim3(512), 0, st, hid, fc2_w,
-                           rows, 4 * D, e);
+                if (wide_v1) {
+                    DTK_LAUNCH("vit_gemm_fc2", (gemm_wide_delta_kernel<T, false>), dim3(dtk_cdiv(rows, WD_M)), dim3(512), 0, st, hid, fc2_w,
+                               rows, 4 * D, e);
+                } else {
+                    DTK_LAUNCH("vit_gemm_fc2", (gemm_wide_delta_kernel<T, true>), dim3(dtk_cdiv(rows, WD_M)), dim3(512), 0, st, hid, fc2_w,
+                               rows, 4 * D, e);
+                }
             } else if (wide_ok) {
                 DTK_WIDE("vit_gemm_fc2", EPI_DELTA, D, hid, fc2_w, rows, D, 4 * D, e);
             } else {

@@ -17,7 +17,7 @@ frames = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 sd = synth.make_vit_weights(name, seed=6, layerscale=0.1)
 ex = VitExtractor(name, stride=7, device="cuda:0", state_dict=sd, on_overflow="raise")
 video = synth.synth_video(frames, 476, 854, seed=82).cuda()
-layer = {"dinov2_vitl14": 15, "dinov2_vitb14": 11}[name]
+layer = {"dinov2_vitl14": 15, "dinov2_vitb14": 11, "dinov2_vits14": 11}[name]
 try:
     ex.encode(video, layer=layer)
 except RuntimeError as err:    # (an ablated pass may leave the fp16 range: the timing is what counts)

@@ -70,7 +70,7 @@ PY
       ;;
     wide_time)   # encoder kernels alone, ViT-L and ViT-B, this tree's wide GEMMs vs their round-5 form (same box)
       : > gpurun_out/wide_time.jsonl
-      for M in dinov2_vitl14 dinov2_vitb14; do
+      for M in ${WIDE_MODELS:-dinov2_vitl14 dinov2_vitb14}; do
         timeout 300 python scripts/dev/wide_abl.py $M 30 >> gpurun_out/wide_time.jsonl 2>> gpurun_out/wide_time.err
         DTK_VIT_GEMM_WIDE_V1=1 timeout 300 python scripts/dev/wide_abl.py $M 30 >> gpurun_out/wide_time.jsonl 2>> gpurun_out/wide_time.err
       done

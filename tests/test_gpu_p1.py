@@ -514,7 +514,7 @@ def test_vitl_layer15_full_resolution_and_all_24_blocks():
         print(f"ViT-L 24 blocks, frame {t}: min token cos {cos:.7f}, rel {rel:.2e}")
 
 
-@pytest.mark.parametrize("name,layer", [("dinov2_vitb14", 3), ("dinov2_vitl14", 2)])
+@pytest.mark.parametrize("name,layer", [("dinov2_vits14", 2), ("dinov2_vitb14", 3), ("dinov2_vitl14", 2)])
 def test_wide_gemm_fragment_prefetch_is_bit_identical(name, layer):
     """Round 6: gemm_wide_kernel (D = 768 / 1024) reads its fragments one half-step ahead of the MFMAs that consume them and its
     stages arrive through buffer descriptors; every accumulator still sums its k-steps in the same order, so the features are
