@@ -1516,6 +1516,14 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
         const bool ws_ok = D == WS_K && !(m->flags & DTK_VIT_TILED_GEMMS);
         const bool ws_v1 = (m->flags & DTK_VIT_GEMM_WS_V1) != 0;
         const bool wide_v1 = (m->flags & DTK_VIT_GEMM_WIDE_V1) != 0;   // the 256 x 256 GEMMs without the half-step fragment prefetch (A / B)
+#define DTK_SPLIT_DMA(NAME, EPI_, N_, ...)                                                                                            \
+    do {                                                                                                                              \
+        if (wide_v1) {                                                                                                                \
+            DTK_LAUNCH(NAME, (gemm_split_dma_kernel<T, EPI_, false>), dim3(gemm_split_dma_grid(N_, rows)), dim3(512), 0, st, __VA_ARGS__); \
+        } else {                                                                                                                      \
+            DTK_LAUNCH(NAME, (gemm_split_dma_kernel<T, EPI_, true>), dim3(gemm_split_dma_grid(N_, rows)), dim3(512), 0, st, __VA_ARGS__);  \
+        }                                                                                                                             \
+    } while (0)
 #define DTK_WIDE(NAME, EPI_, N_, ...)                                                                                          \
     do {                                                                                                                       \
         if (wide_v1) {                                                                                                         \
@@ -1567,7 +1575,7 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                 if (qkv_out && l == m->depth - 1) {
                     se.bias = L.qkv_b; se.inv_wscale = inv_ws; se.out_f32 = qkv_out + (size_t)f0 * S * 3 * D;
                     if (split_dma && (3 * D) % SD_N == 0) {
-                    DTK_LAUNCH("vit_gemm_qkv_facet", (gemm_split_dma_kernel<T, SEPI_F32>), dim3(gemm_split_dma_grid(3 * D, rows)), dim3(512), 0, st, xn, xn_lo, qkv_w, qkv_wl, rows, 3 * D, D, se);
+                    DTK_SPLIT_DMA("vit_gemm_qkv_facet", SEPI_F32, 3 * D, xn, xn_lo, qkv_w, qkv_wl, rows, 3 * D, D, se);
                 } else {
                     DTK_LAUNCH("vit_gemm_qkv_facet", (gemm_split_kernel<T, SEPI_F32>), dim3(gemm_split_grid(3 * D, rows)), dim3(256), 0, st, xn, xn_lo, qkv_w, qkv_wl, rows, 3 * D, D, se);
                 }
@@ -1577,7 +1585,7 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                 se.vt_lo = vt_lo; se.S = S; se.Sp = Sp; se.heads = m->heads; se.D = D; se.qscale = 0.125f * 1.4426950408889634f;
                 se.ovf = epi_ovf;
                 if (split_dma && (3 * D) % SD_N == 0) {
-                    DTK_LAUNCH("vit_gemm_qkv_split", (gemm_split_dma_kernel<T, SEPI_QKV>), dim3(gemm_split_dma_grid(3 * D, rows)), dim3(512), 0, st, xn, xn_lo, qkv_w, qkv_wl, rows, 3 * D, D, se);
+                    DTK_SPLIT_DMA("vit_gemm_qkv_split", SEPI_QKV, 3 * D, xn, xn_lo, qkv_w, qkv_wl, rows, 3 * D, D, se);
                 } else {
                     DTK_LAUNCH("vit_gemm_qkv_split", (gemm_split_kernel<T, SEPI_QKV>), dim3(gemm_split_grid(3 * D, rows)), dim3(256), 0, st, xn, xn_lo, qkv_w, qkv_wl, rows, 3 * D, D, se);
                 }
@@ -1590,7 +1598,7 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                 se = SplitEpi<T>{};
                 se.bias = L.proj_b; se.inv_wscale = inv_ws; se.x = x; se.gamma = L.ls1;
                 if (split_dma && (D) % SD_N == 0) {
-                    DTK_LAUNCH("vit_gemm_proj_split", (gemm_split_dma_kernel<T, SEPI_RESID>), dim3(gemm_split_dma_grid(D, rows)), dim3(512), 0, st, (const T*)ao, (const T*)ao_lo, proj_w, proj_wl, rows, D, D, se);
+                    DTK_SPLIT_DMA("vit_gemm_proj_split", SEPI_RESID, D, (const T*)ao, (const T*)ao_lo, proj_w, proj_wl, rows, D, D, se);
                 } else {
                     DTK_LAUNCH("vit_gemm_proj_split", (gemm_split_kernel<T, SEPI_RESID>), dim3(gemm_split_grid(D, rows)), dim3(256), 0, st, (const T*)ao, (const T*)ao_lo, proj_w, proj_wl, rows, D, D, se);
                 }
@@ -1599,14 +1607,14 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                 se = SplitEpi<T>{};
                 se.bias = L.fc1_b; se.inv_wscale = inv_ws; se.out_hi = hid; se.out_lo = hid_lo; se.ovf = epi_ovf;
                 if (split_dma && (4 * D) % SD_N == 0) {
-                    DTK_LAUNCH("vit_gemm_fc1_split", (gemm_split_dma_kernel<T, SEPI_GELU>), dim3(gemm_split_dma_grid(4 * D, rows)), dim3(512), 0, st, (const T*)xn, (const T*)xn_lo, fc1_w, fc1_wl, rows, 4 * D, D, se);
+                    DTK_SPLIT_DMA("vit_gemm_fc1_split", SEPI_GELU, 4 * D, (const T*)xn, (const T*)xn_lo, fc1_w, fc1_wl, rows, 4 * D, D, se);
                 } else {
                     DTK_LAUNCH("vit_gemm_fc1_split", (gemm_split_kernel<T, SEPI_GELU>), dim3(gemm_split_grid(4 * D, rows)), dim3(256), 0, st, (const T*)xn, (const T*)xn_lo, fc1_w, fc1_wl, rows, 4 * D, D, se);
                 }
                 se = SplitEpi<T>{};
                 se.bias = L.fc2_b; se.inv_wscale = inv_ws; se.x = x; se.gamma = L.ls2;
                 if (split_dma && (D) % SD_N == 0) {
-                    DTK_LAUNCH("vit_gemm_fc2_split", (gemm_split_dma_kernel<T, SEPI_RESID>), dim3(gemm_split_dma_grid(D, rows)), dim3(512), 0, st, (const T*)hid, (const T*)hid_lo, fc2_w, fc2_wl, rows, D, 4 * D, se);
+                    DTK_SPLIT_DMA("vit_gemm_fc2_split", SEPI_RESID, D, (const T*)hid, (const T*)hid_lo, fc2_w, fc2_wl, rows, D, 4 * D, se);
                 } else {
                     DTK_LAUNCH("vit_gemm_fc2_split", (gemm_split_kernel<T, SEPI_RESID>), dim3(gemm_split_grid(D, rows)), dim3(256), 0, st, (const T*)hid, (const T*)hid_lo, fc2_w, fc2_wl, rows, D, 4 * D, se);
                 }

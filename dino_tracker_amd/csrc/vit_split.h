@@ -293,7 +293,10 @@ constexpr int SD_M = 256, SD_N = 128, SD_STAGES = 3;
 constexpr int SD_STAGE_BYTES = (2 * SD_M + 2 * SD_N) * 64;   // 49152
 constexpr int SD_REQ = (2 * SD_M + 2 * SD_N) / 16 / 8;       // DMA requests per wave and stage: 6
 
-template <typename T, int EPI>
+constexpr int SD_OPITCH = SD_N * 2 + 8;     // staged 16-bit output rows (hi and lo plane): 256 B + 8
+constexpr int SD_FPITCH = SD_N * 4 + 16;    // staged fp32 update rows: 512 B + 16 (the 16-byte writes of 8 tokens cover the 32 banks)
+
+template <typename T, int EPI, bool STAGED = true>
 __global__ __launch_bounds__(512, 1) void gemm_split_dma_kernel(const T* __restrict__ Ah, const T* __restrict__ Al,
                                                                 const T* __restrict__ Wh, const T* __restrict__ Wl, long long M, int N,
                                                                 int K, SplitEpi<T> e) {
@@ -372,12 +375,95 @@ __global__ __launch_bounds__(512, 1) void gemm_split_dma_kernel(const T* __restr
     }
     ws_wait<0>();
     float amax = 0.f;
+    typedef typename Vec<T>::t4 T4;
+    // Round 6: the epilogues leave through LDS as whole rows (vit.hip, gemm_wide_kernel: one workgroup per CU, nothing overlaps the
+    // epilogue, and its 8-byte pieces -- 16 tokens x 32 B per store instruction -- ran at 1.5 TB/s).  The stages are dead here.
+    static_assert(2 * SD_M * SD_OPITCH <= SD_STAGES * SD_STAGE_BYTES && SD_M * SD_FPITCH <= SD_STAGES * SD_STAGE_BYTES, "staged tile must fit");
+    if (STAGED && (EPI == SEPI_GELU || (EPI == SEPI_QKV && n0 < 2 * e.D))) {
+        // hi and lo planes of the 256 x 128 tile, 16-bit, then 256-byte rows of each plane: 16 lanes per row and plane
+        __syncthreads();
+        const int which = EPI == SEPI_QKV ? n0 / e.D : 0;
+        const float sc = (EPI == SEPI_QKV && which == 0) ? e.qscale : 1.f;
+        unsigned char* const lo_plane = stages + SD_M * SD_OPITCH;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int nb = n0 + wc * 64 + ni * 16 + fg * 4;
+        for (int ni = 0; ni < 4; ++ni) {
+            const int cb = wc * 64 + ni * 16 + fg * 4;
+            const float4 b4 = e.bias ? *reinterpret_cast<const float4*>(e.bias + n0 + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-            split_store_tile<T, EPI>(acc[mi][ni], m0 + wr * 64 + mi * 16 + fj, nb, M, N, e, amax);
+            for (int mi = 0; mi < 4; ++mi) {
+                const f4& a = acc[mi][ni];
+                float v[4] = {a[0] * e.inv_wscale + b4.x, a[1] * e.inv_wscale + b4.y, a[2] * e.inv_wscale + b4.z, a[3] * e.inv_wscale + b4.w};
+                T4 h, l;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float g = EPI == SEPI_GELU ? gelu_erfc(v[r]) : v[r] * sc;
+                    if (IsF16<T>::value) amax = fmaxf(amax, fabsf(g));
+                    T x0, x1;
+                    split2<T>(g, x0, x1);
+                    h[r] = x0; l[r] = x1;
+                }
+                const int off = (wr * 64 + mi * 16 + fj) * SD_OPITCH + cb * 2;
+                *reinterpret_cast<T4*>(stages + off) = h;
+                *reinterpret_cast<T4*>(lo_plane + off) = l;
+            }
+        }
+        __syncthreads();
+        const int plane = (tid >> 4) & 1, piece = tid & 15;
+        T* dst;
+        if (EPI == SEPI_GELU) dst = (plane ? e.out_lo : e.out_hi) + n0 + piece * 8;
+        else dst = (which == 0 ? (plane ? e.q_lo : e.q_hi) : (plane ? e.k_lo : e.k_hi)) + (piece & 7) * 8;
+        const int hh = EPI == SEPI_QKV ? ((n0 - which * e.D) >> 6) + (piece >> 3) : 0;
+#pragma unroll 4
+        for (int it = 0; it < SD_M / 16; ++it) {
+            const int row = it * 16 + (tid >> 5);
+            const unsigned char* sp = stages + plane * (SD_M * SD_OPITCH) + row * SD_OPITCH + piece * 16;
+            const uint2 lo = *reinterpret_cast<const uint2*>(sp), hi = *reinterpret_cast<const uint2*>(sp + 8);
+            const long long m = m0 + row;
+            if (m < M) {
+                if (EPI == SEPI_GELU) {
+                    *reinterpret_cast<uint4*>(dst + m * N) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                } else {
+                    const unsigned f = (unsigned)m / (unsigned)e.S, pos = (unsigned)m - f * (unsigned)e.S;   // (M < 2^31 tokens)
+                    *reinterpret_cast<uint4*>(dst + (((size_t)f * e.heads + hh) * e.Sp + pos) * 64) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+            }
+        }
+    } else if (STAGED && EPI == SEPI_RESID) {
+        // acc / scale + bias of the 256 x 128 tile in fp32, then x += gamma * that over whole 512-byte rows
+        __syncthreads();
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int cb = wc * 64 + ni * 16 + fg * 4;
+            const float4 b4 = e.bias ? *reinterpret_cast<const float4*>(e.bias + n0 + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const f4& a = acc[mi][ni];
+                *reinterpret_cast<float4*>(stages + (wr * 64 + mi * 16 + fj) * SD_FPITCH + cb * 4) =
+                    make_float4(a[0] * e.inv_wscale + b4.x, a[1] * e.inv_wscale + b4.y, a[2] * e.inv_wscale + b4.z, a[3] * e.inv_wscale + b4.w);
+            }
+        }
+        __syncthreads();
+        float* const xp = e.x + n0 + (tid & 31) * 4;
+        const float4 g4 = *reinterpret_cast<const float4*>(e.gamma + n0 + (tid & 31) * 4);   // (LayerScale where x is updated: the same fma as the direct form)
+#pragma unroll 4
+        for (int it = 0; it < SD_M / 16; ++it) {
+            const int row = it * 16 + (tid >> 5);
+            const float4 u = *reinterpret_cast<const float4*>(stages + row * SD_FPITCH + (tid & 31) * 16);
+            if (m0 + row < M) {
+                float4* q = reinterpret_cast<float4*>(xp + (m0 + row) * N);
+                float4 xv = *q;
+                xv.x += g4.x * u.x; xv.y += g4.y * u.y; xv.z += g4.z * u.z; xv.w += g4.w * u.w;
+                *q = xv;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int nb = n0 + wc * 64 + ni * 16 + fg * 4;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                split_store_tile<T, EPI>(acc[mi][ni], m0 + wr * 64 + mi * 16 + fj, nb, M, N, e, amax);
+        }
     }
     if (IsF16<T>::value && (EPI == SEPI_QKV || EPI == SEPI_GELU) && e.ovf) {
         if (__any(amax >= 65488.f) && lane == 0) atomicOr(e.ovf, EPI == SEPI_QKV ? 2 : 4);

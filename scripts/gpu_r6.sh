@@ -75,6 +75,18 @@ PY
         DTK_VIT_GEMM_WIDE_V1=1 timeout 300 python scripts/dev/wide_abl.py $M 30 >> gpurun_out/wide_time.jsonl 2>> gpurun_out/wide_time.err
       done
       cat gpurun_out/wide_time.jsonl ;;
+    split_ab)   # the split-operand step with this tree's GEMM epilogues vs the direct stores (same box)
+      F="--precision split --steps 3 --warmup 1 --no-train --no-cpu-baseline --no-clock-power --no-live-traffic --no-videos30 --parity-queries 0"
+      timeout 600 python bench.py $F > gpurun_out/split_ab_new.json 2> gpurun_out/split_ab.err
+      DTK_VIT_GEMM_WIDE_V1=1 timeout 600 python bench.py $F > gpurun_out/split_ab_v1.json 2>> gpurun_out/split_ab.err
+      python - <<'PY'
+import json
+r = {k: json.load(open(f"gpurun_out/split_ab_{k}.json")) for k in ("new", "v1")}
+print("split step, ms:", {k: v["ms_per_step"] for k, v in r.items()})
+for kk in sorted(set().union(*[v["roofline"]["kernel_ms"] for v in r.values()])):
+    print(f"  {kk:22s}", "  ".join(f"{k} {r[k]['roofline']['kernel_ms'].get(kk, float('nan')):9.3f}" for k in r))
+PY
+      ;;
     wide_abl)   # DTK_DEV ablations of gemm_wide_kernel (scripts/ubench/libdtk_dev.so = a `make DEV=1` build): where a 256 x 256 tile's time goes
       L=dino_tracker_amd/csrc/libdtk.so
       cp $L /tmp/libdtk_keep.so && cp scripts/ubench/libdtk_dev.so $L

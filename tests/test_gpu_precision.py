@@ -310,3 +310,22 @@ def test_auto_blocks_escalates_only_what_is_needed_at_vitl():
     assert a["px_err_vs_oracle_on_same_video"]["p99"] <= 1e-3, a
     assert a["arbitration_failures"] == 0, a
     assert a["occ_mismatch_same_video_queries_without_a_tie"] == 0, a
+
+
+@pytest.mark.parametrize("name,layer,dt", [("dinov2_vits14", 3, "fp16"), ("dinov2_vits14", 2, "bf16"), ("dinov2_vitl14", 1, "fp16")])
+def test_split_gemm_staged_epilogues_are_bit_identical(name, layer, dt):
+    """Round 6: gemm_split_dma_kernel stages its output tile in LDS (hi / lo planes of the GELU hidden and of Q / K; the fp32 update of
+    the residual stream, LayerScale applied where x is updated) and writes whole rows; its operand stages arrive through buffer
+    descriptors.  Same arithmetic per value, so the features are BIT-identical to the direct 8-byte-store epilogues
+    (DTK_VIT_GEMM_WIDE_V1), on a frame whose token count is not a multiple of the 256-row tile."""
+    sd = synth.make_vit_weights(name, seed=9, layerscale=0.1)
+    video = synth.synth_video(2, 154, 238, seed=84)
+    out = {}
+    for form in ("new", "v1"):
+        ex = VitExtractor(name, stride=7, device="cuda:0", state_dict=sd, precision="split", operand_dtype=dt)
+        ex.gemm_wide_v1 = form == "v1"
+        out[form] = ex.encode(video, layer=layer)
+        q = ex.encode(video[:1], layer=layer, want="qkv")
+        out[form + "_qkv"] = q
+    assert torch.isfinite(out["new"]).all()
+    assert torch.equal(out["new"], out["v1"]) and torch.equal(out["new_qkv"], out["v1_qkv"])
