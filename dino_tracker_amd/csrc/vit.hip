@@ -951,8 +951,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const T* __restrict__
         }
     } else if (PIPE && EPI == EPI_QKV && n0 < 2 * e.D) {
         // Q and K tiles the same way (a 256-feature tile is four heads of ONE of q / k / v: D is a multiple of 256 on this path): a
-        // token's 64 features of a head are 128 contiguous bytes of q / k [frame][head][position][64].  V^T (tokens contiguous, one
-        // row per feature) keeps the direct form below.
+        // token's 64 features of a head are 128 contiguous bytes of q / k [frame][head][position][64].  V^T: the next branch.
         __syncthreads();
         const int which = n0 / e.D, head0 = (n0 - which * e.D) >> 6;
         const float sc = which == 0 ? e.qscale : 1.f;
@@ -980,6 +979,55 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const T* __restrict__
             if (m < M && !DTK_DBG(e.no_store, 4)) {
                 const unsigned f = (unsigned)m / (unsigned)e.S, pos = (unsigned)m - f * (unsigned)e.S;   // (M < 2^31 tokens)
                 *reinterpret_cast<uint4*>(qk + (((size_t)f * e.heads + hh) * e.Sp + pos) * 64) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+        }
+    } else if (PIPE && EPI == EPI_QKV) {
+        // V^T tiles: vt[frame][head][feature][position] keeps TOKENS contiguous, so the tile is staged transposed -- sT[feature][token],
+        // 16-bit, the same pitch: a lane writes its four features of a token as four 2-byte pieces (the 16 tokens of a piece-write share
+        // 8 dwords; the four feature groups of a wave fall on different banks) -- and leaves as 8-byte pieces of four tokens, 64 lanes =
+        // 512 contiguous bytes of one feature row, when positions come in fours (S and Sp multiples of 4: 8108 / 8192 at 854 x 476);
+        // otherwise (odd test sizes) element by element.  The direct form wrote 2-byte pieces, 16 tokens x 4 rows per instruction, and
+        // made a V^T tile's epilogue 2.7 x a Q / K tile's (ViT-L qkv: 39.7 us per tile on average against proj's 34.4).
+        __syncthreads();
+        const int head0 = (n0 - 2 * e.D) >> 6;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int cb = wc * 64 + ni * 16 + fg * 4;
+            const float4 b4 = e.bias ? *reinterpret_cast<const float4*>(e.bias + n0 + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const f4& a = acc[mi][ni];
+                const float v[4] = {a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w};
+                if (IsF16<T>::value) amax = amax2(amax2(amax, v[0], v[1]), v[2], v[3]);
+                unsigned char* sp = stages + cb * W2_OPITCH + (wr * 128 + mi * 16 + fj) * 2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) *reinterpret_cast<T*>(sp + r * W2_OPITCH) = (T)v[r];
+            }
+        }
+        __syncthreads();
+        if (((e.S | e.Sp) & 3) == 0) {
+            const int g = tid & 63;   // tokens 4 g .. 4 g + 3 of the tile: one frame (frames start at multiples of 4), all below M or none
+            const long long m = m0 + 4 * g;
+            if (m < M && !DTK_DBG(e.no_store, 4)) {
+                const unsigned f = (unsigned)m / (unsigned)e.S, pos = (unsigned)m - f * (unsigned)e.S;
+                T* const base = e.vt + (((size_t)f * e.heads + head0) * 64) * e.Sp + pos;   // feature c of the tile: + c Sp
+#pragma unroll 4
+                for (int it = 0; it < W2_N / 8; ++it) {
+                    const int c = it * 8 + (tid >> 6);
+                    *reinterpret_cast<uint2*>(base + (size_t)c * e.Sp) = *reinterpret_cast<const uint2*>(stages + c * W2_OPITCH + g * 8);
+                }
+            }
+        } else {
+            const int t = tid & 255;
+            const long long m = m0 + t;
+            if (m < M && !DTK_DBG(e.no_store, 4)) {
+                const unsigned f = (unsigned)m / (unsigned)e.S, pos = (unsigned)m - f * (unsigned)e.S;
+                T* const base = e.vt + (((size_t)f * e.heads + head0) * 64) * e.Sp + pos;
+#pragma unroll 4
+                for (int it = 0; it < W2_N / 2; ++it) {
+                    const int c = it * 2 + (tid >> 8);
+                    base[(size_t)c * e.Sp] = *reinterpret_cast<const T*>(stages + c * W2_OPITCH + t * 2);
+                }
             }
         }
     } else {

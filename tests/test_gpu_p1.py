@@ -521,14 +521,17 @@ def test_wide_gemm_fragment_prefetch_is_bit_identical(name, layer):
     BIT-identical to the round 4-5 loop (DTK_VIT_GEMM_WIDE_V1), here over a frame whose token count is not a multiple of the 256-row
     tile (clamped tail rows) and, against the tiled kernel (different tile shape, same k order per accumulator), close (the tiled epilogues differ in their GELU form)."""
     sd = synth.make_vit_weights(name, seed=9, layerscale=0.1)
-    video = synth.synth_video(2, 154, 238, seed=84)
-    out = {}
-    for form in ("new", "v1", "tiled"):
-        ex = VitExtractor(name, stride=7, device="cuda:0", state_dict=sd)
-        ex.gemm_wide_v1, ex.tiled_gemms = form == "v1", form == "tiled"
-        out[form] = ex.encode(video, layer=layer)
-    assert torch.isfinite(out["new"]).all()
-    assert torch.equal(out["new"], out["v1"])
-    rel = ((out["new"].double() - out["tiled"].double()).norm() / out["tiled"].double().norm()).item()
-    print(f"{name}: wide vs tiled GEMMs rel {rel:.2e}")
-    assert rel < 2e-4
+    # 154 x 238: S = 694 tokens per frame (V^T leaves element by element); 140 x 154: S = 400, a multiple of 4 (V^T leaves as 8-byte
+    # pieces of four tokens, the form of 854 x 476); three frames: tiles that cross a frame boundary, clamped tail rows
+    for hw in ((154, 238), (140, 154)):
+        video = synth.synth_video(3, hw[0], hw[1], seed=84)
+        out = {}
+        for form in ("new", "v1", "tiled"):
+            ex = VitExtractor(name, stride=7, device="cuda:0", state_dict=sd)
+            ex.gemm_wide_v1, ex.tiled_gemms = form == "v1", form == "tiled"
+            out[form] = ex.encode(video, layer=layer)
+        assert torch.isfinite(out["new"]).all()
+        assert torch.equal(out["new"], out["v1"]), hw
+        rel = ((out["new"].double() - out["tiled"].double()).norm() / out["tiled"].double().norm()).item()
+        print(f"{name} {hw}: wide vs tiled GEMMs rel {rel:.2e}")
+        assert rel < 2e-4
