@@ -1187,6 +1187,9 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const T* __restrict__ A, c
             const int dh = fl;  // 0..63 inside the head
             if (which == 2) {
                 // V^T[f][head][dh][s]: consecutive lanes are consecutive tokens
+                // (round 6, measured and dropped: staging the wave's 64 x 32 tile transposed in LDS and flushing 8-byte pieces of four
+                //  tokens -- 8 store instructions instead of 32 -- made qkv 12.3 -> 15.7 ms per step: the 32 two-byte LDS writes sit in
+                //  the lone wave's issue stream like the stores they replace; docs/NEGATIVE_RESULTS.md)
                 if (ok) {
                     T* vp = e.vt + (((size_t)f_ep * e.heads + head) * 64 + dh) * e.Sp + s_ep;
 #pragma unroll

@@ -532,6 +532,10 @@ def test_wide_gemm_fragment_prefetch_is_bit_identical(name, layer):
             out[form] = ex.encode(video, layer=layer)
         assert torch.isfinite(out["new"]).all()
         assert torch.equal(out["new"], out["v1"]), hw
+        if name == "dinov2_vits14":   # the weight-stationary GEMMs: V^T staged transposed (S % 4 == 0) / direct vs their round 1-3 form
+            ex = VitExtractor(name, stride=7, device="cuda:0", state_dict=sd)
+            ex.gemm_ws_v1 = True
+            assert torch.equal(out["new"], ex.encode(video, layer=layer)), hw
         rel = ((out["new"].double() - out["tiled"].double()).norm() / out["tiled"].double().norm()).item()
         print(f"{name} {hw}: wide vs tiled GEMMs rel {rel:.2e}")
         assert rel < 2e-4
