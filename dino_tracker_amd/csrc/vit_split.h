@@ -428,6 +428,61 @@ __global__ __launch_bounds__(512, 1) void gemm_split_dma_kernel(const T* __restr
                 }
             }
         }
+    } else if (STAGED && EPI == SEPI_QKV) {
+        // V^T tiles (vit.hip, gemm_wide_kernel): both planes staged TRANSPOSED -- sT[feature][token], 16-bit, 520-byte rows -- and written
+        // as 8-byte pieces of four tokens along a feature row where positions come in fours, element by element otherwise
+        static_assert(2 * SD_N * (SD_M * 2 + 8) <= SD_STAGES * SD_STAGE_BYTES, "transposed planes must fit");
+        constexpr int TP = SD_M * 2 + 8;
+        __syncthreads();
+        unsigned char* const lo_plane = stages + SD_N * TP;
+        const int head0 = (n0 - 2 * e.D) >> 6;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int cb = wc * 64 + ni * 16 + fg * 4;
+            const float4 b4 = e.bias ? *reinterpret_cast<const float4*>(e.bias + n0 + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const f4& a = acc[mi][ni];
+                const float v[4] = {a[0] * e.inv_wscale + b4.x, a[1] * e.inv_wscale + b4.y, a[2] * e.inv_wscale + b4.z, a[3] * e.inv_wscale + b4.w};
+                const int off = cb * TP + (wr * 64 + mi * 16 + fj) * 2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (IsF16<T>::value) amax = fmaxf(amax, fabsf(v[r]));
+                    T x0, x1;
+                    split2<T>(v[r], x0, x1);
+                    *reinterpret_cast<T*>(stages + off + r * TP) = x0;
+                    *reinterpret_cast<T*>(lo_plane + off + r * TP) = x1;
+                }
+            }
+        }
+        __syncthreads();
+        if (((e.S | e.Sp) & 3) == 0) {
+            const int g = tid & 63;
+            const long long m = m0 + 4 * g;
+            if (m < M) {
+                const unsigned f = (unsigned)m / (unsigned)e.S, pos = (unsigned)m - f * (unsigned)e.S;
+                const size_t o = (((size_t)f * e.heads + head0) * 64) * e.Sp + pos;
+#pragma unroll 4
+                for (int it = 0; it < SD_N / 8; ++it) {
+                    const int c = it * 8 + (tid >> 6);
+                    *reinterpret_cast<uint2*>(e.vt_hi + o + (size_t)c * e.Sp) = *reinterpret_cast<const uint2*>(stages + c * TP + g * 8);
+                    *reinterpret_cast<uint2*>(e.vt_lo + o + (size_t)c * e.Sp) = *reinterpret_cast<const uint2*>(lo_plane + c * TP + g * 8);
+                }
+            }
+        } else {
+            const int t = tid & 255;
+            const long long m = m0 + t;
+            if (m < M) {
+                const unsigned f = (unsigned)m / (unsigned)e.S, pos = (unsigned)m - f * (unsigned)e.S;
+                const size_t o = (((size_t)f * e.heads + head0) * 64) * e.Sp + pos;
+#pragma unroll 4
+                for (int it = 0; it < SD_N / 2; ++it) {
+                    const int c = it * 2 + (tid >> 8);
+                    e.vt_hi[o + (size_t)c * e.Sp] = *reinterpret_cast<const T*>(stages + c * TP + t * 2);
+                    e.vt_lo[o + (size_t)c * e.Sp] = *reinterpret_cast<const T*>(lo_plane + c * TP + t * 2);
+                }
+            }
+        }
     } else if (STAGED && EPI == SEPI_RESID) {
         // acc / scale + bias of the 256 x 128 tile in fp32, then x += gamma * that over whole 512-byte rows
         __syncthreads();

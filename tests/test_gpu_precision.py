@@ -319,13 +319,15 @@ def test_split_gemm_staged_epilogues_are_bit_identical(name, layer, dt):
     descriptors.  Same arithmetic per value, so the features are BIT-identical to the direct 8-byte-store epilogues
     (DTK_VIT_GEMM_WIDE_V1), on a frame whose token count is not a multiple of the 256-row tile."""
     sd = synth.make_vit_weights(name, seed=9, layerscale=0.1)
-    video = synth.synth_video(2, 154, 238, seed=84)
-    out = {}
-    for form in ("new", "v1"):
-        ex = VitExtractor(name, stride=7, device="cuda:0", state_dict=sd, precision="split", operand_dtype=dt)
-        ex.gemm_wide_v1 = form == "v1"
-        out[form] = ex.encode(video, layer=layer)
-        q = ex.encode(video[:1], layer=layer, want="qkv")
-        out[form + "_qkv"] = q
-    assert torch.isfinite(out["new"]).all()
-    assert torch.equal(out["new"], out["v1"]) and torch.equal(out["new_qkv"], out["v1_qkv"])
+    # 154 x 238: 694 tokens per frame (V^T leaves element by element); 140 x 154: 400 = positions in fours (8-byte pieces, the 854 x 476 form)
+    for hw in ((154, 238), (140, 154)):
+        video = synth.synth_video(3, hw[0], hw[1], seed=84)
+        out = {}
+        for form in ("new", "v1"):
+            ex = VitExtractor(name, stride=7, device="cuda:0", state_dict=sd, precision="split", operand_dtype=dt)
+            ex.gemm_wide_v1 = form == "v1"
+            out[form] = ex.encode(video, layer=layer)
+            q = ex.encode(video[:1], layer=layer, want="qkv")
+            out[form + "_qkv"] = q
+        assert torch.isfinite(out["new"]).all()
+        assert torch.equal(out["new"], out["v1"]) and torch.equal(out["new_qkv"], out["v1_qkv"]), hw
