@@ -83,7 +83,7 @@ class VitExtractor(nn.Module):
         self.attention_v2 = False       # the round-2/3 attention kernel instead of the one-wave-per-SIMD one (cross-check)
         self.attention_v4 = os.environ.get("DTK_VIT_ATTENTION_V4", "0") == "1"   # rounds 4-5: 64 queries per wave (round 6: 128; A / B)
         self.gemm_ws_v1 = False         # the round 1-3 form of the K = 384 weight-stationary GEMMs (A / B measurement)
-        self.gemm_wide_v1 = os.environ.get("DTK_VIT_GEMM_WIDE_V1", "0") == "1"   # D = 768 / 1024: the wide GEMMs without the fragment prefetch (A / B)
+        self.gemm_wide_v1 = os.environ.get("DTK_VIT_GEMM_WIDE_V1", "0") == "1"   # the LDS-DMA GEMMs with round 5's direct-store epilogues (A / B; bit-identical)
         self.frame_batch = 0            # frames per pass of the encoder; 0 = the library's default
         if model_name not in VIT_CONFIGS:
             raise NotImplementedError(f"{model_name}: the HIP encoder covers dinov2_vit{{s,b,l}}14 (d_head 64)")

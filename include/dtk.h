@@ -131,8 +131,9 @@ typedef struct dtk_vit_model {
 #define DTK_VIT_GEMM_WS_V1 16   /* the K = 384 weight-stationary GEMMs in their round 1-3 form (A / B measurement, cross-check) */
 #define DTK_VIT_ATTENTION_V4 32 /* attention on the round-4/5 kernel (one wave per SIMD, 64 queries per wave: csrc/vit_attention4.h) instead of
                                  * round 6's 128 queries per wave (csrc/vit_attention6.h): A / B measurement, cross-check */
-#define DTK_VIT_GEMM_WIDE_V1 64 /* the 256 x 256 GEMMs of D = 768 / 1024 in their round 4-5 form: fragments read at the top of every k-step
-                                 * instead of one half-step ahead of their MFMAs (A / B measurement, cross-check) */
+#define DTK_VIT_GEMM_WIDE_V1 64 /* the LDS-DMA GEMMs (256 x 256 tiles of D = 768 / 1024, fc2 of D = 384, the split-operand GEMMs) in their
+                                 * round 4-5 form: 8-byte stores straight from the D tiles instead of whole rows through LDS, fragments read
+                                 * at the top of every k-step (A / B measurement, cross-check: the results are bit-identical) */
 #define DTK_OPERAND_F16 0
 #define DTK_OPERAND_BF16 1
 #define DTK_OPERAND_ATTENTION_V2 0x100  /* OR-ed into dtk_vit_attention's operand_type: the same selection for the stand-alone stage */
