@@ -122,8 +122,7 @@ class VitExtractor(nn.Module):
             if any(not 0 <= b < depth for b in blocks):
                 raise ValueError(f"precision: block indices must be in [0, {depth})")
             self.precision, self.split_blocks = "blocks", blocks
-        if self.precision not in ("auto", "auto-blocks"):
-            self.calibration = None
+        self.calibration = None   # a new request is measured afresh ("auto" / "auto-blocks": on the next encode; split_blocks restarts empty)
 
     def precision_report(self):
         """What the most recent encode() ran on, for callers that must know the feature-error class of their results:

@@ -56,6 +56,7 @@ def test_precision_argument_and_report():
     assert ex.precision_report()["feature_error_class"].startswith("mixed")
     ex.set_precision("auto")
     assert ex.calibration is None and not ex.split_blocks
+    ex.calibration = {"chosen": "split"}          # (a measurement made under another request does not survive a new one)
     ex.set_precision("auto-blocks")
     assert ex.precision == "auto-blocks" and ex.calibration is None and not ex.split_blocks
     for bad in ("strict", [12], [-1]):
