@@ -35,6 +35,8 @@ for WHAT in "$@"; do
       timeout 900 python bench.py --precision split --steps 3 --warmup 1 --no-train --no-cpu-baseline --no-clock-power --no-videos30 > gpurun_out/bench_split.json 2> gpurun_out/bench_split.err; cat gpurun_out/bench_split.json; tail -5 gpurun_out/bench_split.err ;;
     bench_w1024)
       timeout 900 python bench.py --width 1024 --precision fast --steps 2 --warmup 1 --no-train --no-cpu-baseline --no-clock-power --no-videos30 > gpurun_out/bench_w1024.json 2> gpurun_out/bench_w1024.err; cat gpurun_out/bench_w1024.json; tail -5 gpurun_out/bench_w1024.err ;;
+    bench_w768)
+      timeout 900 python bench.py --width 768 --precision fast --steps 2 --warmup 1 --no-train --no-cpu-baseline --no-clock-power --no-videos30 > gpurun_out/bench_w768.json 2> gpurun_out/bench_w768.err; cat gpurun_out/bench_w768.json | cut -c1-600; tail -3 gpurun_out/bench_w768.err ;;
     bench_ab)   # same-box A / B of the whole step: the tree's library, then scripts/ubench/libdtk_prev.so (a copy of the previous build), then the tree's again
       F="--steps 5 --warmup 2 --no-train --no-cpu-baseline --no-clock-power --no-videos30 --parity-queries 0"
       L=dino_tracker_amd/csrc/libdtk.so
