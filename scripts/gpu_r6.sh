@@ -102,6 +102,14 @@ PY
       timeout 600 python scripts/attn_ab.py scripts/ubench/libdtk_prev.so dino_tracker_amd/csrc/libdtk.so 2>&1 | tee gpurun_out/attn_ab.log ;;
     profile)
       bash scripts/gpu_profile.sh r06 ;;
+    sq1024)   # SQ-counter pass + kernel trace of the C = 1024 step (ViT-L/14)
+      R=$PWD; rm -rf /tmp/prof_sq /tmp/prof_kt
+      A="--width 1024 --precision fast --steps 1 --warmup 0 --no-train --no-cpu-baseline --no-clock-power --no-live-traffic --no-videos30 --parity-queries 0"
+      ( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES \
+          -d /tmp/prof_sq -o sq -- python $R/bench.py $A > /dev/null 2> $R/gpurun_out/r06_sq1024.err )
+      python scripts/pmc_sq.py $(find /tmp/prof_sq -name "*.db" | head -1) > gpurun_out/r06_pmc_sq_width1024.md 2>> gpurun_out/r06_sq1024.err; head -30 gpurun_out/r06_pmc_sq_width1024.md
+      ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python $R/bench.py $A > /dev/null 2>> $R/gpurun_out/r06_sq1024.err )
+      python scripts/rocpd_summary.py $(find /tmp/prof_kt -name "*.db" | head -1) > gpurun_out/r06_kernel_trace_width1024.md 2>> gpurun_out/r06_sq1024.err; head -24 gpurun_out/r06_kernel_trace_width1024.md ;;
     sq)   # the SQ-counter pass alone (scripts/pmc_sq.py: rows per template instantiation since round 6)
       R=$PWD; rm -rf /tmp/prof_sq; ( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES \
           -d /tmp/prof_sq -o sq -- python $R/bench.py --steps 1 --warmup 0 --no-train --no-cpu-baseline --no-clock-power --no-live-traffic --no-videos30 --parity-queries 0 > /dev/null 2> $R/gpurun_out/r06_sq.err )
