@@ -48,7 +48,7 @@ class VitModel(ctypes.Structure):
                 ("tap_out", c_void_p), ("tap_mask", ctypes.c_uint64), ("tap_scale", ctypes.c_float)]
 
 
-VIT_TILED_GEMMS, VIT_BF16, VIT_CHECK_RANGE, VIT_ATTENTION_V2, VIT_GEMM_WS_V1, VIT_ATTENTION_V4, VIT_GEMM_WIDE_V1 = 1, 2, 4, 8, 16, 32, 64  # dtk_vit_model.flags
+VIT_TILED_GEMMS, VIT_BF16, VIT_CHECK_RANGE, VIT_ATTENTION_V2, VIT_GEMM_WS_V1, VIT_ATTENTION_V4, VIT_GEMM_WIDE_V1, VIT_NO_LN_FUSION = 1, 2, 4, 8, 16, 32, 64, 128  # dtk_vit_model.flags
 OPERAND_F16, OPERAND_BF16, OPERAND_ATTENTION_V2, OPERAND_ATTENTION_V4 = 0, 1, 0x100, 0x2000
 OPERAND_ATTENTION_V5, OPERAND_ATTENTION_V5_INPHASE = 0x200, 0x400   # stand-alone stage only: the round-5 experiment kernel (vit_attention5.h)
 

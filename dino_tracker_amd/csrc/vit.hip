@@ -332,6 +332,13 @@ struct GemmEpi {
     // fp16 range (round 5): EPI_QKV / EPI_GELU kernels OR bit 2 / 4 into *ovf when a value they store reaches the fp16 limit --
     // every frame, inside the epilogue (no extra pass); NULL = not tracked (bf16 operands)
     int* ovf;
+    // gemm_wide_delta_kernel<T, true, true> (round 6): the LayerNorm of the NEXT block inside fc2's epilogue -- x += delta where the
+    // delta tile is staged, statistics and the 16-bit normalised row from the same registers (the arithmetic of layernorm_kernel)
+    float* ln_x;             // [M][N] the fp32 residual stream
+    const float *ln_w, *ln_b;
+    T* ln_out;               // [M][N]
+    float ln_eps;
+    int* ln_ovf;             // overflow word: bit 1 = a saturated residual update (fp16 operands)
 };
 
 // running |max| of the values an epilogue stores (the saturation test of the fp16 range, see GemmEpi::ovf): two values per
@@ -655,7 +662,7 @@ constexpr int WD_REQ = (WD_M + WD_N) / 16 / 8;  // DMA requests per wave and sta
 
 constexpr int WD_OPITCH = WD_N * 2 + 8;   // staged output rows (round 6): 768 B + 8
 
-template <typename T, bool STAGED = true>
+template <typename T, bool STAGED = true, bool FUSE_LN = false>
 __global__ __launch_bounds__(512, 2) void gemm_wide_delta_kernel(const T* __restrict__ A, const T* __restrict__ Wt,
                                                                  long long M, int K, GemmEpi<T> e) {
     typedef typename Vec<T>::t8 T8;
@@ -729,6 +736,90 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_delta_kernel(const T* __rest
     // D tiles are TRANSPOSED (round 5): lane (fg, fj) holds features 4 fg + r (r = 0..3) of token fj of each 16 x 16 tile -- four
     // consecutive features of one token: ONE 8-byte store per tile and lane (48 per lane and 256 x 384 tile) where the
     // token-major form needed four 2-byte stores (192)
+    if (STAGED && FUSE_LN) {
+        // Round 6: fc2's epilogue + the NEXT block's LayerNorm.  Two passes; pass p stages the token tiles mi = 4 p .. 4 p + 3 of EVERY
+        // wave (rows wr 128 + 64 p .. + 63 of the tile: every wave frees half of its accumulators per pass, which is what leaves
+        // registers for the rows of x below) as the same 16-bit delta the unfused path stores.  Then a wave takes 16 of the pass's 128
+        // rows, eight at a time: x of the eight rows is requested first, then row by row x += delta, x written back, statistics and
+        // the normalised 16-bit row by layernorm_kernel's own expressions and lane -> column map (lane c: columns 4 c .. 4 c + 3, lanes
+        // 0-31 also 256 + 4 c ..): bit-identical rows.  The delta tile never reaches memory; one launch and one trip of x + delta per
+        // block go away.
+        static_assert(128 * WD_OPITCH <= WD_STAGES * WD_STAGE_BYTES, "staged half tile must fit the stages");
+        const float4 ga = *reinterpret_cast<const float4*>(e.ln_w + lane * 4), ba = *reinterpret_cast<const float4*>(e.ln_b + lane * 4);
+        const float4 gb = *reinterpret_cast<const float4*>(e.ln_w + 256 + (lane & 31) * 4), bb = *reinterpret_cast<const float4*>(e.ln_b + 256 + (lane & 31) * 4);
+        bool sat = false;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            __syncthreads();   // p = 0: every wave's requests have landed and the stages are dead; p = 1: pass 0 has been read
+#pragma unroll
+            for (int ni = 0; ni < 6; ++ni) {
+                const int nb = wc * 96 + ni * 16 + fg * 4;
+                const float4 b4 = e.bias ? *reinterpret_cast<const float4*>(e.bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 g4 = *reinterpret_cast<const float4*>(e.gamma + nb);
+#pragma unroll
+                for (int mq = 0; mq < 4; ++mq) {
+                    const f4& a = acc[4 * p + mq][ni];
+                    *reinterpret_cast<T4*>(stages + (wr * 64 + mq * 16 + fj) * WD_OPITCH + nb * 2) =
+                        T4{(T)(g4.x * (a[0] + b4.x)), (T)(g4.y * (a[1] + b4.y)), (T)(g4.z * (a[2] + b4.z)), (T)(g4.w * (a[3] + b4.w))};
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                // local rows lr = 16 w + 8 half + rr of the pass <-> tile rows (lr >> 6) 128 + 64 p + (lr & 63)
+                const int lr0 = w * 16 + half * 8;
+                const long long rb = m0 + (lr0 >> 6) * 128 + p * 64 + (lr0 & 63);
+                float4 xa[8], xb[8];
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const float* xp = e.ln_x + min(rb + rr, M - 1) * WD_N + lane * 4;
+                    xa[rr] = *reinterpret_cast<const float4*>(xp);
+                    xb[rr] = lane < 32 ? *reinterpret_cast<const float4*>(xp + 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const long long row = rb + rr;
+                    if (row >= M) continue;   // wave-uniform (the last tile's tail)
+                    const unsigned char* sp = stages + (lr0 + rr) * WD_OPITCH + lane * 8;
+                    float4 v[2] = {xa[rr], xb[rr]};
+                    float s = 0.f;
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        if (it == 0 || lane < 32) {
+                            const T4 d = *reinterpret_cast<const T4*>(sp + it * 512);
+                            const float d0 = (float)d[0], d1 = (float)d[1], d2 = (float)d[2], d3 = (float)d[3];
+                            if (IsF16<T>::value) sat |= !(fmaxf(fmaxf(fabsf(d0), fabsf(d1)), fmaxf(fabsf(d2), fabsf(d3))) < 65504.f);
+                            v[it].x += d0; v[it].y += d1; v[it].z += d2; v[it].w += d3;
+                            *reinterpret_cast<float4*>(e.ln_x + row * WD_N + it * 256 + lane * 4) = v[it];
+                            s += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+                        }
+                    }
+                    const float mean = wave_sum(s) / (float)WD_N;
+                    float q = 0.f;
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        if (it == 0 || lane < 32) {
+                            const float a = v[it].x - mean, b = v[it].y - mean, cc = v[it].z - mean, d = v[it].w - mean;
+                            q += (a * a + b * b) + (cc * cc + d * d);
+                        }
+                    }
+                    const float rstd = rsqrtf(wave_sum(q) / (float)WD_N + e.ln_eps);
+                    T* o = e.ln_out + row * WD_N;
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        if (it == 0 || lane < 32) {
+                            const float4 g = it ? gb : ga, b = it ? bb : ba;
+                            T4 r = {(T)((v[it].x - mean) * rstd * g.x + b.x), (T)((v[it].y - mean) * rstd * g.y + b.y),
+                                     (T)((v[it].z - mean) * rstd * g.z + b.z), (T)((v[it].w - mean) * rstd * g.w + b.w)};
+                            *reinterpret_cast<T4*>(o + it * 256 + lane * 4) = r;
+                        }
+                    }
+                }
+            }
+        }
+        if (IsF16<T>::value && e.ln_ovf && __any(sat) && lane == 0) atomicOr(e.ln_ovf, 1);
+        return;
+    }
     if (STAGED) {
         // Round 6: through LDS (see gemm_wide_kernel's epilogue: a CU holds one workgroup of this kernel, nothing overlaps the epilogue,
         // and its 8-byte stores -- 16 tokens x 32 B per instruction -- ran at 1.5 TB/s).  The 256 x 384 tile is 192 KB of 16-bit values:
@@ -1596,6 +1687,8 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
         // GEMMs of widths without a weight-stationary form: the 256 x 256 DMA kernel when the shape allows, else 128 x 128
         const bool wide_ok = !(m->flags & DTK_VIT_TILED_GEMMS) && D % W2_N == 0;
         bool pending = false;   // `delta` holds a residual update that the next LayerNorm (or the final update) has to apply
+        bool ln1_done = false;  // the previous block's fc2 has already written this block's LayerNorm-1 rows to xn (round 6)
+        const bool no_ln_fusion = (m->flags & DTK_VIT_NO_LN_FUSION) != 0;
         auto tap = [&](int l, bool with_delta) -> int {   // dtk_vit_model.tap_out: the block output of layer l joins the mean
             if (!m->tap_out || !((m->tap_mask >> l) & 1)) return DTK_OK;
             const long long t4 = rows * (D / 4);
@@ -1673,8 +1766,10 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                 continue;
             }
             GemmEpi<T> e{};
-            DTK_LAUNCH("vit_layernorm", layernorm_kernel<T>, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x,
-                       pending ? (const T*)delta : (const T*)nullptr, L.ln1_w, L.ln1_b, xn, rows, D, m->ln_eps, ovf);
+            if (!ln1_done)
+                DTK_LAUNCH("vit_layernorm", layernorm_kernel<T>, dim3(dtk_cdiv(rows, 4)), dim3(256), 0, st, x,
+                           pending ? (const T*)delta : (const T*)nullptr, L.ln1_w, L.ln1_b, xn, rows, D, m->ln_eps, ovf);
+            ln1_done = false;
             pending = true;
             if (qkv_out && l == m->depth - 1) {  // the qkv hook of the reference (models/extractor.py:107-118), fp32 out
                 e.bias = L.qkv_b; e.out_f32 = qkv_out + (size_t)f0 * S * 3 * D;
@@ -1743,9 +1838,19 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
             e = GemmEpi<T>{};
             e.bias = L.fc2_b; e.delta = delta; e.gamma = L.ls2; e.no_store = dbg_ns;
             if (ws_ok && D == WD_N) {  // (ws_ok: the fast-path GEMMs are on, dtk_vit_model.flags)
+                // round 6: the LayerNorm of the next block runs inside this epilogue when that block is a fast one (the split blocks
+                // have their own LayerNorm: hi / lo planes); the last block's update goes to the outputs (below)
+                const bool fuse_ln = !wide_v1 && !no_ln_fusion && l + 1 < m->depth && !vit_layer_split(m->layers[l + 1]);
                 if (wide_v1) {
                     DTK_LAUNCH("vit_gemm_fc2", (gemm_wide_delta_kernel<T, false>), dim3(dtk_cdiv(rows, WD_M)), dim3(512), 0, st, hid, fc2_w,
                                rows, 4 * D, e);
+                } else if (fuse_ln) {
+                    const dtk_vit_layer& Ln = m->layers[l + 1];
+                    e.ln_x = x; e.ln_w = Ln.ln1_w; e.ln_b = Ln.ln1_b; e.ln_out = xn; e.ln_eps = m->ln_eps; e.ln_ovf = ovf;
+                    DTK_LAUNCH("vit_gemm_fc2", (gemm_wide_delta_kernel<T, true, true>), dim3(dtk_cdiv(rows, WD_M)), dim3(512), 0, st, hid, fc2_w,
+                               rows, 4 * D, e);
+                    pending = false;      // x is up to date ...
+                    ln1_done = true;      // ... and xn holds the next block's normalised rows
                 } else {
                     DTK_LAUNCH("vit_gemm_fc2", (gemm_wide_delta_kernel<T, true>), dim3(dtk_cdiv(rows, WD_M)), dim3(512), 0, st, hid, fc2_w,
                                rows, 4 * D, e);
@@ -1756,7 +1861,7 @@ int vit_run(const dtk_vit_model* m, const float* frames, int nframes, int video_
                 DTK_LAUNCH("vit_gemm_fc2", (gemm_tiled_kernel<T, EPI_DELTA>), dim3(gemm_grid(D, rows)), dim3(256), 0, st, hid,
                            fc2_w, rows, D, 4 * D, e);
             }
-            if (tap(l, true)) return DTK_E_HIP;
+            if (tap(l, pending)) return DTK_E_HIP;
         }
         if (pending && (tokens_out || feat_out)) {
             // the last MLP's residual update, written straight to the outputs (x itself is dead after the last block)

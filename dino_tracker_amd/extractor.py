@@ -47,7 +47,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from ._lib import VIT_ATTENTION_V2, VIT_ATTENTION_V4, VIT_GEMM_WIDE_V1, VIT_GEMM_WS_V1, VIT_BF16, VIT_CHECK_RANGE, VIT_TILED_GEMMS, VitLayer, VitModel, check, lib
+from ._lib import VIT_ATTENTION_V2, VIT_ATTENTION_V4, VIT_GEMM_WIDE_V1, VIT_GEMM_WS_V1, VIT_NO_LN_FUSION, VIT_BF16, VIT_CHECK_RANGE, VIT_TILED_GEMMS, VitLayer, VitModel, check, lib
 from .synth import VIT_CONFIGS, make_vit_weights
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
@@ -83,6 +83,7 @@ class VitExtractor(nn.Module):
         self.attention_v2 = False       # the round-2/3 attention kernel instead of the one-wave-per-SIMD one (cross-check)
         self.attention_v4 = os.environ.get("DTK_VIT_ATTENTION_V4", "0") == "1"   # rounds 4-5: 64 queries per wave (round 6: 128; A / B)
         self.gemm_ws_v1 = False         # the round 1-3 form of the K = 384 weight-stationary GEMMs (A / B measurement)
+        self.no_ln_fusion = os.environ.get("DTK_VIT_NO_LN_FUSION", "0") == "1"   # D = 384: LayerNorm-1 of the next block as its own launch (A / B)
         self.gemm_wide_v1 = os.environ.get("DTK_VIT_GEMM_WIDE_V1", "0") == "1"   # the LDS-DMA GEMMs with round 5's direct-store epilogues (A / B; bit-identical)
         self.frame_batch = 0            # frames per pass of the encoder; 0 = the library's default
         if model_name not in VIT_CONFIGS:
@@ -256,7 +257,8 @@ class VitExtractor(nn.Module):
         def run(operand_dtype, split_blocks, frames=frames, n=n):
             flags = (VIT_TILED_GEMMS if self.tiled_gemms else 0) | (VIT_BF16 if operand_dtype == "bf16" else 0) | \
                 (VIT_CHECK_RANGE if self.check_range else 0) | (VIT_ATTENTION_V2 if self.attention_v2 else 0) | (VIT_ATTENTION_V4 if self.attention_v4 else 0) | \
-                (VIT_GEMM_WS_V1 if self.gemm_ws_v1 else 0) | (VIT_GEMM_WIDE_V1 if self.gemm_wide_v1 else 0)
+                (VIT_GEMM_WS_V1 if self.gemm_ws_v1 else 0) | (VIT_GEMM_WIDE_V1 if self.gemm_wide_v1 else 0) | \
+                (VIT_NO_LN_FUSION if self.no_ln_fusion else 0)
             m = VitModel(D, self.cfg["heads"], layer + 1, patch, self.stride, 1e-6, flags,
                          self._sd["patch_embed.proj.weight"].data_ptr(),
                          self._sd["patch_embed.proj.bias"].data_ptr(), cls_pos.data_ptr(), pos.data_ptr(), ms.data_ptr(),

@@ -131,6 +131,8 @@ typedef struct dtk_vit_model {
 #define DTK_VIT_GEMM_WS_V1 16   /* the K = 384 weight-stationary GEMMs in their round 1-3 form (A / B measurement, cross-check) */
 #define DTK_VIT_ATTENTION_V4 32 /* attention on the round-4/5 kernel (one wave per SIMD, 64 queries per wave: csrc/vit_attention4.h) instead of
                                  * round 6's 128 queries per wave (csrc/vit_attention6.h): A / B measurement, cross-check */
+#define DTK_VIT_NO_LN_FUSION 128 /* D = 384: keep the LayerNorm of the next block a launch of its own instead of running it inside fc2's
+                                  * epilogue (A / B measurement, cross-check: the results are bit-identical) */
 #define DTK_VIT_GEMM_WIDE_V1 64 /* the LDS-DMA GEMMs (256 x 256 tiles of D = 768 / 1024, fc2 of D = 384, the split-operand GEMMs) in their
                                  * round 4-5 form: 8-byte stores straight from the D tiles instead of whole rows through LDS, fragments read
                                  * at the top of every k-step (A / B measurement, cross-check: the results are bit-identical) */

@@ -89,6 +89,19 @@ for kk in sorted(set().union(*[v["roofline"]["kernel_ms"] for v in r.values()]))
     print(f"  {kk:22s}", "  ".join(f"{k} {r[k]['roofline']['kernel_ms'].get(kk, float('nan')):9.3f}" for k in r))
 PY
       ;;
+    ln_ab)   # fc2 + the next block's LayerNorm in one launch vs two (DTK_VIT_NO_LN_FUSION=1), whole step, same box, alternating
+      F="--steps 5 --warmup 2 --no-train --no-cpu-baseline --no-clock-power --no-live-traffic --no-videos30 --parity-queries 0"
+      timeout 600 python bench.py $F > gpurun_out/ln_ab_new1.json 2> gpurun_out/ln_ab.err
+      DTK_VIT_NO_LN_FUSION=1 timeout 600 python bench.py $F > gpurun_out/ln_ab_off.json 2>> gpurun_out/ln_ab.err
+      timeout 600 python bench.py $F > gpurun_out/ln_ab_new2.json 2>> gpurun_out/ln_ab.err
+      python - <<'PY'
+import json
+r = {k: json.load(open(f"gpurun_out/ln_ab_{k}.json")) for k in ("new1", "off", "new2")}
+print("ms per step:", {k: v["ms_per_step"] for k, v in r.items()})
+for kk in sorted(set().union(*[v["roofline"]["kernel_ms"] for v in r.values()])):
+    print(f"  {kk:18s}", "  ".join(f"{k} {r[k]['roofline']['kernel_ms'].get(kk, float('nan')):8.3f}" for k in r))
+PY
+      ;;
     wide_abl)   # DTK_DEV ablations of gemm_wide_kernel (scripts/ubench/libdtk_dev.so = a `make DEV=1` build): where a 256 x 256 tile's time goes
       L=dino_tracker_amd/csrc/libdtk.so
       cp $L /tmp/libdtk_keep.so && cp scripts/ubench/libdtk_dev.so $L

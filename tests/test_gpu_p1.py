@@ -532,10 +532,14 @@ def test_wide_gemm_fragment_prefetch_is_bit_identical(name, layer):
             out[form] = ex.encode(video, layer=layer)
         assert torch.isfinite(out["new"]).all()
         assert torch.equal(out["new"], out["v1"]), hw
-        if name == "dinov2_vits14":   # the weight-stationary GEMMs: V^T staged transposed (S % 4 == 0) / direct vs their round 1-3 form
+        if name == "dinov2_vits14":   # the weight-stationary GEMMs vs their round 1-3 form; fc2 + the next block's LayerNorm vs two launches
             ex = VitExtractor(name, stride=7, device="cuda:0", state_dict=sd)
             ex.gemm_ws_v1 = True
             assert torch.equal(out["new"], ex.encode(video, layer=layer)), hw
+            ex = VitExtractor(name, stride=7, device="cuda:0", state_dict=sd)
+            ex.no_ln_fusion = True
+            assert torch.equal(out["new"], ex.encode(video, layer=layer)), hw
+            assert torch.equal(ex.encode(video, want="tokens"), VitExtractor(name, stride=7, device="cuda:0", state_dict=sd).encode(video, want="tokens")), hw
         rel = ((out["new"].double() - out["tiled"].double()).norm() / out["tiled"].double().norm()).item()
         print(f"{name} {hw}: wide vs tiled GEMMs rel {rel:.2e}")
         assert rel < 2e-4
