@@ -764,20 +764,20 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_delta_kernel(const T* __rest
                 }
             }
             __syncthreads();
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                // local rows lr = 16 w + 8 half + rr of the pass <-> tile rows (lr >> 6) 128 + 64 p + (lr & 63)
-                const int lr0 = w * 16 + half * 8;
+            // local rows lr0 .. lr0 + NB - 1 of the pass <-> tile rows (lr >> 6) 128 + 64 p + (lr & 63); NB rows of x in flight per wave:
+            // 8 while the second half of the accumulators is live (pass 0), 16 in pass 1
+            auto ln_rows = [&](auto nb_c, int lr0) {
+                constexpr int NB = decltype(nb_c)::value;
                 const long long rb = m0 + (lr0 >> 6) * 128 + p * 64 + (lr0 & 63);
-                float4 xa[8], xb[8];
+                float4 xa[NB], xb[NB];
 #pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
+                for (int rr = 0; rr < NB; ++rr) {
                     const float* xp = e.ln_x + min(rb + rr, M - 1) * WD_N + lane * 4;
                     xa[rr] = *reinterpret_cast<const float4*>(xp);
                     xb[rr] = lane < 32 ? *reinterpret_cast<const float4*>(xp + 256) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
+                for (int rr = 0; rr < NB; ++rr) {
                     const long long row = rb + rr;
                     if (row >= M) continue;   // wave-uniform (the last tile's tail)
                     const unsigned char* sp = stages + (lr0 + rr) * WD_OPITCH + lane * 8;
@@ -815,6 +815,12 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_delta_kernel(const T* __rest
                         }
                     }
                 }
+            };
+            if (p == 0) {
+                ln_rows(std::integral_constant<int, 8>{}, w * 16);
+                ln_rows(std::integral_constant<int, 8>{}, w * 16 + 8);
+            } else {
+                ln_rows(std::integral_constant<int, 16>{}, w * 16);
             }
         }
         if (IsF16<T>::value && e.ln_ovf && __any(sat) && lane == 0) atomicOr(e.ln_ovf, 1);
