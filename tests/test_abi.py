@@ -128,3 +128,18 @@ def test_m0_users(handle, tmp_path):
                 seen += 1
                 assert len(dma) == len(ins), (kern, [i for i in ins if not i.startswith("s_add_u32 m0,")][:4])
     assert seen >= 4   # attention4 (x2 operand types), gemm_ws V2D forms, corr_peaks, refine_corr_dma
+
+
+def test_vit_flag_values_match_header():
+    """dtk_vit_model.flags: the Python constants (dino_tracker_amd/_lib.py) are the header's #defines (include/dtk.h)."""
+    import re
+    import os
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "dtk.h")).read()
+    want = {"DTK_VIT_TILED_GEMMS": _lib.VIT_TILED_GEMMS, "DTK_VIT_BF16": _lib.VIT_BF16, "DTK_VIT_CHECK_RANGE": _lib.VIT_CHECK_RANGE,
+            "DTK_VIT_ATTENTION_V2": _lib.VIT_ATTENTION_V2, "DTK_VIT_GEMM_WS_V1": _lib.VIT_GEMM_WS_V1,
+            "DTK_VIT_ATTENTION_V4": _lib.VIT_ATTENTION_V4, "DTK_VIT_GEMM_WIDE_V1": _lib.VIT_GEMM_WIDE_V1,
+            "DTK_VIT_NO_LN_FUSION": _lib.VIT_NO_LN_FUSION}
+    for name, value in want.items():
+        m = re.search(rf"#define {name} (\d+)", text)
+        assert m and int(m.group(1)) == value, name
+    assert len(set(want.values())) == len(want) and all(v & (v - 1) == 0 for v in want.values())
