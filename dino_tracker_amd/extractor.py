@@ -330,7 +330,7 @@ class VitExtractor(nn.Module):
         amplification by the later blocks included); roundings of different blocks are independent, so a fast set F is predicted
         at sqrt(sum e_b^2) -- F grows from the cheapest block while that stays below block_margin * auto_tol, and is then
         MEASURED as one pass; while the measurement is above the bound the costliest member leaves.  Blocks beyond `layer` do not
-        run and stay un-escalated.  Fills calibration["blocks"]."""
+        run in the calibration and are escalated.  Fills calibration["blocks"]."""
         used = list(range(layer + 1))
         bound = self.block_margin * self.auto_tol
         alone = {}
@@ -354,7 +354,8 @@ class VitExtractor(nn.Module):
         self.calibration.update({"chosen": "blocks" if fast else "split", "blocks": {
             "bound": bound, "alone": [alone[b] for b in used], "fast_blocks": sorted(fast), "split_blocks": sorted(split),
             "passes": tried, "measured": tried[-1]["measured"] if fast else 0.0}})
-        return split if fast else frozenset(range(self.cfg["depth"]))
+        # (blocks beyond `layer` were not measured: escalated, so that a later call to a deeper layer does not run them on trust)
+        return (split | frozenset(range(layer + 1, self.cfg["depth"]))) if fast else frozenset(range(self.cfg["depth"]))
 
     def check_overflow(self, heal: bool = False) -> bool:
         """Reads (one stream synchronisation) and clears the overflow word of the encode() calls since the last check.

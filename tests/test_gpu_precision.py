@@ -289,7 +289,8 @@ def test_auto_blocks_escalates_only_what_is_needed_at_vitl():
     b = c["blocks"]
     assert 0 < len(b["fast_blocks"]) < 16 and sorted(b["fast_blocks"] + b["split_blocks"]) == list(range(16))
     assert b["measured"] <= b["bound"] == 0.8 * c["tol"]
-    assert ex.split_blocks == frozenset(b["split_blocks"]) and ex.precision_report()["feature_error_class"].startswith("mixed")
+    assert ex.split_blocks == frozenset(b["split_blocks"]) | frozenset(range(16, 24))   # (blocks beyond the calibrated layer: escalated)
+    assert ex.precision_report()["feature_error_class"].startswith("mixed")
     r = _rel(got, ref)
     print(f"auto-blocks features vs float64: {r:.2e} ({len(b['split_blocks'])} of 16 blocks split)")
     assert r <= c["tol"]

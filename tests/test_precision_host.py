@@ -95,14 +95,14 @@ def test_auto_blocks_selection_logic():
     ex.calibration, calls = {}, []
     split = ex._pick_blocks(model(1.0, calls), layer=7)
     # ascending: 7 (0.4), 1 (0.5), 2 (0.6), 4 (0.7), 5 (1.0), 6 (1.2): sqrt(.16+.25+.36+.49+1.0) = 1.503e-4 <= 2e-4; + 1.44 -> 1.92e-4 <= 2e-4; + block 0 no
-    assert split == frozenset({0, 3}), split
+    assert split == frozenset({0, 3, 8, 9, 10, 11}), split          # (blocks 8 .. 11 lie beyond `layer`: not measured, escalated)
     c = ex.calibration
     assert c["chosen"] == "blocks" and c["blocks"]["fast_blocks"] == [1, 2, 4, 5, 6, 7] and abs(c["blocks"]["measured"] - 1.924e-4) < 1e-6
     assert calls[:8] == [(b,) for b in range(8)] and len(calls) == 9
     ex.calibration, calls = {}, []
     split = ex._pick_blocks(model(1.2, calls), layer=7)                                  # sets measure 1.2 x the quadrature sum: 2.31e-4 -> block 6 leaves -> 1.80e-4
-    assert split == frozenset({0, 3, 6}) and len(ex.calibration["blocks"]["passes"]) == 2, (split, ex.calibration)
+    assert split == frozenset({0, 3, 6, 8, 9, 10, 11}) and len(ex.calibration["blocks"]["passes"]) == 2, (split, ex.calibration)
     ex.calibration = {}
-    assert ex._pick_blocks(model(100.0, []), layer=7) == frozenset(range(7)) and ex.calibration["blocks"]["fast_blocks"] == [7]
+    assert ex._pick_blocks(model(100.0, []), layer=7) == frozenset(range(12)) - {7} and ex.calibration["blocks"]["fast_blocks"] == [7]
     ex.calibration = {}
     assert ex._pick_blocks(lambda split_blocks: (1e-3, False), layer=7) == frozenset(range(12)) and ex.calibration["chosen"] == "split"
